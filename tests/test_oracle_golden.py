@@ -1,0 +1,159 @@
+"""The oracle restatement against the committed golden vectors (runs anywhere, CPU only).
+
+*_ref.npz hold outputs of the REAL reference (see tests/golden/MANIFEST.json and
+oracle/gen_golden.py); frames.npz pins the oracle against its own recorded outputs so a later edit
+of fo_oracle.c cannot drift silently."""
+import zlib
+
+import numpy as np
+import pytest
+
+
+def test_viterbi_matches_reference_sse(po, golden):
+    g = golden.viterbi_ref
+    for i, nb in enumerate(g["data_bits"]):
+        s = g["symbols"][g["sym_off"][i]:g["sym_off"][i + 1]]
+        want = g["decoded"][g["dec_off"][i]:g["dec_off"][i + 1]]
+        assert np.array_equal(po.conv_decode(s, int(nb)), want), "KAT %d (data_bits %d)" % (i, nb)
+
+
+def test_viterbi_long_block_saturates(po, golden):
+    g = golden.viterbi_ref
+    i = len(g["data_bits"]) - 1
+    s = g["symbols"][g["sym_off"][i]:g["sym_off"][i + 1]]
+    _, _, stats = po.viterbi_forward(s, int(g["data_bits"][i]) + 6)
+    assert stats[0] > 1000 and stats[1] > 10     # saturating adds and renormalisations both happen
+
+
+def test_codec_matches_reference(po, golden):
+    g = golden.codec_ref
+    for r in range(po.NUM_RATES):
+        assert np.array_equal(po.demodulate(g["demod_in_%d" % r], r), g["demod_out_%d" % r]), r
+        assert np.array_equal(po.depuncture(g["bytes_in_%d" % r], r), g["depunct_out_%d" % r]), r
+        assert np.array_equal(po.puncture(g["bits_in_%d" % r], r), g["punct_out_%d" % r]), r
+        assert np.array_equal(po.modulate(g["mod_in_%d" % r], r), g["mod_out_%d" % r]), r
+        rp = po.rate_params(r)
+        assert [rp[k] for k in ("rate_field", "cbps", "dbps", "bpsc", "rate")] == list(g["rate_table"][r])
+    assert np.array_equal(po.interleave(g["il_in"]), g["il_out"])
+    assert np.array_equal(po.deinterleave(g["il_in"]), g["deil_out"])
+    assert np.array_equal(po.conv_encode(g["enc_in"], 130), g["enc_out"])
+    m = po.symbol_map(g["map_in"].astype(np.complex128))
+    assert np.array_equal(m.astype(np.complex64), g["map_out"])
+
+
+def test_tables_match_reference(po, golden):
+    g = golden.codec_ref
+    assert np.array_equal(po.preamble_samples(), g["preamble"])
+    assert np.array_equal(po.lts_freq_domain(), g["lts_freq"])
+    assert np.array_equal(po.lts_time_domain_conj(), g["lts_time_conj"])
+
+
+def test_crc32_check_value(po):
+    # the published check value of the IEEE 802.3 CRC-32 that boost::crc_32_type implements
+    assert po.crc32(np.frombuffer(b"123456789", np.uint8)) == 0xCBF43926
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 2, 1026, 4097):
+        d = rng.integers(0, 256, n, dtype=np.uint8)
+        assert po.crc32(d) == zlib.crc32(d.tobytes())
+
+
+def test_fft_is_the_dft_with_the_reference_index_map(po):
+    rng = np.random.default_rng(6)
+    x = rng.normal(size=64) + 1j * rng.normal(size=64)
+    want = np.fft.fftshift(np.fft.fft(x))          # fft.cpp:20-24: output index = bin + 32 mod 64
+    got = po.fft64(x)
+    assert np.abs(got - want).max() < 1e-13 * np.abs(want).max()
+    back = po.ifft64(got)                           # fft.cpp:68-96 undoes it, scaled 1/64
+    assert np.abs(back - x).max() < 1e-14
+
+
+def test_sync_and_equaliser_blocks_match_reference(po, golden):
+    g = golden.blocks_ref
+    s = g["stream"].astype(np.complex128)
+    chunk = int(g["chunk"])
+    fd, ts, fs, ce, pt = po.FrameDetector(), po.TimingSync(), po.FFTSymbols(), po.ChannelEst(), po.PhaseTracker()
+    fd_tags, ts_tags, ts_s, ce_in, ce_out, ce_tags, pt_out = [], [], [], [], [], [], []
+    for x in range(0, s.size, chunk):
+        a = fd.work(s[x:x + chunk]); b = ts.work(a); v = fs.work(b); e = ce.work(v); p = pt.work(e)
+        fd_tags.append(a["tag"]); ts_tags.append(b["tag"]); ts_s.append(b["sample"])
+        ce_in.append(v["samples"]); ce_out.append(e["samples"]); ce_tags.append(e["tag"]); pt_out.append(p["samples"])
+    assert np.array_equal(np.concatenate(fd_tags), g["fd_tags"])
+    assert np.array_equal(np.concatenate(ts_tags), g["ts_tags"])
+    assert (g["ts_tags"] == po.LTS1).sum() == 2
+    assert np.array_equal(np.concatenate(ts_s), g["ts_samples"])          # bit-exact fp64
+    assert np.array_equal(np.concatenate(ce_in), g["ce_in"])
+    assert np.array_equal(np.concatenate(ce_tags), g["ce_out_tags"])
+    assert np.array_equal(np.concatenate(ce_out), g["ce_out"], equal_nan=True)
+    assert np.array_equal(np.concatenate(pt_out), g["pt_out"], equal_nan=True)
+
+
+def test_frames_fixture(po, golden):
+    g = golden.frames
+    for name in g["names"]:
+        iq = g[name + "_iq"]
+        descs = po.find_alignments_f32(iq)
+        assert descs.tobytes() == g[name + "_desc"].tobytes(), name
+        res, psdu, taps = po.decode_alignment_f32(iq, descs[0], taps=True)
+        assert [res["status"], res["rate"], res["length"], res["num_symbols"]] == list(g[name + "_res"]), name
+        if res["status"] == po.ST_OK:
+            assert np.array_equal(psdu, g[name + "_psdu"]), name
+            assert np.array_equal(psdu, g[name + "_payload"]), name
+        if name + "_soft" in g and res["rate"] >= 0:
+            assert np.array_equal(taps["soft"], g[name + "_soft"]), name
+            assert np.array_equal(taps["eq"].astype(np.complex64), g[name + "_eq"]), name
+
+
+def test_statuses_cover_failures(golden):
+    g = golden.frames
+    st = {str(n): int(g[str(n) + "_res"][0]) for n in g["names"]}
+    assert st["lowsnr"] == 2 and st["hdrfail"] == 1 and st["rate10"] == 0 and st["len0"] == 0
+
+
+@pytest.mark.parametrize("rate", range(11))
+def test_loopback_every_rate(po, rate):
+    rng = np.random.default_rng(100 + rate)
+    pay = rng.integers(0, 256, 64 + 7 * rate, dtype=np.uint8)
+    f = po.build_frame(pay, rate)
+    assert f.size == 320 + 80 * (po.num_symbols(rate, pay.size) + 1)
+    s = np.concatenate([np.zeros(300, complex), f, np.zeros(500, complex)])
+    out = po.ReceiverChain().run_stream(s)
+    assert out == [pay.tobytes()]
+
+
+def test_sim_shape_readme_expectation(po):
+    """examples/test_sim.cpp: 1500-byte text payload, RATE_3_4_QAM16, frames back to back, 4096-sample
+    chunks; README.md:169-183 expects every frame back.  (10 frames here instead of 100.)"""
+    text = b"I'm a little tea pot, short and stout.....here is my handle.....blah blah blah.....this rhyme sucks!"
+    pay = np.frombuffer(text * 15, np.uint8)
+    f = po.build_frame(pay, 8)
+    assert f.size == 7120
+    s = np.concatenate([f] * 10 + [np.zeros(3 * 4096, complex)])
+    chain = po.ReceiverChain()
+    got, first = [], None
+    for k, x in enumerate(range(0, s.size, 4096)):
+        blk = s[x:x + 4096]
+        blk = np.concatenate([blk, np.zeros(4096 - blk.size, complex)])
+        r = chain.process_samples(blk)
+        if r and first is None:
+            first = k
+        got += r
+    for _ in range(6):
+        got += chain.process_samples(np.zeros(4096, complex))
+    assert got == [pay.tobytes()] * 10
+    # frame 0 ends inside call 1; it surfaces 5 calls later (receiver_chain.cpp:118-125)
+    assert first == 1 + 5
+
+
+def test_threaded_chain_equals_serial(po):
+    rng = np.random.default_rng(9)
+    pay = rng.integers(0, 256, 300, dtype=np.uint8)
+    s = np.concatenate([np.zeros(100, complex), po.build_frame(pay, 5), np.zeros(900, complex)] * 3)
+    assert po.ReceiverChain(threaded=True).run_stream(s) == po.ReceiverChain().run_stream(s) == [pay.tobytes()] * 3
+
+
+def test_decode_alignment_truncated(po, golden):
+    g = golden.frames
+    iq = g["rate10_iq"]
+    d = po.find_alignments_f32(iq)[0]
+    res, psdu = po.decode_alignment_f32(iq, d, end=int(d["lts1_pos"]) + 1000)
+    assert res["status"] == po.ST_TRUNCATED and psdu is None
