@@ -1,0 +1,68 @@
+"""Loader for csrc/libfun_ofdm_amd.so (the C ABI of include/fun_ofdm_amd.h)."""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+
+
+class FoaError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(CSRC, "libfun_ofdm_amd.so")
+
+
+def build(force=False):
+    """Compile the gfx950 library in-tree with hipcc (cross-compiles without a GPU)."""
+    if force and os.path.exists(library_path()):
+        os.remove(library_path())
+    subprocess.run(["make", "-s", "-C", CSRC], check=True)
+    return library_path()
+
+
+_lib = None
+
+_SIGS = {
+    "foa_version": (C.c_int, []),
+    "foa_last_error": (C.c_char_p, []),
+    "foa_device_count": (C.c_int, []),
+    "foa_rx_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "foa_rx_destroy": (None, [C.c_void_p]),
+    "foa_rx_reserve": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t]),
+    "foa_rx_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "foa_rx_decode_frames_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "foa_rx_decode_frames_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "foa_rx_sync": (C.c_int, [C.c_void_p]),
+    "foa_rx_stream": (C.c_void_p, [C.c_void_p]),
+    "foa_rx_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "foa_rx_get_taps": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "foa_fft_forward_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "foa_conv_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]),
+}
+
+EXPORTS = tuple(_SIGS)
+
+
+def lib():
+    """The loaded library.  There is deliberately no fallback: a missing or unloadable HIP library
+    is an error."""
+    global _lib
+    if _lib is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise FoaError("%s not found: build it with fun_ofdm_amd.build() / `make -C fun_ofdm_amd/csrc` "
+                           "(this package has no CPU implementation)" % path)
+        L = C.CDLL(path)
+        for name, (res, args) in _SIGS.items():
+            f = getattr(L, name)
+            f.restype, f.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise FoaError("fun_ofdm_amd error %d: %s" % (rc, lib().foa_last_error().decode()))

@@ -1,0 +1,47 @@
+// foa_common.h -- shared declarations of the gfx950 receive path (device + host side).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fun_ofdm_amd.h"
+
+namespace foa {
+
+constexpr int kNumRates = 11;
+constexpr int kWave = 64;
+
+// Per-frame working record kept in HBM between the kernels of one decode call.
+struct FrameInfo {
+    int32_t status;      // FOA_ST_*; frames whose header failed keep nsym = 0
+    int32_t rate;
+    int32_t length;
+    int32_t nsym;        // data symbols to process (0 if nothing to do)
+    int32_t sym_off;     // first data symbol's index in the call-wide symbol numbering
+    int32_t nsteps;      // trellis steps = nsym * dbps
+    int64_t soft_off;    // byte offset of this frame's depunctured soft bytes
+    int64_t dec_off;     // offset (in 8-byte words) of this frame's decision words
+};
+
+// rates.h:52-196 as a device table
+struct RateRow {
+    int32_t rate_field, cbps, dbps, bpsc, punct, numbits;
+    double scale_d;      // qam.h:35-51 d_scale_d
+};
+
+struct DeviceTables {
+    RateRow rates[kNumRates];
+    double tw_re[64], tw_im[64];   // exp(-2*pi*j*k/64)
+    int8_t lts_freq[64];           // preamble.h:363 (index = subcarrier + 32)
+    int8_t polarity[128];          // phase_tracker.cpp:23-32 (+1/-1), entry 127 unused
+    int8_t carrier_kind[64];       // 0 null, 1 data, 2 pilot (by subcarrier index)
+    int8_t data_index[64];         // subcarrier index -> 0..47 (phase_tracker.cpp:46-50), -1 otherwise
+    uint8_t scramble[128];         // ppdu.cpp:256-264 feedback bit per byte index mod 127
+    uint32_t crc_table[256];       // IEEE 802.3 CRC-32, reflected
+};
+
+// Filled once on the host (tables.cpp) and uploaded to __constant__ memory of each translation unit
+// that needs it.
+void build_tables(DeviceTables *t);
+
+}  // namespace foa

@@ -1,0 +1,389 @@
+// foa_rx.hip -- the C ABI of include/fun_ofdm_amd.h over the gfx950 kernels.
+// Built by fun_ofdm_amd/csrc/Makefile:  hipcc --offload-arch=gfx950 -O3 -shared -fPIC
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "frontend_kernels.h"
+#include "viterbi_v1.h"
+#include "viterbi_v2.h"
+
+using namespace foa;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? FOA_E_NOMEM : FOA_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    int ensure(size_t want)
+    {
+        if (want <= n) return FOA_OK;
+        if (p) { (void)hipFree(p); p = nullptr; n = 0; }
+        HIP_TRY(hipMalloc((void **)&p, want * sizeof(T)));
+        n = want;
+        return FOA_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+}  // namespace
+
+// ---- host-built constant tables -------------------------------------------------------------------
+void foa::build_tables(DeviceTables *t)
+{
+    memset(t, 0, sizeof *t);
+    // rates.h:52-196
+    static const int rows[kNumRates][5] = {
+        { 0xD, 48, 24, 1, 0 }, { 0xE, 48, 32, 1, 1 }, { 0xF, 48, 36, 1, 2 }, { 0x5, 96, 48, 2, 0 }, { 0x6, 96, 64, 2, 1 }, { 0x7, 96, 72, 2, 2 },
+        { 0x9, 192, 96, 4, 0 }, { 0xA, 192, 128, 4, 1 }, { 0xB, 192, 144, 4, 2 }, { 0x1, 288, 192, 6, 1 }, { 0x3, 288, 216, 6, 2 } };
+    for (int r = 0; r < kNumRates; r++) {
+        RateRow &x = t->rates[r];
+        x.rate_field = rows[r][0]; x.cbps = rows[r][1]; x.dbps = rows[r][2]; x.bpsc = rows[r][3]; x.punct = rows[r][4];
+        // qam.h:35-51: NumBits = bits per axis, power 1.0 for BPSK else 0.5 (modulator.cpp:117-157)
+        int nb = x.bpsc == 1 ? 1 : x.bpsc / 2;
+        double power = x.bpsc == 1 ? 1.0 : 0.5;
+        int nn = 1 << (nb - 1), sum2 = (4 * nn * nn * nn - nn) / 3;
+        double sf = std::sqrt(power * (double)nn / (double)sum2);
+        x.numbits = nb;
+        x.scale_d = (double)(1 << (8 - nb)) / sf;
+    }
+    for (int k = 0; k < 64; k++) {
+        double a = -2.0 * M_PI * (double)k / 64.0;
+        t->tw_re[k] = std::cos(a); t->tw_im[k] = std::sin(a);
+    }
+    t->tw_re[0] = 1; t->tw_im[0] = 0; t->tw_re[16] = 0; t->tw_im[16] = -1; t->tw_re[32] = -1; t->tw_im[32] = 0; t->tw_re[48] = 0; t->tw_im[48] = 1;
+    // 802.11a-1999 17.3.3 long training sequence L(-26..26); preamble.h:363 stores it at index k+32
+    static const signed char lts[53] = { 1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1, 1, 1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1, 1, 0,
+                                         1, -1, -1, 1, 1, -1, 1, -1, 1, -1, -1, -1, -1, -1, 1, 1, -1, -1, 1, -1, 1, -1, 1, 1, 1, 1 };
+    for (int i = 0; i < 53; i++) t->lts_freq[i + 6] = lts[i];
+    // pilot polarity p_0..126 (17.3.5.9): scrambler sequence for the all-ones seed, 0 -> +1, 1 -> -1
+    int st = 0x7F;
+    for (int i = 0; i < 127; i++) {
+        int fb = ((st >> 6) ^ (st >> 3)) & 1;
+        st = ((st << 1) & 0x7E) | fb;
+        t->polarity[i] = fb ? -1 : 1;
+    }
+    // phase_tracker.cpp:37-50
+    int n = 0;
+    for (int s = 0; s < 64; s++) {
+        t->data_index[s] = -1;
+        if (s < 6 || s > 58 || s == 32) t->carrier_kind[s] = 0;
+        else if (s == 11 || s == 25 || s == 39 || s == 53) t->carrier_kind[s] = 2;
+        else { t->carrier_kind[s] = 1; t->data_index[s] = (int8_t)n++; }
+    }
+    // ppdu.cpp:256-264: per-byte feedback bit of the 7-bit LFSR seeded with 93 (period 127)
+    st = 93;
+    for (int i = 0; i < 128; i++) {
+        int fb = ((st >> 6) & 1) ^ ((st >> 3) & 1);
+        t->scramble[i] = (uint8_t)fb;
+        st = ((st << 1) & 0x7E) | fb;
+    }
+    for (uint32_t i = 0; i < 256; i++) {
+        uint32_t c = i;
+        for (int k = 0; k < 8; k++) c = (c & 1u) ? (c >> 1) ^ 0xEDB88320u : c >> 1;
+        t->crc_table[i] = c;
+    }
+}
+
+struct foa_rx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[6] = {};
+    bool have_timing = false;
+    int viterbi_kind = 1;
+    bool record_eq = false;
+    // workspace
+    DevBuf<FrameInfo> info;
+    DevBuf<double2> hinv;
+    DevBuf<int32_t> sym2frame;
+    DevBuf<uint8_t> soft;
+    DevBuf<uint64_t> dec;
+    DevBuf<int64_t> totals;
+    DevBuf<double2> eq_sig, eq_data;
+    DevBuf<uint8_t> scratch;     // staging for the host-pointer entry points
+    size_t sym_cap = 0, soft_cap = 0, dec_cap = 0;
+    size_t last_frames = 0;
+};
+
+namespace {
+
+int workspace(foa_rx *rx, size_t n_samples, size_t n_frames)
+{
+    size_t sym_cap = n_samples / 80 + 4;
+    size_t soft_cap = 432 * sym_cap + 256 * (n_frames + 1);
+    size_t dec_cap = 216 * sym_cap + 64 * (n_frames + 1);
+    int rc;
+    if ((rc = rx->info.ensure(n_frames + 1)) || (rc = rx->hinv.ensure((n_frames + 1) * 64)) || (rc = rx->sym2frame.ensure(sym_cap)) ||
+        (rc = rx->soft.ensure(soft_cap)) || (rc = rx->dec.ensure(dec_cap)) || (rc = rx->totals.ensure(8)))
+        return rc;
+    if (rx->record_eq && ((rc = rx->eq_sig.ensure((n_frames + 1) * 48)) || (rc = rx->eq_data.ensure(sym_cap * 48)))) return rc;
+    // capacities handed to the scan are those of the buffers actually allocated
+    rx->sym_cap = rx->sym2frame.n; rx->soft_cap = rx->soft.n; rx->dec_cap = rx->dec.n;
+    if (rx->record_eq && rx->eq_data.n / 48 < rx->sym_cap) rx->sym_cap = rx->eq_data.n / 48;
+    return FOA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int foa_version(void) { return FOA_VERSION; }
+const char *foa_last_error(void) { return g_err.c_str(); }
+
+int foa_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(FOA_E_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return n;
+}
+
+int foa_rx_create(foa_rx **out, int device)
+{
+    if (!out) return fail(FOA_E_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(FOA_E_NO_DEVICE, "no HIP device (this library has no CPU path)");
+    if (device < 0 || device >= n) return fail(FOA_E_INVALID, "device %d out of range (0..%d)", device, n - 1);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(FOA_E_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    foa_rx *rx = new foa_rx();
+    rx->device = device;
+    HIP_TRY(hipStreamCreateWithFlags(&rx->stream, hipStreamNonBlocking));
+    for (auto &e : rx->ev) HIP_TRY(hipEventCreate(&e));
+    DeviceTables tab;
+    build_tables(&tab);
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_tab), &tab, sizeof tab));
+    *out = rx;
+    return FOA_OK;
+}
+
+void foa_rx_destroy(foa_rx *rx)
+{
+    if (!rx) return;
+    (void)hipSetDevice(rx->device);
+    (void)hipStreamSynchronize(rx->stream);
+    rx->info.release(); rx->hinv.release(); rx->sym2frame.release(); rx->soft.release(); rx->dec.release(); rx->totals.release();
+    rx->eq_sig.release(); rx->eq_data.release(); rx->scratch.release();
+    for (auto &e : rx->ev) if (e) (void)hipEventDestroy(e);
+    if (rx->stream) (void)hipStreamDestroy(rx->stream);
+    delete rx;
+}
+
+int foa_rx_reserve(foa_rx *rx, size_t n_samples, size_t n_frames)
+{
+    if (!rx) return fail(FOA_E_INVALID, "rx is NULL");
+    HIP_TRY(hipSetDevice(rx->device));
+    return workspace(rx, n_samples, n_frames);
+}
+
+int foa_rx_set_option(foa_rx *rx, const char *name, int64_t value)
+{
+    if (!rx || !name) return fail(FOA_E_INVALID, "NULL argument");
+    if (!strcmp(name, "viterbi")) {
+        if (value != 0 && value != 1) return fail(FOA_E_INVALID, "viterbi must be 0 (lane-per-state) or 1 (packed)");
+        rx->viterbi_kind = (int)value;
+        return FOA_OK;
+    }
+    if (!strcmp(name, "record_eq")) { rx->record_eq = value != 0; return FOA_OK; }
+    return fail(FOA_E_INVALID, "unknown option '%s'", name);
+}
+
+void *foa_rx_stream(foa_rx *rx) { return rx ? (void *)rx->stream : nullptr; }
+
+int foa_rx_sync(foa_rx *rx)
+{
+    if (!rx) return fail(FOA_E_INVALID, "rx is NULL");
+    HIP_TRY(hipStreamSynchronize(rx->stream));
+    return FOA_OK;
+}
+
+int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, const foa_frame_desc *d_descs, const int64_t *d_ends,
+                             size_t n_frames, uint8_t *d_psdu, size_t slot_bytes, foa_frame_result *d_results)
+{
+    if (!rx) return fail(FOA_E_INVALID, "rx is NULL");
+    if (n_frames == 0) { rx->last_frames = 0; return FOA_OK; }
+    if (!d_iq || !d_descs || !d_ends || !d_psdu || !d_results) return fail(FOA_E_INVALID, "NULL device pointer");
+    if (n_frames > 0x7FFFFFF0u) return fail(FOA_E_INVALID, "too many frames");
+    HIP_TRY(hipSetDevice(rx->device));
+    int rc = workspace(rx, n_samples, n_frames);
+    if (rc) return rc;
+    hipStream_t st = rx->stream;
+    const int nf = (int)n_frames;
+    const float2 *iq = (const float2 *)d_iq;
+    double2 *eq_sig = rx->record_eq ? rx->eq_sig.p : nullptr, *eq_data = rx->record_eq ? rx->eq_data.p : nullptr;
+
+    HIP_TRY(hipEventRecord(rx->ev[0], st));
+    hipLaunchKernelGGL(k_header, dim3(nf), dim3(64), 0, st, iq, d_descs, d_ends, nf, rx->info.p, rx->hinv.p, eq_sig);
+    HIP_TRY(hipEventRecord(rx->ev[1], st));
+    int64_t caps[1] = { (int64_t)rx->sym_cap };
+    HIP_TRY(hipMemcpyAsync(rx->totals.p + 3, caps, sizeof caps, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(rx->sym2frame.p, 0xFF, rx->sym_cap * sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, rx->info.p, nf, (int64_t)rx->sym_cap, (int64_t)rx->soft_cap, (int64_t)rx->dec_cap,
+                       rx->totals.p);
+    hipLaunchKernelGGL(k_symmap, dim3((nf + 255) / 256), dim3(256), 0, st, rx->info.p, nf, rx->sym2frame.p);
+    HIP_TRY(hipEventRecord(rx->ev[2], st));
+    // upper bound on data symbols in n_samples samples; waves beyond the real total exit at once
+    const size_t max_sym = rx->sym_cap;
+    hipLaunchKernelGGL(k_data_symbols, dim3((unsigned)((max_sym + kSymWaves - 1) / kSymWaves)), dim3(64 * kSymWaves), 0, st, iq, d_descs,
+                       rx->info.p, rx->sym2frame.p, rx->totals.p, rx->hinv.p, rx->soft.p, eq_data);
+    HIP_TRY(hipEventRecord(rx->ev[3], st));
+    if (rx->viterbi_kind == 0)
+        hipLaunchKernelGGL(k_viterbi_v1, dim3(nf), dim3(64), 0, st, rx->info.p, nf, rx->soft.p, rx->dec.p, d_psdu, slot_bytes, d_results);
+    else
+        launch_viterbi_v2(st, rx->info.p, nf, rx->soft.p, rx->dec.p, d_psdu, slot_bytes, d_results);
+    HIP_TRY(hipEventRecord(rx->ev[4], st));
+    HIP_TRY(hipGetLastError());
+    rx->have_timing = true;
+    rx->last_frames = n_frames;
+    return FOA_OK;
+}
+
+int foa_rx_decode_frames_host(foa_rx *rx, const float *iq, size_t n_samples, const foa_frame_desc *descs, const int64_t *ends,
+                              size_t n_frames, uint8_t *psdu, size_t slot_bytes, foa_frame_result *results)
+{
+    if (!rx) return fail(FOA_E_INVALID, "rx is NULL");
+    if (n_frames == 0) return FOA_OK;
+    if (!iq || !descs || !ends || !psdu || !results) return fail(FOA_E_INVALID, "NULL pointer");
+    HIP_TRY(hipSetDevice(rx->device));
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t o_iq = 0, o_desc = o_iq + up(n_samples * 8), o_end = o_desc + up(n_frames * sizeof(foa_frame_desc)),
+           o_psdu = o_end + up(n_frames * 8), o_res = o_psdu + up(n_frames * slot_bytes), total = o_res + up(n_frames * sizeof(foa_frame_result));
+    int rc = rx->scratch.ensure(total);
+    if (rc) return rc;
+    uint8_t *b = rx->scratch.p;
+    hipStream_t st = rx->stream;
+    HIP_TRY(hipMemcpyAsync(b + o_iq, iq, n_samples * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(b + o_desc, descs, n_frames * sizeof(foa_frame_desc), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(b + o_end, ends, n_frames * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(b + o_psdu, 0, n_frames * slot_bytes, st));
+    rc = foa_rx_decode_frames_dev(rx, (const float *)(b + o_iq), n_samples, (const foa_frame_desc *)(b + o_desc), (const int64_t *)(b + o_end),
+                                  n_frames, b + o_psdu, slot_bytes, (foa_frame_result *)(b + o_res));
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(psdu, b + o_psdu, n_frames * slot_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(results, b + o_res, n_frames * sizeof(foa_frame_result), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return FOA_OK;
+}
+
+int foa_rx_last_kernel_ms(foa_rx *rx, float out_ms[5])
+{
+    if (!rx || !out_ms) return fail(FOA_E_INVALID, "NULL argument");
+    if (!rx->have_timing) return fail(FOA_E_STATE, "no decode call has been made on this handle");
+    HIP_TRY(hipEventSynchronize(rx->ev[4]));
+    for (int i = 0; i < 4; i++) HIP_TRY(hipEventElapsedTime(&out_ms[i], rx->ev[i], rx->ev[i + 1]));
+    HIP_TRY(hipEventElapsedTime(&out_ms[4], rx->ev[0], rx->ev[4]));
+    return FOA_OK;
+}
+
+int foa_rx_get_taps(foa_rx *rx, size_t n_frames, double *hinv, double *eq, size_t eq_cap, uint64_t *eq_off, uint8_t *soft, size_t soft_cap,
+                    uint64_t *soft_off)
+{
+    if (!rx) return fail(FOA_E_INVALID, "rx is NULL");
+    if (n_frames != rx->last_frames || n_frames == 0) return fail(FOA_E_STATE, "n_frames does not match the last decode call");
+    if (eq && !rx->record_eq) return fail(FOA_E_STATE, "set option record_eq=1 before the decode call to get eq");
+    HIP_TRY(hipSetDevice(rx->device));
+    HIP_TRY(hipStreamSynchronize(rx->stream));
+    std::vector<FrameInfo> info(n_frames);
+    HIP_TRY(hipMemcpy(info.data(), rx->info.p, n_frames * sizeof(FrameInfo), hipMemcpyDeviceToHost));
+    if (hinv) HIP_TRY(hipMemcpy(hinv, rx->hinv.p, n_frames * 64 * sizeof(double2), hipMemcpyDeviceToHost));
+    DeviceTables tab;
+    build_tables(&tab);
+    size_t eo = 0, so = 0;
+    for (size_t f = 0; f < n_frames; f++) {
+        const FrameInfo &fi = info[f];
+        if (eq_off) eq_off[f] = eo;
+        if (soft_off) soft_off[f] = so;
+        if (fi.rate < 0) continue;
+        const int nsym = fi.nsym > 0 ? fi.nsym : 0;
+        if (eq) {
+            if (eo + (size_t)(1 + nsym) * 48 > eq_cap) return fail(FOA_E_INVALID, "eq_cap too small");
+            HIP_TRY(hipMemcpy(eq + 2 * eo, rx->eq_sig.p + f * 48, 48 * sizeof(double2), hipMemcpyDeviceToHost));
+            if (nsym) HIP_TRY(hipMemcpy(eq + 2 * (eo + 48), rx->eq_data.p + (size_t)fi.sym_off * 48, (size_t)nsym * 48 * sizeof(double2), hipMemcpyDeviceToHost));
+        }
+        eo += (size_t)(1 + nsym) * 48;
+        const size_t sb = nsym ? (size_t)2 * fi.nsteps : 0;
+        if (soft && sb) {
+            if (so + sb > soft_cap) return fail(FOA_E_INVALID, "soft_cap too small");
+            HIP_TRY(hipMemcpy(soft + so, rx->soft.p + fi.soft_off, sb, hipMemcpyDeviceToHost));
+        }
+        so += sb;
+    }
+    if (eq_off) eq_off[n_frames] = eo;
+    if (soft_off) soft_off[n_frames] = so;
+    return FOA_OK;
+}
+
+// ---- stage-level entry points ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fft_vectors(double2 *__restrict__ v, int n_vec)
+{
+    __shared__ cpx lds_all[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= n_vec) return;
+    double2 x = v[(size_t)i * 64 + lane];
+    cpx y = fft64_lane(cpx{ x.x, x.y }, lds_all[wave], lane);
+    v[(size_t)i * 64 + lane_subcarrier(lane)] = make_double2(y.x, y.y);
+}
+
+int foa_fft_forward_f64(foa_rx *rx, double *vectors, size_t n_vec)
+{
+    if (!rx || !vectors) return fail(FOA_E_INVALID, "NULL argument");
+    if (n_vec == 0) return FOA_OK;
+    HIP_TRY(hipSetDevice(rx->device));
+    size_t bytes = n_vec * 64 * sizeof(double2);
+    int rc = rx->scratch.ensure(bytes);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(rx->scratch.p, vectors, bytes, hipMemcpyHostToDevice, rx->stream));
+    hipLaunchKernelGGL(k_fft_vectors, dim3((unsigned)((n_vec + 3) / 4)), dim3(256), 0, rx->stream, (double2 *)rx->scratch.p, (int)n_vec);
+    HIP_TRY(hipMemcpyAsync(vectors, rx->scratch.p, bytes, hipMemcpyDeviceToHost, rx->stream));
+    HIP_TRY(hipStreamSynchronize(rx->stream));
+    return FOA_OK;
+}
+
+int foa_conv_decode(foa_rx *rx, const uint8_t *symbols, uint8_t *data, int data_bits, size_t n_blocks)
+{
+    if (!rx || !symbols || !data) return fail(FOA_E_INVALID, "NULL argument");
+    if (data_bits < 1 || data_bits > 8 * (kMaxDecodedBytes - 8)) return fail(FOA_E_INVALID, "data_bits out of range");
+    if (n_blocks == 0) return FOA_OK;
+    HIP_TRY(hipSetDevice(rx->device));
+    const size_t nsteps = (size_t)data_bits + 6, sym_bytes = n_blocks * 2 * nsteps, out_bytes = n_blocks * (size_t)((data_bits + 7) / 8);
+    const size_t stride = (nsteps + 63) & ~(size_t)63;
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    int rc = rx->scratch.ensure(up(sym_bytes) + up(out_bytes));
+    if (rc) return rc;
+    if ((rc = rx->dec.ensure(n_blocks * stride))) return rc;
+    uint8_t *d_sym = rx->scratch.p, *d_out = rx->scratch.p + up(sym_bytes);
+    HIP_TRY(hipMemcpyAsync(d_sym, symbols, sym_bytes, hipMemcpyHostToDevice, rx->stream));
+    hipLaunchKernelGGL(k_conv_decode, dim3((unsigned)n_blocks), dim3(64), 0, rx->stream, d_sym, d_out, data_bits, (int)n_blocks, rx->dec.p, (int)stride);
+    HIP_TRY(hipMemcpyAsync(data, d_out, out_bytes, hipMemcpyDeviceToHost, rx->stream));
+    HIP_TRY(hipStreamSynchronize(rx->stream));
+    return FOA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,410 @@
+// frontend_kernels.h -- post-sync samples -> depunctured soft bytes, for gfx950 (wave64).
+//
+// Replaces fft_symbols::work + fft::forward (fft_symbols.cpp:33-79, fft.cpp:50-59),
+// channel_est::work (channel_est.cpp:36-85), phase_tracker::work (phase_tracker.cpp:70-104) and
+// the front half of ppdu::decode_header / decode_data (ppdu.cpp:168-218,223-244):
+// modulator::demodulate (modulator.cpp:108-164, qam.h:110-125), interleaver::deinterleave
+// (interleaver.cpp:28-38) and puncturer::depuncture (puncturer.cpp:78-123).
+//
+// Mapping: one wavefront per OFDM symbol, lane = FFT point.  The 64-point DFT is three radix-4
+// decimation-in-frequency stages exchanged through LDS; its output stays digit-reversed in the
+// lanes (lane p holds bin k = rev4(p)), and every later per-subcarrier step indexes its tables by
+// the lane's subcarrier, so no reordering pass exists.  Arithmetic is fp64 like the reference
+// (std::complex<double> end to end, tagged_vector.h:46): the 20 MS/s stream is float in HBM and is
+// widened on load exactly as the CPU receiver widens it, so soft bytes agree with the CPU to the
+// last bit except where a carrier lands within ~1e-15 of a truncation boundary of qam.h:112.
+// The stage is HBM-light (8 B/sample in, <= 5.4 B/sample out) and nowhere near any roofline; it is
+// written for exactness first.
+#pragma once
+
+#include "foa_common.h"
+
+namespace foa {
+
+__constant__ DeviceTables g_tab;
+
+struct cpx { double x, y; };
+
+__device__ __forceinline__ cpx cadd(cpx a, cpx b) { return { a.x + b.x, a.y + b.y }; }
+__device__ __forceinline__ cpx cneg(cpx a) { return { -a.x, -a.y }; }
+
+// The reference multiplies with the plain four-product formula (libgcc __muldc3 fast path); keep
+// the compiler from fusing it into FMAs so that rounding matches the CPU bit for bit.
+__device__ __forceinline__ cpx cmul(cpx a, cpx b)
+{
+#pragma clang fp contract(off)
+    double ac = a.x * b.x, bd = a.y * b.y, ad = a.x * b.y, bc = a.y * b.x;
+    return { ac - bd, ad + bc };
+}
+
+// Complex division, Smith's method as in libgcc's __divdc3 for operands in normal range
+// (channel_est.cpp:55-57 divides LTS_FREQ_DOMAIN[j] by the received carrier).
+__device__ __forceinline__ cpx cdiv(cpx a, cpx b)
+{
+#pragma clang fp contract(off)
+    cpx r;
+    if (fabs(b.x) < fabs(b.y)) {
+        double ratio = b.x / b.y, denom = b.x * ratio + b.y;
+        r.x = (a.x * ratio + a.y) / denom;
+        r.y = (a.y * ratio - a.x) / denom;
+    } else {
+        double ratio = b.y / b.x, denom = b.y * ratio + b.x;
+        r.x = (a.x + a.y * ratio) / denom;
+        r.y = (a.y - a.x * ratio) / denom;
+    }
+    return r;
+}
+
+// multiply by (-j)^q
+__device__ __forceinline__ cpx rot_mj(cpx z, int q)
+{
+    cpx r = z;
+    if (q == 1) r = { z.y, -z.x };
+    else if (q == 2) r = { -z.x, -z.y };
+    else if (q == 3) r = { -z.y, z.x };
+    return r;
+}
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    // LDS traffic of one wave is ordered; this only stops the compiler from moving accesses and
+    // waits for outstanding LDS operations of this wave.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Subcarrier index (reference numbering: index = bin + 32 mod 64, fft.cpp:20-24) held by lane p
+// after fft64_lane().
+__device__ __forceinline__ int lane_subcarrier(int p)
+{
+    int k = (p >> 4) | (((p >> 2) & 3) << 2) | ((p & 3) << 4);
+    return (k + 32) & 63;
+}
+// inverse: lane that holds subcarrier index s
+__host__ __device__ constexpr int subcarrier_lane(int s)
+{
+    int k = (s + 32) & 63;
+    return ((k & 3) << 4) | (((k >> 2) & 3) << 2) | (k >> 4);
+}
+
+// 64-point forward DFT across the wave; lane n supplies x[n], lane p returns X[rev4(p)].
+// lds: 64 cpx private to this wave.
+__device__ __forceinline__ cpx fft64_lane(cpx v, cpx *lds, int lane)
+{
+#pragma unroll
+    for (int st = 0; st < 3; st++) {
+        const int span = 16 >> (2 * st);
+        lds[lane] = v;
+        wave_lds_sync();
+        const int m = (lane / span) & 3;
+        const int base = lane - m * span;
+        cpx a = lds[base], b = lds[base + span], c = lds[base + 2 * span], d = lds[base + 3 * span];
+        wave_lds_sync();
+        cpx bb = rot_mj(b, m), cc = (m & 1) ? cneg(c) : c, dd = rot_mj(d, (3 * m) & 3);
+        cpx y = cadd(cadd(a, cc), cadd(bb, dd));
+        if (st < 2) {
+            const int e = (lane & (span - 1)) * m * (16 / span);
+            cpx w = { g_tab.tw_re[e], g_tab.tw_im[e] };
+            y = cmul(y, w);
+        }
+        v = y;
+    }
+    return v;
+}
+
+// timing_sync.cpp:124-125 rotation + float->double widening of one window sample
+__device__ __forceinline__ cpx load_rotated(const float2 *iq, int64_t idx, const foa_frame_desc &d)
+{
+    float2 s = iq[idx];
+    cpx v = { (double)s.x, (double)s.y };
+    cpx r = idx >= d.rot_start ? cpx{ d.c, d.s } : cpx{ d.c_prev, d.s_prev };
+    return cmul(v, r);
+}
+
+// phase_tracker.cpp:83-99 for one symbol: returns the derotated carrier of this lane
+__device__ __forceinline__ cpx pilot_derotate(cpx z, int polarity)
+{
+#pragma clang fp contract(off)
+    constexpr int LP[4] = { subcarrier_lane(11), subcarrier_lane(25), subcarrier_lane(39), subcarrier_lane(53) };
+    const double sgn[4] = { 1.0, 1.0, 1.0, -1.0 };
+    cpx pe = { 0.0, 0.0 };
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        double px = __shfl(z.x, LP[p]), py = __shfl(z.y, LP[p]);
+        double pil = (double)(int)(sgn[p] * (double)polarity);
+        pe.x += (px * pil) / 4.0;
+        pe.y += (py * pil) / 4.0;
+    }
+    double angle = atan2(pe.y, pe.x);
+    cpx rot = { cos(-angle), sin(-angle) };
+    return cmul(z, rot);
+}
+
+// qam.h:110-125; `int pt = sym * d_scale_d` has cvttsd2si semantics on the reference's platform
+__device__ __forceinline__ int trunc_to_int(double v)
+{
+    return (v > -2147483649.0 && v < 2147483648.0) ? (int)v : (int)0x80000000;
+}
+
+__device__ __forceinline__ void qam_decode(double sym, int nb, double scale_d, uint8_t *bits)
+{
+#pragma clang fp contract(off)
+    uint32_t pt = (uint32_t)trunc_to_int(sym * scale_d);
+    int flip = 1, amp = 128;
+    for (int i = 0; i < nb; i++) {
+        int v = (int)((uint32_t)flip * pt + 128u);
+        bits[i] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        int bit = ((int)pt < 0) ? -1 : 1;
+        pt -= (uint32_t)(bit * amp);
+        flip = -bit;
+        amp >>= 1;
+    }
+}
+
+// interleaver.h:66-75 with (48,1): index(k) = 3*(k%16) + k/16; its inverse
+__device__ __forceinline__ int deinterleaved_pos(int w) { return 16 * (w % 3) + w / 3; }
+
+// position of deinterleaved coded byte D (frame-wide numbering) in the depunctured stream
+// (puncturer.cpp:94-102,112-118)
+__device__ __forceinline__ int depunct_pos(int D, int punct)
+{
+    if (punct == 2) { const int t[4] = { 0, 1, 3, 5 }; return 6 * (D >> 2) + t[D & 3]; }
+    if (punct == 1) { const int t[3] = { 0, 2, 3 }; return 4 * (D / 3) + t[D % 3]; }
+    return D;
+}
+
+// ---- the lane-per-state K=7 ACS step shared by the SIGNAL decode and viterbi v1 ----
+// viterbi.cpp:208-457.
+// Lane s owns NEW state s; it needs old metrics of states s>>1 and (s>>1)+32.
+struct AcsLane {
+    uint32_t b0, b1;     // Branchtab entries (0/255) of butterfly lane>>1 (viterbi.cpp:86-91)
+    uint32_t flip;       // 63 for odd states (they take 63-m on the lower branch), else 0
+    int src_lo, src_hi;  // byte addresses for ds_bpermute
+};
+
+__device__ __forceinline__ AcsLane acs_lane_init(int lane)
+{
+    AcsLane a;
+    int i = lane >> 1;
+    a.b0 = (__popc((2 * i) & 121) & 1) ? 255u : 0u;
+    a.b1 = (__popc((2 * i) & 91) & 1) ? 255u : 0u;
+    a.flip = (lane & 1) ? 63u : 0u;
+    a.src_lo = i * 4;
+    a.src_hi = (i + 32) * 4;
+    return a;
+}
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        uint32_t t = __shfl_xor(v, o);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint32_t acs_step(uint32_t M, uint32_t s0, uint32_t s1, const AcsLane &a, uint64_t &dec)
+{
+    uint32_t m = ((s0 ^ a.b0) + (s1 ^ a.b1) + 1u) >> 3;      // avg_epu8 then >>2 (0..63)
+    uint32_t ma = m ^ a.flip, mb = ma ^ 63u;
+    uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(a.src_lo, (int)M);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(a.src_hi, (int)M);
+    uint32_t x = lo + ma, y = hi + mb;
+    x = x > 255u ? 255u : x;                                  // _mm_adds_epu8
+    y = y > 255u ? 255u : y;
+    bool d = y <= x;                                          // cmpeq(min, upper)
+    dec = __ballot(d);
+    uint32_t Mn = d ? y : x;
+    uint32_t m0 = __builtin_amdgcn_readfirstlane(Mn);         // lane 0 = state 0
+    if (m0 > 210u) Mn -= wave_min_u32(Mn);                    // viterbi.cpp:314-332
+    return Mn;
+}
+
+// =================================================================================================
+// K1: per alignment: LTS1 + LTS2 + SIGNAL.  Channel estimate -> hinv, SIGNAL decode -> FrameInfo.
+// One wave (64 threads) per block, one block per frame.
+// =================================================================================================
+__global__ __launch_bounds__(64) void k_header(const float2 *__restrict__ iq, const foa_frame_desc *__restrict__ descs,
+                                               const int64_t *__restrict__ ends, int n_frames, FrameInfo *__restrict__ info,
+                                               double2 *__restrict__ hinv, double2 *__restrict__ eq_tap)
+{
+    __shared__ cpx lds[64];
+    __shared__ uint8_t dem[48];
+    __shared__ uint64_t decs[24];
+    const int f = blockIdx.x, lane = threadIdx.x;
+    if (f >= n_frames) return;
+    const foa_frame_desc d = descs[f];
+    const int64_t end = ends[f], p = d.lts1_pos;
+    FrameInfo fi;
+    fi.status = FOA_ST_HEADER_FAIL; fi.rate = -1; fi.length = 0; fi.nsym = 0; fi.sym_off = 0; fi.nsteps = 0;
+    fi.soft_off = 0; fi.dec_off = 0;
+    if (p < 0 || p + 208 > end) {                     // LTS or SIGNAL window cut off
+        fi.status = FOA_ST_TRUNCATED;
+        if (lane == 0) info[f] = fi;
+        return;
+    }
+    const int s = lane_subcarrier(lane);
+    // channel_est.cpp:44-58: est = sum over the two LTS of (LTS_FREQ_DOMAIN / Y) / 2
+    cpx est = { 0.0, 0.0 };
+    const cpx ref = { (double)g_tab.lts_freq[s], 0.0 };
+#pragma unroll
+    for (int w = 0; w < 2; w++) {
+        cpx y = fft64_lane(load_rotated(iq, p + 64 * w + lane, d), lds, lane);
+        cpx q = cdiv(ref, y);
+        est.x += q.x / 2.0;
+        est.y += q.y / 2.0;
+    }
+    hinv[(size_t)f * 64 + s] = make_double2(est.x, est.y);
+    // SIGNAL: equalise (channel_est.cpp:77-81), pilot phase with polarity[0] (phase_tracker.cpp:74-99)
+    cpx y = fft64_lane(load_rotated(iq, p + 144 + lane, d), lds, lane);
+    cpx z = pilot_derotate(cmul(est, y), (int)g_tab.polarity[0]);
+    const int di = g_tab.data_index[s];
+    if (eq_tap && di >= 0) eq_tap[(size_t)f * 48 + di] = make_double2(z.x, z.y);   // SIGNAL tap: one row per frame
+    // ppdu.cpp:171-175: BPSK demap, deinterleave
+    if (di >= 0) {
+        uint8_t b;
+        qam_decode(z.x, 1, 128.0, &b);
+        dem[deinterleaved_pos(di)] = b;
+    }
+    __syncthreads();
+    // ppdu.cpp:178-180: conv_decode(18 bits) = 24 trellis steps
+    const AcsLane acs = acs_lane_init(lane);
+    uint32_t M = lane == 0 ? 0u : 63u;
+    for (int t = 0; t < 24; t++) {
+        uint64_t dec;
+        M = acs_step(M, dem[2 * t], dem[2 * t + 1], acs, dec);
+        if (lane == 0) decs[t] = dec;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        // viterbi.cpp:131-142 chain-back from state 0, 18 bits -> 3 bytes MSB first
+        uint32_t e = 0, hb[3] = { 0, 0, 0 };
+        for (int n = 17; n >= 0; n--) {
+            uint32_t k = (uint32_t)((decs[n + 6] >> (e >> 2)) & 1ull);
+            e = (e >> 1) | (k << 7);
+            hb[n >> 3] = e;
+        }
+        uint32_t field = (hb[0] << 16) | (hb[1] << 8) | hb[2];
+        int rate = -1;
+        if ((__popc(field) & 1) == 0) {                               // ppdu.cpp:187-191
+            int rf = (field >> 19) & 0xF;
+            for (int r = 0; r < kNumRates; r++) if (g_tab.rates[r].rate_field == rf) rate = r;   // ppdu.cpp:198-203
+        }
+        if (rate >= 0) {
+            int length = (field >> 6) & 0xFFF;
+            int dbps = g_tab.rates[rate].dbps;
+            int nsym = (16 + 8 * (length + 4) + 6 + dbps - 1) / dbps;  // ppdu.cpp:206-209 (exact in integers)
+            fi.rate = rate; fi.length = length;
+            if (p + 144 + 80 * (int64_t)nsym + 64 > end) fi.status = FOA_ST_TRUNCATED;
+            else { fi.status = FOA_ST_CRC_FAIL; fi.nsym = nsym; fi.nsteps = nsym * dbps; }   // pending until the CRC is checked
+            // report num_symbols even for truncated frames
+            if (fi.status == FOA_ST_TRUNCATED) fi.nsteps = -nsym;
+        }
+        info[f] = fi;
+    }
+}
+
+// =================================================================================================
+// K2: exclusive scans over frames -> sym_off / soft_off / dec_off.  One block.
+// =================================================================================================
+__global__ __launch_bounds__(1024) void k_scan(FrameInfo *__restrict__ info, int n_frames, int64_t sym_cap, int64_t soft_cap,
+                                               int64_t dec_cap, int64_t *__restrict__ totals)
+{
+    __shared__ int64_t part[3][1024];
+    const int tid = threadIdx.x, per = (n_frames + 1023) / 1024;
+    const int lo = tid * per, hi = min(lo + per, n_frames);
+    int64_t a = 0, b = 0, c = 0;
+    for (int f = lo; f < hi; f++) {
+        const int nsym = info[f].nsym, nsteps = nsym > 0 ? info[f].nsteps : 0;
+        a += nsym; b += ((int64_t)2 * nsteps + 255) & ~(int64_t)255; c += (nsteps + 63) & ~63;
+    }
+    part[0][tid] = a; part[1][tid] = b; part[2][tid] = c;
+    __syncthreads();
+    if (tid < 3) {                                   // 1024-element serial scans: negligible
+        int64_t run = 0;
+        for (int i = 0; i < 1024; i++) { int64_t v = part[tid][i]; part[tid][i] = run; run += v; }
+        totals[tid] = run;
+    }
+    __syncthreads();
+    a = part[0][tid]; b = part[1][tid]; c = part[2][tid];
+    for (int f = lo; f < hi; f++) {
+        FrameInfo fi = info[f];
+        const int nsteps = fi.nsym > 0 ? fi.nsteps : 0;
+        const int64_t sb = ((int64_t)2 * nsteps + 255) & ~(int64_t)255, dw = (nsteps + 63) & ~63;
+        if (fi.nsym > 0 && (a + fi.nsym > sym_cap || b + sb > soft_cap || c + dw > dec_cap)) {
+            // keeps its slots in the numbering (they stay unused: sym2frame = -1 there)
+            info[f].status = FOA_ST_NO_SPACE; info[f].nsteps = -fi.nsym; info[f].nsym = 0;
+        } else {
+            info[f].sym_off = (int32_t)a; info[f].soft_off = b; info[f].dec_off = c;
+        }
+        a += fi.nsym; b += sb; c += dw;
+    }
+}
+
+// =================================================================================================
+// K3: data symbols.  One wave per symbol, 4 waves per block.  sym_index[] built by k_symmap.
+// =================================================================================================
+// Fills sym2frame[] so that K3's wave w finds its frame without a search: one thread per frame
+// writes its nsym entries (frames are short: <= 1368 symbols).
+__global__ void k_symmap(const FrameInfo *__restrict__ info, int n_frames, int32_t *__restrict__ sym2frame)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_frames) return;
+    const int n = info[f].nsym, o = info[f].sym_off;
+    for (int k = 0; k < n; k++) sym2frame[o + k] = f;
+}
+
+constexpr int kSymWaves = 4;
+
+__global__ __launch_bounds__(64 * kSymWaves) void k_data_symbols(const float2 *__restrict__ iq, const foa_frame_desc *__restrict__ descs,
+                                                                 const FrameInfo *__restrict__ info, const int32_t *__restrict__ sym2frame,
+                                                                 const int64_t *__restrict__ totals, const double2 *__restrict__ hinv,
+                                                                 uint8_t *__restrict__ soft, double2 *__restrict__ eq_tap)
+{
+    __shared__ cpx lds_all[kSymWaves][64];
+    __shared__ __attribute__((aligned(16))) uint8_t stage_all[kSymWaves][448];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * kSymWaves + wave;
+    if (w >= totals[0] || w >= totals[3]) return;              // totals[3] = symbol capacity
+    cpx *lds = lds_all[wave];
+    uint8_t *stage = stage_all[wave];
+    const int f = sym2frame[w];
+    if (f < 0) return;
+    const FrameInfo fi = info[f];
+    const int k = (int)(w - fi.sym_off) + 1;                  // 1-based data symbol (SIGNAL is symbol 0)
+    const foa_frame_desc d = descs[f];
+    const RateRow rr = g_tab.rates[fi.rate];
+    const int s = lane_subcarrier(lane);
+
+    cpx y = fft64_lane(load_rotated(iq, d.lts1_pos + 144 + 80 * (int64_t)k + lane, d), lds, lane);
+    double2 h = hinv[(size_t)f * 64 + s];
+    cpx z = pilot_derotate(cmul(cpx{ h.x, h.y }, y), (int)g_tab.polarity[k % 127]);
+    const int di = g_tab.data_index[s];
+    if (eq_tap && di >= 0) eq_tap[(size_t)w * 48 + di] = make_double2(z.x, z.y);          // data tap: one row per symbol
+
+    // erasures first (puncturer.cpp:98,100,114), then scatter this carrier's soft bytes
+    const int out_bytes = 2 * rr.dbps;                         // depunctured bytes of this symbol
+    if (rr.punct != 0) {
+        uint32_t *st32 = (uint32_t *)stage;
+        for (int i = lane; i < out_bytes / 4; i += 64) st32[i] = 0x7F7F7F7Fu;
+    }
+    wave_lds_sync();
+    if (di >= 0) {
+        uint8_t bits[6];
+        qam_decode(z.x, rr.numbits, rr.scale_d, bits);
+        if (rr.bpsc > 1) qam_decode(z.y, rr.numbits, rr.scale_d, bits + rr.numbits);
+        for (int b = 0; b < rr.bpsc; b++) {
+            int c = di * rr.bpsc + b;                          // demodulated byte index within the symbol
+            int dd = 48 * (c / 48) + deinterleaved_pos(c % 48);
+            stage[depunct_pos(dd, rr.punct)] = bits[b];        // symbol-local: cbps is a multiple of 12
+        }
+    }
+    wave_lds_sync();
+    uint32_t *dst = (uint32_t *)(soft + fi.soft_off + (int64_t)(k - 1) * out_bytes);
+    const uint32_t *st32 = (const uint32_t *)stage;
+    for (int i = lane; i < out_bytes / 4; i += 64) dst[i] = st32[i];
+}
+
+}  // namespace foa

@@ -1,0 +1,105 @@
+"""Host-side handle on the gfx950 receive path (ctypes over include/fun_ofdm_amd.h)."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import lib, check
+
+# foa_frame_desc / foa_frame_result (include/fun_ofdm_amd.h)
+frame_desc_dtype = np.dtype([("lts1_pos", np.int64), ("rot_start", np.int64), ("c", np.float64), ("s", np.float64),
+                             ("c_prev", np.float64), ("s_prev", np.float64)])
+frame_result_dtype = np.dtype([("status", np.int32), ("rate", np.int32), ("length", np.int32), ("num_symbols", np.int32)])
+
+ST_OK, ST_HEADER_FAIL, ST_CRC_FAIL, ST_TRUNCATED, ST_NO_SPACE = range(5)
+
+# fun::Rate (src/rates.h:31-44)
+RATE_NAMES = ("1/2 BPSK", "2/3 BPSK", "3/4 BPSK", "1/2 QPSK", "2/3 QPSK", "3/4 QPSK", "1/2 QAM16", "2/3 QAM16", "3/4 QAM16",
+              "2/3 QAM64", "3/4 QAM64")
+RATE_MBPS = (6, 8, 9, 12, 16, 18, 24, 32, 36, 48, 54)
+STANDARD_RATES = (0, 2, 3, 5, 6, 8, 9, 10)
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Receiver:
+    """One receiver handle = one HIP stream on one device."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        check(lib().foa_rx_create(C.byref(self._h), int(device)))
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().foa_rx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_option(self, name, value):
+        check(lib().foa_rx_set_option(self._h, name.encode(), int(value)))
+
+    def reserve(self, n_samples, n_frames):
+        check(lib().foa_rx_reserve(self._h, int(n_samples), int(n_frames)))
+
+    def sync(self):
+        check(lib().foa_rx_sync(self._h))
+
+    # ---- batch decode, host buffers -------------------------------------------------------------
+    def decode_frames_host(self, iq, descs, ends, slot_bytes=4096):
+        """iq: complex64[n]; descs: frame_desc_dtype[m]; ends: int64[m] -> (psdu uint8[m, slot], results[m])."""
+        iq = np.ascontiguousarray(iq, np.complex64)
+        descs = np.ascontiguousarray(descs, frame_desc_dtype)
+        ends = np.ascontiguousarray(ends, np.int64)
+        m = descs.size
+        psdu = np.zeros((m, slot_bytes), np.uint8)
+        res = np.zeros(m, frame_result_dtype)
+        check(lib().foa_rx_decode_frames_host(self._h, _vp(iq), iq.size, _vp(descs), _vp(ends), m, _vp(psdu), slot_bytes, _vp(res)))
+        return psdu, res
+
+    # ---- batch decode, device buffers (torch tensors on this device) ------------------------------
+    def decode_frames_dev(self, iq, descs, ends, psdu, results):
+        """All arguments are CUDA(HIP) torch tensors already resident in HBM:
+        iq complex64[n] (or float32[n,2]); descs uint8[m*48] (frame_desc_dtype bytes); ends int64[m];
+        psdu uint8[m, slot]; results int32[m, 4].  Asynchronous on the handle's stream."""
+        n = iq.numel() if iq.is_complex() else iq.numel() // 2
+        m = ends.numel()
+        assert descs.numel() * descs.element_size() == m * frame_desc_dtype.itemsize
+        assert psdu.shape[0] == m and results.numel() == 4 * m
+        check(lib().foa_rx_decode_frames_dev(self._h, iq.data_ptr(), n, descs.data_ptr(), ends.data_ptr(), m, psdu.data_ptr(),
+                                             psdu.shape[1], results.data_ptr()))
+
+    def kernel_ms(self):
+        """HIP-event durations of the last decode: dict(header, scan, symbols, viterbi, total) in ms."""
+        out = (C.c_float * 5)()
+        check(lib().foa_rx_last_kernel_ms(self._h, out))
+        return dict(zip(("header", "scan", "symbols", "viterbi", "total"), (float(x) for x in out)))
+
+    def taps(self, n_frames, eq=False, soft=True, cap_symbols=None):
+        """Intermediates of the last decode call (host copies): dict(hinv, eq, eq_off, soft, soft_off)."""
+        cap_symbols = cap_symbols or 1400 * n_frames
+        hinv = np.zeros((n_frames, 64), np.complex128)
+        eq_buf = np.zeros((cap_symbols + n_frames) * 48, np.complex128) if eq else None
+        eq_off = np.zeros(n_frames + 1, np.uint64)
+        soft_buf = np.zeros(cap_symbols * 432, np.uint8) if soft else None
+        soft_off = np.zeros(n_frames + 1, np.uint64)
+        check(lib().foa_rx_get_taps(self._h, n_frames, _vp(hinv), _vp(eq_buf) if eq else None, eq_buf.size if eq else 0, _vp(eq_off),
+                                    _vp(soft_buf) if soft else None, soft_buf.size if soft else 0, _vp(soft_off)))
+        return dict(hinv=hinv, eq=eq_buf, eq_off=eq_off.astype(np.int64), soft=soft_buf, soft_off=soft_off.astype(np.int64))
+
+    # ---- stage-level entry points ------------------------------------------------------------------
+    def fft_forward(self, vectors):
+        """fft::forward on [n,64] complex128 (src/fft.cpp:50-59)."""
+        v = np.array(vectors, np.complex128).reshape(-1, 64)
+        check(lib().foa_fft_forward_f64(self._h, _vp(v), v.shape[0]))
+        return v
+
+    def conv_decode(self, symbols, data_bits, n_blocks=1):
+        """viterbi::conv_decode (src/viterbi.cpp:31-37) on n_blocks packed blocks."""
+        s = np.ascontiguousarray(symbols, np.uint8)
+        assert s.size >= n_blocks * 2 * (data_bits + 6)
+        out = np.zeros((n_blocks, (data_bits + 7) // 8), np.uint8)
+        check(lib().foa_conv_decode(self._h, _vp(s), _vp(out), int(data_bits), int(n_blocks)))
+        return out

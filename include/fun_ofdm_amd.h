@@ -1,0 +1,146 @@
+/*
+ * fun_ofdm_amd.h -- C ABI of the MI355X-native 802.11a-like receive hot path.
+ *
+ * The library (fun_ofdm_amd/csrc/libfun_ofdm_amd.so) replaces, for bmorgan5/fun_ofdm, the work done
+ * behind fun::receiver_chain::process_samples() from fft_symbols on:
+ *
+ *   fft_symbols::work   (src/fft_symbols.cpp:33-79)   + fft::forward (src/fft.cpp:50-59)
+ *   channel_est::work   (src/channel_est.cpp:36-85)
+ *   phase_tracker::work (src/phase_tracker.cpp:70-104)
+ *   frame_decoder::work (src/frame_decoder.cpp:45-91) -> ppdu::decode_header / decode_data
+ *                       (src/ppdu.cpp:168-295): modulator::demodulate, interleaver::deinterleave,
+ *                       puncturer::depuncture, viterbi::conv_decode, descrambler, CRC-32
+ *
+ * Conventions: plain C types only; every call returns 0 on success and a negative FOA_E_* code on
+ * error (foa_last_error() gives the text, per thread); the library never frees caller memory; a handle
+ * is used from one thread at a time; each handle owns one HIP stream; there is NO CPU fallback -- a
+ * call fails with FOA_E_NO_DEVICE when no gfx950 device/HIP runtime is usable.
+ *
+ * The reference-side binding a maintainer would add is shown in INTEGRATION.md.
+ */
+#ifndef FUN_OFDM_AMD_H
+#define FUN_OFDM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FOA_VERSION 100
+
+enum {
+    FOA_OK = 0,
+    FOA_E_INVALID = -1,     /* bad argument */
+    FOA_E_NO_DEVICE = -2,   /* no usable HIP device */
+    FOA_E_HIP = -3,         /* a HIP runtime call failed */
+    FOA_E_NOMEM = -4,       /* device allocation failed */
+    FOA_E_STATE = -5        /* call sequence error (e.g. taps requested before any decode) */
+};
+
+/* Per-frame outcome; the reference drops failed frames silently (src/frame_decoder.cpp:63-68,
+ * src/ppdu.cpp:187-203,272-279), here they are reported. */
+enum {
+    FOA_ST_OK = 0,           /* CRC-32 matched: psdu slot holds `length` payload bytes */
+    FOA_ST_HEADER_FAIL = 1,  /* SIGNAL parity or rate check failed (ppdu.cpp:187-203) */
+    FOA_ST_CRC_FAIL = 2,     /* ppdu.cpp:272-279 */
+    FOA_ST_TRUNCATED = 3,    /* not enough samples before `end` for the symbols SIGNAL announces */
+    FOA_ST_NO_SPACE = 4      /* workspace exhausted (overlapping frame ranges) */
+};
+
+/* One alignment = one LTS1/LTS2 tag pair produced by timing_sync (src/timing_sync.cpp:98-113).
+ * Symbol windows relative to lts1_pos follow fft_symbols.cpp:41-73: LTS1 [0,64), LTS2 [64,128),
+ * SIGNAL [144,208), data symbol k (1-based) [144+80k, 208+80k).
+ * timing_sync rotates every sample by exp(+j*m_phase_acc) (timing_sync.cpp:114-125); the phase changes
+ * at the STS_END sample that found the LTS, which may lie up to 8 samples after lts1_pos, hence the
+ * second phasor. */
+typedef struct foa_frame_desc {
+    int64_t lts1_pos;       /* stream index of the sample tagged LTS1 */
+    int64_t rot_start;      /* samples with index >= rot_start use (c,s), earlier ones (c_prev,s_prev) */
+    double c, s;            /* cos/sin of m_phase_acc in force from rot_start on */
+    double c_prev, s_prev;  /* cos/sin of m_phase_acc before */
+} foa_frame_desc;
+
+typedef struct foa_frame_result {
+    int32_t status;         /* FOA_ST_* */
+    int32_t rate;           /* fun::Rate enum value 0..10 (src/rates.h:31-44), -1 if header failed */
+    int32_t length;         /* payload bytes announced by SIGNAL */
+    int32_t num_symbols;    /* data OFDM symbols (ppdu.cpp:40-44) */
+} foa_frame_result;
+
+typedef struct foa_rx foa_rx;
+
+int foa_version(void);
+const char *foa_last_error(void);
+/* number of HIP devices visible, or a negative FOA_E_* */
+int foa_device_count(void);
+
+/* Create a receiver on HIP device `device` (its own non-blocking stream). */
+int foa_rx_create(foa_rx **out, int device);
+void foa_rx_destroy(foa_rx *rx);
+
+/* Pre-size the device workspace for streams of up to n_samples samples holding up to n_frames
+ * alignments, so that later decode calls allocate nothing. */
+int foa_rx_reserve(foa_rx *rx, size_t n_samples, size_t n_frames);
+
+/* Choose the Viterbi kernel: 0 = wave-per-frame lane-per-state (v1), 1 = packed multi-frame (v2).
+ * Results are identical; this exists for A/B measurement. */
+int foa_rx_set_option(foa_rx *rx, const char *name, int64_t value);
+
+/*
+ * Batch decode with DEVICE pointers; asynchronous on the handle's stream (call foa_rx_sync or read
+ * results after your own synchronisation).  Replaces the per-frame work of fft_symbols, channel_est,
+ * phase_tracker and frame_decoder (files and lines above) for n_frames alignments.
+ *   d_iq       n_samples interleaved (re,im) float pairs: the raw stream handed to process_samples,
+ *              before timing_sync's rotation (the kernel applies it from the descriptor)
+ *   d_descs    n_frames descriptors
+ *   d_ends     per frame: exclusive end index of the samples that belong to it (next alignment's
+ *              lts1_pos, or n_samples)
+ *   d_psdu     n_frames slots of slot_bytes bytes (slot_bytes >= longest payload, <= 4095 needed)
+ *   d_results  n_frames results
+ */
+int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, const foa_frame_desc *d_descs,
+                             const int64_t *d_ends, size_t n_frames, uint8_t *d_psdu, size_t slot_bytes,
+                             foa_frame_result *d_results);
+
+/* Same with HOST pointers: copies in, decodes, copies out, synchronises. */
+int foa_rx_decode_frames_host(foa_rx *rx, const float *iq, size_t n_samples, const foa_frame_desc *descs,
+                              const int64_t *ends, size_t n_frames, uint8_t *psdu, size_t slot_bytes,
+                              foa_frame_result *results);
+
+/* Block until everything queued on the handle's stream has finished. */
+int foa_rx_sync(foa_rx *rx);
+
+/* The handle's hipStream_t (as void*) so callers can order their own work against it. */
+void *foa_rx_stream(foa_rx *rx);
+
+/* HIP-event durations (ms) of the kernels of the most recent decode call, measured on the handle's
+ * stream: [0] header (LTS+SIGNAL), [1] offset scan, [2] data-symbol FFT/equalise/demap,
+ * [3] Viterbi (+descramble+CRC), [4] whole call.  Synchronises. */
+int foa_rx_last_kernel_ms(foa_rx *rx, float out_ms[5]);
+
+/* Intermediates of the most recent decode call, copied to HOST memory (parity tests).
+ *   hinv    64 complex doubles (re,im) per frame: channel_est's m_chan_est (channel_est.cpp:53-58)
+ *   eq      per frame (1 + num_symbols) * 48 complex doubles: phase_tracker output incl. SIGNAL
+ *   soft    per frame 2 * num_symbols * dbps depunctured soft bytes (puncturer.cpp:78-123 output)
+ * Any pointer may be NULL.  eq/soft are packed frame after frame in frame order for frames whose header
+ * decoded; eq_off/soft_off (n_frames+1 entries each, may be NULL) receive the element offsets. */
+int foa_rx_get_taps(foa_rx *rx, size_t n_frames, double *hinv, double *eq, size_t eq_cap, uint64_t *eq_off,
+                    uint8_t *soft, size_t soft_cap, uint64_t *soft_off);
+/* Ask the next decode calls to record `eq` (costs memory traffic; off by default). */
+
+/* ---- stage-level entry points (one per replaced fun::block, for the per-block adaptors) ---- */
+
+/* fft::forward over n_vec vectors of 64 complex doubles (host pointers, in place): unscaled DFT with
+ * the reference's index shift (src/fft.cpp:50-59), i.e. what fft_symbols::work applies per vector. */
+int foa_fft_forward_f64(foa_rx *rx, double *vectors, size_t n_vec);
+
+/* viterbi::conv_decode (src/viterbi.cpp:31-37) on host buffers: symbols[2*(data_bits+6)] soft bytes ->
+ * data[(data_bits+7)/8] bytes.  n_blocks independent blocks of identical data_bits, packed. */
+int foa_conv_decode(foa_rx *rx, const uint8_t *symbols, uint8_t *data, int data_bits, size_t n_blocks);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FUN_OFDM_AMD_H */

@@ -1,0 +1,233 @@
+"""Parity of the HIP path (through the C ABI) against the oracle and the golden vectors.  GPU only."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-4     # north_star: FFT / equaliser intermediates within 1e-4 relative (max-norm per symbol)
+
+
+@pytest.fixture(scope="module")
+def rx():
+    import fun_ofdm_amd as foa
+    r = foa.Receiver(0)
+    yield r
+    r.close()
+
+
+def _ends(descs, n):
+    e = np.empty(descs.size, np.int64)
+    e[:-1] = descs["lts1_pos"][1:]
+    e[-1] = n
+    return e
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def test_library_is_native_and_loaded():
+    import fun_ofdm_amd as foa
+    assert foa.lib().foa_version() == 100
+    assert foa.lib().foa_device_count() >= 1
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_conv_decode_matches_reference_sse_vectors(rx, golden, kind):
+    """GPU Viterbi fed the bytes the REAL reference decoder was fed: bit-exact (incl. garbage)."""
+    rx.set_option("viterbi", kind)
+    g = golden.viterbi_ref
+    for i, nb in enumerate(g["data_bits"]):
+        s = g["symbols"][g["sym_off"][i]:g["sym_off"][i + 1]]
+        want = g["decoded"][g["dec_off"][i]:g["dec_off"][i + 1]]
+        got = rx.conv_decode(s, int(nb))[0]
+        assert np.array_equal(got, want), "KAT %d (data_bits %d)" % (i, nb)
+
+
+def test_conv_decode_random_vs_oracle(rx, po):
+    rng = np.random.default_rng(21)
+    for nb in (2, 10, 58, 64, 122, 130, 1000, 8418, 32826):
+        nblk = 5 if nb < 5000 else 2
+        n = 2 * (nb + 6)
+        s = rng.integers(0, 256, nblk * n, dtype=np.uint8)
+        d = rng.integers(0, 256, (nb + 13) // 8 + 1, dtype=np.uint8)
+        e = np.clip(po.conv_encode(d, nb).astype(float) * 255 + rng.normal(0, 80, n), 0, 255).astype(np.uint8)
+        e[2::6] = 127
+        s[:n] = e
+        got = rx.conv_decode(s, nb, nblk)
+        for b in range(nblk):
+            assert np.array_equal(got[b], po.conv_decode(s[b * n:(b + 1) * n], nb)), (nb, b)
+
+
+def test_fft_forward_vs_oracle(rx, po):
+    rng = np.random.default_rng(22)
+    v = rng.normal(size=(37, 64)) + 1j * rng.normal(size=(37, 64))
+    got = rx.fft_forward(v)
+    for i in range(v.shape[0]):
+        want = po.fft64(v[i])
+        assert _rel(got[i], want) < 1e-13
+        assert _rel(got[i], np.fft.fftshift(np.fft.fft(v[i]))) < 1e-13
+
+
+def test_golden_frames(rx, po, golden):
+    g = golden.frames
+    rx.set_option("record_eq", 1)
+    soft_mismatch = soft_total = 0
+    for name in g["names"]:
+        iq, descs = g[name + "_iq"], g[name + "_desc"]
+        psdu, res = rx.decode_frames_host(iq, descs, _ends(descs, iq.size))
+        want = g[name + "_res"]
+        assert [res[0]["status"], res[0]["rate"], res[0]["length"], res[0]["num_symbols"]] == list(want), name
+        if want[0] == 0:
+            assert np.array_equal(psdu[0, :want[2]], g[name + "_psdu"]), name
+        if name + "_hinv" in g:
+            t = rx.taps(1, eq=True)
+            used = np.abs(po.lts_freq_domain()) > 0          # null carriers hold 0/NaN in the reference
+            assert _rel(t["hinv"][0][used], g[name + "_hinv"][used].astype(np.complex128)) < REL_TOL, name
+            eq = t["eq"][:t["eq_off"][1]].reshape(-1, 48)
+            ref = g[name + "_eq"].astype(np.complex128).reshape(-1, 48)
+            assert eq.shape == ref.shape, name
+            for k in range(eq.shape[0]):
+                assert _rel(eq[k], ref[k]) < REL_TOL, (name, k)
+            soft = t["soft"][:t["soft_off"][1]]
+            ws = g[name + "_soft"]
+            assert soft.size == ws.size, name
+            soft_mismatch += int((soft != ws).sum())
+            soft_total += ws.size
+    rx.set_option("record_eq", 0)
+    # fp64 on both sides: soft bytes are expected to agree exactly
+    assert soft_mismatch == 0, "%d of %d soft bytes differ" % (soft_mismatch, soft_total)
+
+
+def _make_stream(po, rng, specs, snr_db=25.0, gap=(150, 600), cfo_hz=0.0):
+    parts, pays = [], []
+    for rate, ln in specs:
+        pay = rng.integers(0, 256, ln, dtype=np.uint8)
+        f = po.build_frame(pay, rate)
+        if cfo_hz:
+            f = f * np.exp(2j * np.pi * rng.uniform(-cfo_hz, cfo_hz) * np.arange(f.size) / 20e6)
+        f = f * np.exp(1j * rng.uniform(0, 2 * np.pi))
+        parts += [np.zeros(int(rng.integers(*gap)), complex), f]
+        pays.append(pay)
+    parts.append(np.zeros(400, complex))
+    s = np.concatenate(parts)
+    sigma = np.sqrt(0.0124 / (2 * 10 ** (snr_db / 10)))
+    s = s + (rng.normal(size=s.size) + 1j * rng.normal(size=s.size)) * sigma
+    return s.astype(np.complex64), pays
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_mixed_rate_stream_vs_oracle(rx, po, kind):
+    """All 11 rates, several lengths, marginal SNR so that some frames fail their CRC: identical
+    status, header fields and PSDU bytes per frame; soft bytes identical."""
+    rx.set_option("viterbi", kind)
+    rng = np.random.default_rng(23)
+    specs = [(r, int(rng.integers(1, 400))) for r in range(11)] * 2 + [(10, 1024), (0, 37), (2, 1500), (9, 4095), (8, 1)]
+    iq, pays = _make_stream(po, rng, specs, snr_db=19.0, cfo_hz=3000.0)
+    descs = po.find_alignments_f32(iq)
+    assert descs.size == len(specs)
+    ends = _ends(descs, iq.size)
+    psdu, res = rx.decode_frames_host(iq, descs, ends)
+    t = rx.taps(descs.size)
+    opsdu, ores = po.decode_batch_f32(iq, descs, ends, threads=4)
+    n_ok = n_fail = 0
+    for f in range(descs.size):
+        assert tuple(res[f]) == tuple(ores[f]), (f, res[f], ores[f])
+        if res[f]["status"] == 0:
+            n_ok += 1
+            assert np.array_equal(psdu[f, :res[f]["length"]], opsdu[f, :res[f]["length"]]), f
+            assert np.array_equal(psdu[f, :res[f]["length"]], pays[f]), f
+        else:
+            n_fail += 1
+        _, _, taps = po.decode_alignment_f32(iq, descs[f], end=ends[f], taps=True)
+        if res[f]["rate"] >= 0 and res[f]["status"] in (0, 2):
+            got = t["soft"][t["soft_off"][f]:t["soft_off"][f + 1]]
+            assert np.array_equal(got, taps["soft"]), f
+    assert n_ok >= 10 and n_fail >= 1, (n_ok, n_fail)      # the case really has both outcomes
+
+
+def test_truncated_and_degenerate_inputs(rx, po, golden):
+    g = golden.frames
+    iq, descs = g["rate10_iq"], g["rate10_desc"]
+    lts1 = int(descs[0]["lts1_pos"])
+    # cut inside the data symbols, inside SIGNAL, and before the LTS is complete
+    for cut, want_rate in ((lts1 + 1000, 10), (lts1 + 200, -1), (lts1 + 100, -1)):
+        psdu, res = rx.decode_frames_host(iq, descs, np.array([cut], np.int64))
+        o_res, _ = po.decode_alignment_f32(iq, descs[0], end=cut)
+        assert res[0]["status"] == 3 == o_res["status"]
+        assert res[0]["rate"] == want_rate
+    # zero frames is a no-op
+    psdu, res = rx.decode_frames_host(iq, descs[:0], np.zeros(0, np.int64))
+    assert psdu.shape[0] == 0
+    # pure noise "frame": both sides must agree (normally header failure)
+    rng = np.random.default_rng(24)
+    noise = (rng.normal(size=4000) + 1j * rng.normal(size=4000)).astype(np.complex64) * 0.05
+    d = np.zeros(1, descs.dtype)
+    d["lts1_pos"] = 100; d["rot_start"] = 90; d["c"] = 1.0; d["c_prev"] = 1.0
+    psdu, res = rx.decode_frames_host(noise, d, np.array([4000], np.int64))
+    o_res, _ = po.decode_alignment_f32(noise, d[0], end=4000)
+    assert tuple(res[0]) == tuple(o_res)
+    # all-zero samples: the channel estimate is NaN everywhere; the reference yields a header failure
+    z = np.zeros(2000, np.complex64)
+    psdu, res = rx.decode_frames_host(z, d, np.array([2000], np.int64))
+    o_res, _ = po.decode_alignment_f32(z, d[0], end=2000)
+    assert tuple(res[0]) == tuple(o_res)
+
+
+def test_rotation_switch_inside_lts(rx, po, golden):
+    """rot_start after lts1_pos: the first samples of the LTS window use the previous phasor
+    (timing_sync.cpp:105,124: the tag may sit up to 8 samples before the STS_END sample)."""
+    g = golden.frames
+    iq, descs = g["rate5_iq"], g["rate5_desc"].copy()
+    descs["rot_start"] = descs["lts1_pos"] + 5
+    descs["c_prev"], descs["s_prev"] = np.cos(0.3), np.sin(0.3)
+    ends = np.array([iq.size], np.int64)
+    psdu, res = rx.decode_frames_host(iq, descs, ends)
+    o_res, o_psdu, taps = po.decode_alignment_f32(iq, descs[0], taps=True)
+    assert tuple(res[0]) == tuple(o_res)
+    t = rx.taps(1)
+    used = np.abs(po.lts_freq_domain()) > 0
+    assert _rel(t["hinv"][0][used], taps["hinv"][used]) < 1e-9
+    assert np.array_equal(t["soft"][:t["soft_off"][1]], taps["soft"])
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_config2_shape_batch(rx, po, kind):
+    """BASELINE config 2 at reduced count: 54 Mbps, 1024-byte payloads, 25 dB, frame pitch 4096;
+    device-resident buffers through the device-pointer entry point."""
+    import torch
+    import fun_ofdm_amd as foa
+    rx.set_option("viterbi", kind)
+    rng = np.random.default_rng(25)
+    n_frames, pitch = 96, 4096
+    iq = np.zeros(n_frames * pitch, np.complex64)
+    pays = []
+    sigma = np.sqrt(0.0124 / (2 * 10 ** 2.5))
+    for f in range(n_frames):
+        pay = rng.integers(0, 256, 1024, dtype=np.uint8)
+        fr = po.build_frame(pay, 10) * np.exp(1j * rng.uniform(0, 2 * np.pi))
+        assert fr.size == 3520
+        iq[f * pitch + 176:f * pitch + 176 + 3520] = fr
+        pays.append(pay)
+    iq = (iq + (rng.normal(size=iq.size) + 1j * rng.normal(size=iq.size)) * sigma).astype(np.complex64)
+    descs = po.find_alignments_f32(iq)
+    assert descs.size == n_frames
+    ends = _ends(descs, iq.size)
+    dev = torch.device("cuda", 0)
+    t_iq = torch.from_numpy(iq.view(np.float32).reshape(-1, 2)).to(dev)
+    t_desc = torch.from_numpy(descs.view(np.uint8).copy()).to(dev)
+    t_ends = torch.from_numpy(ends).to(dev)
+    t_psdu = torch.zeros((n_frames, 1024), dtype=torch.uint8, device=dev)
+    t_res = torch.zeros((n_frames, 4), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    rx.decode_frames_dev(t_iq, t_desc, t_ends, t_psdu, t_res)
+    rx.sync()
+    res = t_res.cpu().numpy()
+    psdu = t_psdu.cpu().numpy()
+    assert (res[:, 0] == 0).all() and (res[:, 1] == 10).all() and (res[:, 2] == 1024).all() and (res[:, 3] == 39).all()
+    for f in range(n_frames):
+        assert np.array_equal(psdu[f], pays[f]), f
+    opsdu, ores = po.decode_batch_f32(iq, descs, ends, slot_bytes=1024, threads=4)
+    assert np.array_equal(opsdu, psdu)
+    ms = rx.kernel_ms()
+    assert ms["total"] > 0 and ms["viterbi"] > 0
