@@ -55,6 +55,13 @@ def lib():
         if not os.path.exists(path):
             raise FoaError("%s not found: build it with fun_ofdm_amd.build() / `make -C fun_ofdm_amd/csrc` "
                            "(this package has no CPU implementation)" % path)
+        # PyTorch-ROCm wheels bundle their own libamdhip64; two HIP runtimes in one process do not
+        # coexist (the second sees no GPU).  Importing torch first makes this library bind to the
+        # runtime torch already loaded, so device buffers and streams can be shared with it.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(path)
         for name, (res, args) in _SIGS.items():
             f = getattr(L, name)

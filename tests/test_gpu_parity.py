@@ -210,24 +210,31 @@ def test_config2_shape_batch(rx, po, kind):
         iq[f * pitch + 176:f * pitch + 176 + 3520] = fr
         pays.append(pay)
     iq = (iq + (rng.normal(size=iq.size) + 1j * rng.normal(size=iq.size)) * sigma).astype(np.complex64)
+    # timing_sync also fires on noise now and then (its correlation is normalised by power, not by
+    # amplitude: timing_sync.cpp:79), so there can be more alignments than frames; all are decoded.
     descs = po.find_alignments_f32(iq)
-    assert descs.size == n_frames
+    assert descs.size >= n_frames
+    m = descs.size
     ends = _ends(descs, iq.size)
     dev = torch.device("cuda", 0)
     t_iq = torch.from_numpy(iq.view(np.float32).reshape(-1, 2)).to(dev)
     t_desc = torch.from_numpy(descs.view(np.uint8).copy()).to(dev)
     t_ends = torch.from_numpy(ends).to(dev)
-    t_psdu = torch.zeros((n_frames, 1024), dtype=torch.uint8, device=dev)
-    t_res = torch.zeros((n_frames, 4), dtype=torch.int32, device=dev)
+    t_psdu = torch.zeros((m, 1024), dtype=torch.uint8, device=dev)
+    t_res = torch.zeros((m, 4), dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
     rx.decode_frames_dev(t_iq, t_desc, t_ends, t_psdu, t_res)
     rx.sync()
     res = t_res.cpu().numpy()
     psdu = t_psdu.cpu().numpy()
-    assert (res[:, 0] == 0).all() and (res[:, 1] == 10).all() and (res[:, 2] == 1024).all() and (res[:, 3] == 39).all()
-    for f in range(n_frames):
-        assert np.array_equal(psdu[f], pays[f]), f
+    real = np.nonzero((descs["lts1_pos"] - 360) % pitch == 0)[0]      # frame start 176 + LTS1 at 184
+    assert real.size == n_frames
+    assert (res[real, 0] == 0).all() and (res[real, 1] == 10).all() and (res[real, 2] == 1024).all() and (res[real, 3] == 39).all()
+    for k, f in enumerate(real):
+        assert np.array_equal(psdu[f], pays[k]), f
     opsdu, ores = po.decode_batch_f32(iq, descs, ends, slot_bytes=1024, threads=4)
-    assert np.array_equal(opsdu, psdu)
+    assert np.array_equal(ores.view(np.int32).reshape(-1, 4), res)
+    ok = res[:, 0] == 0
+    assert np.array_equal(opsdu[ok], psdu[ok])
     ms = rx.kernel_ms()
     assert ms["total"] > 0 and ms["viterbi"] > 0
