@@ -10,6 +10,7 @@
 #include "frontend_kernels.h"
 #include "viterbi_v1.h"
 #include "viterbi_v2.h"
+#include "sync_host.h"
 
 using namespace foa;
 
@@ -338,6 +339,39 @@ int foa_rx_get_taps(foa_rx *rx, size_t n_frames, double *hinv, double *eq, size_
     if (soft_off) soft_off[n_frames] = so;
     return FOA_OK;
 }
+
+}  // extern "C" (reopened below)
+
+// ---- host-side pre-sync ---------------------------------------------------------------------------
+struct foa_sync {
+    foa::SyncHost impl;
+    std::vector<foa_frame_desc> pending;
+};
+
+template <typename T>
+static int sync_push(foa_sync *s, const T *iq, size_t n, foa_frame_desc *out, size_t cap, size_t *n_out)
+{
+    if (!s || (n && !iq) || (cap && !out) || !n_out) return fail(FOA_E_INVALID, "NULL argument");
+    s->impl.push(iq, n, s->pending);
+    size_t k = s->pending.size() < cap ? s->pending.size() : cap;
+    if (k) memcpy(out, s->pending.data(), k * sizeof(foa_frame_desc));
+    s->pending.erase(s->pending.begin(), s->pending.begin() + k);
+    *n_out = k;
+    return FOA_OK;
+}
+
+extern "C" {
+
+int foa_sync_create(foa_sync **out)
+{
+    if (!out) return fail(FOA_E_INVALID, "out is NULL");
+    *out = new foa_sync();
+    return FOA_OK;
+}
+void foa_sync_destroy(foa_sync *s) { delete s; }
+int foa_sync_push_f32(foa_sync *s, const float *iq, size_t n, foa_frame_desc *out, size_t cap, size_t *n_out) { return sync_push(s, iq, n, out, cap, n_out); }
+int foa_sync_push_f64(foa_sync *s, const double *iq, size_t n, foa_frame_desc *out, size_t cap, size_t *n_out) { return sync_push(s, iq, n, out, cap, n_out); }
+int64_t foa_sync_settled(const foa_sync *s) { return s ? s->impl.settled() : 0; }
 
 // ---- stage-level entry points ---------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_fft_vectors(double2 *__restrict__ v, int n_vec)

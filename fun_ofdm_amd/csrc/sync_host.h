@@ -1,0 +1,167 @@
+// sync_host.h -- host-side frame_detector + timing_sync, producing alignment descriptors.
+//
+// The reference's two pre-sync blocks (frame_detector.cpp:41-93 with circular_accumulator.h:88-95, and
+// timing_sync.cpp:51-139) sit in front of the hot path inside receiver_chain::process_samples().
+// Until they run on the device this restatement supplies what the device path needs
+// from them: where each LTS1 tag lands and which constant phasor timing_sync applies from where.
+// It never touches sample values (the rotation itself is applied in-kernel), so it only has to
+// reproduce the blocks' DECISIONS; it does that with the same operation order in fp64.
+//
+// Both blocks are chunk-size independent (their carry-overs make a chunked run equal to a one-shot run),
+// so push() may be called with any chunk sizes.
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <cstdint>
+#include <utility>
+#include <vector>
+
+#include "../../include/fun_ofdm_amd.h"
+
+namespace foa {
+
+class SyncHost {
+public:
+    SyncHost() : lts_conj_(64)
+    {
+        make_lts_time_conj();
+        hist_.assign(kCarry, Tagged{});
+    }
+
+    // Feed n samples (interleaved re,im; T = float or double).  Alignments completed by this chunk are
+    // appended to out with stream-absolute positions.
+    template <typename T>
+    void push(const T *iq, size_t n, std::vector<foa_frame_desc> &out)
+    {
+        if (n == 0) return;
+        // hist_ holds the 160 most recent tagged samples that timing_sync has not walked over yet
+        const size_t base = hist_.size();
+        hist_.resize(base + n);
+        for (size_t i = 0; i < n; i++) {
+            std::complex<double> x((double)iq[2 * i], (double)iq[2 * i + 1]);
+            hist_[base + i].v = x;
+            hist_[base + i].tag = detect(x);
+        }
+        // timing_sync.cpp:66-126: walk x over the first n entries; look-ahead reaches x+159
+        const int64_t origin = consumed_ - (int64_t)kCarry;      // stream index of hist_[0]
+        for (size_t x = 0; x < n; x++) {
+            if (hist_[x].tag != kStsEnd) continue;
+            std::vector<std::pair<double, int>> peaks;
+            for (size_t p = x; p < x + kCarry - 64; p++) {
+                std::complex<double> corr(0, 0);
+                double power = 0;
+                for (int s = 0; s < 64; s++) {
+                    corr += hist_[p + s].v * lts_conj_[s];
+                    power += std::norm(hist_[p + s].v);
+                }
+                double cn = std::abs(corr) / power;
+                if (cn > 0.9) peaks.push_back(std::make_pair(cn, (int)p));
+            }
+            std::sort(peaks.begin(), peaks.end());
+            std::reverse(peaks.begin(), peaks.end());
+            // timing_sync.cpp:91-95: s advances by 5 while s < min(size,3), so only the strongest peak is
+            // paired, against the five strongest
+            if (peaks.empty()) continue;
+            const int lim = std::min((int)peaks.size(), 5);
+            for (int t = 0; t < lim; t++) {
+                if (std::abs(peaks[0].second - peaks[t].second) != 64) continue;
+                const int lts_offset = std::min(peaks[0].second, peaks[t].second) - 32;
+                if (lts_offset < 0) break;
+                hist_[lts_offset + 24].tag = kLts1;               // may overwrite a pending STS_END
+                hist_[lts_offset + 24 + 64].tag = kLts2;
+                const std::complex<double> v = hist_[lts_offset + 32 + 128 - 1].v * lts_conj_[63];
+                const double prev = phase_acc_;
+                phase_acc_ = std::arg(v);                          // m_phase_offset stays 0 (dead loop :109)
+                // the per-sample wrap of timing_sync.cpp:116-117 cannot trigger: |arg| <= pi
+                foa_frame_desc d;
+                d.lts1_pos = origin + lts_offset + 24;
+                d.rot_start = origin + (int64_t)x;
+                d.c = std::cos(phase_acc_); d.s = std::sin(phase_acc_);
+                d.c_prev = std::cos(prev); d.s_prev = std::sin(prev);
+                out.push_back(d);
+                break;
+            }
+        }
+        hist_.erase(hist_.begin(), hist_.begin() + n);
+        consumed_ += (int64_t)n;
+    }
+
+    // Everything up to this stream index has been walked by timing_sync (alignments whose STS_END lies
+    // before it have been reported).
+    int64_t settled() const { return consumed_ - (int64_t)kCarry; }
+    int64_t consumed() const { return consumed_; }
+
+private:
+    enum { kNone = 0, kStsStart = 1, kStsEnd = 2, kLts1 = 4, kLts2 = 5 };
+    static constexpr size_t kCarry = 160;
+    struct Tagged { std::complex<double> v{ 0, 0 }; int tag = 0; };
+
+    // frame_detector.cpp:51-84, one sample
+    int detect(const std::complex<double> &x)
+    {
+        std::complex<double> c = x * std::conj(delay_[dpos_]);
+        delay_[dpos_] = x;
+        dpos_ = (dpos_ + 1) & 15;
+        if (c != c) c = 0;                                         // circular_accumulator.h:90
+        corr_sum_ -= corr_ring_[ridx_];
+        corr_sum_ += c;
+        corr_ring_[ridx_] = c;
+        double pw = std::norm(x);
+        if (pw != pw) pw = 0;
+        pow_sum_ -= pow_ring_[ridx_];
+        pow_sum_ += pw;
+        pow_ring_[ridx_] = pw;
+        ridx_ = (ridx_ + 1) & 15;
+        const double corr = std::abs(corr_sum_) / pow_sum_;
+        int tag = kNone;
+        if (corr > 0.9) {
+            if (++plateau_ == 16) { tag = kStsStart; flag_ = true; }
+        } else {
+            if (flag_) { tag = kStsEnd; flag_ = false; }
+            plateau_ = 0;
+        }
+        return tag;
+    }
+
+    // preamble.h:432: conj of the 64-sample long training symbol, as printed with 12 significant digits
+    void make_lts_time_conj()
+    {
+        static const signed char L[53] = { 1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1, 1, 1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1, 1, 0,
+                                           1, -1, -1, 1, 1, -1, 1, -1, 1, -1, -1, -1, -1, -1, 1, 1, -1, -1, 1, -1, 1, -1, 1, 1, 1, 1 };
+        for (int n = 0; n < 64; n++) {
+            // inverse DFT of L(-26..26) / 64, summed in exact-angle form (k*n mod 64 keeps arguments small)
+            long double re = 0, im = 0;
+            for (int i = 0; i < 53; i++) {
+                int k = i - 26;
+                int e = ((k * n) % 64 + 64) % 64;
+                long double a = 2.0L * 3.141592653589793238462643383279502884L * (long double)e / 64.0L;
+                re += L[i] * cosl(a);
+                im += L[i] * sinl(a);
+            }
+            lts_conj_[n] = std::complex<double>(round12((double)(re / 64.0L)), round12((double)(-im / 64.0L)));
+        }
+    }
+    static double round12(double v)
+    {
+        char buf[64];
+        snprintf(buf, sizeof buf, "%.12g", v);
+        return strtod(buf, nullptr);
+    }
+
+    std::vector<std::complex<double>> lts_conj_;
+    std::vector<Tagged> hist_;
+    int64_t consumed_ = 0;
+    double phase_acc_ = 0;
+    // frame_detector state
+    std::complex<double> delay_[16] = {};
+    std::complex<double> corr_ring_[16] = {};
+    std::complex<double> corr_sum_{ 0, 0 };
+    double pow_ring_[16] = {};
+    double pow_sum_ = 0;
+    int dpos_ = 0, ridx_ = 0, plateau_ = 0;
+    bool flag_ = false;
+};
+
+}  // namespace foa

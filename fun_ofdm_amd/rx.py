@@ -103,3 +103,61 @@ class Receiver:
         out = np.zeros((n_blocks, (data_bits + 7) // 8), np.uint8)
         check(lib().foa_conv_decode(self._h, _vp(s), _vp(out), int(data_bits), int(n_blocks)))
         return out
+
+
+class Sync:
+    """Streaming frame_detector + timing_sync on the host (foa_sync_*): push raw samples, get alignment
+    descriptors with stream-absolute positions."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        check(lib().foa_sync_create(C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().foa_sync_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def push(self, iq):
+        """iq: complex64 or complex128 array -> frame_desc_dtype[k] completed by this chunk."""
+        iq = np.ascontiguousarray(iq)
+        if iq.dtype == np.complex64:
+            fn = lib().foa_sync_push_f32
+        else:
+            iq = iq.astype(np.complex128, copy=False)
+            fn = lib().foa_sync_push_f64
+        out, got = [], C.c_size_t(0)
+        buf = np.zeros(max(iq.size // 400, 0) + 64, frame_desc_dtype)
+        check(fn(self._h, _vp(iq), iq.size, _vp(buf), buf.size, C.byref(got)))
+        out.append(buf[:got.value].copy())
+        while got.value == buf.size:
+            check(fn(self._h, None, 0, _vp(buf), buf.size, C.byref(got)))
+            out.append(buf[:got.value].copy())
+        return np.concatenate(out)
+
+    @property
+    def settled(self):
+        return int(lib().foa_sync_settled(self._h))
+
+
+def find_alignments(iq, flush=True):
+    """One-shot sync over a whole stream (plus 160 zeros so that the tail is examined)."""
+    s = Sync()
+    d = [s.push(iq)]
+    if flush:
+        z = np.zeros(4096, iq.dtype if iq.dtype in (np.complex64, np.complex128) else np.complex64)
+        d.append(s.push(z))
+    d = np.concatenate(d)
+    s.close()
+    return d[d["lts1_pos"] < iq.size]
+
+
+def alignment_ends(descs, n_samples):
+    """Exclusive end of each alignment's samples: the next alignment's LTS1, or the stream end."""
+    e = np.empty(descs.size, np.int64)
+    if descs.size:
+        e[:-1] = descs["lts1_pos"][1:]
+        e[-1] = n_samples
+    return e

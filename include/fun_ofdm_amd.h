@@ -130,6 +130,21 @@ int foa_rx_get_taps(foa_rx *rx, size_t n_frames, double *hinv, double *eq, size_
                     uint8_t *soft, size_t soft_cap, uint64_t *soft_off);
 /* Ask the next decode calls to record `eq` (costs memory traffic; off by default). */
 
+/* ---- pre-sync (host side for now; SURVEY 8f #1 moves it onto the device) ---- */
+
+/* Streaming frame_detector + timing_sync (src/frame_detector.cpp:41-93, src/timing_sync.cpp:51-139):
+ * consumes the raw stream in chunks of any size and reports one descriptor per LTS1/LTS2 tag pair,
+ * with stream-absolute positions.  No GPU needed. */
+typedef struct foa_sync foa_sync;
+int foa_sync_create(foa_sync **out);
+void foa_sync_destroy(foa_sync *s);
+/* Push n_samples interleaved (re,im) samples; up to cap finished descriptors are written to out and
+ * *n_out is set.  Descriptors that did not fit stay queued: call again with n_samples = 0 to drain. */
+int foa_sync_push_f32(foa_sync *s, const float *iq, size_t n_samples, foa_frame_desc *out, size_t cap, size_t *n_out);
+int foa_sync_push_f64(foa_sync *s, const double *iq, size_t n_samples, foa_frame_desc *out, size_t cap, size_t *n_out);
+/* Stream index up to which timing_sync has looked (it trails the input by 160 samples). */
+int64_t foa_sync_settled(const foa_sync *s);
+
 /* ---- stage-level entry points (one per replaced fun::block, for the per-block adaptors) ---- */
 
 /* fft::forward over n_vec vectors of 64 complex doubles (host pointers, in place): unscaled DFT with

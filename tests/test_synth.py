@@ -1,0 +1,86 @@
+"""Host logic: the numpy frame generator and the C-ABI library surface (CPU only)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+
+import fun_ofdm_amd as foa
+from fun_ofdm_amd import synth
+
+
+def test_build_frames_matches_oracle(po):
+    rng = np.random.default_rng(31)
+    for rate in range(11):
+        for length in (0, 1, 57, 100 + rate):
+            pays = rng.integers(0, 256, (3, length), dtype=np.uint8)
+            got = synth.build_frames(pays, rate)
+            assert got.shape[1] == synth.frame_samples(rate, length) == po.frame_samples(rate, length)
+            for i in range(3):
+                want = po.build_frame(pays[i], rate)
+                assert np.abs(got[i] - want).max() < 1e-15, (rate, length)
+    assert np.array_equal(synth.preamble(), po.preamble_samples())
+
+
+def test_splitmix_payloads_are_deterministic_and_distinct():
+    a = synth.splitmix64_bytes(0x0FD2, 50, 1024)
+    b = synth.splitmix64_bytes(0x0FD2, 50, 1024)
+    assert np.array_equal(a, b) and len({x.tobytes() for x in a}) == 50
+    assert abs(a.mean() - 127.5) < 2
+
+
+def test_stream_decodes_in_oracle_chain(po):
+    pays = synth.splitmix64_bytes(7, 6, 300)
+    frames = synth.build_frames(pays, 10)
+    iq, starts = synth.make_stream(frames, pitch=4096, lead=176, snr_db=25.0, seed=3)
+    assert iq.dtype == np.complex64 and iq.size == 6 * 4096
+    out = po.ReceiverChain().run_stream(iq.astype(np.complex128))
+    assert out == [p.tobytes() for p in pays]
+
+
+def test_host_sync_equals_oracle_sync(po, golden):
+    """foa_sync_* (product, host side) makes the same decisions as the oracle's frame_detector +
+    timing_sync, for any chunking."""
+    s = golden.blocks_ref["stream"]
+    want = po.find_alignments_f32(s)
+    assert foa.find_alignments(s).tobytes() == want.tobytes() and want.size == 2
+    pays = synth.splitmix64_bytes(9, 40, 64)
+    iq, _ = synth.make_stream(synth.build_frames(pays, 3), pitch=2048, lead=200, snr_db=22.0, seed=5, cfo_hz=4000.0)
+    want = po.find_alignments_f32(iq)
+    assert want.size >= 38
+    rng = np.random.default_rng(6)
+    sy, got, x = foa.Sync(), [], 0
+    while x < iq.size:
+        n = int(rng.integers(1, 5000))
+        got.append(sy.push(iq[x:x + n]))
+        x += n
+    got.append(sy.push(np.zeros(400, np.complex64)))
+    got = np.concatenate(got)
+    assert got[got["lts1_pos"] < iq.size].tobytes() == want.tobytes()
+    # double-precision input path
+    assert foa.find_alignments(iq.astype(np.complex128)).tobytes() == want.tobytes()
+
+
+def test_library_exports_every_declared_symbol():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "fun_ofdm_amd.h")).read()
+    declared = set(re.findall(r"\b(foa_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    L = ctypes.CDLL(foa.library_path())
+    for name in sorted(declared):
+        assert hasattr(L, name), name
+    from fun_ofdm_amd._lib import EXPORTS
+    assert declared == set(EXPORTS)
+    assert L.foa_version() == 100
+
+
+def test_no_cpu_fallback_without_gpu():
+    """Without a HIP device the product fails loudly instead of computing on the CPU."""
+    if foa.lib().foa_device_count() > 0:
+        return
+    try:
+        foa.Receiver(0)
+    except foa.FoaError as e:
+        assert "no HIP device" in str(e)
+    else:
+        raise AssertionError("Receiver() must not succeed without a GPU")
