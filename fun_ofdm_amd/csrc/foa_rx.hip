@@ -122,6 +122,7 @@ struct foa_rx {
     DevBuf<int32_t> sym2frame;
     DevBuf<uint8_t> soft;
     DevBuf<uint64_t> dec;
+    DevBuf<uint32_t> bm, decoded;
     DevBuf<int64_t> totals;
     DevBuf<double2> eq_sig, eq_data;
     DevBuf<uint8_t> scratch;     // staging for the host-pointer entry points
@@ -138,11 +139,11 @@ int workspace(foa_rx *rx, size_t n_samples, size_t n_frames)
     size_t dec_cap = 216 * sym_cap + 64 * (n_frames + 1);
     int rc;
     if ((rc = rx->info.ensure(n_frames + 1)) || (rc = rx->hinv.ensure((n_frames + 1) * 64)) || (rc = rx->sym2frame.ensure(sym_cap)) ||
-        (rc = rx->soft.ensure(soft_cap)) || (rc = rx->dec.ensure(dec_cap)) || (rc = rx->totals.ensure(8)))
+        (rc = rx->soft.ensure(soft_cap)) || (rc = rx->dec.ensure(dec_cap)) || (rc = rx->bm.ensure(dec_cap)) || (rc = rx->decoded.ensure(dec_cap)) || (rc = rx->totals.ensure(8)))
         return rc;
     if (rx->record_eq && ((rc = rx->eq_sig.ensure((n_frames + 1) * 48)) || (rc = rx->eq_data.ensure(sym_cap * 48)))) return rc;
     // capacities handed to the scan are those of the buffers actually allocated
-    rx->sym_cap = rx->sym2frame.n; rx->soft_cap = rx->soft.n; rx->dec_cap = rx->dec.n;
+    rx->sym_cap = rx->sym2frame.n; rx->soft_cap = rx->soft.n; rx->dec_cap = rx->dec.n < rx->bm.n ? rx->dec.n : rx->bm.n;
     if (rx->record_eq && rx->eq_data.n / 48 < rx->sym_cap) rx->sym_cap = rx->eq_data.n / 48;
     return FOA_OK;
 }
@@ -189,7 +190,7 @@ void foa_rx_destroy(foa_rx *rx)
     if (!rx) return;
     (void)hipSetDevice(rx->device);
     (void)hipStreamSynchronize(rx->stream);
-    rx->info.release(); rx->hinv.release(); rx->sym2frame.release(); rx->soft.release(); rx->dec.release(); rx->totals.release();
+    rx->info.release(); rx->hinv.release(); rx->sym2frame.release(); rx->soft.release(); rx->dec.release(); rx->bm.release(); rx->decoded.release(); rx->totals.release();
     rx->eq_sig.release(); rx->eq_data.release(); rx->scratch.release();
     for (auto &e : rx->ev) if (e) (void)hipEventDestroy(e);
     if (rx->stream) (void)hipStreamDestroy(rx->stream);
@@ -252,12 +253,12 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
     // upper bound on data symbols in n_samples samples; waves beyond the real total exit at once
     const size_t max_sym = rx->sym_cap;
     hipLaunchKernelGGL(k_data_symbols, dim3((unsigned)((max_sym + kSymWaves - 1) / kSymWaves)), dim3(64 * kSymWaves), 0, st, iq, d_descs,
-                       rx->info.p, rx->sym2frame.p, rx->totals.p, rx->hinv.p, rx->soft.p, eq_data);
+                       rx->info.p, rx->sym2frame.p, rx->totals.p, rx->hinv.p, rx->soft.p, rx->bm.p, eq_data);
     HIP_TRY(hipEventRecord(rx->ev[3], st));
     if (rx->viterbi_kind == 0)
         hipLaunchKernelGGL(k_viterbi_v1, dim3(nf), dim3(64), 0, st, rx->info.p, nf, rx->soft.p, rx->dec.p, d_psdu, slot_bytes, d_results);
     else
-        launch_viterbi_v2(st, rx->info.p, nf, rx->soft.p, rx->dec.p, d_psdu, slot_bytes, d_results);
+        launch_viterbi_v2(st, rx->info.p, nf, rx->bm.p, rx->dec.p, rx->decoded.p, d_psdu, slot_bytes, d_results);
     HIP_TRY(hipEventRecord(rx->ev[4], st));
     HIP_TRY(hipGetLastError());
     rx->have_timing = true;

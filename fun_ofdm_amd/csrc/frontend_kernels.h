@@ -195,14 +195,31 @@ __device__ __forceinline__ AcsLane acs_lane_init(int lane)
     return a;
 }
 
+// DPP controls (cdna4 ISA 'DPP_CTRL'): quad_perm xor-1 / xor-2, row_half_mirror, row_mirror
+#define FOA_DPP_XOR1 0xB1
+#define FOA_DPP_XOR2 0x4E
+#define FOA_DPP_HALF_MIRROR 0x141
+#define FOA_DPP_MIRROR 0x140
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+
+__device__ __forceinline__ uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
+// minimum over the 64 lanes, returned wave-uniform (four DPP rounds inside each row of 16, then the four
+// row results meet on the scalar unit)
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        uint32_t t = __shfl_xor(v, o);
-        v = t < v ? t : v;
-    }
-    return v;
+    v = umin32(v, dpp_mov<FOA_DPP_XOR1>(v));
+    v = umin32(v, dpp_mov<FOA_DPP_XOR2>(v));
+    v = umin32(v, dpp_mov<FOA_DPP_HALF_MIRROR>(v));
+    v = umin32(v, dpp_mov<FOA_DPP_MIRROR>(v));
+    uint32_t a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16), c = __builtin_amdgcn_readlane(v, 32),
+             d = __builtin_amdgcn_readlane(v, 48);
+    return umin32(umin32(a, b), umin32(c, d));
 }
 
 __device__ __forceinline__ uint32_t acs_step(uint32_t M, uint32_t s0, uint32_t s1, const AcsLane &a, uint64_t &dec)
@@ -361,7 +378,7 @@ constexpr int kSymWaves = 4;
 __global__ __launch_bounds__(64 * kSymWaves) void k_data_symbols(const float2 *__restrict__ iq, const foa_frame_desc *__restrict__ descs,
                                                                  const FrameInfo *__restrict__ info, const int32_t *__restrict__ sym2frame,
                                                                  const int64_t *__restrict__ totals, const double2 *__restrict__ hinv,
-                                                                 uint8_t *__restrict__ soft, double2 *__restrict__ eq_tap)
+                                                                 uint8_t *__restrict__ soft, uint32_t *__restrict__ bm, double2 *__restrict__ eq_tap)
 {
     __shared__ cpx lds_all[kSymWaves][64];
     __shared__ __attribute__((aligned(16))) uint8_t stage_all[kSymWaves][448];
@@ -405,6 +422,14 @@ __global__ __launch_bounds__(64 * kSymWaves) void k_data_symbols(const float2 *_
     uint32_t *dst = (uint32_t *)(soft + fi.soft_off + (int64_t)(k - 1) * out_bytes);
     const uint32_t *st32 = (const uint32_t *)stage;
     for (int i = lane; i < out_bytes / 4; i += 64) dst[i] = st32[i];
+    // Branch metrics of this symbol's trellis steps for the packed Viterbi kernel: byte j = 2*b0 + b1 holds
+    // (((s0 ^ b0*255) + (s1 ^ b1*255) + 1) >> 1) >> 2, the value viterbi.cpp:242-247 derives per butterfly
+    // from Branchtab entries (b0, b1).
+    uint32_t *bdst = bm + fi.dec_off + (int64_t)(k - 1) * rr.dbps;
+    for (int t = lane; t < rr.dbps; t += 64) {
+        const uint32_t s0 = stage[2 * t], s1 = stage[2 * t + 1], n0 = s0 ^ 255u, n1 = s1 ^ 255u;
+        bdst[t] = ((s0 + s1 + 1u) >> 3) | (((s0 + n1 + 1u) >> 3) << 8) | (((n0 + s1 + 1u) >> 3) << 16) | (((n0 + n1 + 1u) >> 3) << 24);
+    }
 }
 
 }  // namespace foa
