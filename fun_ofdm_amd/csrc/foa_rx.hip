@@ -341,6 +341,21 @@ int foa_rx_get_taps(foa_rx *rx, size_t n_frames, double *hinv, double *eq, size_
     return FOA_OK;
 }
 
+int foa_rx_get_decisions(foa_rx *rx, size_t frame, uint64_t *out, size_t cap, size_t *n_steps)
+{
+    if (!rx || !out || !n_steps) return fail(FOA_E_INVALID, "NULL argument");
+    if (frame >= rx->last_frames) return fail(FOA_E_STATE, "frame index beyond the last decode call");
+    HIP_TRY(hipSetDevice(rx->device));
+    HIP_TRY(hipStreamSynchronize(rx->stream));
+    FrameInfo fi;
+    HIP_TRY(hipMemcpy(&fi, rx->info.p + frame, sizeof fi, hipMemcpyDeviceToHost));
+    const size_t n = fi.nsym > 0 ? (size_t)fi.nsteps : 0;
+    *n_steps = n;
+    if (n > cap) return fail(FOA_E_INVALID, "cap too small (%zu steps)", n);
+    if (n) HIP_TRY(hipMemcpy(out, rx->dec.p + fi.dec_off, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return FOA_OK;
+}
+
 }  // extern "C" (reopened below)
 
 // ---- host-side pre-sync ---------------------------------------------------------------------------

@@ -1,18 +1,26 @@
-// viterbi_v2.h -- K=7 Viterbi forward pass with TWO frames per wavefront, packed 16-bit metrics.
+// viterbi_v2.h -- K=7 Viterbi forward pass, TWO frames per wavefront, in-place trellis, packed u16 metrics.
 //
-// Same recursion as viterbi_v1.h (viterbi.cpp:208-457, exact uint8 saturation / state-0 renormalisation /
-// tie-break), restructured for gfx950 throughput:
-//   * lane s = trellis state s of BOTH frames: a VGPR holds the two frames' path metrics as two u16
-//     halves, biased by 0xFF00 so that `v_pk_add_u16 ... clamp` saturates exactly where the reference's
-//     `_mm_adds_epu8` does (0xFFFF <-> 255); min and compares are bias-invariant;
-//   * one `ds_bpermute_b32` pair per step moves both frames' metrics (lane s needs states s>>1, (s>>1)+32);
-//   * branch metrics arrive precomputed from the data-symbol kernel as one dword per step
-//     (m00,m01,m10,m11); a lane picks its butterfly's class with one `v_perm_b32`;
-//   * the 64 decision bits of a step are the lane mask of a `v_cmp` -- already in the reference's
-//     decision_t bit order (viterbi.h:36-41) -- and leave the wave through the scalar data cache
-//     (`s_store_dwordx2`), so decision traffic costs no vector-memory or VALU issue slots;
-//   * renormalisation (on average every ~9 steps per frame) reduces with DPP row operations.
-// Chain-back, descrambling and CRC run in a second kernel, one wave per frame (finish_frame_wave).
+// Same recursion as viterbi_v1.h (viterbi.cpp:208-457: uint8 saturating metrics, renormalise when state 0
+// exceeds 210, upper predecessor wins ties), laid out for gfx950:
+//
+//   * In-place butterflies.  Physical slot p (= lane) holds state label rotl6^t(p) at trellis time t, so the
+//     butterfly of step t pairs slots that differ in ONE lane bit q = 5 - (t mod 6): old states (i, i+32) sit in
+//     the pair's low/high slot and the new states (2i, 2i+1) are written back to the same two slots.  Label 0
+//     is slot 0 at all times.  The exchange is a lane-xor by 32/16/8/4/2/1, done with v_permlane32_swap,
+//     v_permlane16_swap and DPP row/quad moves -- no LDS round trip on the step's critical path.  After the
+//     exchange every lane holds (low-slot metric, high-slot metric) in the same two registers, so one formula
+//     serves both lanes of a pair; only the branch-metric increments differ per lane (constants per phase).
+//   * A VGPR carries the two frames' metrics as u16 halves biased by 0xFF00: `v_pk_add_u16 ... clamp`
+//     saturates at 0xFFFF exactly where `_mm_adds_epu8` saturates at 255; min/compare are bias-invariant.
+//   * Branch metrics arrive precomputed (one dword m00,m01,m10,m11 per step and frame, written by
+//     k_data_symbols); a lane selects its butterfly's Branchtab class with one v_perm_b32.
+//   * The 64 decision bits of a step are the lane mask of one v_cmp per frame and leave through the scalar
+//     data cache collected with v_writelane and stored 480 B at a time.  Bit p of the word of step t says
+//     "slot p's survivor came from the pair's HIGH slot", which is all the chain-back needs:
+//         p <- (p & ~(1<<q)) | (bit << q).
+//   * Renormalisation (about every 9th step per frame) reduces with DPP inside rows and four v_readlane.
+//   * The scalar unit is shared by a CU's four SIMDs, so per-step scalar work is kept to the renorm test
+//     and loop control; chain-back / descramble / CRC run in a second kernel with one LANE per frame.
 #pragma once
 
 #include "viterbi_v1.h"
@@ -24,10 +32,16 @@ typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
 constexpr uint32_t kBias = 0xFF00u;                      // stored metric = metric + kBias (per 16-bit half)
 constexpr uint32_t kBias2 = kBias | (kBias << 16);
 constexpr uint32_t kRenormThr = kBias + 210u;            // viterbi.cpp:314: renormalise when state 0 > 210
+constexpr int kChunk = 60;                               // trellis steps staged per LDS refill (multiple of 6)
 
 __device__ __forceinline__ uint32_t pk_add_sat(uint32_t a, uint32_t b)
 {
     ushort2_t r = __builtin_elementwise_add_sat(__builtin_bit_cast(ushort2_t, a), __builtin_bit_cast(ushort2_t, b));
+    return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t pk_sub_sat(uint32_t a, uint32_t b)
+{
+    ushort2_t r = __builtin_elementwise_sub_sat(__builtin_bit_cast(ushort2_t, a), __builtin_bit_cast(ushort2_t, b));
     return __builtin_bit_cast(uint32_t, r);
 }
 __device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b)
@@ -36,33 +50,100 @@ __device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b)
     return __builtin_bit_cast(uint32_t, r);
 }
 
+// Decision words are collected in VGPRs, lane J holding the word of the chunk's step J, and leave as one
+// coalesced 8-byte-per-lane store per chunk.  (Scalar stores would cost no VALU slot at all, but gfx950's
+// scalar data cache retires only about one s_store per 10 clocks per CU -- measured, tools/probe_sstore.hip.)
+struct DecAcc { uint32_t lo, hi; };
+
 template <int J>
-__device__ __forceinline__ void sstore_u64(uint64_t *base, uint64_t v)
+__device__ __forceinline__ void dec_put(DecAcc &a, uint64_t v)
 {
-    asm volatile("s_store_dwordx2 %0, %1, %2" ::"s"(v), "s"(base), "n"(J * 8) : "memory");
+    // v comes from a v_cmp (VALU-written SGPR pair).  A v_writelane that reads it as DATA less than two wait
+    // states later gets the old SGPR contents on gfx950 (observed; hipcc pads nothing inside asm statements),
+    // so the first of the two carries its own s_nop.
+    asm volatile("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(a.lo) : "s"((uint32_t)v), "n"(J));
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(a.hi) : "s"((uint32_t)(v >> 32)), "n"(J));
+}
+__device__ __forceinline__ void dec_put_dyn(DecAcc &a, uint64_t v, int j, int lane)
+{
+    a.lo = lane == j ? (uint32_t)v : a.lo;
+    a.hi = lane == j ? (uint32_t)(v >> 32) : a.hi;
 }
 
+// 6-bit rotate left
+__host__ __device__ constexpr int rotl6(int v, int r)
+{
+    r %= 6;
+    return ((v << r) | (v >> (6 - r))) & 63;
+}
+
+// After this every lane has lo = metric of its pair's low slot, hi = metric of the high slot (pair = lanes that
+// differ in bit Q).
+template <int Q>
+__device__ __forceinline__ void pair_exchange(uint32_t M, uint32_t &lo, uint32_t &hi)
+{
+    if constexpr (Q == 5) {
+        auto r = __builtin_amdgcn_permlane32_swap(M, M, false, false);
+        lo = r[0]; hi = r[1];
+    } else if constexpr (Q == 4) {
+        auto r = __builtin_amdgcn_permlane16_swap(M, M, false, false);
+        lo = r[0]; hi = r[1];
+    } else if constexpr (Q == 3) {
+        lo = (uint32_t)__builtin_amdgcn_update_dpp((int)M, (int)M, 0x118, 0xF, 0xC, false);   // row_shr:8 into lanes 8-15
+        hi = (uint32_t)__builtin_amdgcn_update_dpp((int)M, (int)M, 0x108, 0xF, 0x3, false);   // row_shl:8 into lanes 0-7
+    } else if constexpr (Q == 2) {
+        lo = (uint32_t)__builtin_amdgcn_update_dpp((int)M, (int)M, 0x114, 0xF, 0xA, false);   // row_shr:4 into banks 1,3
+        hi = (uint32_t)__builtin_amdgcn_update_dpp((int)M, (int)M, 0x104, 0xF, 0x5, false);   // row_shl:4 into banks 0,2
+    } else if constexpr (Q == 1) {
+        lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)M, 0x44, 0xF, 0xF, true);           // quad_perm [0,1,0,1]
+        hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)M, 0xEE, 0xF, 0xF, true);           // quad_perm [2,3,2,3]
+    } else {
+        lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)M, 0xA0, 0xF, 0xF, true);           // quad_perm [0,0,2,2]
+        hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)M, 0xF5, 0xF, 0xF, true);           // quad_perm [1,1,3,3]
+    }
+}
+
+// per-lane constants of the six phases
 struct Fwd2Lane {
-    uint32_t sel, flip;
-    int src_lo, src_hi;
+    uint32_t sel[6];      // v_perm selector {0, B.byte[cls], 0, A.byte[cls]} of this lane's butterfly class
+    uint32_t flip[6];     // 0x003F003F when this lane is the pair's high slot (it adds 63-m on the low branch)
 };
 
-// One trellis step for both frames.  SA/SB: store frame A's / B's decision word (at da[J] / db[J]).
-template <int J, bool SA, bool SB>
-__device__ __forceinline__ uint32_t fwd2_step(uint32_t M, const uint2 *bml, const Fwd2Lane &c, uint64_t *da, uint64_t *db)
+__device__ __forceinline__ Fwd2Lane fwd2_lane_init(int lane)
 {
-    const uint2 w = bml[J];                                              // same address in every lane: LDS broadcast
-    const uint32_t m = __builtin_amdgcn_perm(w.y, w.x, c.sel);
-    const uint32_t ma = m ^ c.flip, mb = ma ^ 0x003F003Fu;
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(c.src_lo, (int)M);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(c.src_hi, (int)M);
-    const uint32_t x = pk_add_sat(lo, ma), y = pk_add_sat(hi, mb);
-    if (SA) sstore_u64<J>(da, __ballot((y & 0xFFFFu) <= (x & 0xFFFFu)));    // upper predecessor wins ties
-    if (SB) sstore_u64<J>(db, __ballot((y >> 16) <= (x >> 16)));
+    Fwd2Lane c;
+#pragma unroll
+    for (int ph = 0; ph < 6; ph++) {
+        const int q = 5 - ph;
+        const int i = rotl6(lane & ~(1 << q), ph);                       // old label of the pair's low slot (< 32)
+        const uint32_t cls = ((__popc((2 * i) & 121) & 1) << 1) | (__popc((2 * i) & 91) & 1);   // viterbi.cpp:86-91
+        c.sel[ph] = 0x0C000C00u | ((4u + cls) << 16) | cls;
+        c.flip[ph] = ((lane >> q) & 1) ? 0x003F003Fu : 0u;
+    }
+    return c;
+}
+
+// One trellis step (phase PH = t mod 6) for both frames.  SA/SB: record frame A's / B's decision word as the
+// chunk's step J (J < 0: run-time index jdyn).
+template <int PH, int J, bool SA, bool SB>
+__device__ __forceinline__ uint32_t fwd2_step(uint32_t M, const uint2 w, const Fwd2Lane &c, DecAcc &accA, DecAcc &accB, int jdyn, int lane)
+{
+    const uint32_t m = __builtin_amdgcn_perm(w.y, w.x, c.sel[PH]);
+    const uint32_t inc_lo = m ^ c.flip[PH], inc_hi = inc_lo ^ 0x003F003Fu;
+    uint32_t lo, hi;
+    pair_exchange<5 - PH>(M, lo, hi);
+    const uint32_t x = pk_add_sat(lo, inc_lo), y = pk_add_sat(hi, inc_hi);
+    if (SA) {
+        const uint64_t d = __ballot((y & 0xFFFFu) <= (x & 0xFFFFu));        // high (old MSB = 1) predecessor wins ties
+        if constexpr (J >= 0) dec_put<(J >= 0 ? J : 0)>(accA, d); else dec_put_dyn(accA, d, jdyn, lane);
+    }
+    if (SB) {
+        const uint64_t d = __ballot((y >> 16) <= (x >> 16));
+        if constexpr (J >= 0) dec_put<(J >= 0 ? J : 0)>(accB, d); else dec_put_dyn(accB, d, jdyn, lane);
+    }
     uint32_t Mn = pk_min(x, y);
-    // viterbi.cpp:314-332 per frame: renormalise when the new metric of state 0 (lane 0) exceeds 210
-    const ushort2_t over = __builtin_elementwise_sub_sat(__builtin_bit_cast(ushort2_t, Mn), __builtin_bit_cast(ushort2_t, kRenormThr | (kRenormThr << 16)));
-    const uint32_t c0 = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(uint32_t, over));
+    // viterbi.cpp:314-332 per frame: renormalise when the new metric of state 0 (slot 0 = lane 0) exceeds 210
+    const uint32_t c0 = __builtin_amdgcn_readfirstlane(pk_sub_sat(Mn, kRenormThr | (kRenormThr << 16)));
     if (c0) {
         uint32_t v = Mn;
         v = pk_min(v, dpp_mov<FOA_DPP_XOR1>(v));
@@ -78,24 +159,54 @@ __device__ __forceinline__ uint32_t fwd2_step(uint32_t M, const uint2 *bml, cons
     return Mn;
 }
 
-template <bool SA, bool SB>
-__device__ __forceinline__ uint32_t fwd2_run(uint32_t M, int t0, int nn, const uint2 *bml, const Fwd2Lane &c, uint64_t *dA, uint64_t *dB)
+// six steps (one of each phase) whose chunk-relative indices are J0 .. J0+5
+template <int J0, bool SA, bool SB>
+__device__ __forceinline__ uint32_t fwd2_group(uint32_t M, const uint2 *bml, const Fwd2Lane &c, DecAcc &accA, DecAcc &accB, int lane)
 {
-    int j = 0;
-    for (; j + 8 <= nn; j += 8) {
-        uint64_t *da = dA + t0 + j, *db = dB + t0 + j;
-        const uint2 *b = bml + j;
-        M = fwd2_step<0, SA, SB>(M, b, c, da, db);
-        M = fwd2_step<1, SA, SB>(M, b, c, da, db);
-        M = fwd2_step<2, SA, SB>(M, b, c, da, db);
-        M = fwd2_step<3, SA, SB>(M, b, c, da, db);
-        M = fwd2_step<4, SA, SB>(M, b, c, da, db);
-        M = fwd2_step<5, SA, SB>(M, b, c, da, db);
-        M = fwd2_step<6, SA, SB>(M, b, c, da, db);
-        M = fwd2_step<7, SA, SB>(M, b, c, da, db);
-    }
-    for (; j < nn; j++) M = fwd2_step<0, SA, SB>(M, bml + j, c, dA + t0 + j, dB + t0 + j);
+    // the six LDS broadcast reads (same address in every lane) are issued together, ahead of the dependent chain
+    const uint2 w0 = bml[J0], w1 = bml[J0 + 1], w2 = bml[J0 + 2], w3 = bml[J0 + 3], w4 = bml[J0 + 4], w5 = bml[J0 + 5];
+    M = fwd2_step<0, J0 + 0, SA, SB>(M, w0, c, accA, accB, 0, lane);
+    M = fwd2_step<1, J0 + 1, SA, SB>(M, w1, c, accA, accB, 0, lane);
+    M = fwd2_step<2, J0 + 2, SA, SB>(M, w2, c, accA, accB, 0, lane);
+    M = fwd2_step<3, J0 + 3, SA, SB>(M, w3, c, accA, accB, 0, lane);
+    M = fwd2_step<4, J0 + 4, SA, SB>(M, w4, c, accA, accB, 0, lane);
+    M = fwd2_step<5, J0 + 5, SA, SB>(M, w5, c, accA, accB, 0, lane);
     return M;
+}
+
+// a full chunk of kChunk = 60 steps, completely unrolled so that every v_writelane has a constant lane
+template <bool SA, bool SB>
+__device__ __forceinline__ uint32_t fwd2_chunk(uint32_t M, const uint2 *bml, const Fwd2Lane &c, DecAcc &accA, DecAcc &accB, int lane)
+{
+    M = fwd2_group<0, SA, SB>(M, bml, c, accA, accB, lane);
+    M = fwd2_group<6, SA, SB>(M, bml, c, accA, accB, lane);
+    M = fwd2_group<12, SA, SB>(M, bml, c, accA, accB, lane);
+    M = fwd2_group<18, SA, SB>(M, bml, c, accA, accB, lane);
+    M = fwd2_group<24, SA, SB>(M, bml, c, accA, accB, lane);
+    M = fwd2_group<30, SA, SB>(M, bml, c, accA, accB, lane);
+    M = fwd2_group<36, SA, SB>(M, bml, c, accA, accB, lane);
+    M = fwd2_group<42, SA, SB>(M, bml, c, accA, accB, lane);
+    M = fwd2_group<48, SA, SB>(M, bml, c, accA, accB, lane);
+    M = fwd2_group<54, SA, SB>(M, bml, c, accA, accB, lane);
+    return M;
+}
+
+// a single step with run-time index, phase and store flags (chunks in which a frame ends)
+__device__ __forceinline__ uint32_t fwd2_step_dyn(uint32_t M, int j, bool sa, bool sb, const uint2 *bml, const Fwd2Lane &c, DecAcc &accA,
+                                                  DecAcc &accB, int lane)
+{
+    const uint2 w = bml[j];
+#define FOA_DYN(PH)                                                                          \
+    case PH:                                                                                 \
+        if (sa && sb) return fwd2_step<PH, -1, true, true>(M, w, c, accA, accB, j, lane);    \
+        if (sa) return fwd2_step<PH, -1, true, false>(M, w, c, accA, accB, j, lane);         \
+        return fwd2_step<PH, -1, false, true>(M, w, c, accA, accB, j, lane);
+    switch (j % 6) {
+        FOA_DYN(0) FOA_DYN(1) FOA_DYN(2) FOA_DYN(3) FOA_DYN(4)
+    default:
+        FOA_DYN(5)
+    }
+#undef FOA_DYN
 }
 
 __global__ __launch_bounds__(64) void k_viterbi_fwd2(const FrameInfo *__restrict__ info, int n_frames, const uint32_t *__restrict__ bm,
@@ -114,35 +225,28 @@ __global__ __launch_bounds__(64) void k_viterbi_fwd2(const FrameInfo *__restrict
     if (T == 0) return;
     const uint32_t *bmA = bm + ia.dec_off, *bmB = bm + ib.dec_off;
     uint64_t *dA = dec + ia.dec_off, *dB = dec + ib.dec_off;
+    const Fwd2Lane c = fwd2_lane_init(lane);
+    uint32_t M = lane == 0 ? kBias2 : kBias2 + 0x003F003Fu;               // viterbi.cpp:71-78 (label 0 = slot 0)
 
-    // lane constants: butterfly i = lane>>1, its Branchtab class (viterbi.cpp:86-91); odd states swap m / 63-m
-    const int i = lane >> 1;
-    const uint32_t cls = ((__popc((2 * i) & 121) & 1) << 1) | (__popc((2 * i) & 91) & 1);
-    Fwd2Lane c;
-    c.sel = 0x0C000C00u | ((4u + cls) << 16) | cls;                      // {0, B.byte[cls], 0, A.byte[cls]}
-    c.flip = (lane & 1) ? 0x003F003Fu : 0u;
-    c.src_lo = i * 4; c.src_hi = (i + 32) * 4;
-    uint32_t M = lane == 0 ? kBias2 : kBias2 + 0x003F003Fu;               // viterbi.cpp:71-78
-
-    for (int t0 = 0; t0 < T; t0 += 64) {
-        const int nn = min(64, T - t0);
+    for (int t0 = 0; t0 < T; t0 += kChunk) {                              // t0 mod 6 == 0: phase = chunk-relative index mod 6
+        const int nn = min(kChunk, T - t0);
         __builtin_amdgcn_wave_barrier();
         bml[lane] = make_uint2(t0 + lane < TA ? bmA[t0 + lane] : 0u, t0 + lane < TB ? bmB[t0 + lane] : 0u);
         wave_lds_sync();
-        // steps where both frames are alive, then the tail of the longer one (all wave-uniform)
-        const int nb = max(0, min(nn, Tboth - t0));
-        M = fwd2_run<true, true>(M, t0, nb, bml, c, dA, dB);
-        if (nb < nn) {
-            if (TA > TB) M = fwd2_run<true, false>(M, t0 + nb, nn - nb, bml + nb, c, dA, dB);
-            else M = fwd2_run<false, true>(M, t0 + nb, nn - nb, bml + nb, c, dA, dB);
-        }
+        DecAcc accA = { 0u, 0u }, accB = { 0u, 0u };
+        if (t0 + kChunk <= Tboth) M = fwd2_chunk<true, true>(M, bml, c, accA, accB, lane);
+        else if (nn == kChunk && t0 >= TB) M = fwd2_chunk<true, false>(M, bml, c, accA, accB, lane);
+        else if (nn == kChunk && t0 >= TA) M = fwd2_chunk<false, true>(M, bml, c, accA, accB, lane);
+        else
+            for (int j = 0; j < nn; j++) M = fwd2_step_dyn(M, j, t0 + j < TA, t0 + j < TB, bml, c, accA, accB, lane);
+        if (t0 + lane < TA && lane < nn) dA[t0 + lane] = ((uint64_t)accA.hi << 32) | accA.lo;
+        if (t0 + lane < TB && lane < nn) dB[t0 + lane] = ((uint64_t)accB.hi << 32) | accB.lo;
     }
-    asm volatile("s_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-// Chain-back (viterbi.cpp:108-146), descrambler and CRC-32 (ppdu.cpp:256-293), one LANE per frame: the
-// recursion is serial per frame and a handful of integer ops per step, so 64 frames share a wave and
-// nothing runs on the (CU-shared) scalar unit.
+// Chain-back (viterbi.cpp:108-146) in slot space, descrambler and CRC-32 (ppdu.cpp:256-293), one LANE per frame:
+// the recursion is serial per frame and a handful of integer ops per step, so 64 frames share a wave and
+// nothing runs on the CU-shared scalar unit.
 __global__ __launch_bounds__(64) void k_viterbi_finish2(const FrameInfo *__restrict__ info, int n_frames, const uint64_t *__restrict__ dec,
                                                         uint32_t *__restrict__ decoded, uint8_t *__restrict__ psdu, size_t slot_bytes,
                                                         foa_frame_result *__restrict__ results)
@@ -161,12 +265,15 @@ __global__ __launch_bounds__(64) void k_viterbi_finish2(const FrameInfo *__restr
     int maxbits = data_bits;
 #pragma unroll
     for (int o = 32; o; o >>= 1) maxbits = max(maxbits, __shfl_xor(maxbits, o));
-    // chain-back: bit n uses the decision word of step n+6; endstate 0
-    uint32_t e = 0, word = 0;
+    // Data bit n is the decision bit read at step n+6 (viterbi.cpp:131-142); the walk starts in state 0 = slot 0
+    // at time T.  The steps T-1 .. data_bits+6 do not exist (T = data_bits + 6), so the first word read is T-1.
+    uint32_t p = 0, e = 0, word = 0;
     for (int n = maxbits - 1; n >= 0; n--) {
         if (n < data_bits) {
-            const uint64_t w = dp[n + 6];
-            const uint32_t k = (uint32_t)(w >> (e >> 2)) & 1u;
+            const int t = n + 6, q = 5 - t % 6;
+            const uint64_t w = dp[t];
+            const uint32_t k = (uint32_t)(w >> p) & 1u;
+            p = (p & ~(1u << q)) | (k << q);
             e = (e >> 1) | (k << 7);
             if ((n & 7) == 0) {
                 word = (word << 8) | e;

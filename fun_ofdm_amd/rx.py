@@ -89,6 +89,13 @@ class Receiver:
                                     _vp(soft_buf) if soft else None, soft_buf.size if soft else 0, _vp(soft_off)))
         return dict(hinv=hinv, eq=eq_buf, eq_off=eq_off.astype(np.int64), soft=soft_buf, soft_off=soft_off.astype(np.int64))
 
+    def decisions(self, frame, cap=40000):
+        """Raw decision words of one frame of the last decode call (layout: see foa_rx_get_decisions)."""
+        out = np.zeros(cap, np.uint64)
+        n = C.c_size_t(0)
+        check(lib().foa_rx_get_decisions(self._h, int(frame), _vp(out), cap, C.byref(n)))
+        return out[:n.value]
+
     # ---- stage-level entry points ------------------------------------------------------------------
     def fft_forward(self, vectors):
         """fft::forward on [n,64] complex128 (src/fft.cpp:50-59)."""

@@ -128,7 +128,11 @@ int foa_rx_last_kernel_ms(foa_rx *rx, float out_ms[5]);
  * decoded; eq_off/soft_off (n_frames+1 entries each, may be NULL) receive the element offsets. */
 int foa_rx_get_taps(foa_rx *rx, size_t n_frames, double *hinv, double *eq, size_t eq_cap, uint64_t *eq_off,
                     uint8_t *soft, size_t soft_cap, uint64_t *soft_off);
-/* Ask the next decode calls to record `eq` (costs memory traffic; off by default). */
+/* Raw decision words of one frame of the most recent decode call (debugging / unit parity of the forward
+ * kernel): n_steps = num_symbols * dbps words.  Layout depends on the kernel in use: option viterbi=0 writes the
+ * reference's decision_t (bit s = new state s, src/viterbi.h:36-41); viterbi=1 writes slot order (bit p of step t
+ * belongs to the state whose label is the 6-bit left-rotation of p by t+1). */
+int foa_rx_get_decisions(foa_rx *rx, size_t frame, uint64_t *out, size_t cap, size_t *n_steps);
 
 /* ---- pre-sync (host side for now; SURVEY 8f #1 moves it onto the device) ---- */
 
