@@ -242,6 +242,10 @@ __global__ __launch_bounds__(64) void k_viterbi_fwd2(const FrameInfo *__restrict
         if (t0 + lane < TA && lane < nn) dA[t0 + lane] = ((uint64_t)accA.hi << 32) | accA.lo;
         if (t0 + lane < TB && lane < nn) dB[t0 + lane] = ((uint64_t)accB.hi << 32) | accB.lo;
     }
+    // the chain-back kernel reads whole 24-step blocks: words between a frame's last step and the end of its
+    // 64-word-padded region must read as "no decision" (zero keeps its walk parked in slot 0)
+    if (TA + lane < ((TA + 63) & ~63)) dA[TA + lane] = 0;
+    if (TB > 0 && TB + lane < ((TB + 63) & ~63)) dB[TB + lane] = 0;
 }
 
 // Chain-back (viterbi.cpp:108-146) in slot space, descrambler and CRC-32 (ppdu.cpp:256-293), one LANE per frame:
@@ -262,24 +266,48 @@ __global__ __launch_bounds__(64) void k_viterbi_finish2(const FrameInfo *__restr
     const int T = live ? fi.nsteps : 0, data_bits = T - 6;
     const uint64_t *dp = dec + fi.dec_off;
     uint32_t *out = decoded + fi.dec_off;                  // T/8 bytes needed; the region holds >= T dwords
-    int maxbits = data_bits;
-#pragma unroll
-    for (int o = 32; o; o >>= 1) maxbits = max(maxbits, __shfl_xor(maxbits, o));
     // Data bit n is the decision bit read at step n+6 (viterbi.cpp:131-142); the walk starts in state 0 = slot 0
-    // at time T.  The steps T-1 .. data_bits+6 do not exist (T = data_bits + 6), so the first word read is T-1.
+    // at time T and follows  p <- (p & ~(1<<q)) | (bit << q),  q = 5 - t mod 6.  Steps are taken in blocks of 24
+    // (a multiple of the 6 phases, so q and the byte boundaries are compile-time inside the unrolled block); a
+    // block's 24 words are fetched as twelve 16-byte loads one block ahead of their use, since the addresses do not
+    // depend on the walk.  Words past a frame's last step read as zero and leave p = e = 0 untouched.
+    const int Tpad = (T + 63) & ~63;
+    int maxT = T;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) maxT = max(maxT, __shfl_xor(maxT, o));
     uint32_t p = 0, e = 0, word = 0;
-    for (int n = maxbits - 1; n >= 0; n--) {
-        if (n < data_bits) {
-            const int t = n + 6, q = 5 - t % 6;
-            const uint64_t w = dp[t];
-            const uint32_t k = (uint32_t)(w >> p) & 1u;
-            p = (p & ~(1u << q)) | (k << q);
-            e = (e >> 1) | (k << 7);
-            if ((n & 7) == 0) {
-                word = (word << 8) | e;
-                if ((n & 31) == 0) out[n >> 5] = word;
-            }
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    u64x2 cur[12], nxt[12];
+    auto load_block = [&](u64x2 *buf, int tb) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            const int t = tb + 2 * i;
+            buf[i] = t < Tpad ? *(const u64x2 *)(dp + t) : u64x2{ 0ull, 0ull };
         }
+    };
+    auto step = [&](uint64_t w, int j, int tb) {                         // j: compile-time position inside the block
+        const int q = 5 - j % 6;                                           // tb is a multiple of 6
+        const uint32_t k = (uint32_t)(w >> p) & 1u;
+        p = (p & ~(1u << q)) | (k << q);
+        e = (e >> 1) | (k << 7);
+        if (((j - 6) & 7) == 0) {                                          // n = tb + j - 6, tb is a multiple of 8
+            word = (word << 8) | e;
+            const int n = tb + j - 6;
+            if ((n & 31) == 0 && n < data_bits) out[n >> 5] = word;
+        }
+    };
+    if (maxT > 0) {
+        int tb = (maxT - 1) / 24 * 24;
+        load_block(cur, tb);
+        for (; tb >= 24; tb -= 24) {
+            load_block(nxt, tb - 24);
+#pragma unroll
+            for (int j = 23; j >= 0; j--) step(cur[j >> 1][j & 1], j, tb);
+#pragma unroll
+            for (int i = 0; i < 12; i++) cur[i] = nxt[i];
+        }
+#pragma unroll
+        for (int j = 23; j >= 6; j--) step(cur[j >> 1][j & 1], j, 0);      // steps 0..5 carry no data bit
     }
     // descramble (one LFSR bit per byte, ppdu.cpp:256-264) + CRC over service+payload (ppdu.cpp:267-271)
     const int len = fi.length, ncrc = live ? 2 + len : 0, nwords = live ? (ncrc + 4 + 3) / 4 : 0;
