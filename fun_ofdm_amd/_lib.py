@@ -48,6 +48,11 @@ _SIGS = {
     "foa_sync_settled": (C.c_int64, [C.c_void_p]),
     "foa_fft_forward_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "foa_conv_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]),
+    "foa_channel_estimate_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "foa_equalize_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "foa_phase_track_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "foa_decode_header_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "foa_decode_data_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]),
 }
 
 EXPORTS = tuple(_SIGS)

@@ -10,6 +10,7 @@
 #include "frontend_kernels.h"
 #include "viterbi_v1.h"
 #include "viterbi_v2.h"
+#include "stage_kernels.h"
 #include "sync_host.h"
 
 using namespace foa;
@@ -433,6 +434,141 @@ int foa_conv_decode(foa_rx *rx, const uint8_t *symbols, uint8_t *data, int data_
     hipLaunchKernelGGL(k_conv_decode, dim3((unsigned)n_blocks), dim3(64), 0, rx->stream, d_sym, d_out, data_bits, (int)n_blocks, rx->dec.p, (int)stride);
     HIP_TRY(hipMemcpyAsync(data, d_out, out_bytes, hipMemcpyDeviceToHost, rx->stream));
     HIP_TRY(hipStreamSynchronize(rx->stream));
+    return FOA_OK;
+}
+
+int foa_channel_estimate_f64(foa_rx *rx, const double *lts_pairs, double *hinv, size_t n)
+{
+    if (!rx || !lts_pairs || !hinv) return fail(FOA_E_INVALID, "NULL argument");
+    if (n == 0) return FOA_OK;
+    HIP_TRY(hipSetDevice(rx->device));
+    const size_t in_b = n * 128 * sizeof(double2), out_b = n * 64 * sizeof(double2);
+    int rc = rx->scratch.ensure(in_b + out_b);
+    if (rc) return rc;
+    double2 *d_in = (double2 *)rx->scratch.p, *d_out = (double2 *)(rx->scratch.p + in_b);
+    HIP_TRY(hipMemcpyAsync(d_in, lts_pairs, in_b, hipMemcpyHostToDevice, rx->stream));
+    hipLaunchKernelGGL(k_stage_chanest, dim3((unsigned)n), dim3(64), 0, rx->stream, d_in, d_out, (int)n);
+    HIP_TRY(hipMemcpyAsync(hinv, d_out, out_b, hipMemcpyDeviceToHost, rx->stream));
+    HIP_TRY(hipStreamSynchronize(rx->stream));
+    return FOA_OK;
+}
+
+int foa_equalize_f64(foa_rx *rx, double *vectors, size_t n_vec, const double *hinv, size_t n_hinv, const int32_t *hinv_index)
+{
+    if (!rx || !vectors || !hinv || !hinv_index) return fail(FOA_E_INVALID, "NULL argument");
+    if (n_vec == 0) return FOA_OK;
+    for (size_t i = 0; i < n_vec; i++)
+        if (hinv_index[i] < 0 || (size_t)hinv_index[i] >= n_hinv) return fail(FOA_E_INVALID, "hinv_index[%zu] out of range", i);
+    HIP_TRY(hipSetDevice(rx->device));
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t v_b = n_vec * 64 * sizeof(double2), h_b = n_hinv * 64 * sizeof(double2), i_b = n_vec * sizeof(int32_t);
+    int rc = rx->scratch.ensure(up(v_b) + up(h_b) + up(i_b));
+    if (rc) return rc;
+    uint8_t *b = rx->scratch.p;
+    HIP_TRY(hipMemcpyAsync(b, vectors, v_b, hipMemcpyHostToDevice, rx->stream));
+    HIP_TRY(hipMemcpyAsync(b + up(v_b), hinv, h_b, hipMemcpyHostToDevice, rx->stream));
+    HIP_TRY(hipMemcpyAsync(b + up(v_b) + up(h_b), hinv_index, i_b, hipMemcpyHostToDevice, rx->stream));
+    hipLaunchKernelGGL(k_stage_equalize, dim3((unsigned)((n_vec + 3) / 4)), dim3(256), 0, rx->stream, (double2 *)b, (int)n_vec,
+                       (const double2 *)(b + up(v_b)), (const int32_t *)(b + up(v_b) + up(h_b)));
+    HIP_TRY(hipMemcpyAsync(vectors, b, v_b, hipMemcpyDeviceToHost, rx->stream));
+    HIP_TRY(hipStreamSynchronize(rx->stream));
+    return FOA_OK;
+}
+
+int foa_phase_track_f64(foa_rx *rx, const double *vectors, const int32_t *symbol_count, size_t n_vec, double *out48)
+{
+    if (!rx || !vectors || !symbol_count || !out48) return fail(FOA_E_INVALID, "NULL argument");
+    if (n_vec == 0) return FOA_OK;
+    HIP_TRY(hipSetDevice(rx->device));
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t v_b = n_vec * 64 * sizeof(double2), c_b = n_vec * sizeof(int32_t), o_b = n_vec * 48 * sizeof(double2);
+    int rc = rx->scratch.ensure(up(v_b) + up(c_b) + up(o_b));
+    if (rc) return rc;
+    uint8_t *b = rx->scratch.p;
+    HIP_TRY(hipMemcpyAsync(b, vectors, v_b, hipMemcpyHostToDevice, rx->stream));
+    HIP_TRY(hipMemcpyAsync(b + up(v_b), symbol_count, c_b, hipMemcpyHostToDevice, rx->stream));
+    hipLaunchKernelGGL(k_stage_phase, dim3((unsigned)((n_vec + 3) / 4)), dim3(256), 0, rx->stream, (const double2 *)b,
+                       (const int32_t *)(b + up(v_b)), (int)n_vec, (double2 *)(b + up(v_b) + up(c_b)));
+    HIP_TRY(hipMemcpyAsync(out48, b + up(v_b) + up(c_b), o_b, hipMemcpyDeviceToHost, rx->stream));
+    HIP_TRY(hipStreamSynchronize(rx->stream));
+    return FOA_OK;
+}
+
+int foa_decode_header_f64(foa_rx *rx, const double *carriers48, size_t n, foa_frame_result *results)
+{
+    if (!rx || !carriers48 || !results) return fail(FOA_E_INVALID, "NULL argument");
+    if (n == 0) return FOA_OK;
+    HIP_TRY(hipSetDevice(rx->device));
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t c_b = n * 48 * sizeof(double2), r_b = n * sizeof(foa_frame_result);
+    int rc = rx->scratch.ensure(up(c_b) + up(r_b));
+    if (rc) return rc;
+    uint8_t *b = rx->scratch.p;
+    HIP_TRY(hipMemcpyAsync(b, carriers48, c_b, hipMemcpyHostToDevice, rx->stream));
+    hipLaunchKernelGGL(k_stage_header, dim3((unsigned)n), dim3(64), 0, rx->stream, (const double2 *)b, (int)n, (foa_frame_result *)(b + up(c_b)));
+    HIP_TRY(hipMemcpyAsync(results, b + up(c_b), r_b, hipMemcpyDeviceToHost, rx->stream));
+    HIP_TRY(hipStreamSynchronize(rx->stream));
+    return FOA_OK;
+}
+
+int foa_decode_data_f64(foa_rx *rx, const double *carriers, const uint64_t *carrier_off, size_t n_frames, foa_frame_result *results,
+                        uint8_t *psdu, size_t slot_bytes)
+{
+    if (!rx || !carriers || !carrier_off || !results || !psdu) return fail(FOA_E_INVALID, "NULL argument");
+    if (n_frames == 0) return FOA_OK;
+    HIP_TRY(hipSetDevice(rx->device));
+    DeviceTables tab;
+    build_tables(&tab);
+    // frame records and offsets on the host (what k_header + k_scan produce in the fused path)
+    std::vector<FrameInfo> info(n_frames);
+    std::vector<int32_t> sym2frame;
+    std::vector<int64_t> coff(n_frames + 1);
+    int64_t soft_off = 0, dec_off = 0;
+    for (size_t f = 0; f < n_frames; f++) {
+        const int rate = results[f].rate, len = results[f].length;
+        if (rate < 0 || rate >= kNumRates || len < 0 || len > 4095) return fail(FOA_E_INVALID, "frame %zu: bad rate/length", f);
+        const int dbps = tab.rates[rate].dbps, nsym = (16 + 8 * (len + 4) + 6 + dbps - 1) / dbps;
+        if (carrier_off[f + 1] - carrier_off[f] != (uint64_t)nsym * 48) return fail(FOA_E_INVALID, "frame %zu: needs %d carriers", f, nsym * 48);
+        FrameInfo &fi = info[f];
+        fi.status = FOA_ST_CRC_FAIL; fi.rate = rate; fi.length = len; fi.nsym = nsym; fi.sym_off = (int32_t)sym2frame.size();
+        fi.nsteps = nsym * dbps; fi.soft_off = soft_off; fi.dec_off = dec_off;
+        soft_off += ((int64_t)2 * fi.nsteps + 255) & ~(int64_t)255;
+        dec_off += (fi.nsteps + 63) & ~63;
+        coff[f] = (int64_t)carrier_off[f];
+        sym2frame.insert(sym2frame.end(), (size_t)nsym, (int32_t)f);
+        results[f].num_symbols = nsym;
+    }
+    coff[n_frames] = (int64_t)carrier_off[n_frames];
+    const size_t n_sym = sym2frame.size(), n_car = (size_t)carrier_off[n_frames];
+    int rc;
+    if ((rc = rx->info.ensure(n_frames + 1)) || (rc = rx->sym2frame.ensure(n_sym + 1)) || (rc = rx->soft.ensure((size_t)soft_off + 256)) ||
+        (rc = rx->dec.ensure((size_t)dec_off + 64)) || (rc = rx->bm.ensure((size_t)dec_off + 64)) || (rc = rx->decoded.ensure((size_t)dec_off + 64)))
+        return rc;
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t c_b = n_car * sizeof(double2), o_b = (n_frames + 1) * sizeof(int64_t), p_b = n_frames * slot_bytes, r_b = n_frames * sizeof(foa_frame_result);
+    if ((rc = rx->scratch.ensure(up(c_b) + up(o_b) + up(p_b) + up(r_b)))) return rc;
+    uint8_t *b = rx->scratch.p;
+    uint8_t *d_psdu = b + up(c_b) + up(o_b);
+    foa_frame_result *d_res = (foa_frame_result *)(d_psdu + up(p_b));
+    hipStream_t st = rx->stream;
+    HIP_TRY(hipMemcpyAsync(b, carriers, c_b, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(b + up(c_b), coff.data(), o_b, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(rx->info.p, info.data(), n_frames * sizeof(FrameInfo), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(rx->sym2frame.p, sym2frame.data(), n_sym * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(d_psdu, 0, p_b, st));
+    hipLaunchKernelGGL(k_stage_demap, dim3((unsigned)((n_sym + kSymWaves - 1) / kSymWaves)), dim3(64 * kSymWaves), 0, st, (const double2 *)b,
+                       (const int64_t *)(b + up(c_b)), rx->info.p, rx->sym2frame.p, (int)n_sym, rx->soft.p, rx->bm.p);
+    if (rx->viterbi_kind == 0)
+        hipLaunchKernelGGL(k_viterbi_v1, dim3((unsigned)n_frames), dim3(64), 0, st, rx->info.p, (int)n_frames, rx->soft.p, rx->dec.p, d_psdu, slot_bytes, d_res);
+    else
+        launch_viterbi_v2(st, rx->info.p, (int)n_frames, rx->bm.p, rx->dec.p, rx->decoded.p, d_psdu, slot_bytes, d_res);
+    HIP_TRY(hipMemcpyAsync(psdu, d_psdu, p_b, hipMemcpyDeviceToHost, st));
+    std::vector<foa_frame_result> out(n_frames);
+    HIP_TRY(hipMemcpyAsync(out.data(), d_res, r_b, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    for (size_t f = 0; f < n_frames; f++) results[f].status = out[f].status;
+    rx->last_frames = 0;      // the workspace no longer describes a decode_frames call
     return FOA_OK;
 }
 

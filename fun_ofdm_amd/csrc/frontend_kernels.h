@@ -239,6 +239,75 @@ __device__ __forceinline__ uint32_t acs_step(uint32_t M, uint32_t s0, uint32_t s
     return Mn;
 }
 
+
+// ppdu.cpp:178-209: the 48 deinterleaved BPSK soft bytes of a SIGNAL symbol -> conv_decode(18 bits, i.e. 24
+// trellis steps) -> parity / rate checks.  dem, decs: LDS (48 bytes, 24 words).  All lanes return the same values;
+// rate < 0 on failure.
+__device__ __forceinline__ void decode_signal_bits(const uint8_t *dem, uint64_t *decs, int lane, int &rate, int &length, int &nsym)
+{
+    const AcsLane acs = acs_lane_init(lane);
+    uint32_t M = lane == 0 ? 0u : 63u;
+    for (int t = 0; t < 24; t++) {
+        uint64_t dec;
+        M = acs_step(M, dem[2 * t], dem[2 * t + 1], acs, dec);
+        if (lane == 0) decs[t] = dec;
+    }
+    __syncthreads();
+    // viterbi.cpp:131-142 chain-back from state 0, 18 bits -> 3 bytes MSB first
+    uint32_t e = 0, hb[3] = { 0, 0, 0 };
+    for (int n = 17; n >= 0; n--) {
+        uint32_t k = (uint32_t)((decs[n + 6] >> (e >> 2)) & 1ull);
+        e = (e >> 1) | (k << 7);
+        hb[n >> 3] = e;
+    }
+    const uint32_t field = (hb[0] << 16) | (hb[1] << 8) | hb[2];
+    rate = -1; length = 0; nsym = 0;
+    if ((__popc(field) & 1) == 0) {                                       // ppdu.cpp:187-191
+        const int rf = (field >> 19) & 0xF;
+        for (int r = 0; r < kNumRates; r++) if (g_tab.rates[r].rate_field == rf) rate = r;   // ppdu.cpp:198-203
+    }
+    if (rate >= 0) {
+        length = (field >> 6) & 0xFFF;
+        const int dbps = g_tab.rates[rate].dbps;
+        nsym = (16 + 8 * (length + 4) + 6 + dbps - 1) / dbps;             // ppdu.cpp:206-209 (exact in integers)
+    }
+}
+
+// One data symbol's 48 derotated carriers -> depunctured soft bytes (+ branch-metric dwords) of its 2*dbps/dbps
+// trellis positions.  Lane with data index di >= 0 holds carrier z.  stage: 448 B of LDS private to the wave.
+// modulator.cpp:108-164 / qam.h:110-125, interleaver.cpp:28-38, puncturer.cpp:78-123.
+__device__ __forceinline__ void emit_symbol_soft(cpx z, int di, const RateRow &rr, uint8_t *stage, uint8_t *soft_dst, uint32_t *bm_dst, int lane)
+{
+    // erasures first (puncturer.cpp:98,100,114), then scatter this carrier's soft bytes
+    const int out_bytes = 2 * rr.dbps;                         // depunctured bytes of this symbol
+    if (rr.punct != 0) {
+        uint32_t *st32 = (uint32_t *)stage;
+        for (int i = lane; i < out_bytes / 4; i += 64) st32[i] = 0x7F7F7F7Fu;
+    }
+    wave_lds_sync();
+    if (di >= 0) {
+        uint8_t bits[6];
+        qam_decode(z.x, rr.numbits, rr.scale_d, bits);
+        if (rr.bpsc > 1) qam_decode(z.y, rr.numbits, rr.scale_d, bits + rr.numbits);
+        for (int b = 0; b < rr.bpsc; b++) {
+            int c = di * rr.bpsc + b;                          // demodulated byte index within the symbol
+            int dd = 48 * (c / 48) + deinterleaved_pos(c % 48);
+            stage[depunct_pos(dd, rr.punct)] = bits[b];        // symbol-local: cbps is a multiple of 12
+        }
+    }
+    wave_lds_sync();
+    uint32_t *dst = (uint32_t *)soft_dst;
+    const uint32_t *st32 = (const uint32_t *)stage;
+    for (int i = lane; i < out_bytes / 4; i += 64) dst[i] = st32[i];
+    // Branch metrics of this symbol's trellis steps for the packed Viterbi kernel: byte j = 2*b0 + b1 holds
+    // (((s0 ^ b0*255) + (s1 ^ b1*255) + 1) >> 1) >> 2, the value viterbi.cpp:242-247 derives per butterfly
+    // from Branchtab entries (b0, b1).
+    for (int t = lane; t < rr.dbps; t += 64) {
+        const uint32_t s0 = stage[2 * t], s1 = stage[2 * t + 1], n0 = s0 ^ 255u, n1 = s1 ^ 255u;
+        bm_dst[t] = ((s0 + s1 + 1u) >> 3) | (((s0 + n1 + 1u) >> 3) << 8) | (((n0 + s1 + 1u) >> 3) << 16) | (((n0 + n1 + 1u) >> 3) << 24);
+    }
+}
+
 // =================================================================================================
 // K1: per alignment: LTS1 + LTS2 + SIGNAL.  Channel estimate -> hinv, SIGNAL decode -> FrameInfo.
 // One wave (64 threads) per block, one block per frame.
@@ -286,38 +355,13 @@ __global__ __launch_bounds__(64) void k_header(const float2 *__restrict__ iq, co
         dem[deinterleaved_pos(di)] = b;
     }
     __syncthreads();
-    // ppdu.cpp:178-180: conv_decode(18 bits) = 24 trellis steps
-    const AcsLane acs = acs_lane_init(lane);
-    uint32_t M = lane == 0 ? 0u : 63u;
-    for (int t = 0; t < 24; t++) {
-        uint64_t dec;
-        M = acs_step(M, dem[2 * t], dem[2 * t + 1], acs, dec);
-        if (lane == 0) decs[t] = dec;
-    }
-    __syncthreads();
+    int rate, length, nsym;
+    decode_signal_bits(dem, decs, lane, rate, length, nsym);
     if (lane == 0) {
-        // viterbi.cpp:131-142 chain-back from state 0, 18 bits -> 3 bytes MSB first
-        uint32_t e = 0, hb[3] = { 0, 0, 0 };
-        for (int n = 17; n >= 0; n--) {
-            uint32_t k = (uint32_t)((decs[n + 6] >> (e >> 2)) & 1ull);
-            e = (e >> 1) | (k << 7);
-            hb[n >> 3] = e;
-        }
-        uint32_t field = (hb[0] << 16) | (hb[1] << 8) | hb[2];
-        int rate = -1;
-        if ((__popc(field) & 1) == 0) {                               // ppdu.cpp:187-191
-            int rf = (field >> 19) & 0xF;
-            for (int r = 0; r < kNumRates; r++) if (g_tab.rates[r].rate_field == rf) rate = r;   // ppdu.cpp:198-203
-        }
         if (rate >= 0) {
-            int length = (field >> 6) & 0xFFF;
-            int dbps = g_tab.rates[rate].dbps;
-            int nsym = (16 + 8 * (length + 4) + 6 + dbps - 1) / dbps;  // ppdu.cpp:206-209 (exact in integers)
             fi.rate = rate; fi.length = length;
-            if (p + 144 + 80 * (int64_t)nsym + 64 > end) fi.status = FOA_ST_TRUNCATED;
-            else { fi.status = FOA_ST_CRC_FAIL; fi.nsym = nsym; fi.nsteps = nsym * dbps; }   // pending until the CRC is checked
-            // report num_symbols even for truncated frames
-            if (fi.status == FOA_ST_TRUNCATED) fi.nsteps = -nsym;
+            if (p + 144 + 80 * (int64_t)nsym + 64 > end) { fi.status = FOA_ST_TRUNCATED; fi.nsteps = -nsym; }   // nsym still reported
+            else { fi.status = FOA_ST_CRC_FAIL; fi.nsym = nsym; fi.nsteps = nsym * g_tab.rates[rate].dbps; }   // pending until the CRC is checked
         }
         info[f] = fi;
     }
@@ -401,35 +445,7 @@ __global__ __launch_bounds__(64 * kSymWaves) void k_data_symbols(const float2 *_
     const int di = g_tab.data_index[s];
     if (eq_tap && di >= 0) eq_tap[(size_t)w * 48 + di] = make_double2(z.x, z.y);          // data tap: one row per symbol
 
-    // erasures first (puncturer.cpp:98,100,114), then scatter this carrier's soft bytes
-    const int out_bytes = 2 * rr.dbps;                         // depunctured bytes of this symbol
-    if (rr.punct != 0) {
-        uint32_t *st32 = (uint32_t *)stage;
-        for (int i = lane; i < out_bytes / 4; i += 64) st32[i] = 0x7F7F7F7Fu;
-    }
-    wave_lds_sync();
-    if (di >= 0) {
-        uint8_t bits[6];
-        qam_decode(z.x, rr.numbits, rr.scale_d, bits);
-        if (rr.bpsc > 1) qam_decode(z.y, rr.numbits, rr.scale_d, bits + rr.numbits);
-        for (int b = 0; b < rr.bpsc; b++) {
-            int c = di * rr.bpsc + b;                          // demodulated byte index within the symbol
-            int dd = 48 * (c / 48) + deinterleaved_pos(c % 48);
-            stage[depunct_pos(dd, rr.punct)] = bits[b];        // symbol-local: cbps is a multiple of 12
-        }
-    }
-    wave_lds_sync();
-    uint32_t *dst = (uint32_t *)(soft + fi.soft_off + (int64_t)(k - 1) * out_bytes);
-    const uint32_t *st32 = (const uint32_t *)stage;
-    for (int i = lane; i < out_bytes / 4; i += 64) dst[i] = st32[i];
-    // Branch metrics of this symbol's trellis steps for the packed Viterbi kernel: byte j = 2*b0 + b1 holds
-    // (((s0 ^ b0*255) + (s1 ^ b1*255) + 1) >> 1) >> 2, the value viterbi.cpp:242-247 derives per butterfly
-    // from Branchtab entries (b0, b1).
-    uint32_t *bdst = bm + fi.dec_off + (int64_t)(k - 1) * rr.dbps;
-    for (int t = lane; t < rr.dbps; t += 64) {
-        const uint32_t s0 = stage[2 * t], s1 = stage[2 * t + 1], n0 = s0 ^ 255u, n1 = s1 ^ 255u;
-        bdst[t] = ((s0 + s1 + 1u) >> 3) | (((s0 + n1 + 1u) >> 3) << 8) | (((n0 + s1 + 1u) >> 3) << 16) | (((n0 + n1 + 1u) >> 3) << 24);
-    }
+    emit_symbol_soft(z, di, rr, stage, soft + fi.soft_off + (int64_t)(k - 1) * 2 * rr.dbps, bm + fi.dec_off + (int64_t)(k - 1) * rr.dbps, lane);
 }
 
 }  // namespace foa

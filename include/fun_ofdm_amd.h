@@ -159,6 +159,27 @@ int foa_fft_forward_f64(foa_rx *rx, double *vectors, size_t n_vec);
  * data[(data_bits+7)/8] bytes.  n_blocks independent blocks of identical data_bits, packed. */
 int foa_conv_decode(foa_rx *rx, const uint8_t *symbols, uint8_t *data, int data_bits, size_t n_blocks);
 
+/* channel_est::work, estimation half (src/channel_est.cpp:44-58): n pairs of FFT'd LTS vectors
+ * (lts_pairs[n][2][64] complex doubles) -> hinv[n][64] = sum over the pair of (LTS_FREQ_DOMAIN / Y) / 2. */
+int foa_channel_estimate_f64(foa_rx *rx, const double *lts_pairs, double *hinv, size_t n);
+
+/* channel_est::work, correction half (src/channel_est.cpp:77-81), in place: vectors[i][j] *= hinv[hinv_index[i]][j]. */
+int foa_equalize_f64(foa_rx *rx, double *vectors, size_t n_vec, const double *hinv, size_t n_hinv, const int32_t *hinv_index);
+
+/* phase_tracker::work (src/phase_tracker.cpp:70-104): vectors[n][64] equalised symbols with their symbol counters
+ * (0 = SIGNAL) -> out48[n][48] derotated data carriers. */
+int foa_phase_track_f64(foa_rx *rx, const double *vectors, const int32_t *symbol_count, size_t n_vec, double *out48);
+
+/* ppdu::decode_header (src/ppdu.cpp:168-218) on n SIGNAL symbols of 48 carriers: results[i].status is FOA_ST_OK or
+ * FOA_ST_HEADER_FAIL, rate/length/num_symbols filled on success. */
+int foa_decode_header_f64(foa_rx *rx, const double *carriers48, size_t n, foa_frame_result *results);
+
+/* ppdu::decode_data (src/ppdu.cpp:223-295) on n_frames frames: frame i has results[i].rate / .length set by the
+ * caller and its num_symbols*48 carriers at carriers[2*carrier_off[i]] (carrier_off has n_frames+1 entries, in
+ * complex elements).  On return results[i].status is FOA_ST_OK (payload in psdu slot i) or FOA_ST_CRC_FAIL. */
+int foa_decode_data_f64(foa_rx *rx, const double *carriers, const uint64_t *carrier_off, size_t n_frames, foa_frame_result *results,
+                        uint8_t *psdu, size_t slot_bytes);
+
 #ifdef __cplusplus
 }
 #endif

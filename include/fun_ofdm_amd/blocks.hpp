@@ -1,0 +1,398 @@
+// blocks.hpp -- C++ host side of the drop-in: fun_ofdm's plug-in surface over the C ABI (fun_ofdm_amd.h).
+//
+//   fun_amd::receiver_chain      same call as fun::receiver_chain::process_samples (src/receiver_chain.h:56)
+//   fun_amd::fft_symbols         fun::block<tagged_sample, tagged_vector<64>>      (src/fft_symbols.h)
+//   fun_amd::channel_est         fun::block<tagged_vector<64>, tagged_vector<64>>  (src/channel_est.h)
+//   fun_amd::phase_tracker       fun::block<tagged_vector<64>, tagged_vector<48>>  (src/phase_tracker.h)
+//   fun_amd::frame_decoder       fun::block<tagged_vector<48>, std::vector<unsigned char>> (src/frame_decoder.h)
+//
+// Each adaptor keeps the block's control state (tags, counters, partially collected frames) on the host exactly as
+// the reference block does and sends the arithmetic of one work() call to the GPU in as few calls as possible.
+// They are meant for swapping single stages inside an otherwise unchanged reference chain; for throughput use
+// receiver_chain (or the batch C entry point), which keeps everything from the raw samples to the PSDU on the device.
+//
+// Inside the reference tree include the reference's block.h / tagged_vector.h FIRST: this header then uses those
+// types as they are.  Stand-alone (this repository's tests) it declares layout-identical ones.
+//
+// Errors: the reference has no error channel (failed frames are dropped silently).  A failing GPU call throws
+// std::runtime_error from work() / process_samples(); there is no CPU fallback.
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <cstdint>
+#include <cstring>
+#include <deque>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../fun_ofdm_amd.h"
+
+// ---- the reference's plug-in contract, declared only if its own headers are not already in --------------------
+#ifndef BLOCK_H
+#define BLOCK_H
+#define BUFFER_MAX 65536
+namespace fun {
+// src/block.h:36-60: a named unit of work
+class block_base {
+public:
+    explicit block_base(std::string block_name) : name(block_name) {}
+    virtual ~block_base() {}
+    virtual void work() = 0;
+    std::string name;
+};
+// src/block.h:68-112: work() consumes all of input_buffer and replaces output_buffer; the chain swaps the
+// buffers of neighbouring blocks between calls
+template <typename I, typename O>
+class block : public block_base {
+public:
+    explicit block(std::string block_name) : block_base(block_name)
+    {
+        input_buffer.reserve(BUFFER_MAX);
+        output_buffer.reserve(BUFFER_MAX);
+    }
+    virtual void work() = 0;
+    std::vector<I> input_buffer;
+    std::vector<O> output_buffer;
+};
+}  // namespace fun
+#endif
+
+#ifndef TAGGED_VECTOR_H
+#define TAGGED_VECTOR_H
+namespace fun {
+// src/tagged_vector.h:25-34
+enum vector_tag { NONE, STS_START, STS_END, LTS_START, LTS1, LTS2, START_OF_FRAME };
+// src/tagged_vector.h:43-76 (N complex doubles then the tag)
+template <int N>
+struct tagged_vector {
+    std::complex<double> samples[N];
+    vector_tag tag;
+    tagged_vector(vector_tag _tag = NONE) { tag = _tag; }
+};
+// src/tagged_vector.h:82-95
+struct tagged_sample {
+    std::complex<double> sample;
+    vector_tag tag;
+    tagged_sample() { tag = NONE; }
+};
+}  // namespace fun
+#endif
+
+namespace fun_amd {
+
+inline void check(int rc, const char *what)
+{
+    if (rc != FOA_OK) throw std::runtime_error(std::string(what) + ": " + foa_last_error());
+}
+
+// One GPU receiver handle, created on first use (work() runs on a thread the chain created, src/receiver_chain.cpp:65).
+class device_handle {
+public:
+    explicit device_handle(int device = 0) : device_(device), rx_(nullptr) {}
+    ~device_handle() { if (rx_) foa_rx_destroy(rx_); }
+    device_handle(const device_handle &) = delete;
+    device_handle &operator=(const device_handle &) = delete;
+    foa_rx *get()
+    {
+        if (!rx_) check(foa_rx_create(&rx_, device_), "foa_rx_create");
+        return rx_;
+    }
+private:
+    int device_;
+    foa_rx *rx_;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// fft_symbols (src/fft_symbols.cpp:33-79): tag-driven cyclic-prefix removal on the host, all FFTs of the call on the GPU
+// ---------------------------------------------------------------------------------------------------------------
+class fft_symbols : public fun::block<fun::tagged_sample, fun::tagged_vector<64> > {
+public:
+    explicit fft_symbols(int device = 0) : block("fft_symbols"), dev_(device), offset_(0) {}
+    virtual void work()
+    {
+        if (input_buffer.size() == 0) return;
+        output_buffer.resize(0);
+        for (size_t x = 0; x < input_buffer.size(); x++) {
+            if (input_buffer[x].tag == fun::LTS1) {            // start of a frame: flush a vector in progress
+                if (offset_ > 15) output_buffer.push_back(current_);
+                current_.tag = fun::LTS_START;
+                offset_ = 16;
+            }
+            if (input_buffer[x].tag == fun::LTS2) offset_ = 16;   // no cyclic prefix between the two LTS
+            if (offset_ > 15) current_.samples[offset_ - 16] = input_buffer[x].sample;
+            if (++offset_ == 80) {
+                output_buffer.push_back(current_);
+                current_.tag = fun::NONE;
+                offset_ = 0;
+            }
+        }
+        const size_t n = output_buffer.size();
+        if (n == 0) return;
+        std::vector<double> v(n * 128);
+        for (size_t i = 0; i < n; i++) memcpy(&v[i * 128], output_buffer[i].samples, 128 * sizeof(double));
+        check(foa_fft_forward_f64(dev_.get(), v.data(), n), "foa_fft_forward_f64");
+        for (size_t i = 0; i < n; i++) memcpy(output_buffer[i].samples, &v[i * 128], 128 * sizeof(double));
+    }
+private:
+    device_handle dev_;
+    fun::tagged_vector<64> current_;
+    int offset_;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// channel_est (src/channel_est.cpp:36-85)
+// ---------------------------------------------------------------------------------------------------------------
+class channel_est : public fun::block<fun::tagged_vector<64>, fun::tagged_vector<64> > {
+public:
+    explicit channel_est(int device = 0) : block("channel_est"), dev_(device), est_(128, 0.0), lts_flag_(0), frame_start_(false)
+    {
+        for (int j = 0; j < 64; j++) est_[2 * j] = 1.0;           // initial estimate 1+0j (channel_est.cpp:22)
+    }
+    virtual void work()
+    {
+        if (input_buffer.size() == 0) return;
+        output_buffer.resize(0);
+        // pass 1: control flow.  Collect the LTS pairs that complete in this call and, for every vector that is
+        // forwarded, which estimate applies: 0 = the one carried in, k = the k-th pair completed in this call.
+        std::vector<double> pairs;                                 // k pairs x 2 x 64 complex
+        std::vector<int32_t> which;
+        std::vector<size_t> src;
+        int cur = 0;
+        for (size_t i = 0; i < input_buffer.size(); i++) {
+            if (input_buffer[i].tag == fun::LTS_START) lts_flag_ = 1;
+            if (lts_flag_ > 0) {
+                if (lts_flag_ == 1) {
+                    memcpy(lts1_, input_buffer[i].samples, sizeof lts1_);
+                } else {
+                    const size_t o = pairs.size();
+                    pairs.resize(o + 256);
+                    memcpy(&pairs[o], lts1_, sizeof lts1_);
+                    memcpy(&pairs[o + 128], input_buffer[i].samples, sizeof lts1_);
+                    cur = (int)(pairs.size() / 256);
+                }
+                if (++lts_flag_ == 3) { lts_flag_ = 0; frame_start_ = true; }
+            } else {
+                fun::tagged_vector<64> sym;
+                if (frame_start_) { sym.tag = fun::START_OF_FRAME; frame_start_ = false; }
+                output_buffer.push_back(sym);
+                which.push_back(cur);
+                src.push_back(i);
+            }
+        }
+        const size_t np = pairs.size() / 256;
+        std::vector<double> hinv((np + 1) * 128);
+        memcpy(hinv.data(), est_.data(), 128 * sizeof(double));
+        if (np) check(foa_channel_estimate_f64(dev_.get(), pairs.data(), hinv.data() + 128, np), "foa_channel_estimate_f64");
+        if (np) memcpy(est_.data(), hinv.data() + np * 128, 128 * sizeof(double));
+        // pass 2: equalise everything that is forwarded, one GPU call
+        const size_t n = output_buffer.size();
+        if (n == 0) return;
+        std::vector<double> v(n * 128);
+        for (size_t i = 0; i < n; i++) memcpy(&v[i * 128], input_buffer[src[i]].samples, 128 * sizeof(double));
+        check(foa_equalize_f64(dev_.get(), v.data(), n, hinv.data(), np + 1, which.data()), "foa_equalize_f64");
+        for (size_t i = 0; i < n; i++) memcpy(output_buffer[i].samples, &v[i * 128], 128 * sizeof(double));
+    }
+private:
+    device_handle dev_;
+    std::vector<double> est_;        // m_chan_est as (re,im) pairs
+    double lts1_[128];
+    int lts_flag_;
+    bool frame_start_;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// phase_tracker (src/phase_tracker.cpp:70-104)
+// ---------------------------------------------------------------------------------------------------------------
+class phase_tracker : public fun::block<fun::tagged_vector<64>, fun::tagged_vector<48> > {
+public:
+    explicit phase_tracker(int device = 0) : block("phase_tracker"), dev_(device), symbol_count_(0) {}
+    virtual void work()
+    {
+        if (input_buffer.size() == 0) return;
+        const size_t n = input_buffer.size();
+        output_buffer.resize(n);
+        std::vector<double> v(n * 128), o(n * 96);
+        std::vector<int32_t> cnt(n);
+        for (size_t i = 0; i < n; i++) {
+            if (input_buffer[i].tag == fun::START_OF_FRAME) symbol_count_ = 0;
+            cnt[i] = symbol_count_++;
+            memcpy(&v[i * 128], input_buffer[i].samples, 128 * sizeof(double));
+        }
+        check(foa_phase_track_f64(dev_.get(), v.data(), cnt.data(), n, o.data()), "foa_phase_track_f64");
+        for (size_t i = 0; i < n; i++) {
+            memcpy(output_buffer[i].samples, &o[i * 96], 96 * sizeof(double));
+            output_buffer[i].tag = input_buffer[i].tag;
+        }
+    }
+private:
+    device_handle dev_;
+    int symbol_count_;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// frame_decoder (src/frame_decoder.cpp:45-91 over ppdu::decode_header / decode_data, src/ppdu.cpp:168-295)
+// ---------------------------------------------------------------------------------------------------------------
+class frame_decoder : public fun::block<fun::tagged_vector<48>, std::vector<unsigned char> > {
+public:
+    explicit frame_decoder(int device = 0) : block("frame_decoder"), dev_(device), sample_count_(0), copied_(0), rate_(0), length_(0) {}
+    virtual void work()
+    {
+        if (input_buffer.size() == 0) return;
+        output_buffer.resize(0);
+        const size_t n = input_buffer.size();
+        // all SIGNAL symbols of this call in one GPU call (a header's outcome does not depend on decoder state)
+        std::vector<size_t> sof;
+        for (size_t x = 0; x < n; x++) if (input_buffer[x].tag == fun::START_OF_FRAME) sof.push_back(x);
+        std::vector<foa_frame_result> hdr(sof.size());
+        if (!sof.empty()) {
+            std::vector<double> c(sof.size() * 96);
+            for (size_t i = 0; i < sof.size(); i++) memcpy(&c[i * 96], input_buffer[sof[i]].samples, 96 * sizeof(double));
+            check(foa_decode_header_f64(dev_.get(), c.data(), sof.size(), hdr.data()), "foa_decode_header_f64");
+        }
+        // the reference's state machine; completed frames are queued and decoded together afterwards
+        std::vector<double> car;
+        std::vector<uint64_t> off(1, 0);
+        std::vector<foa_frame_result> fr;
+        size_t h = 0;
+        for (size_t x = 0; x < n; x++) {
+            if (copied_ < sample_count_) {
+                const size_t o = frame_.size();
+                frame_.resize(o + 96);
+                memcpy(&frame_[o], input_buffer[x].samples, 96 * sizeof(double));
+                copied_ += 48;
+            }
+            if (copied_ >= sample_count_ && sample_count_ != 0) {
+                car.insert(car.end(), frame_.begin(), frame_.end());
+                off.push_back(car.size() / 2);
+                foa_frame_result r;
+                r.status = 0; r.rate = rate_; r.length = length_; r.num_symbols = sample_count_ / 48;
+                fr.push_back(r);
+                sample_count_ = 0;
+            }
+            if (input_buffer[x].tag == fun::START_OF_FRAME) {
+                const foa_frame_result &r = hdr[h++];
+                if (r.status != FOA_ST_OK) continue;                 // ppdu.cpp:187-203: parity / rate check failed
+                rate_ = r.rate; length_ = r.length; sample_count_ = r.num_symbols * 48; copied_ = 0;
+                frame_.clear();
+            }
+        }
+        if (fr.empty()) return;
+        std::vector<unsigned char> psdu(fr.size() * 4096);
+        check(foa_decode_data_f64(dev_.get(), car.data(), off.data(), fr.size(), fr.data(), psdu.data(), 4096), "foa_decode_data_f64");
+        for (size_t i = 0; i < fr.size(); i++)
+            if (fr[i].status == FOA_ST_OK) output_buffer.push_back(std::vector<unsigned char>(psdu.begin() + i * 4096, psdu.begin() + i * 4096 + fr[i].length));
+    }
+private:
+    device_handle dev_;
+    int sample_count_, copied_, rate_, length_;
+    std::vector<double> frame_;       // carriers of the frame being collected
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// receiver_chain: process_samples() with everything after the host-side pre-sync on the device (fused kernels)
+// ---------------------------------------------------------------------------------------------------------------
+class receiver_chain {
+public:
+    explicit receiver_chain(int device = 0) : dev_(device), sync_(nullptr), base_(0)
+    {
+        check(foa_sync_create(&sync_), "foa_sync_create");
+    }
+    ~receiver_chain() { if (sync_) foa_sync_destroy(sync_); }
+    receiver_chain(const receiver_chain &) = delete;
+    receiver_chain &operator=(const receiver_chain &) = delete;
+
+    // Same signature and meaning as fun::receiver_chain::process_samples (src/receiver_chain.cpp:106-126): feed the
+    // next chunk of the 20 MS/s stream, get the payloads of the frames that completed, in stream order.  A frame is
+    // returned by the call that delivers its last sample (the reference returns it five calls later).
+    std::vector<std::vector<unsigned char> > process_samples(std::vector<std::complex<double> > samples)
+    {
+        std::vector<std::vector<unsigned char> > out;
+        const size_t n = samples.size();
+        if (n == 0) return out;
+        // the device consumes complex<float> (BASELINE north_star); the pre-sync decides on the doubles it was given
+        const size_t o = buf_.size();
+        buf_.resize(o + 2 * n);
+        for (size_t i = 0; i < n; i++) { buf_[o + 2 * i] = (float)samples[i].real(); buf_[o + 2 * i + 1] = (float)samples[i].imag(); }
+        std::vector<foa_frame_desc> found(n / 300 + 8);
+        size_t got = 0;
+        check(foa_sync_push_f64(sync_, reinterpret_cast<const double *>(samples.data()), n, found.data(), found.size(), &got), "foa_sync_push_f64");
+        for (;;) {
+            for (size_t i = 0; i < got; i++) pending_.push_back(entry(found[i]));
+            if (got < found.size()) break;
+            check(foa_sync_push_f64(sync_, nullptr, 0, found.data(), found.size(), &got), "foa_sync_push_f64");
+        }
+        const int64_t avail = base_ + (int64_t)(buf_.size() / 2);    // stream index one past the newest sample
+        const int64_t settled = foa_sync_settled(sync_);             // timing_sync has looked at everything before this
+        // which pending alignments can be finished now?  An alignment's extent ends at the next alignment's LTS1
+        // (fft_symbols re-aligns there) or, if there is none yet, wherever the stream has got to.
+        std::vector<foa_frame_desc> descs;
+        std::vector<int64_t> ends;
+        size_t take = 0;
+        for (; take < pending_.size(); take++) {
+            entry &e = pending_[take];
+            const bool has_next = take + 1 < pending_.size();
+            const int64_t end = has_next ? pending_[take + 1].d.lts1_pos : avail;
+            if (!has_next) {
+                // nothing may re-align before `settled`; wait until the frame is complete (or at least its SIGNAL)
+                const int64_t need = e.need_end > 0 ? e.need_end : e.d.lts1_pos + 208;
+                if (avail < need || settled - 8 < need) break;     // a later alignment could still start up to 8 samples before `settled`
+            }
+            descs.push_back(e.d);
+            ends.push_back(end);
+        }
+        if (descs.empty()) { trim(); return out; }
+        // decode [0, take) on the device; samples are addressed relative to base_
+        std::vector<foa_frame_desc> rel(descs);
+        std::vector<int64_t> rel_end(ends);
+        for (size_t i = 0; i < rel.size(); i++) { rel[i].lts1_pos -= base_; rel[i].rot_start -= base_; rel_end[i] -= base_; }
+        std::vector<unsigned char> psdu(rel.size() * 4096);
+        std::vector<foa_frame_result> res(rel.size());
+        check(foa_rx_decode_frames_host(dev_.get(), buf_.data(), buf_.size() / 2, rel.data(), rel_end.data(), rel.size(), psdu.data(), 4096, res.data()),
+              "foa_rx_decode_frames_host");
+        size_t done = 0;
+        for (size_t i = 0; i < rel.size(); i++) {
+            const bool last = i + 1 == pending_.size();
+            if (res[i].status == FOA_ST_TRUNCATED && last) {
+                // the newest alignment is not complete yet: remember how far it reaches and try again later
+                if (res[i].rate >= 0) pending_[i].need_end = pending_[i].d.lts1_pos + 144 + 80 * (int64_t)res[i].num_symbols + 64;
+                else pending_[i].need_end = pending_[i].d.lts1_pos + 208;
+                break;
+            }
+            if (res[i].status == FOA_ST_OK) out.push_back(std::vector<unsigned char>(psdu.begin() + i * 4096, psdu.begin() + i * 4096 + res[i].length));
+            done++;
+        }
+        pending_.erase(pending_.begin(), pending_.begin() + done);
+        trim();
+        return out;
+    }
+
+private:
+    struct entry {
+        foa_frame_desc d;
+        int64_t need_end;     // stream index the frame needs before it can be decoded (0: SIGNAL not decoded yet)
+        explicit entry(const foa_frame_desc &x) : d(x), need_end(0) {}
+    };
+    // drop samples nothing can refer to any more: before the oldest pending alignment, and before what a future
+    // alignment could reach back to (timing_sync places LTS1 at most 160+8 samples before the point it has reached)
+    void trim()
+    {
+        const int64_t settled = foa_sync_settled(sync_);
+        int64_t keep_from = settled - 400;
+        if (!pending_.empty()) keep_from = std::min(keep_from, pending_.front().d.lts1_pos - 16);
+        if (keep_from > base_) {
+            const size_t drop = (size_t)(keep_from - base_);
+            if (drop * 2 >= buf_.size()) { base_ += (int64_t)(buf_.size() / 2); buf_.clear(); }
+            else { buf_.erase(buf_.begin(), buf_.begin() + 2 * drop); base_ = keep_from; }
+        }
+    }
+    device_handle dev_;
+    foa_sync *sync_;
+    std::vector<float> buf_;          // interleaved samples from stream index base_ on
+    int64_t base_;
+    std::deque<entry> pending_;
+};
+
+}  // namespace fun_amd
