@@ -29,10 +29,15 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def make_workload(n_frames, seed_base):
-    """Synthetic frames -> (iq complex64[n*PITCH], payloads uint8[n, PAYLOAD])."""
+SEED_BASE = 0x0FD2              # payload of global frame i = splitmix64(SEED_BASE + i)
+
+
+def make_workload(frame_ids, noise_seed):
+    """Synthetic frames for the given global frame ids -> (iq complex64[n*PITCH], payloads uint8[n, PAYLOAD])."""
     from fun_ofdm_amd import synth
-    pays = synth.splitmix64_bytes(seed_base, n_frames, PAYLOAD)
+    n_frames = len(frame_ids)
+    seed_base = noise_seed
+    pays = synth.splitmix64_bytes(SEED_BASE, n_frames, PAYLOAD, ids=frame_ids)
     iq = np.empty(n_frames * PITCH, np.complex64)
     step = 500
     for a in range(0, n_frames, step):
@@ -82,16 +87,26 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # FOA_BENCH_BACKEND=gloo lets the N>1 code path be exercised on a box with fewer GPUs than ranks (ranks then
+    # share devices and the gather goes through host memory); the real runs use nccl (= RCCL over xGMI).
+    backend = os.environ.get("FOA_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    dev = torch.device("cuda", dev_index)
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    cdev = dev if backend == "nccl" else torch.device("cpu")       # where collective tensors live
 
     t0 = time.perf_counter()
-    iq, pays = make_workload(args.frames, 0x0FD2 + 7919 * rank)
+    from fun_ofdm_amd import shard, synth
+    n_global = args.frames * world
+    my_ids = shard.local_frame_ids(n_global, rank, world).numpy()       # global frame i -> rank i mod G
+    iq, pays = make_workload(my_ids, 7919 * (rank + 1))
     t1 = time.perf_counter()
     descs = foa.find_alignments(iq)                       # host-side frame_detector + timing_sync
     ends = foa.alignment_ends(descs, iq.size)
@@ -103,7 +118,7 @@ def main():
     m = descs.size
     frame_samples = 320 + 80 * 40
 
-    rx = foa.Receiver(local_rank)
+    rx = foa.Receiver(dev_index)
     rx.set_option("viterbi", args.viterbi)
     rx.reserve(iq.size, m)
     d_iq = torch.from_numpy(iq.view(np.float32).reshape(-1, 2)).to(dev)
@@ -111,23 +126,14 @@ def main():
     d_ends = torch.from_numpy(ends).to(dev)
     d_psdu = torch.zeros((m, PAYLOAD), dtype=torch.uint8, device=dev)
     d_res = torch.zeros((m, 4), dtype=torch.int32, device=dev)
-    gather_list = None
-    m_all = [m]
-    if world > 1:
-        sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(sizes, torch.tensor([m], dtype=torch.int64, device=dev))
-        m_all = [int(s.item()) for s in sizes]
-        m_max = max(m_all)
-        d_psdu_pad = torch.zeros((m_max, PAYLOAD), dtype=torch.uint8, device=dev)
-        if rank == 0:
-            gather_list = [torch.zeros((m_max, PAYLOAD), dtype=torch.uint8, device=dev) for _ in range(world)]
+    d_real = torch.from_numpy(real).to(dev)
+    gathered = [None]
 
     def step():
         rx.decode_frames_dev(d_iq, d_desc, d_ends, d_psdu, d_res)
         if world > 1:
             rx.sync()                                    # the PSDUs must exist before the collective reads them
-            d_psdu_pad[:m].copy_(d_psdu)
-            dist.gather(d_psdu_pad, gather_list, dst=0)
+            gathered[0] = shard.gather_psdus(d_psdu.index_select(0, d_real).to(cdev), n_global, rank, world)
 
     for _ in range(args.warmup):
         step()
@@ -148,7 +154,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t_start
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -160,15 +166,21 @@ def main():
     # every frame whose CRC passed must carry exactly the transmitted payload (a frame may legitimately fail
     # its CRC at 25 dB; the CPU receiver fails the same ones -- checked against the oracle below)
     exact = bool(np.array_equal(psdu[real][okm], pays[okm])) and real.size == args.frames
-    n_frames_total = args.frames * world
+    n_frames_total = n_global
     if world > 1:
-        flag = torch.tensor([1 if exact else 0], dtype=torch.int32, device=dev)
+        flag = torch.tensor([1 if exact else 0], dtype=torch.int32, device=cdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         exact = bool(flag.item())
+        oks = torch.tensor([ok_frames], dtype=torch.int64, device=cdev)
+        dist.all_reduce(oks)
+        ok_frames = int(oks.item())
         if rank == 0:
-            for r in range(world):
-                if r == 0:
-                    exact = exact and bool(np.array_equal(gather_list[0][:m].cpu().numpy(), psdu))
+            # the gathered slots are in global frame order: rows of rank 0's own frames must equal its local result
+            g = gathered[0].cpu().numpy()
+            exact = exact and g.shape == (n_global, PAYLOAD) and bool(np.array_equal(g[0::world][okm], pays[okm]))
+            all_pays = synth.splitmix64_bytes(SEED_BASE, n_global, PAYLOAD)
+            nz = g.any(axis=1)                           # frames whose CRC failed leave their slot zeroed
+            exact = exact and bool(np.array_equal(g[nz], all_pays[nz])) and int(nz.sum()) == ok_frames
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -185,7 +197,7 @@ def main():
                        "counted_samples": "in-frame only (3520/frame)", "value_all_samples_fed": round(value * PITCH / frame_samples, 1),
                        "x_realtime_20MSps": round(value / 20.0, 1), "psdu_bit_exact": exact, "frames_ok": ok_frames,
                        "alignments_decoded_per_gpu": m, "frontend_dtype": "f64", "viterbi_kernel": args.viterbi,
-                       "sharding": "frame shards per rank, PSDU gather to rank 0" if world > 1 else "single GPU"},
+                       "sharding": ("global frame i on rank i mod %d, one %s gather of PSDU slots to rank 0 per step" % (world, backend)) if world > 1 else "single GPU"},
         }
         if args.steps <= 50:
             kms = {k: v / args.steps for k, v in kern.items()}

@@ -157,10 +157,12 @@ def build_frames(payloads, rate):
     return np.concatenate([np.broadcast_to(_PREAMBLE, (n, 320)), sym], axis=1)
 
 
-def splitmix64_bytes(seed, n_frames, length):
-    """Deterministic payload bytes: frame i = splitmix64 stream seeded with seed + i."""
+def splitmix64_bytes(seed, n_frames, length, ids=None):
+    """Deterministic payload bytes: frame i = splitmix64 stream seeded with seed + i (or seed + ids[i])."""
     words = (length + 7) // 8
-    state = (np.uint64(seed) + np.arange(n_frames, dtype=np.uint64))[:, None] + \
+    idx = np.arange(n_frames, dtype=np.uint64) if ids is None else np.asarray(ids, dtype=np.uint64)
+    n_frames = idx.size
+    state = (np.uint64(seed) + idx)[:, None] + \
         np.uint64(0x9E3779B97F4A7C15) * np.arange(1, words + 1, dtype=np.uint64)[None, :]
     z = state
     z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)

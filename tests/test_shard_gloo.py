@@ -1,0 +1,71 @@
+"""The N>1 path's host logic on CPU: round-robin frame shards and the PSDU gather, world_size 2 over gloo."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_psdu(global_ids, slot):
+    g = global_ids.to(torch.int64)
+    col = torch.arange(slot, dtype=torch.int64)
+    return ((g[:, None] * 131 + col[None, :] * 7 + 3) % 251).to(torch.uint8)
+
+
+def _worker(rank, world, port, n_global, slot, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fun_ofdm_amd import shard
+    ids = shard.local_frame_ids(n_global, rank, world)
+    out = shard.gather_psdus(_fake_psdu(ids, slot), n_global, rank, world)
+    dist.barrier()
+    if rank == 0:
+        want = _fake_psdu(torch.arange(n_global), slot)
+        q.put(bool(torch.equal(out, want)) and out.shape == (n_global, slot))
+    else:
+        assert out is None
+    dist.destroy_process_group()
+
+
+def _run(world, n_global, slot):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_global, slot, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return ok
+
+
+def test_round_robin_ids_partition_the_frames():
+    from fun_ofdm_amd import shard
+    for world in (1, 2, 3, 8):
+        for n in (0, 1, 7, 64, 1001):
+            ids = torch.cat([shard.local_frame_ids(n, r, world) for r in range(world)])
+            assert sorted(ids.tolist()) == list(range(n))
+
+
+def test_gather_two_ranks_even_and_ragged():
+    assert _run(2, 10, 16)          # even split
+    assert _run(2, 11, 32)          # ragged: rank 0 has one frame more
+
+
+def test_single_rank_is_identity():
+    from fun_ofdm_amd import shard
+    x = _fake_psdu(torch.arange(5), 8)
+    assert shard.gather_psdus(x, 5, 0, 1) is x
