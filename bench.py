@@ -141,7 +141,7 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    kern = {k: 0.0 for k in ("header", "scan", "symbols", "viterbi", "total")}
+    kern = {k: 0.0 for k in ("header", "scan", "symbols", "viterbi_fwd", "viterbi_finish", "total")}
     t_start = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -201,14 +201,14 @@ def main():
         }
         if args.steps <= 50:
             kms = {k: v / args.steps for k, v in kern.items()}
-            # dominant kernel: Viterbi (+descramble+CRC).  Algorithmic bytes per frame:
-            # coded soft bytes in (nsym*cbps) + payload out + 16-byte result record.
-            alg_bytes = m * 16 + real.size * (39 * 288 + PAYLOAD)
-            ach = alg_bytes / (kms["viterbi"] * 1e-3) / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": "k_viterbi", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            # dominant kernel: the Viterbi forward pass k_viterbi_fwd2.  Algorithmic bytes per frame:
+            # one branch-metric dword in and one 64-bit decision word out per trellis step (39 symbols x 216 steps).
+            alg_bytes = real.size * 39 * 216 * (4 + 8)
+            ach = alg_bytes / (kms["viterbi_fwd"] * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": "k_viterbi_fwd2", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": None,
-                               "algorithmic_bytes_per_launch": int(alg_bytes), "avg_kernel_ms": round(kms["viterbi"], 4),
-                               "note": "integer-VALU/latency bound, not HBM bound (SURVEY 8d); see DESIGN.md"}
+                               "algorithmic_bytes_per_launch": int(alg_bytes), "avg_kernel_ms": round(kms["viterbi_fwd"], 4),
+                               "note": "issue-bound on integer VALU/DPP, not HBM-bound (SURVEY 8d); DESIGN.md 4 gives the instruction-issue accounting"}
             out["kernel_ms"] = {k: round(v, 4) for k, v in kms.items()}
         if not args.no_cpu_baseline:
             cb, opsdu, ores, n_cb = cpu_baseline(iq, descs, ends, pays)

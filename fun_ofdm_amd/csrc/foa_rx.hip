@@ -113,7 +113,7 @@ void foa::build_tables(DeviceTables *t)
 struct foa_rx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[6] = {};
+    hipEvent_t ev[8] = {};
     bool have_timing = false;
     int viterbi_kind = 1;
     bool record_eq = false;
@@ -259,8 +259,9 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
     if (rx->viterbi_kind == 0)
         hipLaunchKernelGGL(k_viterbi_v1, dim3(nf), dim3(64), 0, st, rx->info.p, nf, rx->soft.p, rx->dec.p, d_psdu, slot_bytes, d_results);
     else
-        launch_viterbi_v2(st, rx->info.p, nf, rx->bm.p, rx->dec.p, rx->decoded.p, d_psdu, slot_bytes, d_results);
+        launch_viterbi_v2(st, rx->info.p, nf, rx->bm.p, rx->dec.p, rx->decoded.p, d_psdu, slot_bytes, d_results, rx->ev[5]);
     HIP_TRY(hipEventRecord(rx->ev[4], st));
+    if (rx->viterbi_kind == 0) HIP_TRY(hipEventRecord(rx->ev[5], st));
     HIP_TRY(hipGetLastError());
     rx->have_timing = true;
     rx->last_frames = n_frames;
@@ -294,13 +295,16 @@ int foa_rx_decode_frames_host(foa_rx *rx, const float *iq, size_t n_samples, con
     return FOA_OK;
 }
 
-int foa_rx_last_kernel_ms(foa_rx *rx, float out_ms[5])
+int foa_rx_last_kernel_ms(foa_rx *rx, float out_ms[6])
 {
     if (!rx || !out_ms) return fail(FOA_E_INVALID, "NULL argument");
     if (!rx->have_timing) return fail(FOA_E_STATE, "no decode call has been made on this handle");
     HIP_TRY(hipEventSynchronize(rx->ev[4]));
-    for (int i = 0; i < 4; i++) HIP_TRY(hipEventElapsedTime(&out_ms[i], rx->ev[i], rx->ev[i + 1]));
-    HIP_TRY(hipEventElapsedTime(&out_ms[4], rx->ev[0], rx->ev[4]));
+    HIP_TRY(hipEventSynchronize(rx->ev[5]));
+    for (int i = 0; i < 3; i++) HIP_TRY(hipEventElapsedTime(&out_ms[i], rx->ev[i], rx->ev[i + 1]));
+    HIP_TRY(hipEventElapsedTime(&out_ms[3], rx->ev[3], rx->ev[5]));      // forward pass (or the fused v1 kernel)
+    HIP_TRY(hipEventElapsedTime(&out_ms[4], rx->ev[5], rx->ev[4]));      // chain-back + descramble + CRC (0 for v1)
+    HIP_TRY(hipEventElapsedTime(&out_ms[5], rx->ev[0], rx->ev[4]));
     return FOA_OK;
 }
 
@@ -561,7 +565,7 @@ int foa_decode_data_f64(foa_rx *rx, const double *carriers, const uint64_t *carr
     if (rx->viterbi_kind == 0)
         hipLaunchKernelGGL(k_viterbi_v1, dim3((unsigned)n_frames), dim3(64), 0, st, rx->info.p, (int)n_frames, rx->soft.p, rx->dec.p, d_psdu, slot_bytes, d_res);
     else
-        launch_viterbi_v2(st, rx->info.p, (int)n_frames, rx->bm.p, rx->dec.p, rx->decoded.p, d_psdu, slot_bytes, d_res);
+        launch_viterbi_v2(st, rx->info.p, (int)n_frames, rx->bm.p, rx->dec.p, rx->decoded.p, d_psdu, slot_bytes, d_res, nullptr);
     HIP_TRY(hipMemcpyAsync(psdu, d_psdu, p_b, hipMemcpyDeviceToHost, st));
     std::vector<foa_frame_result> out(n_frames);
     HIP_TRY(hipMemcpyAsync(out.data(), d_res, r_b, hipMemcpyDeviceToHost, st));

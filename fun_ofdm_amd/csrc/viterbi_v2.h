@@ -348,9 +348,10 @@ __global__ __launch_bounds__(64) void k_viterbi_finish2(const FrameInfo *__restr
 }
 
 inline void launch_viterbi_v2(hipStream_t st, const FrameInfo *info, int nf, const uint32_t *bm, uint64_t *dec, uint32_t *decoded,
-                              uint8_t *psdu, size_t slot_bytes, foa_frame_result *results)
+                              uint8_t *psdu, size_t slot_bytes, foa_frame_result *results, hipEvent_t between)
 {
     hipLaunchKernelGGL(k_viterbi_fwd2, dim3((nf + 1) / 2), dim3(64), 0, st, info, nf, bm, dec);
+    if (between) (void)hipEventRecord(between, st);
     hipLaunchKernelGGL(k_viterbi_finish2, dim3((nf + 63) / 64), dim3(64), 0, st, info, nf, dec, decoded, psdu, slot_bytes, results);
 }
 

@@ -72,10 +72,10 @@ class Receiver:
                                              psdu.shape[1], results.data_ptr()))
 
     def kernel_ms(self):
-        """HIP-event durations of the last decode: dict(header, scan, symbols, viterbi, total) in ms."""
-        out = (C.c_float * 5)()
+        """HIP-event durations of the last decode in ms: header, scan, symbols, viterbi_fwd, viterbi_finish, total."""
+        out = (C.c_float * 6)()
         check(lib().foa_rx_last_kernel_ms(self._h, out))
-        return dict(zip(("header", "scan", "symbols", "viterbi", "total"), (float(x) for x in out)))
+        return dict(zip(("header", "scan", "symbols", "viterbi_fwd", "viterbi_finish", "total"), (float(x) for x in out)))
 
     def taps(self, n_frames, eq=False, soft=True, cap_symbols=None):
         """Intermediates of the last decode call (host copies): dict(hinv, eq, eq_off, soft, soft_off)."""

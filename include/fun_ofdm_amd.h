@@ -117,8 +117,8 @@ void *foa_rx_stream(foa_rx *rx);
 
 /* HIP-event durations (ms) of the kernels of the most recent decode call, measured on the handle's
  * stream: [0] header (LTS+SIGNAL), [1] offset scan, [2] data-symbol FFT/equalise/demap,
- * [3] Viterbi (+descramble+CRC), [4] whole call.  Synchronises. */
-int foa_rx_last_kernel_ms(foa_rx *rx, float out_ms[5]);
+ * [3] Viterbi forward pass, [4] chain-back + descramble + CRC, [5] whole call.  Synchronises. */
+int foa_rx_last_kernel_ms(foa_rx *rx, float out_ms[6]);
 
 /* Intermediates of the most recent decode call, copied to HOST memory (parity tests).
  *   hinv    64 complex doubles (re,im) per frame: channel_est's m_chan_est (channel_est.cpp:53-58)

@@ -237,4 +237,4 @@ def test_config2_shape_batch(rx, po, kind):
     ok = res[:, 0] == 0
     assert np.array_equal(opsdu[ok], psdu[ok])
     ms = rx.kernel_ms()
-    assert ms["total"] > 0 and ms["viterbi"] > 0
+    assert ms["total"] > 0 and ms["viterbi_fwd"] > 0
