@@ -70,6 +70,19 @@ def cpu_baseline(iq, descs, ends, pays, budget_s=15.0):
                        % (n, real.size, n_samp, cores, dt)), psdu, res, n
 
 
+def pmc_traffic(kernel, frames):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/), if they were taken on
+    this workload size; PMC counters cannot be read from inside the timed process."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if name.endswith("_pmc_hbm.json"):
+            d = json.load(open(os.path.join(pdir, name)))
+            if d.get("frames_per_gpu") == frames and kernel in d.get("kernels", {}):
+                best = d["kernels"][kernel]["hbm_bytes_per_launch"]
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -206,7 +219,7 @@ def main():
             alg_bytes = real.size * 39 * 216 * (4 + 8)
             ach = alg_bytes / (kms["viterbi_fwd"] * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": "k_viterbi_fwd2", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                               "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": None,
+                               "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": pmc_traffic("k_viterbi_fwd2", args.frames),
                                "algorithmic_bytes_per_launch": int(alg_bytes), "avg_kernel_ms": round(kms["viterbi_fwd"], 4),
                                "note": "issue-bound on integer VALU/DPP, not HBM-bound (SURVEY 8d); DESIGN.md 4 gives the instruction-issue accounting"}
             out["kernel_ms"] = {k: round(v, 4) for k, v in kms.items()}
