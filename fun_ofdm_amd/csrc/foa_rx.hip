@@ -137,7 +137,7 @@ int workspace(foa_rx *rx, size_t n_samples, size_t n_frames)
 {
     size_t sym_cap = n_samples / 80 + 4;
     size_t soft_cap = 432 * sym_cap + 256 * (n_frames + 1);
-    size_t dec_cap = 216 * sym_cap + 64 * (n_frames + 1);
+    size_t dec_cap = 216 * sym_cap + 128 * (n_frames + 1);
     int rc;
     if ((rc = rx->info.ensure(n_frames + 1)) || (rc = rx->hinv.ensure((n_frames + 1) * 64)) || (rc = rx->sym2frame.ensure(sym_cap)) ||
         (rc = rx->soft.ensure(soft_cap)) || (rc = rx->dec.ensure(dec_cap)) || (rc = rx->bm.ensure(dec_cap)) || (rc = rx->decoded.ensure(dec_cap)) || (rc = rx->totals.ensure(8)))
@@ -537,7 +537,7 @@ int foa_decode_data_f64(foa_rx *rx, const double *carriers, const uint64_t *carr
         fi.status = FOA_ST_CRC_FAIL; fi.rate = rate; fi.length = len; fi.nsym = nsym; fi.sym_off = (int32_t)sym2frame.size();
         fi.nsteps = nsym * dbps; fi.soft_off = soft_off; fi.dec_off = dec_off;
         soft_off += ((int64_t)2 * fi.nsteps + 255) & ~(int64_t)255;
-        dec_off += (fi.nsteps + 63) & ~63;
+        dec_off += dec_words(fi.nsteps);
         coff[f] = (int64_t)carrier_off[f];
         sym2frame.insert(sym2frame.end(), (size_t)nsym, (int32_t)f);
         results[f].num_symbols = nsym;

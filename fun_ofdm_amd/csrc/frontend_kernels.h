@@ -209,17 +209,25 @@ __device__ __forceinline__ uint32_t dpp_mov(uint32_t v)
 
 __device__ __forceinline__ uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
 
-// minimum over the 64 lanes, returned wave-uniform (four DPP rounds inside each row of 16, then the four
-// row results meet on the scalar unit)
+// minimum over the 64 lanes, returned wave-uniform: four DPP rounds inside each row of 16 (xor 1, xor 2,
+// half-mirror, mirror), then row_bcast:15 / row_bcast:31 carry the row results to lane 63
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_min_step(uint32_t v)
+{
+    // lanes outside ROW_MASK (and lanes whose source is out of range) see UINT_MAX, the identity of min, so that
+    // the compiler can fold the move into v_min_u32_dpp
+    uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, CTRL, ROW_MASK, 0xF, false);
+    return umin32(v, t);
+}
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 {
-    v = umin32(v, dpp_mov<FOA_DPP_XOR1>(v));
-    v = umin32(v, dpp_mov<FOA_DPP_XOR2>(v));
-    v = umin32(v, dpp_mov<FOA_DPP_HALF_MIRROR>(v));
-    v = umin32(v, dpp_mov<FOA_DPP_MIRROR>(v));
-    uint32_t a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16), c = __builtin_amdgcn_readlane(v, 32),
-             d = __builtin_amdgcn_readlane(v, 48);
-    return umin32(umin32(a, b), umin32(c, d));
+    v = dpp_min_step<FOA_DPP_XOR1, 0xF>(v);
+    v = dpp_min_step<FOA_DPP_XOR2, 0xF>(v);
+    v = dpp_min_step<FOA_DPP_HALF_MIRROR, 0xF>(v);
+    v = dpp_min_step<FOA_DPP_MIRROR, 0xF>(v);
+    v = dpp_min_step<0x142, 0xA>(v);          // row_bcast:15 -> rows 1 and 3
+    v = dpp_min_step<0x143, 0xC>(v);          // row_bcast:31 -> rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 __device__ __forceinline__ uint32_t acs_step(uint32_t M, uint32_t s0, uint32_t s1, const AcsLane &a, uint64_t &dec)
@@ -370,6 +378,9 @@ __global__ __launch_bounds__(64) void k_header(const float2 *__restrict__ iq, co
 // =================================================================================================
 // K2: exclusive scans over frames -> sym_off / soft_off / dec_off.  One block.
 // =================================================================================================
+// words reserved per frame in the per-step buffers (bm / dec / decoded): the chain-back reads whole 24-step blocks
+__host__ __device__ constexpr int64_t dec_words(int64_t nsteps) { return nsteps > 0 ? (nsteps + 24 + 63) & ~(int64_t)63 : 0; }
+
 __global__ __launch_bounds__(1024) void k_scan(FrameInfo *__restrict__ info, int n_frames, int64_t sym_cap, int64_t soft_cap,
                                                int64_t dec_cap, int64_t *__restrict__ totals)
 {
@@ -379,7 +390,7 @@ __global__ __launch_bounds__(1024) void k_scan(FrameInfo *__restrict__ info, int
     int64_t a = 0, b = 0, c = 0;
     for (int f = lo; f < hi; f++) {
         const int nsym = info[f].nsym, nsteps = nsym > 0 ? info[f].nsteps : 0;
-        a += nsym; b += ((int64_t)2 * nsteps + 255) & ~(int64_t)255; c += (nsteps + 63) & ~63;
+        a += nsym; b += ((int64_t)2 * nsteps + 255) & ~(int64_t)255; c += dec_words(nsteps);
     }
     part[0][tid] = a; part[1][tid] = b; part[2][tid] = c;
     __syncthreads();
@@ -393,7 +404,7 @@ __global__ __launch_bounds__(1024) void k_scan(FrameInfo *__restrict__ info, int
     for (int f = lo; f < hi; f++) {
         FrameInfo fi = info[f];
         const int nsteps = fi.nsym > 0 ? fi.nsteps : 0;
-        const int64_t sb = ((int64_t)2 * nsteps + 255) & ~(int64_t)255, dw = (nsteps + 63) & ~63;
+        const int64_t sb = ((int64_t)2 * nsteps + 255) & ~(int64_t)255, dw = dec_words(nsteps);
         if (fi.nsym > 0 && (a + fi.nsym > sym_cap || b + sb > soft_cap || c + dw > dec_cap)) {
             // keeps its slots in the numbering (they stay unused: sym2frame = -1 there)
             info[f].status = FOA_ST_NO_SPACE; info[f].nsteps = -fi.nsym; info[f].nsym = 0;

@@ -53,16 +53,29 @@ __device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b)
 // Decision words are collected in VGPRs, lane J holding the word of the chunk's step J, and leave as one
 // coalesced 8-byte-per-lane store per chunk.  (Scalar stores would cost no VALU slot at all, but gfx950's
 // scalar data cache retires only about one s_store per 10 clocks per CU -- measured, tools/probe_sstore.hip.)
+// The word goes into lane J by narrowing EXEC to that lane around plain v_mov_b32 (about 2 clocks each; a
+// v_writelane_b32 costs about 4.2).  The kernel runs with all 64 lanes active, so EXEC is restored to -1.
+// The two SALU instructions in front also provide the wait states a VALU needs before it may read an SGPR that
+// a VALU compare has just written.
 struct DecAcc { uint32_t lo, hi; };
 
 template <int J>
+__device__ __forceinline__ void dec_put2(DecAcc &a, DecAcc &b, uint64_t va, uint64_t vb)
+{
+    asm volatile("s_mov_b64 exec, 0\n\ts_bitset1_b64 exec, %8\n\t"
+                 "v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7\n\t"
+                 "s_mov_b64 exec, -1"
+                 : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi)
+                 : "s"((uint32_t)va), "s"((uint32_t)(va >> 32)), "s"((uint32_t)vb), "s"((uint32_t)(vb >> 32)), "n"(J));
+}
+template <int J>
 __device__ __forceinline__ void dec_put(DecAcc &a, uint64_t v)
 {
-    // v comes from a v_cmp (VALU-written SGPR pair).  A v_writelane that reads it as DATA less than two wait
-    // states later gets the old SGPR contents on gfx950 (observed; hipcc pads nothing inside asm statements),
-    // so the first of the two carries its own s_nop.
-    asm volatile("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(a.lo) : "s"((uint32_t)v), "n"(J));
-    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(a.hi) : "s"((uint32_t)(v >> 32)), "n"(J));
+    asm volatile("s_mov_b64 exec, 0\n\ts_bitset1_b64 exec, %4\n\t"
+                 "v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3\n\t"
+                 "s_mov_b64 exec, -1"
+                 : "+v"(a.lo), "+v"(a.hi)
+                 : "s"((uint32_t)v), "s"((uint32_t)(v >> 32)), "n"(J));
 }
 __device__ __forceinline__ void dec_put_dyn(DecAcc &a, uint64_t v, int j, int lane)
 {
@@ -133,28 +146,27 @@ __device__ __forceinline__ uint32_t fwd2_step(uint32_t M, const uint2 w, const F
     uint32_t lo, hi;
     pair_exchange<5 - PH>(M, lo, hi);
     const uint32_t x = pk_add_sat(lo, inc_lo), y = pk_add_sat(hi, inc_hi);
-    if (SA) {
-        const uint64_t d = __ballot((y & 0xFFFFu) <= (x & 0xFFFFu));        // high (old MSB = 1) predecessor wins ties
-        if constexpr (J >= 0) dec_put<(J >= 0 ? J : 0)>(accA, d); else dec_put_dyn(accA, d, jdyn, lane);
-    }
-    if (SB) {
-        const uint64_t d = __ballot((y >> 16) <= (x >> 16));
-        if constexpr (J >= 0) dec_put<(J >= 0 ? J : 0)>(accB, d); else dec_put_dyn(accB, d, jdyn, lane);
+    // high (old MSB = 1) predecessor wins ties; the lane mask of the compare is the step's decision word
+    if constexpr (SA && SB && J >= 0) {
+        dec_put2<(J >= 0 ? J : 0)>(accA, accB, __ballot((y & 0xFFFFu) <= (x & 0xFFFFu)), __ballot((y >> 16) <= (x >> 16)));
+    } else {
+        if (SA) {
+            const uint64_t d = __ballot((y & 0xFFFFu) <= (x & 0xFFFFu));
+            if constexpr (J >= 0) dec_put<(J >= 0 ? J : 0)>(accA, d); else dec_put_dyn(accA, d, jdyn, lane);
+        }
+        if (SB) {
+            const uint64_t d = __ballot((y >> 16) <= (x >> 16));
+            if constexpr (J >= 0) dec_put<(J >= 0 ? J : 0)>(accB, d); else dec_put_dyn(accB, d, jdyn, lane);
+        }
     }
     uint32_t Mn = pk_min(x, y);
     // viterbi.cpp:314-332 per frame: renormalise when the new metric of state 0 (slot 0 = lane 0) exceeds 210
     const uint32_t c0 = __builtin_amdgcn_readfirstlane(pk_sub_sat(Mn, kRenormThr | (kRenormThr << 16)));
     if (c0) {
-        uint32_t v = Mn;
-        v = pk_min(v, dpp_mov<FOA_DPP_XOR1>(v));
-        v = pk_min(v, dpp_mov<FOA_DPP_XOR2>(v));
-        v = pk_min(v, dpp_mov<FOA_DPP_HALF_MIRROR>(v));
-        v = pk_min(v, dpp_mov<FOA_DPP_MIRROR>(v));
-        uint32_t r = pk_min(pk_min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
-                            pk_min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
-        r -= kBias2;                                                        // per-half minimum, unbiased
-        const uint32_t amt = ((c0 & 0xFFFFu) ? (r & 0xFFFFu) : 0u) | ((c0 >> 16) ? (r & 0xFFFF0000u) : 0u);
-        Mn -= amt;                                                          // no borrow: every half >= its minimum
+        // usually only one of the two frames is due: reduce just that half, as plain u32 (v_min_u32 takes the DPP
+        // operand directly, one instruction per round)
+        if (c0 & 0xFFFFu) Mn -= wave_min_u32(Mn & 0xFFFFu) - kBias;
+        if (c0 >> 16) Mn -= (wave_min_u32(Mn >> 16) - kBias) << 16;
     }
     return Mn;
 }
@@ -209,12 +221,15 @@ __device__ __forceinline__ uint32_t fwd2_step_dyn(uint32_t M, int j, bool sa, bo
 #undef FOA_DYN
 }
 
-__global__ __launch_bounds__(64) void k_viterbi_fwd2(const FrameInfo *__restrict__ info, int n_frames, const uint32_t *__restrict__ bm,
-                                                     uint64_t *__restrict__ dec)
+constexpr int kFwdWaves = 4;     // waves (frame pairs) per workgroup: whole workgroups spread evenly over a CU's four SIMDs
+
+__global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd2(const FrameInfo *__restrict__ info, int n_frames,
+                                                                 const uint32_t *__restrict__ bm, uint64_t *__restrict__ dec)
 {
-    __shared__ uint2 bml[64];
-    const int lane = threadIdx.x;
-    const int fA = 2 * blockIdx.x, fB = fA + 1;
+    __shared__ uint2 bml_all[kFwdWaves][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint2 *bml = bml_all[wave];
+    const int fA = 2 * (blockIdx.x * kFwdWaves + wave), fB = fA + 1;
     if (fA >= n_frames) return;
     const FrameInfo ia = info[fA];
     FrameInfo ib = ia;
@@ -242,10 +257,11 @@ __global__ __launch_bounds__(64) void k_viterbi_fwd2(const FrameInfo *__restrict
         if (t0 + lane < TA && lane < nn) dA[t0 + lane] = ((uint64_t)accA.hi << 32) | accA.lo;
         if (t0 + lane < TB && lane < nn) dB[t0 + lane] = ((uint64_t)accB.hi << 32) | accB.lo;
     }
-    // the chain-back kernel reads whole 24-step blocks: words between a frame's last step and the end of its
-    // 64-word-padded region must read as "no decision" (zero keeps its walk parked in slot 0)
-    if (TA + lane < ((TA + 63) & ~63)) dA[TA + lane] = 0;
-    if (TB > 0 && TB + lane < ((TB + 63) & ~63)) dB[TB + lane] = 0;
+    // the chain-back kernel reads whole 24-step blocks: the words after a frame's last step, up to the end of its
+    // region (padded to T + 24, rounded up to 64 words), must read as "no decision" (zero keeps the walk in slot 0)
+    for (int i = TA + lane; i < ((TA + 24 + 63) & ~63); i += 64) dA[i] = 0;
+    if (TB > 0)
+        for (int i = TB + lane; i < ((TB + 24 + 63) & ~63); i += 64) dB[i] = 0;
 }
 
 // Chain-back (viterbi.cpp:108-146) in slot space, descrambler and CRC-32 (ppdu.cpp:256-293), one LANE per frame:
@@ -268,46 +284,62 @@ __global__ __launch_bounds__(64) void k_viterbi_finish2(const FrameInfo *__restr
     uint32_t *out = decoded + fi.dec_off;                  // T/8 bytes needed; the region holds >= T dwords
     // Data bit n is the decision bit read at step n+6 (viterbi.cpp:131-142); the walk starts in state 0 = slot 0
     // at time T and follows  p <- (p & ~(1<<q)) | (bit << q),  q = 5 - t mod 6.  Steps are taken in blocks of 24
-    // (a multiple of the 6 phases, so q and the byte boundaries are compile-time inside the unrolled block); a
-    // block's 24 words are fetched as twelve 16-byte loads one block ahead of their use, since the addresses do not
-    // depend on the walk.  Words past a frame's last step read as zero and leave p = e = 0 untouched.
-    const int Tpad = (T + 63) & ~63;
-    int maxT = T;
+    // (a multiple of the 6 phases and of 8, so q and the byte boundaries are compile-time inside the unrolled
+    // block).  A block's 24 words are fetched as twelve 16-byte loads one block ahead of their use (addresses do
+    // not depend on the walk) into two alternating register sets.  Lanes whose frame is shorter than the wave's
+    // longest join at their own top block; the words between a frame's last step and the end of that block are
+    // zero (written by the forward kernel) and leave the walk parked in slot 0.
+    // The slot index is kept as 5 low bits (p) plus the top bit as a predicate (hi5): bit 5 changes only on every
+    // sixth step, so the right half of the 64-bit word is picked off the critical path and the walk itself is a
+    // 32-bit bit-field extract followed by a shift-or.  Decoded bits are shifted into a 32-bit register, newest
+    // (lowest n) last, and turned into four MSB-first bytes by one bit-reverse + byte swap per 32 steps.
+    const int top_lane = live ? (T - 1) / 24 * 24 : -24;
+    int top = top_lane;
 #pragma unroll
-    for (int o = 32; o; o >>= 1) maxT = max(maxT, __shfl_xor(maxT, o));
-    uint32_t p = 0, e = 0, word = 0;
+    for (int o = 32; o; o >>= 1) top = max(top, __shfl_xor(top, o));
+    uint32_t p = 0, acc = 0;
+    bool hi5 = false;
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-    u64x2 cur[12], nxt[12];
+    u64x2 bufA[12], bufB[12];
     auto load_block = [&](u64x2 *buf, int tb) {
+        if (tb <= top_lane) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) {
-            const int t = tb + 2 * i;
-            buf[i] = t < Tpad ? *(const u64x2 *)(dp + t) : u64x2{ 0ull, 0ull };
+            for (int i = 0; i < 12; i++) buf[i] = *(const u64x2 *)(dp + tb + 2 * i);
         }
     };
     auto step = [&](uint64_t w, int j, int tb) {                         // j: compile-time position inside the block
         const int q = 5 - j % 6;                                           // tb is a multiple of 6
-        const uint32_t k = (uint32_t)(w >> p) & 1u;
-        p = (p & ~(1u << q)) | (k << q);
-        e = (e >> 1) | (k << 7);
-        if (((j - 6) & 7) == 0) {                                          // n = tb + j - 6, tb is a multiple of 8
-            word = (word << 8) | e;
+        const uint32_t half = hi5 ? (uint32_t)(w >> 32) : (uint32_t)w;
+        const uint32_t k = __builtin_amdgcn_ubfe(half, p, 1);              // offset taken modulo 32
+        if (q == 5) hi5 = k != 0;
+        else p = (p & ~(1u << q)) | (k << q);
+        acc = (acc << 1) | k;
+        if (((j - 6) & 7) == 0) {                                          // n = tb + j - 6 is a multiple of 8 (tb is)
+            // acc bit i = data bit n+i; the reference packs MSB first: byte n/8+b holds bits n+8b .. n+8b+7, high to low
             const int n = tb + j - 6;
-            if ((n & 31) == 0 && n < data_bits) out[n >> 5] = word;
+            if ((n & 31) == 0 && n < data_bits) out[n >> 5] = __builtin_bswap32(__builtin_bitreverse32(acc));
         }
     };
-    if (maxT > 0) {
-        int tb = (maxT - 1) / 24 * 24;
-        load_block(cur, tb);
-        for (; tb >= 24; tb -= 24) {
-            load_block(nxt, tb - 24);
+    auto block = [&](const u64x2 *buf, int tb, int jlo) {
+        if (tb <= top_lane) {
 #pragma unroll
-            for (int j = 23; j >= 0; j--) step(cur[j >> 1][j & 1], j, tb);
-#pragma unroll
-            for (int i = 0; i < 12; i++) cur[i] = nxt[i];
+            for (int j = 23; j >= 0; j--)
+                if (j >= jlo) step(buf[j >> 1][j & 1], j, tb);
         }
-#pragma unroll
-        for (int j = 23; j >= 6; j--) step(cur[j >> 1][j & 1], j, 0);      // steps 0..5 carry no data bit
+    };
+    if (top >= 0) {
+        int tb = top;
+        load_block(bufA, tb);
+        for (;;) {
+            if (tb == 0) { block(bufA, 0, 6); break; }                     // steps 0..5 carry no data bit
+            load_block(bufB, tb - 24);
+            block(bufA, tb, 0);
+            tb -= 24;
+            if (tb == 0) { block(bufB, 0, 6); break; }
+            load_block(bufA, tb - 24);
+            block(bufB, tb, 0);
+            tb -= 24;
+        }
     }
     // descramble (one LFSR bit per byte, ppdu.cpp:256-264) + CRC over service+payload (ppdu.cpp:267-271)
     const int len = fi.length, ncrc = live ? 2 + len : 0, nwords = live ? (ncrc + 4 + 3) / 4 : 0;
@@ -350,7 +382,7 @@ __global__ __launch_bounds__(64) void k_viterbi_finish2(const FrameInfo *__restr
 inline void launch_viterbi_v2(hipStream_t st, const FrameInfo *info, int nf, const uint32_t *bm, uint64_t *dec, uint32_t *decoded,
                               uint8_t *psdu, size_t slot_bytes, foa_frame_result *results, hipEvent_t between)
 {
-    hipLaunchKernelGGL(k_viterbi_fwd2, dim3((nf + 1) / 2), dim3(64), 0, st, info, nf, bm, dec);
+    hipLaunchKernelGGL(k_viterbi_fwd2, dim3(((nf + 1) / 2 + kFwdWaves - 1) / kFwdWaves), dim3(64 * kFwdWaves), 0, st, info, nf, bm, dec);
     if (between) (void)hipEventRecord(between, st);
     hipLaunchKernelGGL(k_viterbi_finish2, dim3((nf + 63) / 64), dim3(64), 0, st, info, nf, dec, decoded, psdu, slot_bytes, results);
 }
