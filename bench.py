@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=10000, help="frames per GPU (BASELINE config 2: 10000)")
     ap.add_argument("--viterbi", type=int, default=1, help="0: lane-per-state kernel, 1: packed kernel")
+    ap.add_argument("--frontend", type=int, default=1, help="0: wave-per-symbol kernel, 1: lane-per-symbol kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -133,6 +134,8 @@ def main():
 
     rx = foa.Receiver(dev_index)
     rx.set_option("viterbi", args.viterbi)
+    rx.set_option("frontend", args.frontend)
+    rx.set_option("record_soft", 0)        # PSDUs are the output; soft bytes are only kept for diagnostics
     rx.reserve(iq.size, m)
     d_iq = torch.from_numpy(iq.view(np.float32).reshape(-1, 2)).to(dev)
     d_desc = torch.from_numpy(descs.view(np.uint8).copy()).to(dev)
@@ -209,7 +212,7 @@ def main():
                        "frames_per_gpu": args.frames, "frame_samples": frame_samples, "slot_pitch_samples": PITCH,
                        "counted_samples": "in-frame only (3520/frame)", "value_all_samples_fed": round(value * PITCH / frame_samples, 1),
                        "x_realtime_20MSps": round(value / 20.0, 1), "psdu_bit_exact": exact, "frames_ok": ok_frames,
-                       "alignments_decoded_per_gpu": m, "frontend_dtype": "f64", "viterbi_kernel": args.viterbi,
+                       "alignments_decoded_per_gpu": m, "frontend_dtype": "f64", "viterbi_kernel": args.viterbi, "frontend_kernel": args.frontend,
                        "sharding": ("global frame i on rank i mod %d, one %s gather of PSDU slots to rank 0 per step" % (world, backend)) if world > 1 else "single GPU"},
         }
         if args.steps <= 50:

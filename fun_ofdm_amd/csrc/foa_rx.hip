@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "frontend_kernels.h"
+#include "frontend_lps.h"
 #include "viterbi_v1.h"
 #include "viterbi_v2.h"
 #include "stage_kernels.h"
@@ -117,6 +118,8 @@ struct foa_rx {
     bool have_timing = false;
     int viterbi_kind = 1;
     bool record_eq = false;
+    bool record_soft = true;     // keep the depunctured soft bytes (taps, lane-per-state kernel); off = branch metrics only
+    int frontend_kind = 1;       // 1: one lane per symbol (frontend_lps.h), 0: one wave per symbol
     // workspace
     DevBuf<FrameInfo> info;
     DevBuf<double2> hinv;
@@ -214,6 +217,12 @@ int foa_rx_set_option(foa_rx *rx, const char *name, int64_t value)
         return FOA_OK;
     }
     if (!strcmp(name, "record_eq")) { rx->record_eq = value != 0; return FOA_OK; }
+    if (!strcmp(name, "record_soft")) { rx->record_soft = value != 0; return FOA_OK; }
+    if (!strcmp(name, "frontend")) {
+        if (value != 0 && value != 1) return fail(FOA_E_INVALID, "frontend must be 0 (wave per symbol) or 1 (lane per symbol)");
+        rx->frontend_kind = (int)value;
+        return FOA_OK;
+    }
     return fail(FOA_E_INVALID, "unknown option '%s'", name);
 }
 
@@ -253,8 +262,14 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
     HIP_TRY(hipEventRecord(rx->ev[2], st));
     // upper bound on data symbols in n_samples samples; waves beyond the real total exit at once
     const size_t max_sym = rx->sym_cap;
-    hipLaunchKernelGGL(k_data_symbols, dim3((unsigned)((max_sym + kSymWaves - 1) / kSymWaves)), dim3(64 * kSymWaves), 0, st, iq, d_descs,
-                       rx->info.p, rx->sym2frame.p, rx->totals.p, rx->hinv.p, rx->soft.p, rx->bm.p, eq_data);
+    if (rx->frontend_kind == 1) {
+        uint8_t *soft_out = (rx->record_soft || rx->viterbi_kind == 0) ? rx->soft.p : nullptr;
+        hipLaunchKernelGGL(k_data_symbols_lps, dim3((unsigned)((max_sym + 63) / 64)), dim3(64), 0, st, iq, d_descs, rx->info.p, rx->sym2frame.p,
+                           rx->totals.p, rx->hinv.p, soft_out, rx->bm.p, eq_data);
+    } else {
+        hipLaunchKernelGGL(k_data_symbols, dim3((unsigned)((max_sym + kSymWaves - 1) / kSymWaves)), dim3(64 * kSymWaves), 0, st, iq, d_descs,
+                           rx->info.p, rx->sym2frame.p, rx->totals.p, rx->hinv.p, rx->soft.p, rx->bm.p, eq_data);
+    }
     HIP_TRY(hipEventRecord(rx->ev[3], st));
     if (rx->viterbi_kind == 0)
         hipLaunchKernelGGL(k_viterbi_v1, dim3(nf), dim3(64), 0, st, rx->info.p, nf, rx->soft.p, rx->dec.p, d_psdu, slot_bytes, d_results);
@@ -314,6 +329,7 @@ int foa_rx_get_taps(foa_rx *rx, size_t n_frames, double *hinv, double *eq, size_
     if (!rx) return fail(FOA_E_INVALID, "rx is NULL");
     if (n_frames != rx->last_frames || n_frames == 0) return fail(FOA_E_STATE, "n_frames does not match the last decode call");
     if (eq && !rx->record_eq) return fail(FOA_E_STATE, "set option record_eq=1 before the decode call to get eq");
+    if (soft && !rx->record_soft && rx->viterbi_kind != 0 && rx->frontend_kind == 1) return fail(FOA_E_STATE, "set option record_soft=1 before the decode call to get soft bytes");
     HIP_TRY(hipSetDevice(rx->device));
     HIP_TRY(hipStreamSynchronize(rx->stream));
     std::vector<FrameInfo> info(n_frames);

@@ -122,6 +122,23 @@ __device__ __forceinline__ cpx load_rotated(const float2 *iq, int64_t idx, const
     return cmul(v, r);
 }
 
+// phase_tracker.cpp:97-98 rotates by (cos(-angle), sin(-angle)) with angle = arg(pe): that is conj(pe)/|pe|.
+// Computing it as such (one sqrt, one divide) instead of atan2 + cos + sin removes ~250 fp64 instructions per
+// symbol; both forms are within an ulp or two of the exact value, like the host's libm, and eight orders below
+// the 1e-4 parity tolerance.  pe == 0 (no pilots at all) gives angle 0 in the reference.
+__device__ __forceinline__ cpx unit_conj(cpx pe)
+{
+#pragma clang fp contract(off)
+    const double r2 = pe.x * pe.x + pe.y * pe.y;
+    if (!(r2 > 0.0)) {
+        // zero, NaN or underflow: fall back to the reference's own sequence of calls
+        const double angle = atan2(pe.y, pe.x);
+        return cpx{ cos(-angle), sin(-angle) };
+    }
+    const double r = sqrt(r2);
+    return cpx{ pe.x / r, -pe.y / r };
+}
+
 // phase_tracker.cpp:83-99 for one symbol: returns the derotated carrier of this lane
 __device__ __forceinline__ cpx pilot_derotate(cpx z, int polarity)
 {
@@ -136,9 +153,7 @@ __device__ __forceinline__ cpx pilot_derotate(cpx z, int polarity)
         pe.x += (px * pil) / 4.0;
         pe.y += (py * pil) / 4.0;
     }
-    double angle = atan2(pe.y, pe.x);
-    cpx rot = { cos(-angle), sin(-angle) };
-    return cmul(z, rot);
+    return cmul(z, unit_conj(pe));
 }
 
 // qam.h:110-125; `int pt = sym * d_scale_d` has cvttsd2si semantics on the reference's platform

@@ -48,9 +48,7 @@ __device__ __forceinline__ cpx pilot_derotate_natural(cpx z, int polarity)
         pe.x += (px * pil) / 4.0;
         pe.y += (py * pil) / 4.0;
     }
-    double angle = atan2(pe.y, pe.x);
-    cpx rot = { cos(-angle), sin(-angle) };
-    return cmul(z, rot);
+    return cmul(z, unit_conj(pe));
 }
 
 __global__ __launch_bounds__(256) void k_stage_phase(const double2 *__restrict__ v, const int32_t *__restrict__ symbol_count, int n_vec,

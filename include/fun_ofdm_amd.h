@@ -84,8 +84,11 @@ void foa_rx_destroy(foa_rx *rx);
  * alignments, so that later decode calls allocate nothing. */
 int foa_rx_reserve(foa_rx *rx, size_t n_samples, size_t n_frames);
 
-/* Choose the Viterbi kernel: 0 = wave-per-frame lane-per-state (v1), 1 = packed multi-frame (v2).
- * Results are identical; this exists for A/B measurement. */
+/* Options (results are identical for every setting; they exist for A/B measurement and diagnostics):
+ *   "viterbi"     0 = one wave per frame, lane per state (viterbi_v1.h); 1 = two frames per wave, in-place (default)
+ *   "frontend"    0 = one wave per data symbol; 1 = one lane per data symbol (default)
+ *   "record_soft" keep the depunctured soft bytes for foa_rx_get_taps (default 1; 0 saves their HBM writes)
+ *   "record_eq"   keep the equalised carriers for foa_rx_get_taps (default 0) */
 int foa_rx_set_option(foa_rx *rx, const char *name, int64_t value);
 
 /*
