@@ -140,7 +140,7 @@ int workspace(foa_rx *rx, size_t n_samples, size_t n_frames)
 {
     size_t sym_cap = n_samples / 80 + 4;
     size_t soft_cap = 432 * sym_cap + 256 * (n_frames + 1);
-    size_t dec_cap = 216 * sym_cap + 128 * (n_frames + 1);
+    size_t dec_cap = 216 * sym_cap + 192 * (n_frames + 1);
     int rc;
     if ((rc = rx->info.ensure(n_frames + 1)) || (rc = rx->hinv.ensure((n_frames + 1) * 64)) || (rc = rx->sym2frame.ensure(sym_cap)) ||
         (rc = rx->soft.ensure(soft_cap)) || (rc = rx->dec.ensure(dec_cap)) || (rc = rx->bm.ensure(dec_cap)) || (rc = rx->decoded.ensure(dec_cap)) || (rc = rx->totals.ensure(8)))

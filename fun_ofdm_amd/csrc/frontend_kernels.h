@@ -393,8 +393,8 @@ __global__ __launch_bounds__(64) void k_header(const float2 *__restrict__ iq, co
 // =================================================================================================
 // K2: exclusive scans over frames -> sym_off / soft_off / dec_off.  One block.
 // =================================================================================================
-// words reserved per frame in the per-step buffers (bm / dec / decoded): the chain-back reads whole 24-step blocks
-__host__ __device__ constexpr int64_t dec_words(int64_t nsteps) { return nsteps > 0 ? (nsteps + 24 + 63) & ~(int64_t)63 : 0; }
+// words reserved per frame in the per-step buffers (bm / dec / decoded): the chain-back reads whole 48-step chunks
+__host__ __device__ constexpr int64_t dec_words(int64_t nsteps) { return nsteps > 0 ? (nsteps + 48 + 63) & ~(int64_t)63 : 0; }
 
 __global__ __launch_bounds__(1024) void k_scan(FrameInfo *__restrict__ info, int n_frames, int64_t sym_cap, int64_t soft_cap,
                                                int64_t dec_cap, int64_t *__restrict__ totals)

@@ -258,11 +258,13 @@ __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd2(const FrameInfo
         if (t0 + lane < TB && lane < nn) dB[t0 + lane] = ((uint64_t)accB.hi << 32) | accB.lo;
     }
     // the chain-back kernel reads whole 24-step blocks: the words after a frame's last step, up to the end of its
-    // region (padded to T + 24, rounded up to 64 words), must read as "no decision" (zero keeps the walk in slot 0)
-    for (int i = TA + lane; i < ((TA + 24 + 63) & ~63); i += 64) dA[i] = 0;
+    // region (dec_words(T)), must read as "no decision" (zero keeps the walk in slot 0)
+    for (int i = TA + lane; i < dec_words(TA); i += 64) dA[i] = 0;
     if (TB > 0)
-        for (int i = TB + lane; i < ((TB + 24 + 63) & ~63); i += 64) dB[i] = 0;
+        for (int i = TB + lane; i < dec_words(TB); i += 64) dB[i] = 0;
 }
+
+constexpr int kTbChunk = 48;      // chain-back steps per LDS-DMA chunk (multiple of 6 and 8; two chunks = 48 loads in flight)
 
 // Chain-back (viterbi.cpp:108-146) in slot space, descrambler and CRC-32 (ppdu.cpp:256-293), one LANE per frame:
 // the recursion is serial per frame and a handful of integer ops per step, so 64 frames share a wave and
@@ -271,9 +273,22 @@ __global__ __launch_bounds__(64) void k_viterbi_finish2(const FrameInfo *__restr
                                                         uint32_t *__restrict__ decoded, uint8_t *__restrict__ psdu, size_t slot_bytes,
                                                         foa_frame_result *__restrict__ results)
 {
-    __shared__ uint32_t crc_tab[256];
+    __shared__ uint32_t crc_tab[1024];                   // slicing-by-4: T0 | T1 | T2 | T3
+    __shared__ uint32_t scr_tab[128];                    // descrambling mask of word q mod 127
+    __shared__ ulonglong2 tbuf[2][kTbChunk / 2][64];     // two chunks of decision words, [piece][lane] x 16 B
     const int lane = threadIdx.x, f = blockIdx.x * 64 + lane;
-    for (int i = lane; i < 256; i += 64) crc_tab[i] = g_tab.crc_table[i];
+    for (int i = lane; i < 256; i += 64) {
+        const uint32_t t0 = g_tab.crc_table[i];
+        const uint32_t t1 = (t0 >> 8) ^ g_tab.crc_table[t0 & 0xFFu];
+        const uint32_t t2 = (t1 >> 8) ^ g_tab.crc_table[t1 & 0xFFu];
+        const uint32_t t3 = (t2 >> 8) ^ g_tab.crc_table[t2 & 0xFFu];
+        crc_tab[i] = t0; crc_tab[256 + i] = t1; crc_tab[512 + i] = t2; crc_tab[768 + i] = t3;
+    }
+    for (int i = lane; i < 127; i += 64) {
+        uint32_t m = 0;
+        for (int b = 0; b < 4; b++) m |= (uint32_t)g_tab.scramble[(4 * i + b) % 127] << (8 * b);
+        scr_tab[i] = m;
+    }
     __syncthreads();
     FrameInfo fi;
     fi.status = FOA_ST_HEADER_FAIL; fi.rate = -1; fi.length = 0; fi.nsym = 0; fi.sym_off = 0; fi.nsteps = 0; fi.soft_off = 0; fi.dec_off = 0;
@@ -283,83 +298,107 @@ __global__ __launch_bounds__(64) void k_viterbi_finish2(const FrameInfo *__restr
     const uint64_t *dp = dec + fi.dec_off;
     uint32_t *out = decoded + fi.dec_off;                  // T/8 bytes needed; the region holds >= T dwords
     // Data bit n is the decision bit read at step n+6 (viterbi.cpp:131-142); the walk starts in state 0 = slot 0
-    // at time T and follows  p <- (p & ~(1<<q)) | (bit << q),  q = 5 - t mod 6.  Steps are taken in blocks of 24
-    // (a multiple of the 6 phases and of 8, so q and the byte boundaries are compile-time inside the unrolled
-    // block).  A block's 24 words are fetched as twelve 16-byte loads one block ahead of their use (addresses do
-    // not depend on the walk) into two alternating register sets.  Lanes whose frame is shorter than the wave's
-    // longest join at their own top block; the words between a frame's last step and the end of that block are
-    // zero (written by the forward kernel) and leave the walk parked in slot 0.
+    // at time T and follows  p <- (p & ~(1<<q)) | (bit << q),  q = 5 - t mod 6.
+    // The walk is a few integer ops per step; what limits this kernel is getting 8 B per step and frame out of HBM
+    // with only one wave per 64 frames.  The words are therefore streamed with LDS-DMA (global_load_lds_dwordx4: each
+    // lane fetches 16 B = two steps of its own frame straight into LDS, no VGPRs), 48 steps per chunk, two chunks
+    // (48 loads, 768 B per frame) in flight while the previous chunk is walked.  Addresses do not depend on the walk.
+    // Lanes whose frame is shorter than the wave's longest join at their own top chunk; the words after a frame's
+    // last step are zero (written by the forward kernel) and leave the walk parked in slot 0.
     // The slot index is kept as 5 low bits (p) plus the top bit as a predicate (hi5): bit 5 changes only on every
     // sixth step, so the right half of the 64-bit word is picked off the critical path and the walk itself is a
     // 32-bit bit-field extract followed by a shift-or.  Decoded bits are shifted into a 32-bit register, newest
     // (lowest n) last, and turned into four MSB-first bytes by one bit-reverse + byte swap per 32 steps.
-    const int top_lane = live ? (T - 1) / 24 * 24 : -24;
+    const int top_lane = live ? (T - 1) / kTbChunk * kTbChunk : -kTbChunk;
     int top = top_lane;
 #pragma unroll
     for (int o = 32; o; o >>= 1) top = max(top, __shfl_xor(top, o));
     uint32_t p = 0, acc = 0;
     bool hi5 = false;
-    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-    u64x2 bufA[12], bufB[12];
-    auto load_block = [&](u64x2 *buf, int tb) {
-        if (tb <= top_lane) {
+    // chunk tc -> LDS buffer `which`: piece i = steps tc+2i, tc+2i+1 of every lane's frame
+    auto fetch = [&](int tc, int which) {
+        // lanes that have not started (or dead lanes) fetch their own first words instead: always inside their region
+        const uint64_t *src = dp + (tc <= top_lane ? tc : 0);
+        // Issued from inline asm on purpose: hipcc tracks LDS-DMA issued through the builtin and puts `s_waitcnt vmcnt(0)`
+        // in front of every later LDS read, which would serialise fetch and walk; the counted wait below is ours.
+        const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)&tbuf[which][0][0];
 #pragma unroll
-            for (int i = 0; i < 12; i++) buf[i] = *(const u64x2 *)(dp + tb + 2 * i);
+        for (int i = 0; i < kTbChunk / 2; i++) {
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(src + 2 * i), "s"(lds0 + (uint32_t)i * 1024u)
+                         : "memory");
         }
     };
-    auto step = [&](uint64_t w, int j, int tb) {                         // j: compile-time position inside the block
-        const int q = 5 - j % 6;                                           // tb is a multiple of 6
+    auto step = [&](uint64_t w, int j, int tc) {                         // j: compile-time position inside the chunk
+        const int q = 5 - j % 6;                                           // tc is a multiple of 6
         const uint32_t half = hi5 ? (uint32_t)(w >> 32) : (uint32_t)w;
         const uint32_t k = __builtin_amdgcn_ubfe(half, p, 1);              // offset taken modulo 32
         if (q == 5) hi5 = k != 0;
         else p = (p & ~(1u << q)) | (k << q);
         acc = (acc << 1) | k;
-        if (((j - 6) & 7) == 0) {                                          // n = tb + j - 6 is a multiple of 8 (tb is)
+        if (((j - 6) & 7) == 0) {                                          // n = tc + j - 6 is a multiple of 8 (tc is)
             // acc bit i = data bit n+i; the reference packs MSB first: byte n/8+b holds bits n+8b .. n+8b+7, high to low
-            const int n = tb + j - 6;
+            const int n = tc + j - 6;
             if ((n & 31) == 0 && n < data_bits) out[n >> 5] = __builtin_bswap32(__builtin_bitreverse32(acc));
         }
     };
-    auto block = [&](const u64x2 *buf, int tb, int jlo) {
-        if (tb <= top_lane) {
+    auto walk = [&](int which, int tc, int jlo) {
+        if (tc <= top_lane) {
 #pragma unroll
-            for (int j = 23; j >= 0; j--)
-                if (j >= jlo) step(buf[j >> 1][j & 1], j, tb);
+            for (int j = kTbChunk - 1; j >= 0; j--)
+                if (j >= jlo) {
+                    const ulonglong2 v = tbuf[which][j >> 1][lane];
+                    step((j & 1) ? v.y : v.x, j, tc);
+                }
         }
     };
     if (top >= 0) {
-        int tb = top;
-        load_block(bufA, tb);
+        int tc = top, which = 0;
+        fetch(tc, 0);
         for (;;) {
-            if (tb == 0) { block(bufA, 0, 6); break; }                     // steps 0..5 carry no data bit
-            load_block(bufB, tb - 24);
-            block(bufA, tb, 0);
-            tb -= 24;
-            if (tb == 0) { block(bufB, 0, 6); break; }
-            load_block(bufA, tb - 24);
-            block(bufB, tb, 0);
-            tb -= 24;
+            if (tc >= kTbChunk) {
+                fetch(tc - kTbChunk, which ^ 1);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kTbChunk / 2) : "memory");   // the older chunk has landed
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_wave_barrier();
+            walk(which, tc, tc == 0 ? 6 : 0);                              // steps 0..5 carry no data bit
+            __builtin_amdgcn_wave_barrier();
+            if (tc == 0) break;
+            tc -= kTbChunk;
+            which ^= 1;
         }
     }
-    // descramble (one LFSR bit per byte, ppdu.cpp:256-264) + CRC over service+payload (ppdu.cpp:267-271)
+    // descramble (one LFSR bit per byte, ppdu.cpp:256-264) + CRC over service+payload (ppdu.cpp:267-271).
+    // Whole words go through four table look-ups that do not depend on each other (slicing-by-4); the scrambler's
+    // 127-byte period makes a 127-word table of descrambling masks.
     const int len = fi.length, ncrc = live ? 2 + len : 0, nwords = live ? (ncrc + 4 + 3) / 4 : 0;
     int maxw = nwords;
 #pragma unroll
     for (int o = 32; o; o >>= 1) maxw = max(maxw, __shfl_xor(maxw, o));
     uint32_t crc = 0xFFFFFFFFu, given = 0;
+    const int full = ncrc >> 2;                                            // words that lie entirely inside the CRC range
+    int qs = 0;                                                            // q mod 127
     for (int q = 0; q < maxw; q++) {
-        uint32_t scr = 0;
-#pragma unroll
-        for (int b = 0; b < 4; b++) scr |= (uint32_t)g_tab.scramble[(4 * q + b) % 127] << (8 * b);
+        const uint32_t scr = scr_tab[qs];
+        qs = qs == 126 ? 0 : qs + 1;
         if (q < nwords) {
             const uint32_t d = out[q] ^ scr;
             out[q] = d;
+            if (q < full) {
+                const uint32_t c = crc ^ d;
+                crc = crc_tab[768 + (c & 0xFFu)] ^ crc_tab[512 + ((c >> 8) & 0xFFu)] ^ crc_tab[256 + ((c >> 16) & 0xFFu)] ^ crc_tab[c >> 24];
+            } else {
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const int x = 4 * q + b;
-                const uint32_t byte = (d >> (8 * b)) & 0xFFu;
-                if (x < ncrc) crc = crc_tab[(crc ^ byte) & 0xFFu] ^ (crc >> 8);
-                else if (x < ncrc + 4) given |= byte << (8 * (x - ncrc));
+                for (int b = 0; b < 4; b++) {
+                    const int x = 4 * q + b;
+                    const uint32_t byte = (d >> (8 * b)) & 0xFFu;
+                    if (x < ncrc) crc = crc_tab[(crc ^ byte) & 0xFFu] ^ (crc >> 8);
+                    else if (x < ncrc + 4) given |= byte << (8 * (x - ncrc));
+                }
             }
         }
     }
@@ -370,9 +409,19 @@ __global__ __launch_bounds__(64) void k_viterbi_finish2(const FrameInfo *__restr
         const int ncopy = min((size_t)len, slot_bytes);
         int y = 0;
         if ((((uintptr_t)slot) & 3) == 0)
-            for (; y + 4 <= ncopy; y += 4) {
-                const int q = (y + 2) >> 2;                                  // bytes y+2 .. y+5 straddle words q, q+1
-                ((uint32_t *)slot)[y >> 2] = (out[q] >> 16) | (out[q + 1] << 16);
+            {
+                // bytes y+2 .. y+5 straddle words q, q+1; four words per trip keep several loads in flight
+                for (; y + 16 <= ncopy; y += 16) {
+                    const int q = (y + 2) >> 2;
+                    const uint32_t a0 = out[q], a1 = out[q + 1], a2 = out[q + 2], a3 = out[q + 3], a4 = out[q + 4];
+                    uint32_t *dst = (uint32_t *)slot + (y >> 2);
+                    dst[0] = (a0 >> 16) | (a1 << 16); dst[1] = (a1 >> 16) | (a2 << 16);
+                    dst[2] = (a2 >> 16) | (a3 << 16); dst[3] = (a3 >> 16) | (a4 << 16);
+                }
+                for (; y + 4 <= ncopy; y += 4) {
+                    const int q = (y + 2) >> 2;
+                    ((uint32_t *)slot)[y >> 2] = (out[q] >> 16) | (out[q + 1] << 16);
+                }
             }
         for (; y < ncopy; y++) slot[y] = (uint8_t)(out[(y + 2) >> 2] >> (8 * ((y + 2) & 3)));
     }
