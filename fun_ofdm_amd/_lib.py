@@ -41,6 +41,7 @@ _SIGS = {
     "foa_rx_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "foa_rx_get_taps": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "foa_rx_get_decisions": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "foa_rx_sync_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "foa_sync_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "foa_sync_destroy": (None, [C.c_void_p]),
     "foa_sync_push_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),

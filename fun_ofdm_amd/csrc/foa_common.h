@@ -38,6 +38,7 @@ struct DeviceTables {
     int8_t data_index[64];         // subcarrier index -> 0..47 (phase_tracker.cpp:46-50), -1 otherwise
     uint8_t scramble[128];         // ppdu.cpp:256-264 feedback bit per byte index mod 127
     uint32_t crc_table[256];       // IEEE 802.3 CRC-32, reflected
+    double lts_conj_re[64], lts_conj_im[64];   // preamble.h:432 LTS_TIME_DOMAIN_CONJ
 };
 
 // Filled once on the host (tables.cpp) and uploaded to __constant__ memory of each translation unit

@@ -1,6 +1,8 @@
 // foa_rx.hip -- the C ABI of include/fun_ofdm_amd.h over the gfx950 kernels.
 // Built by fun_ofdm_amd/csrc/Makefile:  hipcc --offload-arch=gfx950 -O3 -shared -fPIC
+#include <algorithm>
 #include <cmath>
+#include <complex>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -13,6 +15,7 @@
 #include "viterbi_v2.h"
 #include "stage_kernels.h"
 #include "sync_host.h"
+#include "sync_kernels.h"
 
 using namespace foa;
 
@@ -109,6 +112,9 @@ void foa::build_tables(DeviceTables *t)
         for (int k = 0; k < 8; k++) c = (c & 1u) ? (c >> 1) ^ 0xEDB88320u : c >> 1;
         t->crc_table[i] = c;
     }
+    std::complex<double> ltc[64];
+    foa::make_lts_time_conj(ltc);
+    for (int i = 0; i < 64; i++) { t->lts_conj_re[i] = ltc[i].real(); t->lts_conj_im[i] = ltc[i].imag(); }
 }
 
 struct foa_rx {
@@ -130,6 +136,10 @@ struct foa_rx {
     DevBuf<int64_t> totals;
     DevBuf<double2> eq_sig, eq_data;
     DevBuf<uint8_t> scratch;     // staging for the host-pointer entry points
+    DevBuf<uint32_t> sy_flags;   // device pre-sync workspace
+    DevBuf<int32_t> sy_cnt, sy_off, sy_keep, sy_n;
+    DevBuf<int64_t> sy_x;
+    DevBuf<SyncCand> sy_cand;
     size_t sym_cap = 0, soft_cap = 0, dec_cap = 0;
     size_t last_frames = 0;
 };
@@ -196,6 +206,7 @@ void foa_rx_destroy(foa_rx *rx)
     (void)hipStreamSynchronize(rx->stream);
     rx->info.release(); rx->hinv.release(); rx->sym2frame.release(); rx->soft.release(); rx->dec.release(); rx->bm.release(); rx->decoded.release(); rx->totals.release();
     rx->eq_sig.release(); rx->eq_data.release(); rx->scratch.release();
+    rx->sy_flags.release(); rx->sy_cnt.release(); rx->sy_off.release(); rx->sy_keep.release(); rx->sy_n.release(); rx->sy_x.release(); rx->sy_cand.release();
     for (auto &e : rx->ev) if (e) (void)hipEventDestroy(e);
     if (rx->stream) (void)hipStreamDestroy(rx->stream);
     delete rx;
@@ -374,6 +385,46 @@ int foa_rx_get_decisions(foa_rx *rx, size_t frame, uint64_t *out, size_t cap, si
     *n_steps = n;
     if (n > cap) return fail(FOA_E_INVALID, "cap too small (%zu steps)", n);
     if (n) HIP_TRY(hipMemcpy(out, rx->dec.p + fi.dec_off, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return FOA_OK;
+}
+
+int foa_rx_sync_dev(foa_rx *rx, const float *d_iq, size_t n_samples, foa_frame_desc *d_descs, int64_t *d_ends, size_t cap, size_t *n_found)
+{
+    if (!rx || !d_iq || !d_descs || !d_ends || !n_found) return fail(FOA_E_INVALID, "NULL argument");
+    *n_found = 0;
+    if (n_samples == 0 || cap == 0) return FOA_OK;
+    if (n_samples > 0x7FFFFFFFull * 16) return fail(FOA_E_INVALID, "stream too long for one call");
+    HIP_TRY(hipSetDevice(rx->device));
+    const int64_t n = (int64_t)n_samples, n_words = (n + 31) / 32;
+    const int n_blocks = (int)((n_words + kSyncBlockWords - 1) / kSyncBlockWords);
+    const int32_t ccap = (int32_t)std::min<size_t>(n_samples / 64 + 64, 0x7FFFFFF0u);
+    int rc;
+    if ((rc = rx->sy_flags.ensure((size_t)n_words)) || (rc = rx->sy_cnt.ensure((size_t)n_blocks)) || (rc = rx->sy_off.ensure((size_t)n_blocks)) ||
+        (rc = rx->sy_x.ensure((size_t)ccap)) || (rc = rx->sy_cand.ensure((size_t)ccap)) || (rc = rx->sy_keep.ensure((size_t)ccap)) || (rc = rx->sy_n.ensure(8)))
+        return rc;
+    hipStream_t st = rx->stream;
+    const float2 *iq = (const float2 *)d_iq;
+    hipLaunchKernelGGL(k_sync_flags, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, iq, n, rx->sy_flags.p);
+    hipLaunchKernelGGL(k_sync_sts_end, dim3(n_blocks), dim3(kSyncBlockWords), 0, st, rx->sy_flags.p, n_words, 0, rx->sy_cnt.p, rx->sy_off.p, rx->sy_x.p, ccap);
+    hipLaunchKernelGGL(k_sync_scan, dim3(1), dim3(1024), 0, st, rx->sy_cnt.p, n_blocks, rx->sy_off.p, rx->sy_n.p);
+    hipLaunchKernelGGL(k_sync_sts_end, dim3(n_blocks), dim3(kSyncBlockWords), 0, st, rx->sy_flags.p, n_words, 1, rx->sy_cnt.p, rx->sy_off.p, rx->sy_x.p, ccap);
+    // one wave per candidate; the candidate count lives on the device, so launch for the capacity that can occur in
+    // practice (an STS_END needs 17 samples) and let surplus waves exit -- but first learn the count to keep the grid small
+    int32_t ncand = 0;
+    HIP_TRY(hipMemcpyAsync(&ncand, rx->sy_n.p, sizeof ncand, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (ncand > ccap) return fail(FOA_E_NOMEM, "too many STS_END candidates (%d)", ncand);
+    if (ncand == 0) return FOA_OK;
+    hipLaunchKernelGGL(k_sync_lts, dim3(ncand), dim3(64), 0, st, iq, n, rx->sy_x.p, rx->sy_n.p, ccap, rx->sy_cand.p);
+    hipLaunchKernelGGL(k_sync_keep, dim3((ncand + 255) / 256), dim3(256), 0, st, rx->sy_cand.p, rx->sy_n.p, ccap, rx->sy_keep.p);
+    hipLaunchKernelGGL(k_sync_finish, dim3(1), dim3(1024), 0, st, rx->sy_cand.p, rx->sy_keep.p, rx->sy_n.p, ccap, n, d_descs, d_ends,
+                       (int32_t)std::min<size_t>(cap, 0x7FFFFFF0u), rx->sy_n.p + 2);
+    int32_t nout[2] = { 0, 0 };
+    HIP_TRY(hipMemcpyAsync(nout, rx->sy_n.p + 2, sizeof nout, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    if ((size_t)nout[1] > cap) return fail(FOA_E_INVALID, "cap too small: %d alignments found", nout[1]);
+    *n_found = (size_t)nout[0];
     return FOA_OK;
 }
 

@@ -15,6 +15,8 @@
 #include <cmath>
 #include <complex>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <utility>
 #include <vector>
 
@@ -22,11 +24,35 @@
 
 namespace foa {
 
+// preamble.h:432: conj of the 64-sample long training symbol, as printed with 12 significant digits
+inline void make_lts_time_conj(std::complex<double> *out)
+{
+    static const signed char L[53] = { 1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1, 1, 1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1, 1, 0,
+                                       1, -1, -1, 1, 1, -1, 1, -1, 1, -1, -1, -1, -1, -1, 1, 1, -1, -1, 1, -1, 1, -1, 1, 1, 1, 1 };
+    auto round12 = [](double v) {
+        char buf[64];
+        snprintf(buf, sizeof buf, "%.12g", v);
+        return strtod(buf, nullptr);
+    };
+    for (int n = 0; n < 64; n++) {
+        // inverse DFT of L(-26..26) / 64, summed in exact-angle form (k*n mod 64 keeps arguments small)
+        long double re = 0, im = 0;
+        for (int i = 0; i < 53; i++) {
+            int k = i - 26;
+            int e = ((k * n) % 64 + 64) % 64;
+            long double a = 2.0L * 3.141592653589793238462643383279502884L * (long double)e / 64.0L;
+            re += L[i] * cosl(a);
+            im += L[i] * sinl(a);
+        }
+        out[n] = std::complex<double>(round12((double)(re / 64.0L)), round12((double)(-im / 64.0L)));
+    }
+}
+
 class SyncHost {
 public:
     SyncHost() : lts_conj_(64)
     {
-        make_lts_time_conj();
+        make_lts_time_conj(lts_conj_.data());
         hist_.assign(kCarry, Tagged{});
     }
 
@@ -123,31 +149,6 @@ private:
             plateau_ = 0;
         }
         return tag;
-    }
-
-    // preamble.h:432: conj of the 64-sample long training symbol, as printed with 12 significant digits
-    void make_lts_time_conj()
-    {
-        static const signed char L[53] = { 1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1, 1, 1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1, 1, 0,
-                                           1, -1, -1, 1, 1, -1, 1, -1, 1, -1, -1, -1, -1, -1, 1, 1, -1, -1, 1, -1, 1, -1, 1, 1, 1, 1 };
-        for (int n = 0; n < 64; n++) {
-            // inverse DFT of L(-26..26) / 64, summed in exact-angle form (k*n mod 64 keeps arguments small)
-            long double re = 0, im = 0;
-            for (int i = 0; i < 53; i++) {
-                int k = i - 26;
-                int e = ((k * n) % 64 + 64) % 64;
-                long double a = 2.0L * 3.141592653589793238462643383279502884L * (long double)e / 64.0L;
-                re += L[i] * cosl(a);
-                im += L[i] * sinl(a);
-            }
-            lts_conj_[n] = std::complex<double>(round12((double)(re / 64.0L)), round12((double)(-im / 64.0L)));
-        }
-    }
-    static double round12(double v)
-    {
-        char buf[64];
-        snprintf(buf, sizeof buf, "%.12g", v);
-        return strtod(buf, nullptr);
     }
 
     std::vector<std::complex<double>> lts_conj_;

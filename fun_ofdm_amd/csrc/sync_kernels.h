@@ -1,0 +1,245 @@
+// sync_kernels.h -- frame_detector + timing_sync on the device.
+//
+// What the host restatement (sync_host.h) does sample by sample, restructured for a GPU:
+//   k_sync_flags     frame_detector.cpp:51-66: lag-16 autocorrelation / power over a 16-sample window, threshold 0.9.
+//                    The reference keeps running sums (sum -= old; sum += new, circular_accumulator.h:88-95) whose
+//                    rounding errors drift for ever; here every thread sums its first window directly and then slides
+//                    for 32 samples, so values agree to ~1e-15 relative and decisions differ only when the normalised
+//                    correlation lies within that distance of the threshold (and on exactly-zero input, where the
+//                    reference's leftovers decide; there this version gives the clean 0/0 = NaN -> "below").
+//   k_sync_sts_end   frame_detector.cpp:67-84 is local once the flags exist: STS_END sits on the first sample that is
+//                    below threshold after >= 16 consecutive samples above it.  Bit tricks on 32-sample words,
+//                    ordered compaction of the candidates through a per-block count + scan.
+//   k_sync_lts       timing_sync.cpp:69-113 per candidate: 96 x 64-tap cross-correlation with the LTS (same summation
+//                    order as the reference), the five strongest peaks above 0.9, the 64-apart test against the
+//                    strongest, the phase of timing_sync.cpp:113.
+//   k_sync_finish    tags written by an earlier hit can overwrite a later STS_END (timing_sync.cpp:105-106); drop those,
+//                    compact in stream order, chain the "previous phasor", derive the per-alignment end.
+#pragma once
+
+#include "frontend_kernels.h"
+
+namespace foa {
+
+constexpr int kSyncRun = 32;          // samples per thread in k_sync_flags (= one flag word)
+constexpr int kSyncBlockWords = 256;  // flag words per block of k_sync_sts_end (8192 samples)
+
+struct SyncCand {
+    int64_t x;            // stream index of the STS_END sample
+    int64_t lts1_pos;     // valid if found
+    double c, s;
+    int32_t found, pad;
+};
+
+__device__ __forceinline__ cpx widen(float2 v) { return cpx{ (double)v.x, (double)v.y }; }
+
+// flags[w] bit i = (|corr_sum| / pow_sum > 0.9) at sample 32*w + i
+__global__ __launch_bounds__(256) void k_sync_flags(const float2 *__restrict__ iq, int64_t n, uint32_t *__restrict__ flags)
+{
+#pragma clang fp contract(off)
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n0 = w * kSyncRun;
+    if (n0 >= n) return;
+    auto at = [&](int64_t i) -> cpx { return (i >= 0 && i < n) ? widen(iq[i]) : cpx{ 0.0, 0.0 }; };
+    // window ending at n0: products c_k = x_k * conj(x_{k-16}) and powers |x_k|^2 for k = n0-15 .. n0
+    cpx S = { 0.0, 0.0 };
+    double P = 0.0;
+    for (int k = -15; k <= 0; k++) {
+        const cpx a = at(n0 + k), b = at(n0 + k - 16);
+        S.x += a.x * b.x + a.y * b.y;
+        S.y += a.y * b.x - a.x * b.y;
+        P += a.x * a.x + a.y * a.y;
+    }
+    uint32_t bits = 0;
+    for (int i = 0; i < kSyncRun; i++) {
+        if (i > 0) {
+            const cpx a = at(n0 + i), b = at(n0 + i - 16), oa = at(n0 + i - 16), ob = at(n0 + i - 32);
+            S.x += (a.x * b.x + a.y * b.y) - (oa.x * ob.x + oa.y * ob.y);
+            S.y += (a.y * b.x - a.x * b.y) - (oa.y * ob.x - oa.x * ob.y);
+            P += (a.x * a.x + a.y * a.y) - (oa.x * oa.x + oa.y * oa.y);
+        }
+        const double corr = hypot(S.x, S.y) / P;
+        if (n0 + i < n && corr > 0.9) bits |= 1u << i;
+    }
+    flags[w] = bits;
+}
+
+// STS_END candidates of one block of flag words: count (pass 0) or write in order at offsets[block] (pass 1)
+__global__ __launch_bounds__(kSyncBlockWords) void k_sync_sts_end(const uint32_t *__restrict__ flags, int64_t n_words, int pass,
+                                                                   int32_t *__restrict__ block_count, const int32_t *__restrict__ block_off,
+                                                                   int64_t *__restrict__ cand_x, int32_t cap)
+{
+    __shared__ int32_t cnt[kSyncBlockWords];
+    const int t = threadIdx.x;
+    const int64_t w = (int64_t)blockIdx.x * kSyncBlockWords + t;
+    uint32_t ends = 0;
+    if (w < n_words) {
+        const uint64_t cur = flags[w], prev = w > 0 ? flags[w - 1] : 0u;
+        const uint64_t B = (cur << 32) | prev;
+        uint64_t u = B & (B << 1);          // b[n] & b[n-1]
+        u &= u << 2;
+        u &= u << 4;
+        u &= u << 8;                        // u[n] = b[n-15..n] all set
+        ends = (uint32_t)((~B & (u << 1)) >> 32);   // below threshold now, the 16 before all above
+    }
+    cnt[t] = __popc(ends);
+    __syncthreads();
+    // exclusive scan of the 256 counts (serial over 256 by one lane would do; log-step keeps it short)
+    for (int o = 1; o < kSyncBlockWords; o <<= 1) {
+        int v = t >= o ? cnt[t - o] : 0;
+        __syncthreads();
+        cnt[t] += v;
+        __syncthreads();
+    }
+    if (pass == 0) {
+        if (t == kSyncBlockWords - 1) block_count[blockIdx.x] = cnt[t];
+        return;
+    }
+    int pos = block_off[blockIdx.x] + cnt[t] - __popc(ends);
+    while (ends) {
+        const int i = __ffs(ends) - 1;
+        ends &= ends - 1;
+        if (pos < cap) cand_x[pos] = w * 32 + i;
+        pos++;
+    }
+}
+
+// exclusive scan of block counts (one block); total -> out_total[0]
+__global__ __launch_bounds__(1024) void k_sync_scan(const int32_t *__restrict__ cnt, int n_blocks, int32_t *__restrict__ off, int32_t *__restrict__ out_total)
+{
+    __shared__ int32_t part[1024];
+    const int t = threadIdx.x, per = (n_blocks + 1023) / 1024, lo = t * per, hi = min(lo + per, n_blocks);
+    int s = 0;
+    for (int i = lo; i < hi; i++) s += cnt[i];
+    part[t] = s;
+    __syncthreads();
+    if (t == 0) {
+        int run = 0;
+        for (int i = 0; i < 1024; i++) { int v = part[i]; part[i] = run; run += v; }
+        out_total[0] = run;
+    }
+    __syncthreads();
+    s = part[t];
+    for (int i = lo; i < hi; i++) { off[i] = s; s += cnt[i]; }
+}
+
+// (value, index) of the lane with the largest (value, then index); lanes with v < 0 never win
+__device__ __forceinline__ void wave_argmax(double &v, int &p)
+{
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+        const double ov = __shfl_xor(v, o);
+        const int op = __shfl_xor(p, o);
+        if (ov > v || (ov == v && op > p)) { v = ov; p = op; }
+    }
+}
+
+// timing_sync.cpp:69-113 for one STS_END candidate per wave
+__global__ __launch_bounds__(64) void k_sync_lts(const float2 *__restrict__ iq, int64_t n, const int64_t *__restrict__ cand_x, const int32_t *__restrict__ n_cand,
+                                                  int32_t cap, SyncCand *__restrict__ out)
+{
+#pragma clang fp contract(off)
+    const int c = blockIdx.x, lane = threadIdx.x;
+    if (c >= min(*n_cand, cap)) return;
+    const int64_t x = cand_x[c];
+    auto at = [&](int64_t i) -> cpx { return (i >= 0 && i < n) ? widen(iq[i]) : cpx{ 0.0, 0.0 }; };
+    // corr_norm for p = x + lane and (lanes < 32) p = x + 64 + lane
+    double v[2] = { -1.0, -1.0 };
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        if (h == 1 && lane >= 32) break;
+        const int64_t p = x + 64 * h + lane;
+        cpx corr = { 0.0, 0.0 };
+        double power = 0.0;
+        for (int s = 0; s < 64; s++) {
+            const cpx a = at(p + s);
+            const cpx m = cmul(a, cpx{ g_tab.lts_conj_re[s], g_tab.lts_conj_im[s] });
+            corr.x += m.x; corr.y += m.y;
+            power += a.x * a.x + a.y * a.y;
+        }
+        const double cn = hypot(corr.x, corr.y) / power;
+        if (cn > 0.9) v[h] = cn;                         // NaN (no power) fails the test like in the reference
+    }
+    // five strongest, in the reference's order (descending value, then descending position)
+    int pk[5];
+    int npk = 0;
+    for (int r = 0; r < 5; r++) {
+        double bv = v[0];
+        int bp = lane;
+        if (v[1] > bv || (v[1] == bv && v[1] >= 0.0)) { bv = v[1]; bp = 64 + lane; }
+        wave_argmax(bv, bp);
+        if (bv < 0.0) break;
+        pk[npk++] = bp;
+        if (bp == lane) v[0] = -1.0;
+        if (bp == 64 + lane) v[1] = -1.0;
+    }
+    SyncCand o;
+    o.x = x; o.found = 0; o.lts1_pos = 0; o.c = 1.0; o.s = 0.0; o.pad = 0;
+    for (int t = 0; t < npk; t++) {
+        if (abs(pk[0] - pk[t]) != 64) continue;
+        // positions are relative to x; the reference's working buffer starts 160 samples before the stream
+        const int64_t lts_offset = x + min(pk[0], pk[t]) - 32;
+        if (lts_offset < -160) break;
+        const cpx a = at(lts_offset + 159);
+        const cpx m = cmul(a, cpx{ g_tab.lts_conj_re[63], g_tab.lts_conj_im[63] });
+        const double phase = atan2(m.y, m.x);            // timing_sync.cpp:113
+        o.found = 1; o.lts1_pos = lts_offset + 24; o.c = cos(phase); o.s = sin(phase);
+        break;
+    }
+    if (lane == 0) out[c] = o;
+}
+
+// keep[c] = found and not overwritten by the tags of one of the four candidates before it
+__global__ void k_sync_keep(const SyncCand *__restrict__ cand, const int32_t *__restrict__ n_cand, int32_t cap, int32_t *__restrict__ keep)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nc = min(*n_cand, cap);
+    if (c >= nc) return;
+    int k = cand[c].found;
+    for (int b = 1; b <= 4 && c - b >= 0 && k; b++) {
+        const SyncCand &e = cand[c - b];
+        if (e.found && (cand[c].x == e.lts1_pos || cand[c].x == e.lts1_pos + 64)) k = 0;
+    }
+    keep[c] = k;
+}
+
+// ordered compaction of kept candidates -> descriptors; one block (candidates are few: one per frame or so)
+__global__ __launch_bounds__(1024) void k_sync_finish(const SyncCand *__restrict__ cand, const int32_t *__restrict__ keep, const int32_t *__restrict__ n_cand,
+                                                       int32_t cap, int64_t n_samples, foa_frame_desc *__restrict__ descs, int64_t *__restrict__ ends,
+                                                       int32_t desc_cap, int32_t *__restrict__ n_out)
+{
+    __shared__ int32_t part[1024];
+    const int nc = min(*n_cand, cap);
+    const int t = threadIdx.x, per = (nc + 1023) / 1024, lo = t * per, hi = min(lo + per, nc);
+    int s = 0;
+    for (int i = lo; i < hi; i++) s += keep[i];
+    part[t] = s;
+    __syncthreads();
+    if (t == 0) {
+        int run = 0;
+        for (int i = 0; i < 1024; i++) { int v = part[i]; part[i] = run; run += v; }
+        n_out[0] = min(run, desc_cap);
+        n_out[1] = run;
+    }
+    __syncthreads();
+    int pos = part[t];
+    for (int i = lo; i < hi; i++) {
+        if (!keep[i]) continue;
+        if (pos < desc_cap) {
+            foa_frame_desc d;
+            d.lts1_pos = cand[i].lts1_pos; d.rot_start = cand[i].x; d.c = cand[i].c; d.s = cand[i].s;
+            d.c_prev = 1.0; d.s_prev = 0.0;              // fixed up below
+            descs[pos] = d;
+        }
+        pos++;
+    }
+    __syncthreads();
+    __threadfence_block();
+    const int total = min(n_out[1], desc_cap);
+    for (int k = t; k < total; k += 1024) {
+        if (k > 0) { descs[k].c_prev = descs[k - 1].c; descs[k].s_prev = descs[k - 1].s; }
+        ends[k] = k + 1 < total ? descs[k + 1].lts1_pos : n_samples;
+    }
+}
+
+}  // namespace foa

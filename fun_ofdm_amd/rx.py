@@ -71,6 +71,16 @@ class Receiver:
         check(lib().foa_rx_decode_frames_dev(self._h, iq.data_ptr(), n, descs.data_ptr(), ends.data_ptr(), m, psdu.data_ptr(),
                                              psdu.shape[1], results.data_ptr()))
 
+    def sync_dev(self, iq, descs, ends):
+        """Device-side frame_detector + timing_sync: iq complex64[n] (CUDA tensor), descs uint8[cap*48], ends int64[cap]
+        (CUDA tensors, filled in place).  Returns the number of alignments found."""
+        n = iq.numel() if iq.is_complex() else iq.numel() // 2
+        cap = ends.numel()
+        assert descs.numel() * descs.element_size() >= cap * frame_desc_dtype.itemsize
+        got = C.c_size_t(0)
+        check(lib().foa_rx_sync_dev(self._h, iq.data_ptr(), n, descs.data_ptr(), ends.data_ptr(), cap, C.byref(got)))
+        return int(got.value)
+
     def kernel_ms(self):
         """HIP-event durations of the last decode in ms: header, scan, symbols, viterbi_fwd, viterbi_finish, total."""
         out = (C.c_float * 6)()

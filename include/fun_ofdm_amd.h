@@ -152,6 +152,13 @@ int foa_sync_push_f64(foa_sync *s, const double *iq, size_t n_samples, foa_frame
 /* Stream index up to which timing_sync has looked (it trails the input by 160 samples). */
 int64_t foa_sync_settled(const foa_sync *s);
 
+/* The same two blocks on the DEVICE, over a stream that is already resident in HBM: fills d_descs / d_ends (device
+ * pointers, capacity cap) in stream order and returns the number of alignments in *n_found (synchronises).  The decisions
+ * are the reference's up to floating-point ties: windowed sums are formed directly instead of by the reference's
+ * ever-drifting running sums, so a threshold decision can differ when the normalised correlation is within ~1e-15 of
+ * 0.9. */
+int foa_rx_sync_dev(foa_rx *rx, const float *d_iq, size_t n_samples, foa_frame_desc *d_descs, int64_t *d_ends, size_t cap, size_t *n_found);
+
 /* ---- stage-level entry points (one per replaced fun::block, for the per-block adaptors) ---- */
 
 /* fft::forward over n_vec vectors of 64 complex doubles (host pointers, in place): unscaled DFT with

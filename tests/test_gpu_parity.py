@@ -295,3 +295,50 @@ def test_config5_back_to_back_mixed_rates_with_cfo(rx, po):
     chain = po.ReceiverChain().run_stream(s.astype(np.complex128))
     assert got == chain                           # same ordered PSDU list as the reference-shaped chain
     assert len(got) >= 20
+
+
+def test_device_sync_matches_host_sync(rx, po):
+    """frame_detector + timing_sync on the device against the host restatement (which equals the reference bit for bit):
+    same alignments (LTS1 position, rotation start) and the same phasors to 1e-12; then PSDUs decoded from the
+    device-made descriptors equal the oracle's."""
+    import torch
+    import fun_ofdm_amd as foa
+    from fun_ofdm_amd import synth
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(77)
+    for trial, (snr, cfo, gap) in enumerate(((25.0, None, 0), (20.0, 3000.0, 1), (25.0, 4000.0, 2))):
+        parts, pays = [], []
+        for i in range(40):
+            rate = (0, 2, 3, 5, 6, 8, 9, 10)[i % 8]
+            pay = synth.splitmix64_bytes(500 + 100 * trial + i, 1, 64 + 13 * i)[0]
+            f = synth.build_frames(pay[None, :], rate)[0] * np.exp(1j * rng.uniform(0, 6.28))
+            if cfo:
+                f = f * np.exp(2j * np.pi * rng.uniform(-cfo, cfo) * np.arange(f.size) / 20e6)
+            parts += [np.zeros(int(rng.integers(0, 900)) if gap else 0, complex), f]
+            pays.append(pay)
+        parts.append(np.zeros(777, complex))
+        s = np.concatenate([np.zeros(123, complex)] + parts)
+        s = (s + (rng.normal(size=s.size) + 1j * rng.normal(size=s.size)) * np.sqrt(0.0124 / 2 / 10 ** (snr / 10))).astype(np.complex64)
+        want = foa.find_alignments(s)
+        t_iq = torch.from_numpy(s.view(np.float32).reshape(-1, 2)).to(dev)
+        cap = s.size // 300 + 16
+        t_desc = torch.zeros(cap * 48, dtype=torch.uint8, device=dev)
+        t_ends = torch.zeros(cap, dtype=torch.int64, device=dev)
+        n = rx.sync_dev(t_iq, t_desc, t_ends)
+        got = t_desc.cpu().numpy()[:n * 48].view(foa.frame_desc_dtype)
+        assert n == want.size, (trial, n, want.size)
+        assert np.array_equal(got["lts1_pos"], want["lts1_pos"]) and np.array_equal(got["rot_start"], want["rot_start"])
+        for k in ("c", "s", "c_prev", "s_prev"):
+            assert np.abs(got[k] - want[k]).max() < 1e-12, k
+        ends = t_ends.cpu().numpy()[:n]
+        assert np.array_equal(ends, foa.alignment_ends(want, s.size))
+        # decode from the device-made descriptors without leaving the device
+        t_psdu = torch.zeros((n, 4096), dtype=torch.uint8, device=dev)
+        t_res = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+        rx.decode_frames_dev(t_iq, t_desc[:n * 48], t_ends[:n], t_psdu, t_res)
+        rx.sync()
+        opsdu, ores = po.decode_batch_f32(s, want, ends, threads=4)
+        res = t_res.cpu().numpy()
+        assert np.array_equal(res, ores.view(np.int32).reshape(-1, 4))
+        ok = res[:, 0] == 0
+        assert np.array_equal(t_psdu.cpu().numpy()[ok], opsdu[ok]) and ok.sum() >= 30
