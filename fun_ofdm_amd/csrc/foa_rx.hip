@@ -404,7 +404,7 @@ int foa_rx_sync_dev(foa_rx *rx, const float *d_iq, size_t n_samples, foa_frame_d
         return rc;
     hipStream_t st = rx->stream;
     const float2 *iq = (const float2 *)d_iq;
-    hipLaunchKernelGGL(k_sync_flags, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, iq, n, rx->sy_flags.p);
+    hipLaunchKernelGGL(k_sync_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, iq, n, rx->sy_flags.p);
     hipLaunchKernelGGL(k_sync_sts_end, dim3(n_blocks), dim3(kSyncBlockWords), 0, st, rx->sy_flags.p, n_words, 0, rx->sy_cnt.p, rx->sy_off.p, rx->sy_x.p, ccap);
     hipLaunchKernelGGL(k_sync_scan, dim3(1), dim3(1024), 0, st, rx->sy_cnt.p, n_blocks, rx->sy_off.p, rx->sy_n.p);
     hipLaunchKernelGGL(k_sync_sts_end, dim3(n_blocks), dim3(kSyncBlockWords), 0, st, rx->sy_flags.p, n_words, 1, rx->sy_cnt.p, rx->sy_off.p, rx->sy_x.p, ccap);

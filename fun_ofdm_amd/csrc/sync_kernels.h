@@ -3,10 +3,10 @@
 // What the host restatement (sync_host.h) does sample by sample, restructured for a GPU:
 //   k_sync_flags     frame_detector.cpp:51-66: lag-16 autocorrelation / power over a 16-sample window, threshold 0.9.
 //                    The reference keeps running sums (sum -= old; sum += new, circular_accumulator.h:88-95) whose
-//                    rounding errors drift for ever; here every thread sums its first window directly and then slides
-//                    for 32 samples, so values agree to ~1e-15 relative and decisions differ only when the normalised
-//                    correlation lies within that distance of the threshold (and on exactly-zero input, where the
-//                    reference's leftovers decide; there this version gives the clean 0/0 = NaN -> "below").
+//                    rounding errors drift for ever; here every sample's window is summed directly, so values agree
+//                    to ~1e-15 relative and decisions differ only when the normalised correlation lies within that
+//                    distance of the threshold (and on exactly-zero input, where the reference's leftovers decide;
+//                    there this version gives the clean 0/0 = NaN -> "below").
 //   k_sync_sts_end   frame_detector.cpp:67-84 is local once the flags exist: STS_END sits on the first sample that is
 //                    below threshold after >= 16 consecutive samples above it.  Bit tricks on 32-sample words,
 //                    ordered compaction of the candidates through a per-block count + scan.
@@ -21,7 +21,6 @@
 
 namespace foa {
 
-constexpr int kSyncRun = 32;          // samples per thread in k_sync_flags (= one flag word)
 constexpr int kSyncBlockWords = 256;  // flag words per block of k_sync_sts_end (8192 samples)
 
 struct SyncCand {
@@ -33,35 +32,32 @@ struct SyncCand {
 
 __device__ __forceinline__ cpx widen(float2 v) { return cpx{ (double)v.x, (double)v.y }; }
 
-// flags[w] bit i = (|corr_sum| / pow_sum > 0.9) at sample 32*w + i
+// flags[w] bit i = (|corr_sum| / pow_sum > 0.9) at sample 32*w + i.  One thread per sample: the 16 products of its
+// window are summed directly (neighbouring lanes read neighbouring samples, so the 32 loads per lane are coalesced and
+// served by L1), a wave's 64 verdicts leave as one ballot.
 __global__ __launch_bounds__(256) void k_sync_flags(const float2 *__restrict__ iq, int64_t n, uint32_t *__restrict__ flags)
 {
 #pragma clang fp contract(off)
-    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t n0 = w * kSyncRun;
-    if (n0 >= n) return;
-    auto at = [&](int64_t i) -> cpx { return (i >= 0 && i < n) ? widen(iq[i]) : cpx{ 0.0, 0.0 }; };
-    // window ending at n0: products c_k = x_k * conj(x_{k-16}) and powers |x_k|^2 for k = n0-15 .. n0
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;        // grid covers a multiple of 64 samples
+    auto at = [&](int64_t k) -> cpx { return (k >= 0 && k < n) ? widen(iq[k]) : cpx{ 0.0, 0.0 }; };
     cpx S = { 0.0, 0.0 };
     double P = 0.0;
-    for (int k = -15; k <= 0; k++) {
-        const cpx a = at(n0 + k), b = at(n0 + k - 16);
-        S.x += a.x * b.x + a.y * b.y;
+    cpx x[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++) x[k] = at(i - 31 + k);                      // x[31] = sample i, x[15] = sample i-16
+#pragma unroll
+    for (int k = 0; k < 16; k++) {                                           // oldest product first, like a running sum would hold them
+        const cpx a = x[16 + k], b = x[k];
+        S.x += a.x * b.x + a.y * b.y;                                        // a * conj(b)
         S.y += a.y * b.x - a.x * b.y;
         P += a.x * a.x + a.y * a.y;
     }
-    uint32_t bits = 0;
-    for (int i = 0; i < kSyncRun; i++) {
-        if (i > 0) {
-            const cpx a = at(n0 + i), b = at(n0 + i - 16), oa = at(n0 + i - 16), ob = at(n0 + i - 32);
-            S.x += (a.x * b.x + a.y * b.y) - (oa.x * ob.x + oa.y * ob.y);
-            S.y += (a.y * b.x - a.x * b.y) - (oa.y * ob.x - oa.x * ob.y);
-            P += (a.x * a.x + a.y * a.y) - (oa.x * oa.x + oa.y * oa.y);
-        }
-        const double corr = hypot(S.x, S.y) / P;
-        if (n0 + i < n && corr > 0.9) bits |= 1u << i;
-    }
-    flags[w] = bits;
+    const double corr = hypot(S.x, S.y) / P;
+    const uint64_t m = __ballot(i < n && corr > 0.9);
+    const int lane = threadIdx.x & 63;
+    const int64_t w = i >> 5;
+    if (lane == 0 && i < n) flags[w] = (uint32_t)m;
+    if (lane == 32 && i < n) flags[w] = (uint32_t)(m >> 32);
 }
 
 // STS_END candidates of one block of flag words: count (pass 0) or write in order at offsets[block] (pass 1)
