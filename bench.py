@@ -89,7 +89,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=10000, help="frames per GPU (BASELINE config 2: 10000)")
-    ap.add_argument("--viterbi", type=int, default=1, help="0: lane-per-state kernel, 1: packed kernel")
+    ap.add_argument("--viterbi", type=int, default=2, help="0: lane per state, 1: packed + serial chain-back, 2: packed + segment chain-back")
+    ap.add_argument("--tb-segment", type=int, default=0, help="viterbi 2: data steps per chain-back segment (0: library default)")
+    ap.add_argument("--tb-overlap", type=int, default=-1, help="viterbi 2: run-in steps of a segment (-1: library default)")
     ap.add_argument("--frontend", type=int, default=1, help="0: wave-per-symbol kernel, 1: lane-per-symbol kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -134,6 +136,10 @@ def main():
 
     rx = foa.Receiver(dev_index)
     rx.set_option("viterbi", args.viterbi)
+    if args.tb_segment > 0:
+        rx.set_option("tb_segment", args.tb_segment)
+    if args.tb_overlap >= 0:
+        rx.set_option("tb_overlap", args.tb_overlap)
     rx.set_option("frontend", args.frontend)
     rx.set_option("record_soft", 0)        # PSDUs are the output; soft bytes are only kept for diagnostics
     rx.reserve(iq.size, m)
@@ -244,8 +250,9 @@ def main():
             # one branch-metric dword in and one 64-bit decision word out per trellis step (39 symbols x 216 steps).
             alg_bytes = real.size * 39 * 216 * (4 + 8)
             ach = alg_bytes / (kms["viterbi_fwd"] * 1e-3) / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": "k_viterbi_fwd2", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                               "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": pmc_traffic("k_viterbi_fwd2", args.frames),
+            fwd_kernel = {0: "k_viterbi_v1", 1: "k_viterbi_fwd2", 2: "k_viterbi_fwd3"}[args.viterbi]
+            out["roofline"] = {"bound": "hbm", "kernel": fwd_kernel, "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                               "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": pmc_traffic(fwd_kernel, args.frames),
                                "algorithmic_bytes_per_launch": int(alg_bytes), "avg_kernel_ms": round(kms["viterbi_fwd"], 4),
                                "note": "issue-bound on integer VALU/DPP, not HBM-bound (SURVEY 8d); DESIGN.md 4 gives the instruction-issue accounting"}
             out["kernel_ms"] = {k: round(v, 4) for k, v in kms.items()}

@@ -12,7 +12,7 @@
 #include "frontend_kernels.h"
 #include "frontend_lps.h"
 #include "viterbi_v1.h"
-#include "viterbi_v2.h"
+#include "viterbi_v3.h"
 #include "stage_kernels.h"
 #include "sync_host.h"
 #include "sync_kernels.h"
@@ -122,14 +122,16 @@ struct foa_rx {
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
     bool have_timing = false;
-    int viterbi_kind = 1;
+    int viterbi_kind = 2;        // 0: lane per state (viterbi_v1.h), 1: packed, serial chain-back (v2), 2: packed, segment chain-back (v3)
+    int tb_segment = 960, tb_overlap = 96;   // v3 chain-back: data steps per segment / run-in steps (multiples of 96)
     bool record_eq = false;
     bool record_soft = true;     // keep the depunctured soft bytes (taps, lane-per-state kernel); off = branch metrics only
     int frontend_kind = 1;       // 1: one lane per symbol (frontend_lps.h), 0: one wave per symbol
     // workspace
     DevBuf<FrameInfo> info;
     DevBuf<double2> hinv;
-    DevBuf<int32_t> sym2frame;
+    DevBuf<int32_t> sym2frame, seg2frame;
+    DevBuf<uint16_t> tb_state;
     DevBuf<uint8_t> soft;
     DevBuf<uint64_t> dec;
     DevBuf<uint32_t> bm, decoded;
@@ -156,6 +158,9 @@ int workspace(foa_rx *rx, size_t n_samples, size_t n_frames)
         (rc = rx->soft.ensure(soft_cap)) || (rc = rx->dec.ensure(dec_cap)) || (rc = rx->bm.ensure(dec_cap)) || (rc = rx->decoded.ensure(dec_cap)) || (rc = rx->totals.ensure(8)))
         return rc;
     if (rx->record_eq && ((rc = rx->eq_sig.ensure((n_frames + 1) * 48)) || (rc = rx->eq_data.ensure(sym_cap * 48)))) return rc;
+    // chain-back segments: every frame has at most dec_words/segment + 1 of them
+    const size_t seg_cap = dec_cap / 96 + n_frames + 64;
+    if ((rc = rx->seg2frame.ensure(seg_cap)) || (rc = rx->tb_state.ensure(seg_cap))) return rc;
     // capacities handed to the scan are those of the buffers actually allocated
     rx->sym_cap = rx->sym2frame.n; rx->soft_cap = rx->soft.n; rx->dec_cap = rx->dec.n < rx->bm.n ? rx->dec.n : rx->bm.n;
     if (rx->record_eq && rx->eq_data.n / 48 < rx->sym_cap) rx->sym_cap = rx->eq_data.n / 48;
@@ -223,8 +228,18 @@ int foa_rx_set_option(foa_rx *rx, const char *name, int64_t value)
 {
     if (!rx || !name) return fail(FOA_E_INVALID, "NULL argument");
     if (!strcmp(name, "viterbi")) {
-        if (value != 0 && value != 1) return fail(FOA_E_INVALID, "viterbi must be 0 (lane-per-state) or 1 (packed)");
+        if (value < 0 || value > 2) return fail(FOA_E_INVALID, "viterbi must be 0 (lane per state), 1 (packed, serial chain-back) or 2 (packed, segment chain-back)");
         rx->viterbi_kind = (int)value;
+        return FOA_OK;
+    }
+    if (!strcmp(name, "tb_segment")) {
+        if (value < 96 || value > kTbMaxSeg || value % 96) return fail(FOA_E_INVALID, "tb_segment must be a multiple of 96 in [96, %d]", kTbMaxSeg);
+        rx->tb_segment = (int)value;
+        return FOA_OK;
+    }
+    if (!strcmp(name, "tb_overlap")) {
+        if (value < 0 || value > 3072 || value % 96) return fail(FOA_E_INVALID, "tb_overlap must be a multiple of 96 in [0, 3072]");
+        rx->tb_overlap = (int)value;
         return FOA_OK;
     }
     if (!strcmp(name, "record_eq")) { rx->record_eq = value != 0; return FOA_OK; }
@@ -267,9 +282,12 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
     int64_t caps[1] = { (int64_t)rx->sym_cap };
     HIP_TRY(hipMemcpyAsync(rx->totals.p + 3, caps, sizeof caps, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(rx->sym2frame.p, 0xFF, rx->sym_cap * sizeof(int32_t), st));
+    // segments of this call: at most (total data steps)/S + one per frame; lanes beyond the real total idle
+    const size_t max_segs = std::min(rx->seg2frame.n, rx->dec_cap / (size_t)rx->tb_segment + n_frames + 1);
+    HIP_TRY(hipMemsetAsync(rx->seg2frame.p, 0xFF, max_segs * sizeof(int32_t), st));
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, rx->info.p, nf, (int64_t)rx->sym_cap, (int64_t)rx->soft_cap, (int64_t)rx->dec_cap,
-                       rx->totals.p);
-    hipLaunchKernelGGL(k_symmap, dim3((nf + 255) / 256), dim3(256), 0, st, rx->info.p, nf, rx->sym2frame.p);
+                       rx->tb_segment, rx->totals.p);
+    hipLaunchKernelGGL(k_symmap, dim3((nf + 255) / 256), dim3(256), 0, st, rx->info.p, nf, rx->sym2frame.p, rx->tb_segment, rx->seg2frame.p);
     HIP_TRY(hipEventRecord(rx->ev[2], st));
     // upper bound on data symbols in n_samples samples; waves beyond the real total exit at once
     const size_t max_sym = rx->sym_cap;
@@ -284,8 +302,11 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
     HIP_TRY(hipEventRecord(rx->ev[3], st));
     if (rx->viterbi_kind == 0)
         hipLaunchKernelGGL(k_viterbi_v1, dim3(nf), dim3(64), 0, st, rx->info.p, nf, rx->soft.p, rx->dec.p, d_psdu, slot_bytes, d_results);
-    else
+    else if (rx->viterbi_kind == 1)
         launch_viterbi_v2(st, rx->info.p, nf, rx->bm.p, rx->dec.p, rx->decoded.p, d_psdu, slot_bytes, d_results, rx->ev[5]);
+    else
+        launch_viterbi_v3(st, rx->info.p, nf, rx->bm.p, rx->dec.p, rx->decoded.p, rx->seg2frame.p, rx->totals.p, rx->tb_state.p, max_segs,
+                          rx->tb_segment, rx->tb_overlap, d_psdu, slot_bytes, d_results, rx->ev[5]);
     HIP_TRY(hipEventRecord(rx->ev[4], st));
     if (rx->viterbi_kind == 0) HIP_TRY(hipEventRecord(rx->ev[5], st));
     HIP_TRY(hipGetLastError());
@@ -592,7 +613,7 @@ int foa_decode_data_f64(foa_rx *rx, const double *carriers, const uint64_t *carr
     build_tables(&tab);
     // frame records and offsets on the host (what k_header + k_scan produce in the fused path)
     std::vector<FrameInfo> info(n_frames);
-    std::vector<int32_t> sym2frame;
+    std::vector<int32_t> sym2frame, seg2frame;
     std::vector<int64_t> coff(n_frames + 1);
     int64_t soft_off = 0, dec_off = 0;
     for (size_t f = 0; f < n_frames; f++) {
@@ -603,6 +624,8 @@ int foa_decode_data_f64(foa_rx *rx, const double *carriers, const uint64_t *carr
         FrameInfo &fi = info[f];
         fi.status = FOA_ST_CRC_FAIL; fi.rate = rate; fi.length = len; fi.nsym = nsym; fi.sym_off = (int32_t)sym2frame.size();
         fi.nsteps = nsym * dbps; fi.soft_off = soft_off; fi.dec_off = dec_off;
+        fi.seg_off = (int32_t)seg2frame.size(); fi.reserved_ = 0;
+        seg2frame.insert(seg2frame.end(), (size_t)tb_segments(fi.nsteps, rx->tb_segment), (int32_t)f);
         soft_off += ((int64_t)2 * fi.nsteps + 255) & ~(int64_t)255;
         dec_off += dec_words(fi.nsteps);
         coff[f] = (int64_t)carrier_off[f];
@@ -613,7 +636,8 @@ int foa_decode_data_f64(foa_rx *rx, const double *carriers, const uint64_t *carr
     const size_t n_sym = sym2frame.size(), n_car = (size_t)carrier_off[n_frames];
     int rc;
     if ((rc = rx->info.ensure(n_frames + 1)) || (rc = rx->sym2frame.ensure(n_sym + 1)) || (rc = rx->soft.ensure((size_t)soft_off + 256)) ||
-        (rc = rx->dec.ensure((size_t)dec_off + 64)) || (rc = rx->bm.ensure((size_t)dec_off + 64)) || (rc = rx->decoded.ensure((size_t)dec_off + 64)))
+        (rc = rx->dec.ensure((size_t)dec_off + 64)) || (rc = rx->bm.ensure((size_t)dec_off + 64)) || (rc = rx->decoded.ensure((size_t)dec_off + 64)) ||
+        (rc = rx->seg2frame.ensure(seg2frame.size() + 64)) || (rc = rx->tb_state.ensure(seg2frame.size() + 64)) || (rc = rx->totals.ensure(8)))
         return rc;
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t c_b = n_car * sizeof(double2), o_b = (n_frames + 1) * sizeof(int64_t), p_b = n_frames * slot_bytes, r_b = n_frames * sizeof(foa_frame_result);
@@ -626,13 +650,19 @@ int foa_decode_data_f64(foa_rx *rx, const double *carriers, const uint64_t *carr
     HIP_TRY(hipMemcpyAsync(b + up(c_b), coff.data(), o_b, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(rx->info.p, info.data(), n_frames * sizeof(FrameInfo), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(rx->sym2frame.p, sym2frame.data(), n_sym * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    const int64_t n_segs = (int64_t)seg2frame.size();
+    HIP_TRY(hipMemcpyAsync(rx->seg2frame.p, seg2frame.data(), seg2frame.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(rx->totals.p + 4, &n_segs, sizeof n_segs, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(d_psdu, 0, p_b, st));
     hipLaunchKernelGGL(k_stage_demap, dim3((unsigned)((n_sym + kSymWaves - 1) / kSymWaves)), dim3(64 * kSymWaves), 0, st, (const double2 *)b,
                        (const int64_t *)(b + up(c_b)), rx->info.p, rx->sym2frame.p, (int)n_sym, rx->soft.p, rx->bm.p);
     if (rx->viterbi_kind == 0)
         hipLaunchKernelGGL(k_viterbi_v1, dim3((unsigned)n_frames), dim3(64), 0, st, rx->info.p, (int)n_frames, rx->soft.p, rx->dec.p, d_psdu, slot_bytes, d_res);
-    else
+    else if (rx->viterbi_kind == 1)
         launch_viterbi_v2(st, rx->info.p, (int)n_frames, rx->bm.p, rx->dec.p, rx->decoded.p, d_psdu, slot_bytes, d_res, nullptr);
+    else
+        launch_viterbi_v3(st, rx->info.p, (int)n_frames, rx->bm.p, rx->dec.p, rx->decoded.p, rx->seg2frame.p, rx->totals.p, rx->tb_state.p,
+                          seg2frame.size(), rx->tb_segment, rx->tb_overlap, d_psdu, slot_bytes, d_res, nullptr);
     HIP_TRY(hipMemcpyAsync(psdu, d_psdu, p_b, hipMemcpyDeviceToHost, st));
     std::vector<foa_frame_result> out(n_frames);
     HIP_TRY(hipMemcpyAsync(out.data(), d_res, r_b, hipMemcpyDeviceToHost, st));

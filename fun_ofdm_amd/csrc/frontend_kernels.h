@@ -395,27 +395,29 @@ __global__ __launch_bounds__(64) void k_header(const float2 *__restrict__ iq, co
 // =================================================================================================
 // words reserved per frame in the per-step buffers (bm / dec / decoded): the chain-back reads whole 48-step chunks
 __host__ __device__ constexpr int64_t dec_words(int64_t nsteps) { return nsteps > 0 ? (nsteps + 48 + 63) & ~(int64_t)63 : 0; }
+// chain-back segments of a frame (viterbi_v3.h): its nsteps - 6 data steps in pieces of seg_steps
+__host__ __device__ constexpr int tb_segments(int nsteps, int seg_steps) { return nsteps > 6 ? (nsteps - 6 + seg_steps - 1) / seg_steps : 0; }
 
 __global__ __launch_bounds__(1024) void k_scan(FrameInfo *__restrict__ info, int n_frames, int64_t sym_cap, int64_t soft_cap,
-                                               int64_t dec_cap, int64_t *__restrict__ totals)
+                                               int64_t dec_cap, int seg_steps, int64_t *__restrict__ totals)
 {
-    __shared__ int64_t part[3][1024];
+    __shared__ int64_t part[4][1024];
     const int tid = threadIdx.x, per = (n_frames + 1023) / 1024;
     const int lo = tid * per, hi = min(lo + per, n_frames);
-    int64_t a = 0, b = 0, c = 0;
+    int64_t a = 0, b = 0, c = 0, d = 0;
     for (int f = lo; f < hi; f++) {
         const int nsym = info[f].nsym, nsteps = nsym > 0 ? info[f].nsteps : 0;
-        a += nsym; b += ((int64_t)2 * nsteps + 255) & ~(int64_t)255; c += dec_words(nsteps);
+        a += nsym; b += ((int64_t)2 * nsteps + 255) & ~(int64_t)255; c += dec_words(nsteps); d += tb_segments(nsteps, seg_steps);
     }
-    part[0][tid] = a; part[1][tid] = b; part[2][tid] = c;
+    part[0][tid] = a; part[1][tid] = b; part[2][tid] = c; part[3][tid] = d;
     __syncthreads();
-    if (tid < 3) {                                   // 1024-element serial scans: negligible
+    if (tid < 4) {                                   // 1024-element serial scans: negligible
         int64_t run = 0;
         for (int i = 0; i < 1024; i++) { int64_t v = part[tid][i]; part[tid][i] = run; run += v; }
-        totals[tid] = run;
+        totals[tid < 3 ? tid : 4] = run;             // totals[3] is the caller's symbol capacity
     }
     __syncthreads();
-    a = part[0][tid]; b = part[1][tid]; c = part[2][tid];
+    a = part[0][tid]; b = part[1][tid]; c = part[2][tid]; d = part[3][tid];
     for (int f = lo; f < hi; f++) {
         FrameInfo fi = info[f];
         const int nsteps = fi.nsym > 0 ? fi.nsteps : 0;
@@ -426,7 +428,8 @@ __global__ __launch_bounds__(1024) void k_scan(FrameInfo *__restrict__ info, int
         } else {
             info[f].sym_off = (int32_t)a; info[f].soft_off = b; info[f].dec_off = c;
         }
-        a += fi.nsym; b += sb; c += dw;
+        info[f].seg_off = (int32_t)d;
+        a += fi.nsym; b += sb; c += dw; d += tb_segments(nsteps, seg_steps);
     }
 }
 
@@ -435,12 +438,16 @@ __global__ __launch_bounds__(1024) void k_scan(FrameInfo *__restrict__ info, int
 // =================================================================================================
 // Fills sym2frame[] so that K3's wave w finds its frame without a search: one thread per frame
 // writes its nsym entries (frames are short: <= 1368 symbols).
-__global__ void k_symmap(const FrameInfo *__restrict__ info, int n_frames, int32_t *__restrict__ sym2frame)
+__global__ void k_symmap(const FrameInfo *__restrict__ info, int n_frames, int32_t *__restrict__ sym2frame, int seg_steps,
+                         int32_t *__restrict__ seg2frame)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n_frames) return;
     const int n = info[f].nsym, o = info[f].sym_off;
     for (int k = 0; k < n; k++) sym2frame[o + k] = f;
+    // same for the chain-back segments (a frame that lost its space in k_scan has nsym = 0 here)
+    const int ns = n > 0 ? tb_segments(info[f].nsteps, seg_steps) : 0, so = info[f].seg_off;
+    for (int k = 0; k < ns; k++) seg2frame[so + k] = f;
 }
 
 constexpr int kSymWaves = 4;

@@ -264,6 +264,82 @@ __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd2(const FrameInfo
         for (int i = TB + lane; i < dec_words(TB); i += 64) dB[i] = 0;
 }
 
+// descramble + CRC-32 + payload copy of one frame per lane; shared by k_viterbi_finish2 and k_tb_finish
+struct FinishTables { uint32_t crc[1024]; uint32_t scr[128]; };
+
+__device__ __forceinline__ void finish_tables_init(FinishTables &t, int tid, int nthreads)
+{
+    for (int i = tid; i < 256; i += nthreads) {
+        const uint32_t t0 = g_tab.crc_table[i];
+        const uint32_t t1 = (t0 >> 8) ^ g_tab.crc_table[t0 & 0xFFu];
+        const uint32_t t2 = (t1 >> 8) ^ g_tab.crc_table[t1 & 0xFFu];
+        const uint32_t t3 = (t2 >> 8) ^ g_tab.crc_table[t2 & 0xFFu];
+        t.crc[i] = t0; t.crc[256 + i] = t1; t.crc[512 + i] = t2; t.crc[768 + i] = t3;
+    }
+    for (int i = tid; i < 127; i += nthreads) {
+        uint32_t m = 0;
+        for (int b = 0; b < 4; b++) m |= (uint32_t)g_tab.scramble[(4 * i + b) % 127] << (8 * b);
+        t.scr[i] = m;
+    }
+}
+
+// descramble (one LFSR bit per byte, ppdu.cpp:256-264) + CRC over service+payload (ppdu.cpp:267-271) + payload copy
+// (ppdu.cpp:283-285).  Whole words go through four table look-ups that do not depend on each other (slicing-by-4);
+// the scrambler's 127-byte period makes a 127-word table of descrambling masks.  Wave-uniform control flow.
+__device__ __forceinline__ void finish_crc_psdu(const FinishTables &t, const FrameInfo &fi, bool live, int f, int n_frames, uint32_t *out,
+                                                uint8_t *__restrict__ psdu, size_t slot_bytes, foa_frame_result *__restrict__ results)
+{
+    const int len = fi.length, ncrc = live ? 2 + len : 0, nwords = live ? (ncrc + 4 + 3) / 4 : 0;
+    int maxw = nwords;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) maxw = max(maxw, __shfl_xor(maxw, o));
+    uint32_t crc = 0xFFFFFFFFu, given = 0;
+    const int full = ncrc >> 2;                                            // words that lie entirely inside the CRC range
+    int qs = 0;                                                            // q mod 127
+    for (int q = 0; q < maxw; q++) {
+        const uint32_t scr = t.scr[qs];
+        qs = qs == 126 ? 0 : qs + 1;
+        if (q < nwords) {
+            const uint32_t d = out[q] ^ scr;
+            out[q] = d;
+            if (q < full) {
+                const uint32_t c = crc ^ d;
+                crc = t.crc[768 + (c & 0xFFu)] ^ t.crc[512 + ((c >> 8) & 0xFFu)] ^ t.crc[256 + ((c >> 16) & 0xFFu)] ^ t.crc[c >> 24];
+            } else {
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const int x = 4 * q + b;
+                    const uint32_t byte = (d >> (8 * b)) & 0xFFu;
+                    if (x < ncrc) crc = t.crc[(crc ^ byte) & 0xFFu] ^ (crc >> 8);
+                    else if (x < ncrc + 4) given |= byte << (8 * (x - ncrc));
+                }
+            }
+        }
+    }
+    const bool ok = live && (crc ^ 0xFFFFFFFFu) == given;
+    if (ok) {
+        uint8_t *slot = psdu + (size_t)f * slot_bytes;
+        const int ncopy = min((size_t)len, slot_bytes);
+        int y = 0;
+        if ((((uintptr_t)slot) & 3) == 0) {
+            // bytes y+2 .. y+5 straddle words q, q+1; four words per trip keep several loads in flight
+            for (; y + 16 <= ncopy; y += 16) {
+                const int q = (y + 2) >> 2;
+                const uint32_t a0 = out[q], a1 = out[q + 1], a2 = out[q + 2], a3 = out[q + 3], a4 = out[q + 4];
+                uint32_t *dst = (uint32_t *)slot + (y >> 2);
+                dst[0] = (a0 >> 16) | (a1 << 16); dst[1] = (a1 >> 16) | (a2 << 16);
+                dst[2] = (a2 >> 16) | (a3 << 16); dst[3] = (a3 >> 16) | (a4 << 16);
+            }
+            for (; y + 4 <= ncopy; y += 4) {
+                const int q = (y + 2) >> 2;
+                ((uint32_t *)slot)[y >> 2] = (out[q] >> 16) | (out[q + 1] << 16);
+            }
+        }
+        for (; y < ncopy; y++) slot[y] = (uint8_t)(out[(y + 2) >> 2] >> (8 * ((y + 2) & 3)));
+    }
+    if (f < n_frames) write_result(&results[f], fi, live ? (ok ? FOA_ST_OK : FOA_ST_CRC_FAIL) : fi.status);
+}
+
 constexpr int kTbChunk = 48;      // chain-back steps per LDS-DMA chunk (multiple of 6 and 8; two chunks = 48 loads in flight)
 
 // Chain-back (viterbi.cpp:108-146) in slot space, descrambler and CRC-32 (ppdu.cpp:256-293), one LANE per frame:
@@ -273,25 +349,14 @@ __global__ __launch_bounds__(64) void k_viterbi_finish2(const FrameInfo *__restr
                                                         uint32_t *__restrict__ decoded, uint8_t *__restrict__ psdu, size_t slot_bytes,
                                                         foa_frame_result *__restrict__ results)
 {
-    __shared__ uint32_t crc_tab[1024];                   // slicing-by-4: T0 | T1 | T2 | T3
-    __shared__ uint32_t scr_tab[128];                    // descrambling mask of word q mod 127
+    __shared__ FinishTables tabs;
     __shared__ ulonglong2 tbuf[2][kTbChunk / 2][64];     // two chunks of decision words, [piece][lane] x 16 B
     const int lane = threadIdx.x, f = blockIdx.x * 64 + lane;
-    for (int i = lane; i < 256; i += 64) {
-        const uint32_t t0 = g_tab.crc_table[i];
-        const uint32_t t1 = (t0 >> 8) ^ g_tab.crc_table[t0 & 0xFFu];
-        const uint32_t t2 = (t1 >> 8) ^ g_tab.crc_table[t1 & 0xFFu];
-        const uint32_t t3 = (t2 >> 8) ^ g_tab.crc_table[t2 & 0xFFu];
-        crc_tab[i] = t0; crc_tab[256 + i] = t1; crc_tab[512 + i] = t2; crc_tab[768 + i] = t3;
-    }
-    for (int i = lane; i < 127; i += 64) {
-        uint32_t m = 0;
-        for (int b = 0; b < 4; b++) m |= (uint32_t)g_tab.scramble[(4 * i + b) % 127] << (8 * b);
-        scr_tab[i] = m;
-    }
+    finish_tables_init(tabs, lane, 64);
     __syncthreads();
     FrameInfo fi;
     fi.status = FOA_ST_HEADER_FAIL; fi.rate = -1; fi.length = 0; fi.nsym = 0; fi.sym_off = 0; fi.nsteps = 0; fi.soft_off = 0; fi.dec_off = 0;
+    fi.seg_off = 0;
     if (f < n_frames) fi = info[f];
     const bool live = f < n_frames && fi.nsym > 0;
     const int T = live ? fi.nsteps : 0, data_bits = T - 6;
@@ -372,60 +437,7 @@ __global__ __launch_bounds__(64) void k_viterbi_finish2(const FrameInfo *__restr
             which ^= 1;
         }
     }
-    // descramble (one LFSR bit per byte, ppdu.cpp:256-264) + CRC over service+payload (ppdu.cpp:267-271).
-    // Whole words go through four table look-ups that do not depend on each other (slicing-by-4); the scrambler's
-    // 127-byte period makes a 127-word table of descrambling masks.
-    const int len = fi.length, ncrc = live ? 2 + len : 0, nwords = live ? (ncrc + 4 + 3) / 4 : 0;
-    int maxw = nwords;
-#pragma unroll
-    for (int o = 32; o; o >>= 1) maxw = max(maxw, __shfl_xor(maxw, o));
-    uint32_t crc = 0xFFFFFFFFu, given = 0;
-    const int full = ncrc >> 2;                                            // words that lie entirely inside the CRC range
-    int qs = 0;                                                            // q mod 127
-    for (int q = 0; q < maxw; q++) {
-        const uint32_t scr = scr_tab[qs];
-        qs = qs == 126 ? 0 : qs + 1;
-        if (q < nwords) {
-            const uint32_t d = out[q] ^ scr;
-            out[q] = d;
-            if (q < full) {
-                const uint32_t c = crc ^ d;
-                crc = crc_tab[768 + (c & 0xFFu)] ^ crc_tab[512 + ((c >> 8) & 0xFFu)] ^ crc_tab[256 + ((c >> 16) & 0xFFu)] ^ crc_tab[c >> 24];
-            } else {
-#pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    const int x = 4 * q + b;
-                    const uint32_t byte = (d >> (8 * b)) & 0xFFu;
-                    if (x < ncrc) crc = crc_tab[(crc ^ byte) & 0xFFu] ^ (crc >> 8);
-                    else if (x < ncrc + 4) given |= byte << (8 * (x - ncrc));
-                }
-            }
-        }
-    }
-    const bool ok = live && (crc ^ 0xFFFFFFFFu) == given;
-    // payload = descrambled bytes [2, 2+len) (ppdu.cpp:283-285), only for frames whose CRC matched
-    if (ok) {
-        uint8_t *slot = psdu + (size_t)f * slot_bytes;
-        const int ncopy = min((size_t)len, slot_bytes);
-        int y = 0;
-        if ((((uintptr_t)slot) & 3) == 0)
-            {
-                // bytes y+2 .. y+5 straddle words q, q+1; four words per trip keep several loads in flight
-                for (; y + 16 <= ncopy; y += 16) {
-                    const int q = (y + 2) >> 2;
-                    const uint32_t a0 = out[q], a1 = out[q + 1], a2 = out[q + 2], a3 = out[q + 3], a4 = out[q + 4];
-                    uint32_t *dst = (uint32_t *)slot + (y >> 2);
-                    dst[0] = (a0 >> 16) | (a1 << 16); dst[1] = (a1 >> 16) | (a2 << 16);
-                    dst[2] = (a2 >> 16) | (a3 << 16); dst[3] = (a3 >> 16) | (a4 << 16);
-                }
-                for (; y + 4 <= ncopy; y += 4) {
-                    const int q = (y + 2) >> 2;
-                    ((uint32_t *)slot)[y >> 2] = (out[q] >> 16) | (out[q + 1] << 16);
-                }
-            }
-        for (; y < ncopy; y++) slot[y] = (uint8_t)(out[(y + 2) >> 2] >> (8 * ((y + 2) & 3)));
-    }
-    if (f < n_frames) write_result(&results[f], fi, live ? (ok ? FOA_ST_OK : FOA_ST_CRC_FAIL) : fi.status);
+    finish_crc_psdu(tabs, fi, live, f, n_frames, out, psdu, slot_bytes, results);
 }
 
 inline void launch_viterbi_v2(hipStream_t st, const FrameInfo *info, int nf, const uint32_t *bm, uint64_t *dec, uint32_t *decoded,

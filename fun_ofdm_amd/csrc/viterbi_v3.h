@@ -1,0 +1,397 @@
+// viterbi_v3.h -- K=7 Viterbi: forward pass with lane-resident decision bits, segment-parallel chain-back.
+//
+// Same recursion and the same in-place trellis as viterbi_v2.h (two frames per wave, packed u16 metrics, slot
+// p = lane holds label rotl6^t(p)).  What changes is where the decision bits go, because on gfx950 the forward
+// pass is bound by VALU issue (a wave64 instruction occupies its SIMD for four clocks) and v2 spends six of its
+// eighteen VALU instructions per step on turning the compare into a lane mask and parking it in a VGPR lane:
+//
+//   * The decision of slot p stays in lane p.  `x - y` as a packed 16-bit subtract has the decision of both
+//     frames in its two sign bits; one shift and one v_bfi_b32 file them as bit j of a packed accumulator
+//     (3 VALU for both frames).  Sixteen steps fill the accumulator: one 16-bit store per lane and frame.
+//     Decision memory is therefore TRANSPOSED relative to v2: u16 [block of 16 steps][slot], same 8 bytes per
+//     step and frame.  Stored bit = 1 means "survivor came from the pair's LOW slot" (the complement of v2's bit),
+//     and slot p's word sits at index 63 - p, so that a chain-back that keeps the complemented slot index
+//     pbar = 63 - p simply copies the bit it reads:   pbar <- (pbar & ~(1<<q)) | (bit << q),  q = 5 - n mod 6.
+//     Steps 0..5 of the trellis carry no data bit (viterbi.cpp:131-142) and are not recorded at all: "data step"
+//     n = t - 6 is the index used from here on; block b holds data steps 16b .. 16b+15.
+//   * Branch-metric increments of both predecessors come from two v_perm_b32 (v2: one v_perm + two v_xor): the
+//     staging copy in LDS holds each step's metric dwords and their 63-complements in both orders, and a lane
+//     reads the order that suits its side of the butterfly.
+//   * The renormalisation test reads state 0 with one v_readfirstlane and decides on the scalar unit.
+//
+// Chain-back.  With the decisions transposed, the address of the bit a path needs depends on the path, so the
+// serial walk of one frame cannot be fed ahead of time.  Instead the walk is cut into SEGMENTS of S data steps,
+// one LANE per segment, all segments of all frames at once (k_tb_walk).  A lane does not know the state at the
+// top of its segment, so it starts L steps higher in an arbitrary state and discards those bits; survivor paths
+// merge quickly, so after L steps it is on the true path -- almost always.  "Almost" is not bit-exact, so each
+// lane records the state it assumed at its top boundary (e) and the state it reached at its bottom boundary (s);
+// k_tb_finish checks e(k) == s(k+1) down each frame (the top segment starts from the true terminal state, so by
+// induction every segment that passes is the true path) and re-walks a segment from the proven state when the
+// check fails.  That keeps the result identical to the serial chain-back whatever L is; L only trades overlap
+// work against the frequency of re-walks (tests run with L = 0, where nearly every segment is re-walked).
+#pragma once
+
+#include "viterbi_v2.h"
+
+namespace foa {
+
+constexpr int kChunk3 = 48;                  // data steps per forward chunk: 3 decision blocks, 8 phase groups
+constexpr int kTbPieces = 24;                // LDS-DMA instructions per chunk: 8 lane groups x 3 blocks, 1 KiB each
+constexpr int kTbChunkBytes = kTbPieces * 1024;   // LDS: [lane / 8][block][lane % 8] x 128 B
+constexpr int kTbMaxSeg = 3072;              // largest segment length (LDS of the re-walk path: 8 B per step)
+
+__device__ __forceinline__ uint32_t pk_sub_wrap(uint32_t a, uint32_t b)
+{
+    ushort2_t r = __builtin_bit_cast(ushort2_t, a) - __builtin_bit_cast(ushort2_t, b);
+    return __builtin_bit_cast(uint32_t, r);
+}
+
+struct Fwd3Lane {
+    uint32_t sel[6];      // v_perm selector {0, B.byte[cls], 0, A.byte[cls]} of this lane's butterfly class
+    uint32_t ofs[6];      // uint4 index offset into a staging entry: 0 = (m, 63-m) order, 1 = (63-m, m) order
+};
+
+__device__ __forceinline__ Fwd3Lane fwd3_lane_init(int lane)
+{
+    Fwd3Lane c;
+#pragma unroll
+    for (int ph = 0; ph < 6; ph++) {
+        const int q = 5 - ph;
+        const int i = rotl6(lane & ~(1 << q), ph);                       // old label of the pair's low slot (< 32)
+        const uint32_t cls = ((__popc((2 * i) & 121) & 1) << 1) | (__popc((2 * i) & 91) & 1);   // viterbi.cpp:86-91
+        c.sel[ph] = 0x0C000C00u | ((4u + cls) << 16) | cls;
+        c.ofs[ph] = (lane >> q) & 1;                                      // the pair's high slot adds 63-m on the low branch
+    }
+    return c;
+}
+
+// One trellis step (phase PH) for both frames.  J >= 0: data step J of the chunk (compile time); J == -1: no
+// decision is recorded (trellis steps 0..5); J == -2: data step jdyn (run time).
+template <int PH, int J>
+__device__ __forceinline__ uint32_t fwd3_step(uint32_t M, const uint4 w, const Fwd3Lane &c, uint32_t (&acc)[3], int jdyn)
+{
+    const uint32_t inc_lo = __builtin_amdgcn_perm(w.y, w.x, c.sel[PH]), inc_hi = __builtin_amdgcn_perm(w.w, w.z, c.sel[PH]);
+    uint32_t lo, hi;
+    pair_exchange<5 - PH>(M, lo, hi);
+    const uint32_t x = pk_add_sat(lo, inc_lo), y = pk_add_sat(hi, inc_hi);
+    // upper predecessor wins ties (viterbi.cpp): survivor = low slot iff x < y iff the 16-bit difference is negative
+    // (both operands lie in [0xFF00, 0xFFFF])
+    if constexpr (J >= 0) {
+        // Written as one volatile block: left to itself the compiler sinks these three instructions of all 48 steps
+        // to the end of the chunk and keeps every step's x and y alive until then (148 VGPRs, 3 waves per SIMD).
+        constexpr int blk = J >> 4, j = J & 15;
+        constexpr uint32_t m = 0x00010001u << j;
+        uint32_t tmp;
+        if constexpr (j == 15)
+            asm volatile("v_pk_sub_u16 %1, %2, %3\n\tv_bfi_b32 %0, %4, %1, %0" : "+v"(acc[blk]), "=&v"(tmp) : "v"(x), "v"(y), "s"(m));
+        else
+            asm volatile("v_pk_sub_u16 %1, %2, %3\n\tv_lshrrev_b32 %1, %5, %1\n\tv_bfi_b32 %0, %4, %1, %0"
+                         : "+v"(acc[blk]), "=&v"(tmp)
+                         : "v"(x), "v"(y), "s"(m), "n"(15 - j));
+    } else if constexpr (J == -2) {
+        const int blk = jdyn >> 4, j = jdyn & 15;
+        const uint32_t m = 0x00010001u << j;
+        const uint32_t tmp = pk_sub_wrap(x, y) >> (15 - j);
+#pragma unroll
+        for (int b = 0; b < 3; b++) acc[b] = blk == b ? ((acc[b] & ~m) | (tmp & m)) : acc[b];
+    }
+    uint32_t Mn = pk_min(x, y);
+    // viterbi.cpp:314-332 per frame: renormalise when the new metric of state 0 (slot 0 = lane 0) exceeds 210.
+    // Stored halves are 0xFF00 + metric: adding 45 to the low byte of a half carries into bit 8 iff metric > 210.
+    const uint32_t s0 = __builtin_amdgcn_readfirstlane(Mn);
+    const uint32_t over = ((s0 & 0x00FF00FFu) + 0x002D002Du) & 0x01000100u;
+    if (over) {
+        if (over & 0x100u) Mn -= wave_min_u32(Mn & 0xFFFFu) - kBias;
+        if (over >> 16) Mn -= (wave_min_u32(Mn >> 16) - kBias) << 16;
+    }
+    return Mn;
+}
+
+// six steps (one of each phase); entry e of the staging buffer is two uint4: {A.m, B.m, A.~m, B.~m} {A.~m, B.~m, A.m, B.m}
+template <int E0, int J0>
+__device__ __forceinline__ uint32_t fwd3_group(uint32_t M, const uint4 *bml, const Fwd3Lane &c, uint32_t (&acc)[3])
+{
+    const uint4 w0 = bml[2 * (E0 + 0) + c.ofs[0]], w1 = bml[2 * (E0 + 1) + c.ofs[1]], w2 = bml[2 * (E0 + 2) + c.ofs[2]],
+                w3 = bml[2 * (E0 + 3) + c.ofs[3]], w4 = bml[2 * (E0 + 4) + c.ofs[4]], w5 = bml[2 * (E0 + 5) + c.ofs[5]];
+    M = fwd3_step<0, (J0 < 0 ? J0 : J0 + 0)>(M, w0, c, acc, 0);
+    M = fwd3_step<1, (J0 < 0 ? J0 : J0 + 1)>(M, w1, c, acc, 0);
+    M = fwd3_step<2, (J0 < 0 ? J0 : J0 + 2)>(M, w2, c, acc, 0);
+    M = fwd3_step<3, (J0 < 0 ? J0 : J0 + 3)>(M, w3, c, acc, 0);
+    M = fwd3_step<4, (J0 < 0 ? J0 : J0 + 4)>(M, w4, c, acc, 0);
+    M = fwd3_step<5, (J0 < 0 ? J0 : J0 + 5)>(M, w5, c, acc, 0);
+    __builtin_amdgcn_sched_barrier(0);          // keep the next groups' LDS reads from being hoisted (registers)
+    return M;
+}
+
+__device__ __forceinline__ uint32_t fwd3_step_dyn(uint32_t M, int j, const uint4 *bml, const Fwd3Lane &c, uint32_t (&acc)[3])
+{
+    switch (j % 6) {
+    case 0: return fwd3_step<0, -2>(M, bml[2 * j + c.ofs[0]], c, acc, j);
+    case 1: return fwd3_step<1, -2>(M, bml[2 * j + c.ofs[1]], c, acc, j);
+    case 2: return fwd3_step<2, -2>(M, bml[2 * j + c.ofs[2]], c, acc, j);
+    case 3: return fwd3_step<3, -2>(M, bml[2 * j + c.ofs[3]], c, acc, j);
+    case 4: return fwd3_step<4, -2>(M, bml[2 * j + c.ofs[4]], c, acc, j);
+    default: return fwd3_step<5, -2>(M, bml[2 * j + c.ofs[5]], c, acc, j);
+    }
+}
+
+// five resident waves per SIMD (10 000 frames = 4.9 waves per SIMD on 256 CUs): cap the register budget accordingly
+__global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd3(const FrameInfo *__restrict__ info, int n_frames,
+                                                                 const uint32_t *__restrict__ bm, uint64_t *__restrict__ dec)
+{
+    __shared__ uint4 bml_all[kFwdWaves][2 * kChunk3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint4 *bml = bml_all[wave];
+    const int fA = 2 * (blockIdx.x * kFwdWaves + wave), fB = fA + 1;
+    if (fA >= n_frames) return;
+    const FrameInfo ia = info[fA];
+    FrameInfo ib = ia;
+    if (fB < n_frames) ib = info[fB];
+    const int TA = ia.nsym > 0 ? ia.nsteps : 0;
+    const int TB = (fB < n_frames && ib.nsym > 0) ? ib.nsteps : 0;
+    if (max(TA, TB) == 0) return;
+    const int NA = max(TA - 6, 0), NB = max(TB - 6, 0), N = max(NA, NB);             // data steps
+    const int NAtop = (NA + kChunk3 - 1) / kChunk3 * kChunk3, NBtop = (NB + kChunk3 - 1) / kChunk3 * kChunk3;
+    const uint32_t *bmA = bm + ia.dec_off, *bmB = bm + ib.dec_off;
+    uint16_t *dA = (uint16_t *)(dec + ia.dec_off), *dB = (uint16_t *)(dec + ib.dec_off);
+    const Fwd3Lane c = fwd3_lane_init(lane);
+    uint32_t M = lane == 0 ? kBias2 : kBias2 + 0x003F003Fu;               // viterbi.cpp:71-78 (label 0 = slot 0)
+    uint32_t acc[3] = { 0u, 0u, 0u };
+
+    // trellis steps t0 .. t0+cnt-1 -> staging entries 0 .. cnt-1
+    auto stage = [&](int t0, int cnt) {
+        __builtin_amdgcn_wave_barrier();
+        if (lane < cnt) {
+            const uint32_t a = t0 + lane < TA ? bmA[t0 + lane] : 0u, b = t0 + lane < TB ? bmB[t0 + lane] : 0u;
+            const uint32_t an = a ^ 0x3F3F3F3Fu, bn = b ^ 0x3F3F3F3Fu;   // 63 - m per byte (m <= 63)
+            bml[2 * lane] = make_uint4(a, b, an, bn);
+            bml[2 * lane + 1] = make_uint4(an, bn, a, b);
+        }
+        wave_lds_sync();
+    };
+    stage(0, 6);
+    M = fwd3_group<0, -1>(M, bml, c, acc);
+    for (int n0 = 0; n0 < N; n0 += kChunk3) {                             // n0 mod 6 == 0: phase = chunk-relative index mod 6
+        const int nn = min(kChunk3, N - n0);
+        stage(n0 + 6, kChunk3);
+        acc[0] = acc[1] = acc[2] = 0xFFFFFFFFu;
+        if (nn == kChunk3) {
+            M = fwd3_group<0, 0>(M, bml, c, acc);   M = fwd3_group<6, 6>(M, bml, c, acc);   M = fwd3_group<12, 12>(M, bml, c, acc);
+            M = fwd3_group<18, 18>(M, bml, c, acc); M = fwd3_group<24, 24>(M, bml, c, acc); M = fwd3_group<30, 30>(M, bml, c, acc);
+            M = fwd3_group<36, 36>(M, bml, c, acc); M = fwd3_group<42, 42>(M, bml, c, acc);
+        } else {
+            for (int j = 0; j < nn; j++) M = fwd3_step_dyn(M, j, bml, c, acc);
+        }
+        // Bits of data steps at or beyond a frame's last one, up to the end of the frame's last chunk, are stored
+        // as 1: they hold a chain-back that starts above the frame's end in pbar = 63 (state 0) until it gets there.
+#pragma unroll
+        for (int blk = 0; blk < 3; blk++) {
+            const int b0 = n0 + 16 * blk;
+            if (b0 < NAtop) {
+                const int v = NA - b0;
+                dA[(size_t)(b0 >> 4) * 64 + 63 - lane] = (uint16_t)(acc[blk] | (v >= 16 ? 0u : v <= 0 ? 0xFFFFu : 0xFFFFu << v));
+            }
+            if (b0 < NBtop) {
+                const int v = NB - b0;
+                dB[(size_t)(b0 >> 4) * 64 + 63 - lane] = (uint16_t)((acc[blk] >> 16) | (v >= 16 ? 0u : v <= 0 ? 0xFFFFu : 0xFFFFu << v));
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// chain-back, one lane per segment
+// ---------------------------------------------------------------------------------------------------------
+// LDS holds, per chunk buffer, the three 128-byte decision blocks of every lane's chunk as whole lines:
+// [lane / 8][block][lane % 8][slot] u16.  Eight consecutive lanes of an LDS-DMA instruction fetch the eight 16-byte
+// pieces of ONE line (one block of one segment), so every instruction moves eight full 128-byte lines.  The lane's
+// LDS byte offset carries the complemented slot index in bits 1-6; block and buffer are immediate offsets.  A step
+// is then: read 16 bits, shift the step's bit to its place, v_bfi it in.
+__device__ __forceinline__ uint32_t tb_lane_base(int lane) { return (uint32_t)(lane >> 3) * 3072u + (uint32_t)(lane & 7) * 128u; }
+__device__ __forceinline__ uint32_t tb_gather(uint32_t a) { return (a >> 1) & 63u; }
+
+// 48 steps of one chunk (data steps 48c+47 .. 48c), decoded bits into w[] (data bit 96u+i at bit 31-(i mod 32) of
+// w[i/32]: the reference's MSB-first byte order once the word is byte-swapped).  UPPER: the chunk is the upper half
+// of its 96-step unit.
+template <int BUF, bool UPPER>
+__device__ __forceinline__ void tb_walk_chunk(const uint8_t *tb, uint32_t &a, uint32_t (&w)[3])
+{
+#pragma unroll
+    for (int j = kChunk3 - 1; j >= 0; j--) {
+        const int blk = j >> 4, bit = j & 15, q = 5 - j % 6, pos = q + 1;
+        const uint32_t v = *(const uint16_t *)(tb + a + (BUF * kTbChunkBytes + blk * 1024));
+        const uint32_t tmp = pos >= bit ? v << (pos - bit) : v >> (bit - pos);
+        asm("v_bfi_b32 %0, %1, %2, %0" : "+v"(a) : "s"(1u << pos), "v"(tmp));
+        if (j % 6 == 0) {
+            // the six bits just written are the six data bits of this group, complemented; p bit i = data bit 5-i
+            const int o = 6 * ((UPPER ? 8 : 0) + j / 6), wi = o >> 5, r = o & 31;
+            const uint32_t p = tb_gather(a) ^ 63u;
+            if (r <= 26) {
+                w[wi] |= p << (26 - r);
+            } else {
+                w[wi] |= p >> (r - 26);
+                w[wi + 1] |= p << (58 - r);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_tb_walk(const FrameInfo *__restrict__ info, const int32_t *__restrict__ seg2frame,
+                                                const int64_t *__restrict__ totals, const uint64_t *__restrict__ dec,
+                                                uint32_t *__restrict__ decoded, uint16_t *__restrict__ tb_state, int S, int L)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t tb[2 * kTbChunkBytes];
+    const int lane = threadIdx.x, g = blockIdx.x * 64 + lane;
+    const int n_seg = (int)totals[4];
+    if (blockIdx.x * 64 >= n_seg) return;
+    const int f = g < n_seg ? seg2frame[g] : -1;
+    const bool live = f >= 0;
+    FrameInfo fi;
+    fi.nsteps = 0; fi.dec_off = 0; fi.seg_off = 0;
+    if (live) fi = info[f];
+    const int k = g - fi.seg_off, N = fi.nsteps - 6;
+    const int n_lo = k * S, n_own = min(n_lo + S, N), n_hi = min(n_lo + S + L, N);
+    const int cnt = live ? (n_hi - n_lo + kChunk3 - 1) / kChunk3 : 0;      // chunks this lane walks, numbered from its bottom
+    const int own = live ? (n_own - n_lo + kChunk3 - 1) / kChunk3 : 0;     // of which the lowest `own` are its own
+    const uint8_t *src = live ? (const uint8_t *)(dec + fi.dec_off) + (size_t)(n_lo / kChunk3) * 384 : (const uint8_t *)dec;
+    uint32_t *out = decoded + fi.dec_off + n_lo / 32;
+    int cmax = cnt;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) cmax = max(cmax, __shfl_xor(cmax, o));
+    uint32_t a = tb_lane_base(lane) + (63u << 1);                          // state 0; true at the frame's end, a guess elsewhere
+    uint32_t e = 63u, w[3] = { 0u, 0u, 0u };
+
+    // Fetch roles: in the instruction for lane group gi, this lane moves piece lane % 8 of the blocks of segment lane
+    // 8 gi + lane / 8.  Chunk i of every segment lane -> LDS buffer `which`; a segment lane that has no chunk i gets
+    // its chunk 0 again (always inside its region).
+    const uint8_t *fsrc[8];
+    int fcnt[8];
+#pragma unroll
+    for (int gi = 0; gi < 8; gi++) {
+        const int from = 8 * gi + (lane >> 3);
+        fsrc[gi] = (const uint8_t *)__shfl((unsigned long long)(uintptr_t)src, from) + (lane & 7) * 16;
+        fcnt[gi] = __shfl(cnt, from);
+    }
+    auto fetch = [&](int i, int which) {
+        const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)&tb[which * kTbChunkBytes];
+#pragma unroll
+        for (int gi = 0; gi < 8; gi++) {
+            const uint8_t *p = fsrc[gi] + (size_t)(i < fcnt[gi] ? i : 0) * 384;
+#pragma unroll
+            for (int blk = 0; blk < 3; blk++) {
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep)
+                             : "v"(p + 128 * blk), "s"(lds0 + (uint32_t)(gi * 3 + blk) * 1024u)
+                             : "memory");
+            }
+        }
+    };
+    const int U = (cmax - 1) / 2;                                           // top unit
+    fetch(2 * U + 1, 1);
+    for (int u = U; u >= 0; u--) {
+        // upper chunk 2u+1 in buffer 1, lower chunk 2u in buffer 0; the next chunk streams in while one is walked
+        fetch(2 * u, 0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kTbPieces) : "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (2 * u + 1 == own - 1) e = tb_gather(a);
+        if (2 * u + 1 < cnt) tb_walk_chunk<1, true>(tb, a, w);
+        __builtin_amdgcn_wave_barrier();
+        if (u > 0) {
+            fetch(2 * u - 1, 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kTbPieces) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (2 * u == own - 1) e = tb_gather(a);
+        if (2 * u < cnt) tb_walk_chunk<0, false>(tb, a, w);
+        __builtin_amdgcn_wave_barrier();
+        // own is even except in a frame's last segment, whose chunks above `own` lie beyond the frame's end (zeros)
+        if (2 * u < own) {
+            out[3 * u] = __builtin_bswap32(w[0]); out[3 * u + 1] = __builtin_bswap32(w[1]); out[3 * u + 2] = __builtin_bswap32(w[2]);
+        }
+        w[0] = w[1] = w[2] = 0u;
+    }
+    if (live) tb_state[g] = (uint16_t)(e | (tb_gather(a) << 8));
+}
+
+// Serial walk of data steps n_hi-1 .. n_lo (n_lo a multiple of 32) of one frame from state pbar, every lane of the
+// wave with the same arguments (decisions staged through lds by the whole wave; lane 0 writes the decoded words).
+// Returns the state at n_lo.  Only used when a segment's assumed start state turned out wrong.
+__device__ __noinline__ uint32_t tb_rewalk(const uint16_t *__restrict__ d16, int n_lo, int n_hi, uint32_t pbar, uint32_t *__restrict__ out,
+                                           uint16_t *lds, int lane)
+{
+    const int b_lo = n_lo >> 4, nblk = ((n_hi + 15) >> 4) - b_lo;
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < nblk * 64; i += 64) lds[i] = d16[(size_t)b_lo * 64 + i];
+    wave_lds_sync();
+    uint32_t word = 0;
+    for (int n = n_hi - 1; n >= n_lo; n--) {
+        const uint32_t s = (lds[((n >> 4) - b_lo) * 64 + pbar] >> (n & 15)) & 1u;
+        const int q = 5 - n % 6;
+        pbar = (pbar & ~(1u << q)) | (s << q);
+        word |= (s ^ 1u) << (8 * ((n & 31) >> 3) + 7 - (n & 7));          // data bit n, MSB-first bytes in a little-endian word
+        if ((n & 31) == 0) {
+            if (lane == 0) out[n >> 5] = word;
+            word = 0;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    return pbar;
+}
+
+// One lane per frame: stitch the segments (re-walking the rare one whose start state was wrong), then descramble,
+// CRC and payload copy.
+__global__ __launch_bounds__(64) void k_tb_finish(const FrameInfo *__restrict__ info, int n_frames, const uint64_t *__restrict__ dec,
+                                                  uint32_t *__restrict__ decoded, const uint16_t *__restrict__ tb_state, int S,
+                                                  uint8_t *__restrict__ psdu, size_t slot_bytes, foa_frame_result *__restrict__ results)
+{
+    __shared__ FinishTables tabs;
+    __shared__ uint16_t rw[kTbMaxSeg / 16 * 64];
+    const int lane = threadIdx.x, f = blockIdx.x * 64 + lane;
+    finish_tables_init(tabs, lane, 64);
+    __syncthreads();
+    FrameInfo fi;
+    fi.status = FOA_ST_HEADER_FAIL; fi.rate = -1; fi.length = 0; fi.nsym = 0; fi.sym_off = 0; fi.nsteps = 0; fi.soft_off = 0; fi.dec_off = 0;
+    fi.seg_off = 0;
+    if (f < n_frames) fi = info[f];
+    const bool live = f < n_frames && fi.nsym > 0;
+    const int N = live ? fi.nsteps - 6 : 0, nseg = live ? tb_segments(fi.nsteps, S) : 0;
+    uint32_t *out = decoded + fi.dec_off;
+
+    int maxseg = nseg;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) maxseg = max(maxseg, __shfl_xor(maxseg, o));
+    uint32_t s_next = nseg > 0 ? (uint32_t)(tb_state[fi.seg_off + nseg - 1] >> 8) : 0u;    // state at the bottom of the top segment
+    for (int k = maxseg - 2; k >= 0; k--) {
+        const bool has = k < nseg - 1;
+        const uint32_t st = has ? tb_state[fi.seg_off + k] : 0u;
+        uint32_t s_k = st >> 8;
+        uint64_t redo = __ballot(has && (st & 0xFFu) != s_next);           // assumed start state != proven one
+        while (redo) {
+            const int l = __ffsll((unsigned long long)redo) - 1;
+            redo &= redo - 1;
+            const int64_t off = __shfl(fi.dec_off, l);
+            const int n_l = __shfl(N, l);
+            const uint32_t sn = __shfl(s_next, l);
+            const uint32_t r = tb_rewalk((const uint16_t *)(dec + off), k * S, min(k * S + S, n_l), sn, decoded + off, rw, lane);
+            if (lane == l) s_k = r;
+        }
+        if (has) s_next = s_k;
+    }
+    __threadfence();                                                       // re-walked words were written by lane 0
+    finish_crc_psdu(tabs, fi, live, f, n_frames, out, psdu, slot_bytes, results);
+}
+
+inline void launch_viterbi_v3(hipStream_t st, const FrameInfo *info, int nf, const uint32_t *bm, uint64_t *dec, uint32_t *decoded,
+                              const int32_t *seg2frame, const int64_t *totals, uint16_t *tb_state, size_t max_segs, int S, int L,
+                              uint8_t *psdu, size_t slot_bytes, foa_frame_result *results, hipEvent_t between)
+{
+    hipLaunchKernelGGL(k_viterbi_fwd3, dim3(((nf + 1) / 2 + kFwdWaves - 1) / kFwdWaves), dim3(64 * kFwdWaves), 0, st, info, nf, bm, dec);
+    if (between) (void)hipEventRecord(between, st);
+    hipLaunchKernelGGL(k_tb_walk, dim3((unsigned)((max_segs + 63) / 64)), dim3(64), 0, st, info, seg2frame, totals, dec, decoded, tb_state, S, L);
+    hipLaunchKernelGGL(k_tb_finish, dim3((nf + 63) / 64), dim3(64), 0, st, info, nf, dec, decoded, tb_state, S, psdu, slot_bytes, results);
+}
+
+}  // namespace foa

@@ -15,6 +15,22 @@ def rx():
     r.close()
 
 
+# Viterbi kernel variants: 0 = lane per state; 1 = packed, serial chain-back; 2 = packed, segment chain-back with
+# (tb_segment, tb_overlap): default, no run-in at all (most segments get re-walked), short segments, one long segment
+VITERBI_KINDS = [(0, 0, 0), (1, 0, 0), (2, 960, 96), (2, 96, 0), (2, 192, 96), (2, 3072, 0)]
+
+
+def _kind_id(k):
+    return "v%d-S%d-L%d" % k
+
+
+def _set_viterbi(rx, kind):
+    rx.set_option("viterbi", kind[0])
+    if kind[0] == 2:
+        rx.set_option("tb_segment", kind[1])
+        rx.set_option("tb_overlap", kind[2])
+
+
 def _ends(descs, n):
     e = np.empty(descs.size, np.int64)
     e[:-1] = descs["lts1_pos"][1:]
@@ -116,11 +132,11 @@ def _make_stream(po, rng, specs, snr_db=25.0, gap=(150, 600), cfo_hz=0.0):
     return s.astype(np.complex64), pays
 
 
-@pytest.mark.parametrize("kind", [0, 1])
+@pytest.mark.parametrize("kind", VITERBI_KINDS, ids=_kind_id)
 def test_mixed_rate_stream_vs_oracle(rx, po, kind):
     """All 11 rates, several lengths, marginal SNR so that some frames fail their CRC: identical
     status, header fields and PSDU bytes per frame; soft bytes identical."""
-    rx.set_option("viterbi", kind)
+    _set_viterbi(rx, kind)
     rng = np.random.default_rng(23)
     specs = [(r, int(rng.integers(1, 400))) for r in range(11)] * 2 + [(10, 1024), (0, 37), (2, 1500), (9, 4095), (8, 1)]
     iq, pays = _make_stream(po, rng, specs, snr_db=19.0, cfo_hz=3000.0)
@@ -191,13 +207,13 @@ def test_rotation_switch_inside_lts(rx, po, golden):
     assert np.array_equal(t["soft"][:t["soft_off"][1]], taps["soft"])
 
 
-@pytest.mark.parametrize("kind", [0, 1])
+@pytest.mark.parametrize("kind", VITERBI_KINDS, ids=_kind_id)
 def test_config2_shape_batch(rx, po, kind):
     """BASELINE config 2 at reduced count: 54 Mbps, 1024-byte payloads, 25 dB, frame pitch 4096;
     device-resident buffers through the device-pointer entry point."""
     import torch
     import fun_ofdm_amd as foa
-    rx.set_option("viterbi", kind)
+    _set_viterbi(rx, kind)
     rng = np.random.default_rng(25)
     n_frames, pitch = 96, 4096
     iq = np.zeros(n_frames * pitch, np.complex64)
@@ -246,7 +262,7 @@ def test_config3_rate_sweep_4096_byte_psdu(rx, po, rate):
     length field cannot express more): identical status / PSDU as the oracle, frame by frame."""
     from fun_ofdm_amd import synth
     import fun_ofdm_amd as foa
-    rx.set_option("viterbi", 1)
+    _set_viterbi(rx, VITERBI_KINDS[2])
     n = 3
     pays = synth.splitmix64_bytes(0x0FD3 + rate, n, 4092)
     frames = synth.build_frames(pays, rate)
