@@ -14,9 +14,10 @@
 //     pbar = 63 - p simply copies the bit it reads:   pbar <- (pbar & ~(1<<q)) | (bit << q),  q = 5 - n mod 6.
 //     Steps 0..5 of the trellis carry no data bit (viterbi.cpp:131-142) and are not recorded at all: "data step"
 //     n = t - 6 is the index used from here on; block b holds data steps 16b .. 16b+15.
-//   * Branch-metric increments of both predecessors come from two v_perm_b32 (v2: one v_perm + two v_xor): the
-//     staging copy in LDS holds each step's metric dwords and their 63-complements in both orders, and a lane
-//     reads the order that suits its side of the butterfly.
+//   * Branch-metric increments cost no VALU in the step: when a chunk's metric dwords are staged in LDS, each step
+//     gets all eight (Branchtab class, side of the butterfly) variants of the packed increment pair, and a lane
+//     reads the 8 bytes of its variant (v2: one v_perm + two v_xor per step; half the LDS bytes of reading both
+//     frames' dwords and their complements).
 //   * The renormalisation test reads state 0 with one v_readfirstlane and decides on the scalar unit.
 //
 // Chain-back.  With the decisions transposed, the address of the bit a path needs depends on the path, so the
@@ -35,6 +36,9 @@
 
 namespace foa {
 
+#ifndef FOA_ABL
+#define FOA_ABL 0        // timing experiments only (tools/ablate.sh): 1 no decision ops, 2 no renormalisation
+#endif
 constexpr int kChunk3 = 48;                  // data steps per forward chunk: 3 decision blocks, 8 phase groups
 constexpr int kTbPieces = 24;                // LDS-DMA instructions per chunk: 8 lane groups x 3 blocks, 1 KiB each
 constexpr int kTbChunkBytes = kTbPieces * 1024;   // LDS: [lane / 8][block][lane % 8] x 128 B
@@ -47,8 +51,7 @@ __device__ __forceinline__ uint32_t pk_sub_wrap(uint32_t a, uint32_t b)
 }
 
 struct Fwd3Lane {
-    uint32_t sel[6];      // v_perm selector {0, B.byte[cls], 0, A.byte[cls]} of this lane's butterfly class
-    uint32_t ofs[6];      // uint4 index offset into a staging entry: 0 = (m, 63-m) order, 1 = (63-m, m) order
+    uint32_t ofs[6];      // byte offset of this lane's variant inside a step's 64-byte staging entry: 16 cls + 8 side
 };
 
 __device__ __forceinline__ Fwd3Lane fwd3_lane_init(int lane)
@@ -59,8 +62,7 @@ __device__ __forceinline__ Fwd3Lane fwd3_lane_init(int lane)
         const int q = 5 - ph;
         const int i = rotl6(lane & ~(1 << q), ph);                       // old label of the pair's low slot (< 32)
         const uint32_t cls = ((__popc((2 * i) & 121) & 1) << 1) | (__popc((2 * i) & 91) & 1);   // viterbi.cpp:86-91
-        c.sel[ph] = 0x0C000C00u | ((4u + cls) << 16) | cls;
-        c.ofs[ph] = (lane >> q) & 1;                                      // the pair's high slot adds 63-m on the low branch
+        c.ofs[ph] = 16u * cls + 8u * ((lane >> q) & 1);                   // the pair's high slot adds 63-m on the low branch
     }
     return c;
 }
@@ -68,15 +70,15 @@ __device__ __forceinline__ Fwd3Lane fwd3_lane_init(int lane)
 // One trellis step (phase PH) for both frames.  J >= 0: data step J of the chunk (compile time); J == -1: no
 // decision is recorded (trellis steps 0..5); J == -2: data step jdyn (run time).
 template <int PH, int J>
-__device__ __forceinline__ uint32_t fwd3_step(uint32_t M, const uint4 w, const Fwd3Lane &c, uint32_t (&acc)[3], int jdyn)
+__device__ __forceinline__ uint32_t fwd3_step(uint32_t M, const uint2 w, const Fwd3Lane &c, uint32_t (&acc)[3], int jdyn)
 {
-    const uint32_t inc_lo = __builtin_amdgcn_perm(w.y, w.x, c.sel[PH]), inc_hi = __builtin_amdgcn_perm(w.w, w.z, c.sel[PH]);
+    const uint32_t inc_lo = w.x, inc_hi = w.y;
     uint32_t lo, hi;
     pair_exchange<5 - PH>(M, lo, hi);
     const uint32_t x = pk_add_sat(lo, inc_lo), y = pk_add_sat(hi, inc_hi);
     // upper predecessor wins ties (viterbi.cpp): survivor = low slot iff x < y iff the 16-bit difference is negative
     // (both operands lie in [0xFF00, 0xFFFF])
-    if constexpr (J >= 0) {
+    if constexpr (J >= 0 && !(FOA_ABL & 1)) {
         // Written as one volatile block: left to itself the compiler sinks these three instructions of all 48 steps
         // to the end of the chunk and keeps every step's x and y alive until then (148 VGPRs, 3 waves per SIMD).
         constexpr int blk = J >> 4, j = J & 15;
@@ -98,21 +100,29 @@ __device__ __forceinline__ uint32_t fwd3_step(uint32_t M, const uint4 w, const F
     uint32_t Mn = pk_min(x, y);
     // viterbi.cpp:314-332 per frame: renormalise when the new metric of state 0 (slot 0 = lane 0) exceeds 210.
     // Stored halves are 0xFF00 + metric: adding 45 to the low byte of a half carries into bit 8 iff metric > 210.
+    if constexpr (FOA_ABL & 2) return Mn;
     const uint32_t s0 = __builtin_amdgcn_readfirstlane(Mn);
     const uint32_t over = ((s0 & 0x00FF00FFu) + 0x002D002Du) & 0x01000100u;
-    if (over) {
+    if (__builtin_expect(over != 0u, 0)) {      // cold: keeps the common path free of taken branches
         if (over & 0x100u) Mn -= wave_min_u32(Mn & 0xFFFFu) - kBias;
         if (over >> 16) Mn -= (wave_min_u32(Mn >> 16) - kBias) << 16;
     }
     return Mn;
 }
 
-// six steps (one of each phase); entry e of the staging buffer is two uint4: {A.m, B.m, A.~m, B.~m} {A.~m, B.~m, A.m, B.m}
+// Staging entry of a step: for each Branchtab class c, 16 bytes {lo, hi, hi, lo} with lo = (A.m[c], B.m[c]) as u16
+// halves and hi = lo ^ 0x003F003F (63 - m); the pair's low slot reads (lo, hi) at +0, its high slot (hi, lo) at +8.
+__device__ __forceinline__ uint2 fwd3_inc(const uint4 *bml, int e, uint32_t ofs)
+{
+    return *(const uint2 *)((const uint8_t *)bml + 64 * e + ofs);
+}
+
+// six steps (one of each phase) on staging entries E0 .. E0+5
 template <int E0, int J0>
 __device__ __forceinline__ uint32_t fwd3_group(uint32_t M, const uint4 *bml, const Fwd3Lane &c, uint32_t (&acc)[3])
 {
-    const uint4 w0 = bml[2 * (E0 + 0) + c.ofs[0]], w1 = bml[2 * (E0 + 1) + c.ofs[1]], w2 = bml[2 * (E0 + 2) + c.ofs[2]],
-                w3 = bml[2 * (E0 + 3) + c.ofs[3]], w4 = bml[2 * (E0 + 4) + c.ofs[4]], w5 = bml[2 * (E0 + 5) + c.ofs[5]];
+    const uint2 w0 = fwd3_inc(bml, E0 + 0, c.ofs[0]), w1 = fwd3_inc(bml, E0 + 1, c.ofs[1]), w2 = fwd3_inc(bml, E0 + 2, c.ofs[2]),
+                w3 = fwd3_inc(bml, E0 + 3, c.ofs[3]), w4 = fwd3_inc(bml, E0 + 4, c.ofs[4]), w5 = fwd3_inc(bml, E0 + 5, c.ofs[5]);
     M = fwd3_step<0, (J0 < 0 ? J0 : J0 + 0)>(M, w0, c, acc, 0);
     M = fwd3_step<1, (J0 < 0 ? J0 : J0 + 1)>(M, w1, c, acc, 0);
     M = fwd3_step<2, (J0 < 0 ? J0 : J0 + 2)>(M, w2, c, acc, 0);
@@ -126,12 +136,12 @@ __device__ __forceinline__ uint32_t fwd3_group(uint32_t M, const uint4 *bml, con
 __device__ __forceinline__ uint32_t fwd3_step_dyn(uint32_t M, int j, const uint4 *bml, const Fwd3Lane &c, uint32_t (&acc)[3])
 {
     switch (j % 6) {
-    case 0: return fwd3_step<0, -2>(M, bml[2 * j + c.ofs[0]], c, acc, j);
-    case 1: return fwd3_step<1, -2>(M, bml[2 * j + c.ofs[1]], c, acc, j);
-    case 2: return fwd3_step<2, -2>(M, bml[2 * j + c.ofs[2]], c, acc, j);
-    case 3: return fwd3_step<3, -2>(M, bml[2 * j + c.ofs[3]], c, acc, j);
-    case 4: return fwd3_step<4, -2>(M, bml[2 * j + c.ofs[4]], c, acc, j);
-    default: return fwd3_step<5, -2>(M, bml[2 * j + c.ofs[5]], c, acc, j);
+    case 0: return fwd3_step<0, -2>(M, fwd3_inc(bml, j, c.ofs[0]), c, acc, j);
+    case 1: return fwd3_step<1, -2>(M, fwd3_inc(bml, j, c.ofs[1]), c, acc, j);
+    case 2: return fwd3_step<2, -2>(M, fwd3_inc(bml, j, c.ofs[2]), c, acc, j);
+    case 3: return fwd3_step<3, -2>(M, fwd3_inc(bml, j, c.ofs[3]), c, acc, j);
+    case 4: return fwd3_step<4, -2>(M, fwd3_inc(bml, j, c.ofs[4]), c, acc, j);
+    default: return fwd3_step<5, -2>(M, fwd3_inc(bml, j, c.ofs[5]), c, acc, j);
     }
 }
 
@@ -139,7 +149,7 @@ __device__ __forceinline__ uint32_t fwd3_step_dyn(uint32_t M, int j, const uint4
 __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd3(const FrameInfo *__restrict__ info, int n_frames,
                                                                  const uint32_t *__restrict__ bm, uint64_t *__restrict__ dec)
 {
-    __shared__ uint4 bml_all[kFwdWaves][2 * kChunk3];
+    __shared__ uint4 bml_all[kFwdWaves][4 * kChunk3];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint4 *bml = bml_all[wave];
     const int fA = 2 * (blockIdx.x * kFwdWaves + wave), fB = fA + 1;
@@ -158,22 +168,32 @@ __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd3(const FrameInfo
     uint32_t M = lane == 0 ? kBias2 : kBias2 + 0x003F003Fu;               // viterbi.cpp:71-78 (label 0 = slot 0)
     uint32_t acc[3] = { 0u, 0u, 0u };
 
-    // trellis steps t0 .. t0+cnt-1 -> staging entries 0 .. cnt-1
-    auto stage = [&](int t0, int cnt) {
+    // The metric dwords of trellis steps t0 .. t0+47 (lane = step) are fetched one chunk ahead into registers, so a
+    // chunk never waits for HBM; put() turns them into staging entries 0 .. cnt-1.
+    uint32_t pa = 0, pb = 0;
+    auto get = [&](int t0) {
+        pa = (lane < kChunk3 && t0 + lane < TA) ? bmA[t0 + lane] : 0u;
+        pb = (lane < kChunk3 && t0 + lane < TB) ? bmB[t0 + lane] : 0u;
+    };
+    auto put = [&](int cnt) {
         __builtin_amdgcn_wave_barrier();
         if (lane < cnt) {
-            const uint32_t a = t0 + lane < TA ? bmA[t0 + lane] : 0u, b = t0 + lane < TB ? bmB[t0 + lane] : 0u;
-            const uint32_t an = a ^ 0x3F3F3F3Fu, bn = b ^ 0x3F3F3F3Fu;   // 63 - m per byte (m <= 63)
-            bml[2 * lane] = make_uint4(a, b, an, bn);
-            bml[2 * lane + 1] = make_uint4(an, bn, a, b);
+#pragma unroll
+            for (uint32_t cls = 0; cls < 4; cls++) {
+                const uint32_t lo = __builtin_amdgcn_perm(pb, pa, 0x0C000C00u | ((4u + cls) << 16) | cls), hi = lo ^ 0x003F003Fu;
+                bml[4 * lane + cls] = make_uint4(lo, hi, hi, lo);
+            }
         }
         wave_lds_sync();
     };
-    stage(0, 6);
+    get(0);
+    put(6);
+    get(6);
     M = fwd3_group<0, -1>(M, bml, c, acc);
     for (int n0 = 0; n0 < N; n0 += kChunk3) {                             // n0 mod 6 == 0: phase = chunk-relative index mod 6
         const int nn = min(kChunk3, N - n0);
-        stage(n0 + 6, kChunk3);
+        put(kChunk3);
+        get(n0 + kChunk3 + 6);
         acc[0] = acc[1] = acc[2] = 0xFFFFFFFFu;
         if (nn == kChunk3) {
             M = fwd3_group<0, 0>(M, bml, c, acc);   M = fwd3_group<6, 6>(M, bml, c, acc);   M = fwd3_group<12, 12>(M, bml, c, acc);
