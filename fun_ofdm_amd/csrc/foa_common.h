@@ -41,6 +41,10 @@ struct DeviceTables {
     uint8_t scramble[128];         // ppdu.cpp:256-264 feedback bit per byte index mod 127
     uint32_t crc_table[256];       // IEEE 802.3 CRC-32, reflected
     double lts_conj_re[64], lts_conj_im[64];   // preamble.h:432 LTS_TIME_DOMAIN_CONJ
+    // look-up forms of two integer formulas, used by the lane-per-symbol front end (frontend_lps.h)
+    uint32_t qam_lut[641];         // qam.h:110-125 for pt = -320..320 (constant outside): soft byte i in bits 8i..8i+7
+    uint32_t bm_sum[511];          // viterbi.cpp:242-247: index s0+s1      -> m00 | m11 << 24
+    uint32_t bm_dif[511];          //                      index s0-s1+255  -> m01 << 8 | m10 << 16
 };
 
 // Filled once on the host (tables.cpp) and uploaded to __constant__ memory of each translation unit

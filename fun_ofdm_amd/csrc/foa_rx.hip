@@ -115,6 +115,23 @@ void foa::build_tables(DeviceTables *t)
     std::complex<double> ltc[64];
     foa::make_lts_time_conj(ltc);
     for (int i = 0; i < 64; i++) { t->lts_conj_re[i] = ltc[i].real(); t->lts_conj_im[i] = ltc[i].imag(); }
+    // qam.h:110-125 with NumBits = 3 (fewer bits = a prefix of the same loop); |pt| >= 320 gives the value of +-320
+    for (int p = -320; p <= 320; p++) {
+        uint32_t pt = (uint32_t)p, word = 0;
+        int flip = 1, amp = 128;
+        for (int i = 0; i < 3; i++) {
+            int v = (int)((uint32_t)flip * pt + 128u);
+            word |= (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v)) << (8 * i);
+            int bit = ((int)pt < 0) ? -1 : 1;
+            pt -= (uint32_t)(bit * amp);
+            flip = -bit;
+            amp >>= 1;
+        }
+        t->qam_lut[p + 320] = word;
+    }
+    // (((s0 ^ b0*255) + (s1 ^ b1*255) + 1) >> 1) >> 2 for (b0,b1) = 00, 01, 10, 11 in terms of s0+s1 and s0-s1
+    for (int a = 0; a <= 510; a++) t->bm_sum[a] = (uint32_t)((a + 1) >> 3) | ((uint32_t)((511 - a) >> 3) << 24);
+    for (int b = -255; b <= 255; b++) t->bm_dif[b + 255] = ((uint32_t)((b + 256) >> 3) << 8) | ((uint32_t)((256 - b) >> 3) << 16);
 }
 
 struct foa_rx {

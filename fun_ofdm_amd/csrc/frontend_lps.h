@@ -80,8 +80,17 @@ __device__ __forceinline__ uint32_t bm_word(uint32_t s0, uint32_t s1)
     return ((s0 + s1 + 1u) >> 3) | (((s0 + n1 + 1u) >> 3) << 8) | (((n0 + s1 + 1u) >> 3) << 16) | (((n0 + n1 + 1u) >> 3) << 24);
 }
 
-// LDS of one wave: staging rows for the coalesced input loads and output stores
+// qam.h:110-125 through the table: the three soft bytes of one axis in one dword
+__device__ __forceinline__ uint32_t qam_lookup(const uint32_t *qam, double sym, double scale_d)
+{
+#pragma clang fp contract(off)
+    const int pt = trunc_to_int(sym * scale_d);
+    return qam[min(max(pt, -320), 320) + 320];
+}
+
+// LDS of one wave: staging rows for the coalesced input loads and output stores, and the look-up tables
 struct LpsShared {
+    uint32_t qam[641], bm_sum[511], bm_dif[511];
     int64_t in_base[64];                 // per lane: first sample index of its symbol
     int64_t out_base[64];                // per lane: first bm word index of its symbol
     float4 in[64][9];                    // 16 samples (8 x 16 B) per lane and round, one 16-B pad
@@ -107,21 +116,16 @@ __device__ __forceinline__ void emit_symbol_lps(const cpx (&zx)[64], double scal
 #pragma unroll
         for (int cc = 0; cc < CPB; cc++) {
             const int di = q * CPB + cc;
-            uint32_t bi[3], bq[3];
             const cpx zc = zx[subcarrier_lane(data_subcarrier(di))];
-            qam_decode_n<NB>(zc.x, scale_d, bi);
-            if (BPSC > 1) qam_decode_n<NB>(zc.y, scale_d, bq);
+            const uint32_t li = qam_lookup(sh->qam, zc.x, scale_d), lq = BPSC > 1 ? qam_lookup(sh->qam, zc.y, scale_d) : 0u;
 #pragma unroll
             for (int b = 0; b < BPSC; b++) {
                 const int w = cc * BPSC + b;                        // byte index inside the block, demodulated order
-                d[16 * (w % 3) + w / 3] = b < NB ? bi[b] : bq[b - NB];   // interleaver.cpp:33-36
+                d[16 * (w % 3) + w / 3] = b < NB ? (li >> (8 * b)) & 255u : (lq >> (8 * (b - NB))) & 255u;   // interleaver.cpp:33-36
             }
         }
         // puncturer.cpp:94-102,112-118: step -> (first, second) soft byte, 127 where punctured
-        uint32_t wds[STEPS];
-#pragma unroll
-        for (int t = 0; t < STEPS; t++) {
-            uint32_t s0, s1;
+        auto soft_pair = [&](int t, uint32_t &s0, uint32_t &s1) {
             if (PUNCT == 0) { s0 = d[2 * t]; s1 = d[2 * t + 1]; }
             else if (PUNCT == 2) {                                  // 4 in -> {d0,d1,127,d2,127,d3}
                 const int g = t / 3, r = t % 3;
@@ -132,8 +136,21 @@ __device__ __forceinline__ void emit_symbol_lps(const cpx (&zx)[64], double scal
                 s0 = r == 0 ? d[3 * g] : d[3 * g + 1];
                 s1 = r == 0 ? 127u : d[3 * g + 2];
             }
-            wds[t] = bm_word(s0, s1);
-            if (soft_dst) { soft_dst[2 * (q * STEPS + t)] = (uint8_t)s0; soft_dst[2 * (q * STEPS + t) + 1] = (uint8_t)s1; }
+        };
+        uint32_t wds[STEPS];
+#pragma unroll
+        for (int t = 0; t < STEPS; t++) {
+            uint32_t s0, s1;
+            soft_pair(t, s0, s1);
+            wds[t] = sh->bm_sum[s0 + s1] | sh->bm_dif[s0 + 255u - s1];
+        }
+        if (soft_dst) {                                             // diagnostics only: one branch per block, not per step
+#pragma unroll
+            for (int t = 0; t < STEPS; t++) {
+                uint32_t s0, s1;
+                soft_pair(t, s0, s1);
+                *(uint16_t *)(soft_dst + 2 * (q * STEPS + t)) = (uint16_t)(s0 | (s1 << 8));
+            }
         }
         if constexpr (COOP) {
 #pragma unroll
@@ -182,6 +199,9 @@ __global__ __launch_bounds__(64) void k_data_symbols_lps(const float2 *__restric
     const int64_t w0 = (int64_t)blockIdx.x * 64, w = w0 + lane;
     const int64_t total = min(totals[0], totals[3]);
     if (w0 >= total) return;
+    // tables first, while all 64 lanes are still here (the next wave_lds_sync orders them)
+    for (int i = lane; i < 641; i += 64) sh.qam[i] = g_tab.qam_lut[i];
+    for (int i = lane; i < 511; i += 64) { sh.bm_sum[i] = g_tab.bm_sum[i]; sh.bm_dif[i] = g_tab.bm_dif[i]; }
     // lanes past the end (or in unused slots) shadow the wave's first symbol and write nothing
     int f = w < total ? sym2frame[w] : -1;
     const bool valid = f >= 0;
