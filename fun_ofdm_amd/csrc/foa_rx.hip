@@ -172,7 +172,8 @@ int workspace(foa_rx *rx, size_t n_samples, size_t n_frames)
     size_t dec_cap = 216 * sym_cap + 192 * (n_frames + 1);
     int rc;
     if ((rc = rx->info.ensure(n_frames + 1)) || (rc = rx->hinv.ensure((n_frames + 1) * 64)) || (rc = rx->sym2frame.ensure(sym_cap)) ||
-        (rc = rx->soft.ensure(soft_cap)) || (rc = rx->dec.ensure(dec_cap)) || (rc = rx->bm.ensure(dec_cap)) || (rc = rx->decoded.ensure(dec_cap)) || (rc = rx->totals.ensure(8)))
+        (rc = rx->soft.ensure(soft_cap)) || (rc = rx->dec.ensure(dec_cap)) || (rc = rx->bm.ensure(dec_cap)) || (rc = rx->decoded.ensure(dec_cap)) ||
+        (rc = rx->totals.ensure(8 + 4 * ((n_frames + kScanBlock - 1) / kScanBlock + 1))))
         return rc;
     if (rx->record_eq && ((rc = rx->eq_sig.ensure((n_frames + 1) * 48)) || (rc = rx->eq_data.ensure(sym_cap * 48)))) return rc;
     // chain-back segments: every frame has at most dec_words/segment + 1 of them
@@ -302,9 +303,12 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
     // segments of this call: at most (total data steps)/S + one per frame; lanes beyond the real total idle
     const size_t max_segs = std::min(rx->seg2frame.n, rx->dec_cap / (size_t)rx->tb_segment + n_frames + 1);
     HIP_TRY(hipMemsetAsync(rx->seg2frame.p, 0xFF, max_segs * sizeof(int32_t), st));
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, rx->info.p, nf, (int64_t)rx->sym_cap, (int64_t)rx->soft_cap, (int64_t)rx->dec_cap,
-                       rx->tb_segment, rx->totals.p);
-    hipLaunchKernelGGL(k_symmap, dim3((nf + 255) / 256), dim3(256), 0, st, rx->info.p, nf, rx->sym2frame.p, rx->tb_segment, rx->seg2frame.p);
+    const int n_sb = (nf + kScanBlock - 1) / kScanBlock;
+    int64_t *blk = rx->totals.p + 8;
+    hipLaunchKernelGGL(k_scan_sums, dim3(n_sb), dim3(kScanBlock), 0, st, rx->info.p, nf, rx->tb_segment, blk);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, blk, n_sb, rx->totals.p);
+    hipLaunchKernelGGL(k_scan_apply, dim3(n_sb), dim3(kScanBlock), 0, st, rx->info.p, nf, (int64_t)rx->sym_cap, (int64_t)rx->soft_cap,
+                       (int64_t)rx->dec_cap, rx->tb_segment, blk, rx->sym2frame.p, rx->seg2frame.p);
     HIP_TRY(hipEventRecord(rx->ev[2], st));
     // upper bound on data symbols in n_samples samples; waves beyond the real total exit at once
     const size_t max_sym = rx->sym_cap;

@@ -391,65 +391,130 @@ __global__ __launch_bounds__(64) void k_header(const float2 *__restrict__ iq, co
 }
 
 // =================================================================================================
-// K2: exclusive scans over frames -> sym_off / soft_off / dec_off.  One block.
+// K2: exclusive scans over frames -> sym_off / soft_off / dec_off / seg_off, and the symbol / segment maps.
 // =================================================================================================
 // words reserved per frame in the per-step buffers (bm / dec / decoded): the chain-back reads whole 48-step chunks
 __host__ __device__ constexpr int64_t dec_words(int64_t nsteps) { return nsteps > 0 ? (nsteps + 48 + 63) & ~(int64_t)63 : 0; }
 // chain-back segments of a frame (viterbi_v3.h): its nsteps - 6 data steps in pieces of seg_steps
 __host__ __device__ constexpr int tb_segments(int nsteps, int seg_steps) { return nsteps > 6 ? (nsteps - 6 + seg_steps - 1) / seg_steps : 0; }
 
-__global__ __launch_bounds__(1024) void k_scan(FrameInfo *__restrict__ info, int n_frames, int64_t sym_cap, int64_t soft_cap,
-                                               int64_t dec_cap, int seg_steps, int64_t *__restrict__ totals)
+// Three small kernels instead of one block: a single CU's memory pipeline (one 64-line request per wave instruction)
+// made the one-block version the 50 us tail of a 2 ms call.  One thread per frame throughout.
+constexpr int kScanBlock = 256;
+
+struct ScanQ { int64_t v[4]; };          // data symbols, soft bytes (256-aligned), decision words, chain-back segments
+
+__device__ __forceinline__ ScanQ scan_quantities(const FrameInfo *info, int f, int n_frames, int seg_steps)
 {
-    __shared__ int64_t part[4][1024];
-    const int tid = threadIdx.x, per = (n_frames + 1023) / 1024;
-    const int lo = tid * per, hi = min(lo + per, n_frames);
-    int64_t a = 0, b = 0, c = 0, d = 0;
-    for (int f = lo; f < hi; f++) {
+    ScanQ q = { { 0, 0, 0, 0 } };
+    if (f < n_frames) {
         const int nsym = info[f].nsym, nsteps = nsym > 0 ? info[f].nsteps : 0;
-        a += nsym; b += ((int64_t)2 * nsteps + 255) & ~(int64_t)255; c += dec_words(nsteps); d += tb_segments(nsteps, seg_steps);
+        q.v[0] = nsym; q.v[1] = ((int64_t)2 * nsteps + 255) & ~(int64_t)255; q.v[2] = dec_words(nsteps); q.v[3] = tb_segments(nsteps, seg_steps);
     }
-    part[0][tid] = a; part[1][tid] = b; part[2][tid] = c; part[3][tid] = d;
-    __syncthreads();
-    if (tid < 4) {                                   // 1024-element serial scans: negligible
-        int64_t run = 0;
-        for (int i = 0; i < 1024; i++) { int64_t v = part[tid][i]; part[tid][i] = run; run += v; }
-        totals[tid < 3 ? tid : 4] = run;             // totals[3] is the caller's symbol capacity
-    }
-    __syncthreads();
-    a = part[0][tid]; b = part[1][tid]; c = part[2][tid]; d = part[3][tid];
-    for (int f = lo; f < hi; f++) {
-        FrameInfo fi = info[f];
-        const int nsteps = fi.nsym > 0 ? fi.nsteps : 0;
-        const int64_t sb = ((int64_t)2 * nsteps + 255) & ~(int64_t)255, dw = dec_words(nsteps);
-        if (fi.nsym > 0 && (a + fi.nsym > sym_cap || b + sb > soft_cap || c + dw > dec_cap)) {
-            // keeps its slots in the numbering (they stay unused: sym2frame = -1 there)
-            info[f].status = FOA_ST_NO_SPACE; info[f].nsteps = -fi.nsym; info[f].nsym = 0;
-        } else {
-            info[f].sym_off = (int32_t)a; info[f].soft_off = b; info[f].dec_off = c;
-        }
-        info[f].seg_off = (int32_t)d;
-        a += fi.nsym; b += sb; c += dw; d += tb_segments(nsteps, seg_steps);
-    }
+    return q;
 }
 
-// =================================================================================================
-// K3: data symbols.  One wave per symbol, 4 waves per block.  sym_index[] built by k_symmap.
-// =================================================================================================
-// Fills sym2frame[] so that K3's wave w finds its frame without a search: one thread per frame
-// writes its nsym entries (frames are short: <= 1368 symbols).
-__global__ void k_symmap(const FrameInfo *__restrict__ info, int n_frames, int32_t *__restrict__ sym2frame, int seg_steps,
-                         int32_t *__restrict__ seg2frame)
+// exclusive scan over the block's threads; totals in tot[] (valid in every thread)
+__device__ __forceinline__ ScanQ block_exclusive_scan(const ScanQ &q, int64_t (&tot)[4], int64_t (*part)[kScanBlock / 64])
 {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= n_frames) return;
-    const int n = info[f].nsym, o = info[f].sym_off;
-    for (int k = 0; k < n; k++) sym2frame[o + k] = f;
-    // same for the chain-back segments (a frame that lost its space in k_scan has nsym = 0 here)
-    const int ns = n > 0 ? tb_segments(info[f].nsteps, seg_steps) : 0, so = info[f].seg_off;
-    for (int k = 0; k < ns; k++) seg2frame[so + k] = f;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    ScanQ r;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int64_t x = q.v[i];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int64_t y = __shfl_up(x, o);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) part[i][wv] = x;
+        r.v[i] = x - q.v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int64_t run = 0;
+#pragma unroll
+        for (int w = 0; w < kScanBlock / 64; w++) {
+            if (w == wv) r.v[i] += run;
+            run += part[i][w];
+        }
+        tot[i] = run;
+    }
+    return r;
 }
 
+// pass 1: per-block sums -> blk[4][n_blocks]
+__global__ __launch_bounds__(kScanBlock) void k_scan_sums(const FrameInfo *__restrict__ info, int n_frames, int seg_steps, int64_t *__restrict__ blk)
+{
+    __shared__ int64_t part[4][kScanBlock / 64];
+    int64_t tot[4];
+    block_exclusive_scan(scan_quantities(info, blockIdx.x * kScanBlock + threadIdx.x, n_frames, seg_steps), tot, part);
+    if (threadIdx.x < 4) blk[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = tot[threadIdx.x];
+}
+
+// pass 2: exclusive scan of the block sums in place, grand totals -> totals[0..2] and totals[4]  (one block)
+__global__ __launch_bounds__(1024) void k_scan_blocks(int64_t *__restrict__ blk, int n_blocks, int64_t *__restrict__ totals)
+{
+    __shared__ int64_t wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = 0; i < 4; i++) {
+        int64_t carry = 0;
+        for (int base = 0; base < n_blocks; base += 1024) {
+            const int j = base + tid;
+            const int64_t v = j < n_blocks ? blk[(size_t)i * n_blocks + j] : 0;
+            int64_t x = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int64_t y = __shfl_up(x, o);
+                if (lane >= o) x += y;
+            }
+            __syncthreads();
+            if (lane == 63) wsum[wv] = x;
+            __syncthreads();
+            int64_t before = 0, all = 0;
+            for (int w = 0; w < 16; w++) {
+                if (w < wv) before += wsum[w];
+                all += wsum[w];
+            }
+            if (j < n_blocks) blk[(size_t)i * n_blocks + j] = carry + before + x - v;
+            carry += all;
+        }
+        if (tid == 0) totals[i < 3 ? i : 4] = carry;          // totals[3] is the caller's symbol capacity
+    }
+}
+
+// pass 3: offsets into the frame records (frames that do not fit are marked FOA_ST_NO_SPACE), and the symbol -> frame
+// and segment -> frame maps (so that the data-symbol and chain-back kernels find their frame without a search;
+// frames are short: <= 1368 symbols)
+__global__ __launch_bounds__(kScanBlock) void k_scan_apply(FrameInfo *__restrict__ info, int n_frames, int64_t sym_cap, int64_t soft_cap,
+                                                           int64_t dec_cap, int seg_steps, const int64_t *__restrict__ blk,
+                                                           int32_t *__restrict__ sym2frame, int32_t *__restrict__ seg2frame)
+{
+    __shared__ int64_t part[4][kScanBlock / 64];
+    const int f = blockIdx.x * kScanBlock + threadIdx.x;
+    const ScanQ q = scan_quantities(info, f, n_frames, seg_steps);
+    int64_t tot[4];
+    const ScanQ ex = block_exclusive_scan(q, tot, part);
+    if (f >= n_frames) return;
+    const int64_t a = ex.v[0] + blk[blockIdx.x], b = ex.v[1] + blk[(size_t)gridDim.x + blockIdx.x],
+                  c = ex.v[2] + blk[(size_t)2 * gridDim.x + blockIdx.x], d = ex.v[3] + blk[(size_t)3 * gridDim.x + blockIdx.x];
+    const int nsym = (int)q.v[0];
+    info[f].seg_off = (int32_t)d;
+    if (nsym > 0 && (a + nsym > sym_cap || b + q.v[1] > soft_cap || c + q.v[2] > dec_cap)) {
+        // keeps its slots in the numbering (they stay unused: sym2frame / seg2frame = -1 there)
+        info[f].status = FOA_ST_NO_SPACE; info[f].nsteps = -nsym; info[f].nsym = 0;
+        return;
+    }
+    info[f].sym_off = (int32_t)a; info[f].soft_off = b; info[f].dec_off = c;
+    for (int k = 0; k < nsym; k++) sym2frame[a + k] = f;
+    const int ns = (int)q.v[3];
+    for (int k = 0; k < ns; k++) seg2frame[d + k] = f;
+}
+
+// =================================================================================================
+// K3: data symbols.  One wave per symbol, 4 waves per block.
+// =================================================================================================
 constexpr int kSymWaves = 4;
 
 __global__ __launch_bounds__(64 * kSymWaves) void k_data_symbols(const float2 *__restrict__ iq, const foa_frame_desc *__restrict__ descs,
