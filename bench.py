@@ -83,6 +83,18 @@ def pmc_traffic(kernel, frames):
     return best
 
 
+def pmc_valu(kernel, frames):
+    """VALU instructions per launch of `kernel` from the committed SQ counter pass (profiles/*_pmc_sq.json)."""
+    pdir = os.path.join(ROOT, "profiles")
+    best = None
+    for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if name.endswith("_pmc_sq.json"):
+            d = json.load(open(os.path.join(pdir, name)))
+            if d.get("frames_per_gpu") == frames and kernel in d.get("per_launch", {}):
+                best = d["per_launch"][kernel].get("SQ_INSTS_VALU")
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -246,15 +258,23 @@ def main():
             out["config"]["incl_device_pre_sync"] = with_sync
         if args.steps <= 50:
             kms = {k: v / args.steps for k, v in kern.items()}
-            # dominant kernel: the Viterbi forward pass k_viterbi_fwd2.  Algorithmic bytes per frame:
-            # one branch-metric dword in and one 64-bit decision word out per trellis step (39 symbols x 216 steps).
+            # dominant kernel: the Viterbi forward pass.  Algorithmic bytes per frame: one branch-metric dword
+            # in and 64 decision bits out per trellis step (39 symbols x 216 steps).
             alg_bytes = real.size * 39 * 216 * (4 + 8)
             ach = alg_bytes / (kms["viterbi_fwd"] * 1e-3) / 1e9
             fwd_kernel = {0: "k_viterbi_v1", 1: "k_viterbi_fwd2", 2: "k_viterbi_fwd3"}[args.viterbi]
             out["roofline"] = {"bound": "hbm", "kernel": fwd_kernel, "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": pmc_traffic(fwd_kernel, args.frames),
                                "algorithmic_bytes_per_launch": int(alg_bytes), "avg_kernel_ms": round(kms["viterbi_fwd"], 4),
-                               "note": "issue-bound on integer VALU/DPP, not HBM-bound (SURVEY 8d); DESIGN.md 4 gives the instruction-issue accounting"}
+                               "note": "bound by VALU issue, not by HBM (SURVEY 8d): see valu_issue and DESIGN.md 4"}
+            # the limit that actually binds: a wave64 VALU instruction holds its SIMD for 4 clocks -> 1024 SIMDs x 2.4 GHz / 4
+            nv = pmc_valu(fwd_kernel, args.frames)
+            if nv:
+                peak_gi = 1024 * 2.4 / 4.0
+                ach_gi = nv / (kms["viterbi_fwd"] * 1e-3) / 1e9
+                out["roofline"]["valu_issue"] = {"achieved": round(ach_gi, 1), "peak": round(peak_gi, 1), "unit": "G wave-instr/s",
+                                                 "frac": round(ach_gi / peak_gi, 4), "valu_instr_per_launch": int(nv),
+                                                 "source": "SQ_INSTS_VALU, profiles/*_pmc_sq.json; duration live from HIP events"}
             out["kernel_ms"] = {k: round(v, 4) for k, v in kms.items()}
         if not args.no_cpu_baseline:
             cb, opsdu, ores, n_cb = cpu_baseline(iq, descs, ends, pays)

@@ -1,0 +1,16 @@
+#!/bin/bash
+# usage (on the GPU box, from the repo root):  tools/profile_round.sh <tag> [bench args]
+# Takes the three rocprofv3 passes the judged numbers come from and writes their summaries under gpurun_out/prof_<tag>/:
+#   kernel trace + stats of a default bench run, one --pmc pass for FETCH_SIZE, one for WRITE_SIZE (never combined
+#   with traces).  Copy <tag>_* from there into profiles/.
+tag=$1; shift
+root=$PWD
+cd /tmp && export TMPDIR=/tmp && cd $root
+out=gpurun_out/prof_$tag; rm -rf $out; mkdir -p $out
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline "$@" > $out/${tag}_bench_under_rocprof.json 2> $out/kt.log
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pf -o pf -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > /dev/null 2> $out/pf.log
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pw -o pw -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > /dev/null 2> $out/pw.log
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVES --output-format csv -d $out/ps -o ps -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > /dev/null 2> $out/ps.log
+find $out -name '*kernel_stats.csv' -exec cp {} $out/${tag}_bench_kernel_stats.csv \;
+python3 tools/reduce_pmc.py $out $tag "$@"
+ls -la $out

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Reduce the two rocprofv3 --pmc passes of tools/profile_round.sh to HBM bytes per launch and kernel."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+out, tag = sys.argv[1], sys.argv[2]
+frames = 10000
+args = sys.argv[3:]
+if "--frames" in args:
+    frames = int(args[args.index("--frames") + 1])
+
+
+def per_kernel(sub, counter):
+    acc = defaultdict(lambda: [0.0, set()])
+    for path in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
+        with open(path, newline="") as fh:
+            for row in csv.DictReader(fh):
+                low = {k.lower(): v for k, v in row.items()}
+                if low.get("counter_name") != counter:
+                    continue
+                name = low["kernel_name"].split("(")[0].split("::")[-1]
+                acc[name][0] += float(low["counter_value"])
+                acc[name][1].add(low.get("dispatch_id"))
+    return {k: v[0] / max(1, len(v[1])) for k, v in acc.items()}
+
+
+fetch, write = per_kernel("pf", "FETCH_SIZE"), per_kernel("pw", "WRITE_SIZE")
+kern = {}
+for k in sorted(set(fetch) | set(write)):
+    if not k.startswith("k_"):
+        continue
+    f, w = fetch.get(k, 0.0), write.get(k, 0.0)
+    kern[k] = {"FETCH_SIZE_KB_per_launch": round(f, 1), "WRITE_SIZE_KB_per_launch": round(w, 1),
+               "hbm_bytes_per_launch": int((2.0 * f + w) * 1024)}
+doc = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline " + " ".join(args),
+       "frames_per_gpu": frames,
+       "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) KB * 1024 (gfx950: FETCH_SIZE counts 128-B requests as 64 B; MI355X_MICROARCH.md HBM section)",
+       "kernels": kern}
+json.dump(doc, open(os.path.join(out, tag + "_pmc_hbm.json"), "w"), indent=1)
+sq = {}
+for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAVES"):
+    for k, v in per_kernel("ps", c).items():
+        if k.startswith("k_"):
+            sq.setdefault(k, {})[c] = round(v, 1)
+if sq:
+    json.dump({"command": "rocprofv3 --pmc SQ_* (own pass) -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline " + " ".join(args),
+               "frames_per_gpu": frames, "per_launch": sq}, open(os.path.join(out, tag + "_pmc_sq.json"), "w"), indent=1)
+print(json.dumps(kern, indent=1))
