@@ -85,7 +85,11 @@ void foa_rx_destroy(foa_rx *rx);
 int foa_rx_reserve(foa_rx *rx, size_t n_samples, size_t n_frames);
 
 /* Options (results are identical for every setting; they exist for A/B measurement and diagnostics):
- *   "viterbi"     0 = one wave per frame, lane per state (viterbi_v1.h); 1 = two frames per wave, in-place (default)
+ *   "viterbi"     0 = one wave per frame, lane per state (viterbi_v1.h); 1 = two frames per wave, serial chain-back
+ *                 (viterbi_v2.h); 2 = two frames per wave, chain-back in parallel segments (viterbi_v3.h, default)
+ *   "tb_segment"  viterbi 2: data steps per chain-back segment, a multiple of 96 in [96, 3072] (default 960)
+ *   "tb_overlap"  viterbi 2: run-in steps above a segment, a multiple of 96 in [0, 3072] (default 96); any value gives
+ *                 the same result as the serial chain-back, small values cost re-walks
  *   "frontend"    0 = one wave per data symbol; 1 = one lane per data symbol (default)
  *   "record_soft" keep the depunctured soft bytes for foa_rx_get_taps (default 1; 0 saves their HBM writes)
  *   "record_eq"   keep the equalised carriers for foa_rx_get_taps (default 0) */
@@ -134,7 +138,9 @@ int foa_rx_get_taps(foa_rx *rx, size_t n_frames, double *hinv, double *eq, size_
 /* Raw decision words of one frame of the most recent decode call (debugging / unit parity of the forward
  * kernel): n_steps = num_symbols * dbps words.  Layout depends on the kernel in use: option viterbi=0 writes the
  * reference's decision_t (bit s = new state s, src/viterbi.h:36-41); viterbi=1 writes slot order (bit p of step t
- * belongs to the state whose label is the 6-bit left-rotation of p by t+1). */
+ * belongs to the state whose label is the 6-bit left-rotation of p by t+1); viterbi=2 returns the raw region of the
+ * transposed layout (16-bit words [block of 16 data steps][63 - slot], complemented bits, trellis steps 6.. only; see
+ * fun_ofdm_amd/csrc/viterbi_v3.h). */
 int foa_rx_get_decisions(foa_rx *rx, size_t frame, uint64_t *out, size_t cap, size_t *n_steps);
 
 /* ---- pre-sync (host side for now; SURVEY 8f #1 moves it onto the device) ---- */
