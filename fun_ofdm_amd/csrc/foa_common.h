@@ -45,6 +45,9 @@ struct DeviceTables {
     uint32_t qam_lut[641];         // qam.h:110-125 for pt = -320..320 (constant outside): soft byte i in bits 8i..8i+7
     uint32_t bm_sum[511];          // viterbi.cpp:242-247: index s0+s1      -> m00 | m11 << 24
     uint32_t bm_dif[511];          //                      index s0-s1+255  -> m01 << 8 | m10 << 16
+    // interleaver.cpp:28-38 + puncturer.cpp:94-118 as one map per rate: demodulated byte c = carrier * bpsc + bit of a
+    // symbol -> its position among the symbol's 2 * dbps depunctured soft bytes (frontend_q4.h)
+    uint16_t sym_pos[kNumRates][288];
 };
 
 // Filled once on the host (tables.cpp) and uploaded to __constant__ memory of each translation unit

@@ -11,6 +11,7 @@
 
 #include "frontend_kernels.h"
 #include "frontend_lps.h"
+#include "frontend_q4.h"
 #include "viterbi_v1.h"
 #include "viterbi_v3.h"
 #include "stage_kernels.h"
@@ -131,6 +132,12 @@ void foa::build_tables(DeviceTables *t)
     }
     // (((s0 ^ b0*255) + (s1 ^ b1*255) + 1) >> 1) >> 2 for (b0,b1) = 00, 01, 10, 11 in terms of s0+s1 and s0-s1
     for (int a = 0; a <= 510; a++) t->bm_sum[a] = (uint32_t)((a + 1) >> 3) | ((uint32_t)((511 - a) >> 3) << 24);
+    for (int r = 0; r < kNumRates; r++)
+        for (int c = 0; c < t->rates[r].cbps; c++) {
+            const int w = c % 48, dd = 48 * (c / 48) + 16 * (w % 3) + w / 3, punct = t->rates[r].punct;     // interleaver.h:66-75 inverse
+            static const int k34[4] = { 0, 1, 3, 5 }, k23[3] = { 0, 2, 3 };
+            t->sym_pos[r][c] = (uint16_t)(punct == 2 ? 6 * (dd >> 2) + k34[dd & 3] : punct == 1 ? 4 * (dd / 3) + k23[dd % 3] : dd);
+        }
     for (int b = -255; b <= 255; b++) t->bm_dif[b + 255] = ((uint32_t)((b + 256) >> 3) << 8) | ((uint32_t)((256 - b) >> 3) << 16);
 }
 
@@ -263,7 +270,7 @@ int foa_rx_set_option(foa_rx *rx, const char *name, int64_t value)
     if (!strcmp(name, "record_eq")) { rx->record_eq = value != 0; return FOA_OK; }
     if (!strcmp(name, "record_soft")) { rx->record_soft = value != 0; return FOA_OK; }
     if (!strcmp(name, "frontend")) {
-        if (value != 0 && value != 1) return fail(FOA_E_INVALID, "frontend must be 0 (wave per symbol) or 1 (lane per symbol)");
+        if (value < 0 || value > 2) return fail(FOA_E_INVALID, "frontend must be 0 (wave per symbol), 1 (lane per symbol) or 2 (quad per symbol)");
         rx->frontend_kind = (int)value;
         return FOA_OK;
     }
@@ -312,7 +319,11 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
     HIP_TRY(hipEventRecord(rx->ev[2], st));
     // upper bound on data symbols in n_samples samples; waves beyond the real total exit at once
     const size_t max_sym = rx->sym_cap;
-    if (rx->frontend_kind == 1) {
+    if (rx->frontend_kind == 2) {
+        uint8_t *soft_out = (rx->record_soft || rx->viterbi_kind == 0) ? rx->soft.p : nullptr;
+        hipLaunchKernelGGL(k_data_symbols_q4, dim3((unsigned)((max_sym + 16 * kQ4Waves - 1) / (16 * kQ4Waves))), dim3(64 * kQ4Waves), 0, st, iq,
+                           d_descs, rx->info.p, rx->sym2frame.p, rx->totals.p, rx->hinv.p, soft_out, rx->bm.p, eq_data);
+    } else if (rx->frontend_kind == 1) {
         uint8_t *soft_out = (rx->record_soft || rx->viterbi_kind == 0) ? rx->soft.p : nullptr;
         hipLaunchKernelGGL(k_data_symbols_lps, dim3((unsigned)((max_sym + 63) / 64)), dim3(64), 0, st, iq, d_descs, rx->info.p, rx->sym2frame.p,
                            rx->totals.p, rx->hinv.p, soft_out, rx->bm.p, eq_data);
@@ -382,7 +393,7 @@ int foa_rx_get_taps(foa_rx *rx, size_t n_frames, double *hinv, double *eq, size_
     if (!rx) return fail(FOA_E_INVALID, "rx is NULL");
     if (n_frames != rx->last_frames || n_frames == 0) return fail(FOA_E_STATE, "n_frames does not match the last decode call");
     if (eq && !rx->record_eq) return fail(FOA_E_STATE, "set option record_eq=1 before the decode call to get eq");
-    if (soft && !rx->record_soft && rx->viterbi_kind != 0 && rx->frontend_kind == 1) return fail(FOA_E_STATE, "set option record_soft=1 before the decode call to get soft bytes");
+    if (soft && !rx->record_soft && rx->viterbi_kind != 0 && rx->frontend_kind != 0) return fail(FOA_E_STATE, "set option record_soft=1 before the decode call to get soft bytes");
     HIP_TRY(hipSetDevice(rx->device));
     HIP_TRY(hipStreamSynchronize(rx->stream));
     std::vector<FrameInfo> info(n_frames);

@@ -1,0 +1,196 @@
+// frontend_q4.h -- data symbols, FOUR LANES (one DPP quad) PER OFDM SYMBOL, sixteen symbols per wave.
+//
+// Same arithmetic and the same operation order as k_data_symbols_lps (fft_symbols.cpp:33-79 + fft.cpp:50-59,
+// channel_est.cpp:77-81, phase_tracker.cpp:83-99, modulator.cpp:108-164 / qam.h:110-125, interleaver.cpp:28-38,
+// puncturer.cpp:78-123), so the results are bit-identical to it; what changes is who holds what.
+// The lane-per-symbol kernel keeps 64 complex doubles per lane: 512 VGPRs, one wave per SIMD, VALU 17 % busy.
+// Here lane m of a quad holds the 16 samples n = m (mod 4) of its symbol:
+//   * radix-4 DIF stage 1 pairs n, n+16, n+32, n+48 and stage 2 pairs n, n+4, n+8, n+12 inside every 16-block --
+//     all four operands have the same n mod 4, so both stages run in the lane's own registers;
+//   * stage 3 pairs n, n+1, n+2, n+3 = one operand per lane: a 4x4 transpose inside the quad (through LDS, 4 KB per
+//     wave, four rounds), after which lane m holds the bins k = 16 j + 4 m + a (j, a = 0..3);
+//   * equaliser, derotation and soft demapping stay per lane (12 data carriers each on average); the four pilot
+//     terms live in lanes 1 and 2 and are broadcast so that every lane adds them in the reference's order;
+//   * soft bytes are scattered into the symbol's depunctured order in LDS ((carrier, bit) -> position table per
+//     rate), and each lane turns 4 consecutive trellis steps at a time into branch-metric words: 16-byte stores.
+// 128 VGPRs, four waves per SIMD.  Measured (config 2): 0.52 ms against 0.34 ms for the lane-per-symbol kernel, and the
+// time does not move with occupancy (2, 3 or 4 waves per SIMD): the fp64 butterflies issue at about 8 clocks per wave
+// instruction and the quad layout spends 2 024 VALU instructions per 16 symbols where lane-per-symbol spends 4 400 per
+// 64, so it is selectable (option "frontend" = 2) and covered by the parity suite, but not the default.
+#pragma once
+
+#include "frontend_lps.h"
+
+namespace foa {
+
+#ifndef FOA_Q4_WPE
+#define FOA_Q4_WPE 4
+#endif
+constexpr int kQ4Waves = 5;                  // waves per block: 14 KB of tables + 7 KB per wave = 50 KB, three blocks per CU
+
+struct Q4Wave {                              // LDS private to one wave
+    union {
+        double2 xpose[16][4][4];             // [quad][s][m]: one round of the stage-3 transpose
+        uint8_t soft[16][464];               // [quad][depunctured soft byte of the symbol] (432 used; 464 = 116 dwords:
+                                             //  the 16 rows start 52 q mod 64 banks apart, all distinct)
+    };
+};
+
+struct Q4Shared {
+    uint32_t qam[641], bm_sum[511], bm_dif[511];
+    double2 tw[64];                          // exp(-2 pi j k / 64)
+    uint16_t pos[kNumRates][288];            // demodulated byte (carrier * bpsc + bit) -> depunctured position
+    int8_t dindex[64];                       // subcarrier index -> data carrier 0..47, -1 otherwise
+    Q4Wave w[kQ4Waves];
+};
+
+// the radix-4 butterfly of fft64_regs / fft64_lane (same association)
+__device__ __forceinline__ void q4_butterfly(cpx a, cpx b, cpx c, cpx d, cpx &y0, cpx &y1, cpx &y2, cpx &y3)
+{
+    const cpx t0 = cadd(a, c), t1 = cadd(a, cneg(c));
+    const cpx u = cadd(b, d);
+    const cpx v1 = cadd(cpx{ b.y, -b.x }, cpx{ -d.y, d.x });     // (-j) b + (j) d
+    const cpx v3 = cadd(cpx{ -b.y, b.x }, cpx{ d.y, -d.x });     // (j) b + (-j) d
+    y0 = cadd(t0, u); y1 = cadd(t1, v1); y2 = cadd(t0, cadd(cneg(b), cneg(d))); y3 = cadd(t1, v3);
+}
+
+__global__ __launch_bounds__(64 * kQ4Waves) __attribute__((amdgpu_waves_per_eu(FOA_Q4_WPE, 8)))
+void k_data_symbols_q4(const float2 *__restrict__ iq, const foa_frame_desc *__restrict__ descs, const FrameInfo *__restrict__ info,
+                       const int32_t *__restrict__ sym2frame, const int64_t *__restrict__ totals, const double2 *__restrict__ hinv,
+                       uint8_t *__restrict__ soft, uint32_t *__restrict__ bm, double2 *__restrict__ eq_tap)
+{
+    __shared__ Q4Shared sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, qd = lane >> 2, m = lane & 3;
+    for (int i = tid; i < 641; i += 64 * kQ4Waves) sh.qam[i] = g_tab.qam_lut[i];
+    for (int i = tid; i < 511; i += 64 * kQ4Waves) { sh.bm_sum[i] = g_tab.bm_sum[i]; sh.bm_dif[i] = g_tab.bm_dif[i]; }
+    for (int i = tid; i < kNumRates * 288; i += 64 * kQ4Waves) sh.pos[i / 288][i % 288] = g_tab.sym_pos[i / 288][i % 288];
+    if (tid < 64) { sh.tw[tid] = make_double2(g_tab.tw_re[tid], g_tab.tw_im[tid]); sh.dindex[tid] = g_tab.data_index[tid]; }
+    __syncthreads();
+    Q4Wave &ws = sh.w[wave];
+
+    const int64_t total = min(totals[0], totals[3]);
+    const int64_t w0 = ((int64_t)blockIdx.x * kQ4Waves + wave) * 16, w = w0 + qd;      // this quad's symbol slot
+    if (w0 >= total) return;                                       // whole wave idle (wave-uniform; no block sync below)
+    const int fq = w < total ? sym2frame[w] : -1;
+    const bool valid = fq >= 0;
+    const int f = valid ? fq : 0;
+    const FrameInfo fi = info[f];
+    const int rate = valid ? fi.rate : 0;
+    const int k = valid ? (int)(w - fi.sym_off) + 1 : 1;             // 1-based data symbol (SIGNAL is symbol 0)
+    const foa_frame_desc d = descs[f];
+    const int64_t start = d.lts1_pos + 144 + 80 * (int64_t)k;
+    const RateRow rr = g_tab.rates[rate];
+    const int64_t my_out = fi.dec_off + (int64_t)(k - 1) * rr.dbps;
+
+    // ---- samples n = m + 4u, rotated (timing_sync.cpp:124-125) ----
+    cpx x[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+        const int64_t idx = start + m + 4 * u;
+        x[u] = valid ? load_rotated(iq, idx, d) : cpx{ 0.0, 0.0 };
+    }
+    // ---- stage 1: operands u = s, s+4, s+8, s+12; twiddle exponent e = n = m + 4 s ----
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        cpx y0, y1, y2, y3;
+        q4_butterfly(x[s], x[s + 4], x[s + 8], x[s + 12], y0, y1, y2, y3);
+        const int e = m + 4 * s;
+        if (e > 0) {
+            const double2 t1 = sh.tw[e], t2 = sh.tw[2 * e], t3 = sh.tw[3 * e];
+            y1 = cmul(y1, cpx{ t1.x, t1.y }); y2 = cmul(y2, cpx{ t2.x, t2.y }); y3 = cmul(y3, cpx{ t3.x, t3.y });
+        }
+        x[s] = y0; x[s + 4] = y1; x[s + 8] = y2; x[s + 12] = y3;
+    }
+    // ---- stage 2 inside each 16-block r: operands u = 4r + 0..3; twiddle exponent e = 4 m ----
+    {
+        const double2 t1 = sh.tw[4 * m], t2 = sh.tw[8 * m], t3 = sh.tw[12 * m];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            cpx y0, y1, y2, y3;
+            q4_butterfly(x[4 * r], x[4 * r + 1], x[4 * r + 2], x[4 * r + 3], y0, y1, y2, y3);
+            if (m > 0) { y1 = cmul(y1, cpx{ t1.x, t1.y }); y2 = cmul(y2, cpx{ t2.x, t2.y }); y3 = cmul(y3, cpx{ t3.x, t3.y }); }
+            x[4 * r] = y0; x[4 * r + 1] = y1; x[4 * r + 2] = y2; x[4 * r + 3] = y3;
+        }
+    }
+    // ---- stage 3: position 16 a + 4 s + m sits in lane m as x[4a + s]; group (a, s) goes to lane s ----
+    cpx (&X)[16] = x;                                              // afterwards X[4a + j] = bin k = 16 j + 4 m + a, in place
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+#pragma unroll
+        for (int s = 0; s < 4; s++) ws.xpose[qd][s][m] = make_double2(x[4 * a + s].x, x[4 * a + s].y);
+        wave_lds_sync();
+        const double2 i0 = ws.xpose[qd][m][0], i1 = ws.xpose[qd][m][1], i2 = ws.xpose[qd][m][2], i3 = ws.xpose[qd][m][3];
+        wave_lds_sync();
+        q4_butterfly(cpx{ i0.x, i0.y }, cpx{ i1.x, i1.y }, cpx{ i2.x, i2.y }, cpx{ i3.x, i3.y }, X[4 * a], X[4 * a + 1], X[4 * a + 2], X[4 * a + 3]);
+    }
+
+    __builtin_amdgcn_sched_barrier(0);                             // keep the tap loads below from crowding the FFT's registers
+    // ---- channel_est.cpp:77-81 + phase_tracker.cpp:83-99 ----
+    const double2 *h = hinv + (size_t)f * 64;
+    cpx pe = { 0.0, 0.0 };
+    {
+#pragma clang fp contract(off)
+        // pilots: subcarrier 11 = bin 43 (j 2, m 2, a 3), 25 = bin 57 (j 3, m 2, a 1), 39 = bin 7 (j 0, m 1, a 3), 53 = bin 21 (j 1, m 1, a 1)
+        const int ps[4] = { 11, 25, 39, 53 }, xi[4] = { 14, 7, 12, 5 }, owner[4] = { 2, 2, 1, 1 };
+        const double sgn[4] = { 1.0, 1.0, 1.0, -1.0 };
+        const double pol = (double)g_tab.polarity[k % 127];
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const double2 hh = h[ps[p]];
+            const cpx mine = cmul(cpx{ hh.x, hh.y }, X[xi[p]]);    // meaningful in lane owner[p] of the quad only
+            const cpx zp = { __shfl(mine.x, owner[p], 4), __shfl(mine.y, owner[p], 4) };
+            const double pil = (double)(int)(sgn[p] * pol);
+            pe.x += (zp.x * pil) / 4.0;
+            pe.y += (zp.y * pil) / 4.0;
+        }
+    }
+    const cpx rot = unit_conj(pe);
+
+    // the symbol's depunctured soft bytes start as erasures (puncturer.cpp:94-102)
+    {
+        const uint4 fill = make_uint4(0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu);
+#pragma unroll
+        for (int i = 0; i < 7; i++) *(uint4 *)&ws.soft[qd][112 * m + 16 * i] = fill;
+    }
+    wave_lds_sync();
+    const int bpsc = rr.bpsc, nb = bpsc == 1 ? 1 : bpsc / 2;
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int s_idx = (16 * j + 4 * m + a + 32) & 63;
+            const int di = sh.dindex[s_idx];
+            if (di < 0) continue;
+            const double2 hh = h[s_idx];
+            const cpx zc = cmul(cmul(cpx{ hh.x, hh.y }, X[4 * a + j]), rot);
+            if (eq_tap && valid) eq_tap[(size_t)w * 48 + di] = make_double2(zc.x, zc.y);
+            const uint32_t li = qam_lookup(sh.qam, zc.x, rr.scale_d), lq = bpsc > 1 ? qam_lookup(sh.qam, zc.y, rr.scale_d) : 0u;
+#pragma unroll
+            for (int b = 0; b < 6; b++) {
+                if (b < bpsc) {
+                    const uint32_t byte = b < nb ? (li >> (8 * b)) & 255u : (lq >> (8 * (b - nb))) & 255u;
+                    ws.soft[qd][sh.pos[rate][di * bpsc + b]] = (uint8_t)byte;      // interleaver.cpp:33-36, puncturer.cpp:112-118
+                }
+            }
+        }
+    }
+    wave_lds_sync();
+    // ---- four trellis steps (8 soft bytes) per lane and trip -> branch-metric words (viterbi.cpp:242-247) ----
+    uint8_t *soft_dst = (soft && valid) ? soft + fi.soft_off + (int64_t)(k - 1) * 2 * rr.dbps : nullptr;
+    const int ngroups = rr.dbps / 4;
+    for (int g4 = m; g4 < ngroups; g4 += 4) {
+        const uint2 sb = *(const uint2 *)&ws.soft[qd][8 * g4];
+        uint32_t wd[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const uint32_t pair = (t < 2 ? sb.x : sb.y) >> (16 * (t & 1));
+            const uint32_t s0 = pair & 255u, s1 = (pair >> 8) & 255u;
+            wd[t] = sh.bm_sum[s0 + s1] | sh.bm_dif[s0 + 255u - s1];
+        }
+        if (valid) *(uint4 *)(bm + my_out + 4 * g4) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+        if (soft_dst) *(uint2 *)(soft_dst + 8 * g4) = sb;
+    }
+}
+
+}  // namespace foa

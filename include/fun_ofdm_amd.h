@@ -90,7 +90,7 @@ int foa_rx_reserve(foa_rx *rx, size_t n_samples, size_t n_frames);
  *   "tb_segment"  viterbi 2: data steps per chain-back segment, a multiple of 96 in [96, 3072] (default 960)
  *   "tb_overlap"  viterbi 2: run-in steps above a segment, a multiple of 96 in [0, 3072] (default 96); any value gives
  *                 the same result as the serial chain-back, small values cost re-walks
- *   "frontend"    0 = one wave per data symbol; 1 = one lane per data symbol (default)
+ *   "frontend"    0 = one wave per data symbol; 1 = one lane per data symbol (default); 2 = four lanes per data symbol
  *   "record_soft" keep the depunctured soft bytes for foa_rx_get_taps (default 1; 0 saves their HBM writes)
  *   "record_eq"   keep the equalised carriers for foa_rx_get_taps (default 0) */
 int foa_rx_set_option(foa_rx *rx, const char *name, int64_t value);

@@ -162,6 +162,43 @@ def test_mixed_rate_stream_vs_oracle(rx, po, kind):
     assert n_ok >= 10 and n_fail >= 1, (n_ok, n_fail)      # the case really has both outcomes
 
 
+@pytest.mark.parametrize("frontend", [0, 1, 2], ids=["wave-per-symbol", "lane-per-symbol", "quad-per-symbol"])
+def test_frontends_vs_oracle(rx, po, frontend):
+    """Each front-end kernel on a mixed-rate stream with CFO: status, PSDUs, every soft byte and the equalised
+    carriers (1e-4 relative, north_star) against the oracle; the three kernels share the arithmetic, not the code."""
+    rx.set_option("frontend", frontend)
+    rx.set_option("record_soft", 1)
+    rx.set_option("record_eq", 1)
+    _set_viterbi(rx, VITERBI_KINDS[2])
+    try:
+        rng = np.random.default_rng(29)
+        specs = [(r, int(rng.integers(20, 300))) for r in range(11)] + [(10, 1024), (5, 700), (0, 61), (8, 1)]
+        iq, pays = _make_stream(po, rng, specs, snr_db=22.0, cfo_hz=2500.0)
+        descs = po.find_alignments_f32(iq)
+        assert descs.size == len(specs)
+        ends = _ends(descs, iq.size)
+        psdu, res = rx.decode_frames_host(iq, descs, ends)
+        t = rx.taps(descs.size, eq=True)
+        opsdu, ores = po.decode_batch_f32(iq, descs, ends, threads=4)
+        for f in range(descs.size):
+            assert tuple(res[f]) == tuple(ores[f]), (f, res[f], ores[f])
+            if res[f]["status"] == 0:
+                assert np.array_equal(psdu[f, :res[f]["length"]], pays[f]), f
+            _, _, taps = po.decode_alignment_f32(iq, descs[f], end=ends[f], taps=True)
+            if res[f]["rate"] < 0:
+                continue
+            got = t["soft"][t["soft_off"][f]:t["soft_off"][f + 1]]
+            assert np.array_equal(got, taps["soft"]), f
+            eq = t["eq"][t["eq_off"][f]:t["eq_off"][f + 1]].reshape(-1, 48)
+            want = taps["eq"].reshape(-1, 48)
+            assert eq.shape == want.shape
+            for k in range(eq.shape[0]):
+                assert _rel(eq[k], want[k]) < REL_TOL, (f, k)
+    finally:
+        rx.set_option("frontend", 1)
+        rx.set_option("record_eq", 0)
+
+
 def test_truncated_and_degenerate_inputs(rx, po, golden):
     g = golden.frames
     iq, descs = g["rate10_iq"], g["rate10_desc"]
