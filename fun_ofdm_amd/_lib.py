@@ -41,6 +41,9 @@ _SIGS = {
     "foa_rx_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "foa_rx_get_taps": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "foa_rx_get_decisions": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "foa_tx_build_frames_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]),
+    "foa_tx_channel_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_double, C.c_double,
+                                     C.c_uint64, C.c_void_p]),
     "foa_rx_sync_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "foa_sync_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "foa_sync_destroy": (None, [C.c_void_p]),

@@ -48,6 +48,7 @@ struct DeviceTables {
     // interleaver.cpp:28-38 + puncturer.cpp:94-118 as one map per rate: demodulated byte c = carrier * bpsc + bit of a
     // symbol -> its position among the symbol's 2 * dbps depunctured soft bytes (frontend_q4.h)
     uint16_t sym_pos[kNumRates][288];
+    double preamble_re[320], preamble_im[320];   // preamble.h:24 PREAMBLE_SAMPLES (transmit side, tx_kernels.h)
 };
 
 // Filled once on the host (tables.cpp) and uploaded to __constant__ memory of each translation unit

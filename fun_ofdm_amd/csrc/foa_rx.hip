@@ -17,6 +17,7 @@
 #include "stage_kernels.h"
 #include "sync_host.h"
 #include "sync_kernels.h"
+#include "tx_kernels.h"
 
 using namespace foa;
 
@@ -116,6 +117,9 @@ void foa::build_tables(DeviceTables *t)
     std::complex<double> ltc[64];
     foa::make_lts_time_conj(ltc);
     for (int i = 0; i < 64; i++) { t->lts_conj_re[i] = ltc[i].real(); t->lts_conj_im[i] = ltc[i].imag(); }
+    std::complex<double> pre[320];
+    foa::make_preamble(pre);
+    for (int i = 0; i < 320; i++) { t->preamble_re[i] = pre[i].real(); t->preamble_im[i] = pre[i].imag(); }
     // qam.h:110-125 with NumBits = 3 (fewer bits = a prefix of the same loop); |pt| >= 320 gives the value of +-320
     for (int p = -320; p <= 320; p++) {
         uint32_t pt = (uint32_t)p, word = 0;
@@ -702,6 +706,50 @@ int foa_decode_data_f64(foa_rx *rx, const double *carriers, const uint64_t *carr
     HIP_TRY(hipGetLastError());
     for (size_t f = 0; f < n_frames; f++) results[f].status = out[f].status;
     rx->last_frames = 0;      // the workspace no longer describes a decode_frames call
+    return FOA_OK;
+}
+
+int foa_tx_build_frames_dev(foa_rx *rx, const uint8_t *d_payloads, size_t payload_pitch, int length, int rate, size_t n_frames,
+                            double *d_frames, size_t *frame_samples)
+{
+    if (!rx || !frame_samples) return fail(FOA_E_INVALID, "NULL argument");
+    if (rate < 0 || rate >= kNumRates || length < 0 || length > 4095) return fail(FOA_E_INVALID, "bad rate/length");
+    DeviceTables tab;
+    build_tables(&tab);
+    const int dbps = tab.rates[rate].dbps, nsym = (16 + 8 * (length + 4) + 6 + dbps - 1) / dbps, nbytes = nsym * dbps / 8;
+    *frame_samples = 320 + (size_t)80 * (nsym + 1);
+    if (n_frames == 0) return FOA_OK;
+    if ((!d_payloads && length > 0) || !d_frames) return fail(FOA_E_INVALID, "NULL device pointer");
+    if (payload_pitch < (size_t)length) return fail(FOA_E_INVALID, "payload_pitch smaller than length");
+    if (n_frames > 0x7FFFFFF0u / (size_t)(nsym + 1)) return fail(FOA_E_INVALID, "too many frames for one call");
+    HIP_TRY(hipSetDevice(rx->device));
+    const size_t stride = ((size_t)nbytes + 1 + 15) & ~(size_t)15;
+    int rc = rx->scratch.ensure(n_frames * stride);
+    if (rc) return rc;
+    hipStream_t st = rx->stream;
+    const int nf = (int)n_frames;
+    hipLaunchKernelGGL(k_tx_prepare, dim3((nf + 63) / 64), dim3(64), 0, st, d_payloads, payload_pitch, length, nf, nbytes, rx->scratch.p, stride);
+    const int64_t threads = (int64_t)nf * (nsym + 1);
+    hipLaunchKernelGGL(k_tx_symbols, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, st, rx->scratch.p, stride, length, rate, nsym, nf,
+                       (double2 *)d_frames, *frame_samples);
+    HIP_TRY(hipGetLastError());
+    return FOA_OK;
+}
+
+int foa_tx_channel_dev(foa_rx *rx, const double *d_frames, size_t n_frames, size_t frame_samples, size_t pitch, size_t lead, double snr_db,
+                       double cfo_hz, uint64_t seed, float *d_iq)
+{
+    if (!rx) return fail(FOA_E_INVALID, "rx is NULL");
+    if (n_frames == 0) return FOA_OK;
+    if (!d_frames || !d_iq) return fail(FOA_E_INVALID, "NULL device pointer");
+    if (lead + frame_samples > pitch) return fail(FOA_E_INVALID, "lead + frame_samples exceeds the pitch");
+    HIP_TRY(hipSetDevice(rx->device));
+    // sigma^2 per real component = P_ref / (2 10^(SNR/10)), P_ref = 0.0124
+    const double sigma = std::sqrt(0.0124 / (2.0 * std::pow(10.0, snr_db / 10.0)));
+    const int64_t total = (int64_t)n_frames * (int64_t)pitch;
+    hipLaunchKernelGGL(k_tx_channel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, rx->stream, (const double2 *)d_frames, (int64_t)n_frames,
+                       (int64_t)frame_samples, (int64_t)pitch, (int64_t)lead, sigma, cfo_hz, seed, (float2 *)d_iq);
+    HIP_TRY(hipGetLastError());
     return FOA_OK;
 }
 

@@ -30,6 +30,7 @@ inline void make_lts_time_conj(std::complex<double> *out)
     static const signed char L[53] = { 1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1, 1, 1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1, 1, 0,
                                        1, -1, -1, 1, 1, -1, 1, -1, 1, -1, -1, -1, -1, -1, 1, 1, -1, -1, 1, -1, 1, -1, 1, 1, 1, 1 };
     auto round12 = [](double v) {
+        if (std::fabs(v) < 1e-15) return 0.0;                   // exact zeros of the table (sums that cancel up to rounding)
         char buf[64];
         snprintf(buf, sizeof buf, "%.12g", v);
         return strtod(buf, nullptr);
@@ -46,6 +47,39 @@ inline void make_lts_time_conj(std::complex<double> *out)
         }
         out[n] = std::complex<double>(round12((double)(re / 64.0L)), round12((double)(-im / 64.0L)));
     }
+}
+
+// preamble.h:24: the 320 preamble samples as the literal table holds them -- ten short symbols, the long symbol's
+// last 32 samples, two long symbols; 12 significant digits, [0] halved by the window, [160] = -0.078 (not -0.078125).
+inline void make_preamble(std::complex<double> *out)
+{
+    auto round12 = [](double v) {
+        if (std::fabs(v) < 1e-15) return 0.0;                   // exact zeros of the table (sums that cancel up to rounding)
+        char buf[64];
+        snprintf(buf, sizeof buf, "%.12g", v);
+        return strtod(buf, nullptr);
+    };
+    // 802.11a-1999 17.3.3: S(-26..26) = sqrt(13/6) (1+j) x {+-1 at multiples of 4}
+    static const int sk[12] = { -24, -20, -16, -12, -8, -4, 4, 8, 12, 16, 20, 24 };
+    static const int sv[12] = { 1, -1, 1, -1, -1, 1, -1, -1, 1, 1, 1, 1 };
+    const long double amp = sqrtl(13.0L / 6.0L);
+    std::complex<double> sts[16], ltc[64];
+    for (int n = 0; n < 16; n++) {
+        long double re = 0, im = 0;
+        for (int i = 0; i < 12; i++) {
+            const int e = ((sk[i] * n) % 64 + 64) % 64;
+            const long double a = 2.0L * 3.141592653589793238462643383279502884L * (long double)e / 64.0L;
+            // (1 + j) (cos a + j sin a)
+            re += sv[i] * (cosl(a) - sinl(a));
+            im += sv[i] * (cosl(a) + sinl(a));
+        }
+        sts[n] = std::complex<double>((double)(amp * re / 64.0L), (double)(amp * im / 64.0L));
+    }
+    make_lts_time_conj(ltc);                                     // conj of the long symbol, already rounded
+    for (int i = 0; i < 160; i++) out[i] = std::complex<double>(round12(sts[i % 16].real()), round12(sts[i % 16].imag()));
+    for (int i = 0; i < 160; i++) out[160 + i] = std::conj(ltc[(32 + i) % 64]);
+    out[0] = std::complex<double>(round12(sts[0].real() / 2.0), round12(sts[0].imag() / 2.0));
+    out[160] = std::complex<double>(-0.078, 0.0);
 }
 
 class SyncHost {

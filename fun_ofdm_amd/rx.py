@@ -81,6 +81,34 @@ class Receiver:
         check(lib().foa_rx_sync_dev(self._h, iq.data_ptr(), n, descs.data_ptr(), ends.data_ptr(), cap, C.byref(got)))
         return int(got.value)
 
+    def tx_frame_samples(self, length, rate):
+        n = C.c_size_t(0)
+        check(lib().foa_tx_build_frames_dev(self._h, None, 0, int(length), int(rate), 0, None, C.byref(n)))
+        return int(n.value)
+
+    def tx_build_frames(self, payloads, rate):
+        """frame_builder::build_frame on the device: payloads uint8[n, L] (CUDA tensor) -> float64[n, S, 2] (CUDA tensor)."""
+        import torch
+        assert payloads.dtype == torch.uint8 and payloads.is_cuda and payloads.dim() == 2 and payloads.stride(1) == 1
+        n, length = payloads.shape
+        s = self.tx_frame_samples(length, rate)
+        out = torch.empty((n, s, 2), dtype=torch.float64, device=payloads.device)
+        got = C.c_size_t(0)
+        torch.cuda.current_stream(payloads.device).synchronize()
+        check(lib().foa_tx_build_frames_dev(self._h, payloads.data_ptr(), payloads.stride(0), int(length), int(rate), n, out.data_ptr(), C.byref(got)))
+        self.sync()
+        return out
+
+    def tx_channel(self, frames, pitch, lead, snr_db, seed, cfo_hz=0.0):
+        """Synthetic channel on the device: frames float64[n, S, 2] -> float32[n * pitch, 2] (CUDA tensors)."""
+        import torch
+        n, s, _ = frames.shape
+        iq = torch.empty((n * pitch, 2), dtype=torch.float32, device=frames.device)
+        torch.cuda.current_stream(frames.device).synchronize()
+        check(lib().foa_tx_channel_dev(self._h, frames.data_ptr(), n, s, int(pitch), int(lead), float(snr_db), float(cfo_hz), int(seed), iq.data_ptr()))
+        self.sync()
+        return iq
+
     def kernel_ms(self):
         """HIP-event durations of the last decode in ms: header, scan, symbols, viterbi_fwd, viterbi_finish, total."""
         out = (C.c_float * 6)()

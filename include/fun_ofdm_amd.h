@@ -196,6 +196,22 @@ int foa_decode_header_f64(foa_rx *rx, const double *carriers48, size_t n, foa_fr
 int foa_decode_data_f64(foa_rx *rx, const double *carriers, const uint64_t *carrier_off, size_t n_frames, foa_frame_result *results,
                         uint8_t *psdu, size_t slot_bytes);
 
+/* ---- transmit side on the device: synthetic workloads and loop-back tests in HBM --------------------- */
+
+/* frame_builder::build_frame (src/frame_builder.cpp:53-82: ppdu::encode src/ppdu.cpp:65-165, symbol_mapper::map
+ * src/symbol_mapper.cpp:81-119, fft::inverse src/fft.cpp:68-96, preamble src/preamble.h:24) for n_frames payloads of the
+ * same length and rate (Rate enum 0..10): payload i at d_payloads + i * payload_pitch; frame i as *frame_samples =
+ * 320 + 80 (num_symbols + 1) complex<double> samples at d_frames + 2 * i * *frame_samples (interleaved re, im).
+ * Asynchronous on the handle's stream.  With n_frames = 0 only *frame_samples is computed. */
+int foa_tx_build_frames_dev(foa_rx *rx, const uint8_t *d_payloads, size_t payload_pitch, int length, int rate, size_t n_frames,
+                            double *d_frames, size_t *frame_samples);
+/* The synthetic channel the benchmark workloads use, not a reference component: frame i starts at sample
+ * i * pitch + lead of the output stream, gets a uniformly random carrier phase and, if cfo_hz > 0, a constant frequency
+ * offset uniform in +-cfo_hz (20 Msample/s); complex white Gaussian noise with sigma^2 = 0.0124 / (2 10^(snr_db/10)) per
+ * real component is added everywhere; the result is rounded to complex<float>.  Deterministic in (seed, sample index). */
+int foa_tx_channel_dev(foa_rx *rx, const double *d_frames, size_t n_frames, size_t frame_samples, size_t pitch, size_t lead, double snr_db,
+                       double cfo_hz, uint64_t seed, float *d_iq);
+
 #ifdef __cplusplus
 }
 #endif
