@@ -65,9 +65,23 @@ def cpu_baseline(iq, descs, ends, pays, budget_s=15.0):
     dt = time.perf_counter() - t0
     real = np.nonzero((descs["lts1_pos"][:n] - (LEAD + 184)) % PITCH == 0)[0]
     in_frame = real.size * (320 + 80 * 40)
-    return dict(value=in_frame / dt / 1e6, unit="Msamples/s", cores=cores, kind="port",
-                sample="%d of the workload's alignments (%d frames, %d samples fed), oracle fo_decode_batch_f32 on %d threads, %.1f s"
-                       % (n, real.size, n_samp, cores, dt)), psdu, res, n
+    out = dict(value=in_frame / dt / 1e6, unit="Msamples/s", cores=cores, kind="port",
+               sample="%d of the workload's alignments (%d frames, %d samples fed), oracle fo_decode_batch_f32 on %d threads, %.1f s"
+                      % (n, real.size, n_samp, cores, dt))
+    # the reference's own structure for comparison: process_samples() over six block threads + the caller,
+    # 4096-sample chunks, pre-sync included -- one chain, on a few hundred frames
+    try:
+        nf = min(len(pays), 400)
+        chain = po.ReceiverChain(threaded=True)
+        t0 = time.perf_counter()
+        got = chain.run_stream(iq[:nf * PITCH], chunk=4096)
+        dt_c = time.perf_counter() - t0
+        out["reference_structure"] = {"value": round(nf * (320 + 80 * 40) / dt_c / 1e6, 2), "unit": "Msamples/s", "threads": 7,
+                                      "sample": "%d frames through the oracle's receiver_chain (frame_detector .. frame_decoder as "
+                                                "six block threads, 4096-sample calls), %d payloads out, %.1f s" % (nf, len(got), dt_c)}
+    except Exception as e:                                # the headline baseline above does not depend on this leg
+        out["reference_structure"] = {"error": str(e)}
+    return out, psdu, res, n
 
 
 def pmc_traffic(kernel, frames):

@@ -283,61 +283,131 @@ __device__ __forceinline__ void finish_tables_init(FinishTables &t, int tid, int
     }
 }
 
+// LDS of the wave-cooperative finish (one per 64-frame wave)
+struct FinishWave {
+    uint32_t tile[64][17];         // 16 words of each of the wave's 64 frames (row stride 17: one bank per lane)
+    int64_t base[64];              // each frame's offset (in words) into the decoded buffer
+    int nwords[64], ncopy[64];     // words to descramble; payload bytes to copy (0 unless the CRC matched)
+};
+
 // descramble (one LFSR bit per byte, ppdu.cpp:256-264) + CRC over service+payload (ppdu.cpp:267-271) + payload copy
-// (ppdu.cpp:283-285).  Whole words go through four table look-ups that do not depend on each other (slicing-by-4);
-// the scrambler's 127-byte period makes a 127-word table of descrambling masks.  Wave-uniform control flow.
-__device__ __forceinline__ void finish_crc_psdu(const FinishTables &t, const FrameInfo &fi, bool live, int f, int n_frames, uint32_t *out,
-                                                uint8_t *__restrict__ psdu, size_t slot_bytes, foa_frame_result *__restrict__ results)
+// (ppdu.cpp:283-285), one frame per lane.  Whole words go through four table look-ups that do not depend on each other
+// (slicing-by-4); the scrambler's 127-byte period makes a 127-word table of descrambling masks.
+// A lane that walks its own frame's words touches a different cache line than every other lane with each load and
+// store, which is what this step used to spend its time on.  So memory is moved by the wave as a whole: four lanes
+// per frame fetch 64 contiguous bytes of each of 16 frames per instruction into an LDS tile, each lane then works on
+// its own row, and the descrambled words (and later the payload) leave the same way.  Wave-uniform control flow.
+__device__ __forceinline__ void finish_crc_psdu(const FinishTables &t, FinishWave &fw, const FrameInfo &fi, bool live, int f, int n_frames,
+                                                uint32_t *__restrict__ decoded, uint8_t *__restrict__ psdu, size_t slot_bytes,
+                                                foa_frame_result *__restrict__ results)
 {
+    const int lane = threadIdx.x & 63, sub = lane >> 2, pc = lane & 3;
     const int len = fi.length, ncrc = live ? 2 + len : 0, nwords = live ? (ncrc + 4 + 3) / 4 : 0;
     int maxw = nwords;
 #pragma unroll
     for (int o = 32; o; o >>= 1) maxw = max(maxw, __shfl_xor(maxw, o));
+    fw.base[lane] = live ? fi.dec_off : 0;
+    fw.nwords[lane] = nwords;
+    wave_lds_sync();
     uint32_t crc = 0xFFFFFFFFu, given = 0;
     const int full = ncrc >> 2;                                            // words that lie entirely inside the CRC range
     int qs = 0;                                                            // q mod 127
-    for (int q = 0; q < maxw; q++) {
-        const uint32_t scr = t.scr[qs];
-        qs = qs == 126 ? 0 : qs + 1;
-        if (q < nwords) {
-            const uint32_t d = out[q] ^ scr;
-            out[q] = d;
-            if (q < full) {
-                const uint32_t c = crc ^ d;
-                crc = t.crc[768 + (c & 0xFFu)] ^ t.crc[512 + ((c >> 8) & 0xFFu)] ^ t.crc[256 + ((c >> 16) & 0xFFu)] ^ t.crc[c >> 24];
-            } else {
+    // in: frame 16 r + sub, words q0 + 4 pc .. + 3 (the regions are 256-byte aligned and padded past their last word);
+    // the next 16-word chunk is fetched into registers while the current one is worked on
+    uint4 pre[4];
+    auto fetch = [&](int q0) {
 #pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    const int x = 4 * q + b;
-                    const uint32_t byte = (d >> (8 * b)) & 0xFFu;
-                    if (x < ncrc) crc = t.crc[(crc ^ byte) & 0xFFu] ^ (crc >> 8);
-                    else if (x < ncrc + 4) given |= byte << (8 * (x - ncrc));
+        for (int r = 0; r < 4; r++) {
+            const int fr = 16 * r + sub;
+            pre[r] = make_uint4(0u, 0u, 0u, 0u);
+            if (q0 + 4 * pc < fw.nwords[fr]) pre[r] = *(const uint4 *)(decoded + fw.base[fr] + q0 + 4 * pc);
+        }
+    };
+    fetch(0);
+    for (int q0 = 0; q0 < maxw; q0 += 16) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int fr = 16 * r + sub;
+            fw.tile[fr][4 * pc] = pre[r].x; fw.tile[fr][4 * pc + 1] = pre[r].y; fw.tile[fr][4 * pc + 2] = pre[r].z; fw.tile[fr][4 * pc + 3] = pre[r].w;
+        }
+        if (q0 + 16 < maxw) fetch(q0 + 16);
+        wave_lds_sync();
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int q = q0 + i;
+            const uint32_t scr = t.scr[qs];
+            qs = qs == 126 ? 0 : qs + 1;
+            if (q < nwords) {
+                const uint32_t d = fw.tile[lane][i] ^ scr;
+                fw.tile[lane][i] = d;
+                if (q < full) {
+                    const uint32_t c = crc ^ d;
+                    crc = t.crc[768 + (c & 0xFFu)] ^ t.crc[512 + ((c >> 8) & 0xFFu)] ^ t.crc[256 + ((c >> 16) & 0xFFu)] ^ t.crc[c >> 24];
+                } else {
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        const int x = 4 * q + b;
+                        const uint32_t byte = (d >> (8 * b)) & 0xFFu;
+                        if (x < ncrc) crc = t.crc[(crc ^ byte) & 0xFFu] ^ (crc >> 8);
+                        else if (x < ncrc + 4) given |= byte << (8 * (x - ncrc));
+                    }
                 }
             }
         }
+        wave_lds_sync();
+        // out: the descrambled words, same pieces (words of a piece beyond the frame's last one are pad bits, descrambled or not)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int fr = 16 * r + sub;
+            if (q0 + 4 * pc < fw.nwords[fr])
+                *(uint4 *)(decoded + fw.base[fr] + q0 + 4 * pc) =
+                    make_uint4(fw.tile[fr][4 * pc], fw.tile[fr][4 * pc + 1], fw.tile[fr][4 * pc + 2], fw.tile[fr][4 * pc + 3]);
+        }
+        wave_lds_sync();
     }
     const bool ok = live && (crc ^ 0xFFFFFFFFu) == given;
-    if (ok) {
-        uint8_t *slot = psdu + (size_t)f * slot_bytes;
-        const int ncopy = min((size_t)len, slot_bytes);
-        int y = 0;
-        if ((((uintptr_t)slot) & 3) == 0) {
-            // bytes y+2 .. y+5 straddle words q, q+1; four words per trip keep several loads in flight
-            for (; y + 16 <= ncopy; y += 16) {
-                const int q = (y + 2) >> 2;
-                const uint32_t a0 = out[q], a1 = out[q + 1], a2 = out[q + 2], a3 = out[q + 3], a4 = out[q + 4];
-                uint32_t *dst = (uint32_t *)slot + (y >> 2);
-                dst[0] = (a0 >> 16) | (a1 << 16); dst[1] = (a1 >> 16) | (a2 << 16);
-                dst[2] = (a2 >> 16) | (a3 << 16); dst[3] = (a3 >> 16) | (a4 << 16);
-            }
-            for (; y + 4 <= ncopy; y += 4) {
-                const int q = (y + 2) >> 2;
-                ((uint32_t *)slot)[y >> 2] = (out[q] >> 16) | (out[q + 1] << 16);
+    if (f < n_frames) write_result(&results[f], fi, live ? (ok ? FOA_ST_OK : FOA_ST_CRC_FAIL) : fi.status);
+
+    // payload = descrambled bytes [2, 2+len) (ppdu.cpp:283-285), only for frames whose CRC matched: 16 bytes per lane,
+    // payload bytes 64 c + 16 pc .. + 15 of frame 16 r + sub = bytes 2 .. 17 of the five words from 16 c + 4 pc on
+    const int ncopy = ok ? (int)min((size_t)len, slot_bytes) : 0;
+    fw.ncopy[lane] = ncopy;
+    int maxc = ncopy;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) maxc = max(maxc, __shfl_xor(maxc, o));
+    __threadfence();                                                       // the words were stored by other lanes of this wave
+    wave_lds_sync();
+    const int f0 = f - lane;                                               // the wave's first frame
+    for (int c = 0; 64 * c < maxc; c++) {
+        const int y = 64 * c + 16 * pc;
+        uint4 a[4];
+        uint32_t a4[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {                                      // all loads of the trip first
+            const int fr = 16 * r + sub;
+            // unconditional: the words exist for every frame of the wave (a frame that is not copied starts at offset 0
+            // and the buffer is far longer than one PSDU), and four loads in flight beat four round trips
+            const uint32_t *src = decoded + fw.base[fr] + 16 * c + 4 * pc;
+            a[r] = *(const uint4 *)src;
+            a4[r] = src[4];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int fr = 16 * r + sub, nc = fw.ncopy[fr];
+            if (y >= nc) continue;
+            const uint4 v = make_uint4((a[r].x >> 16) | (a[r].y << 16), (a[r].y >> 16) | (a[r].z << 16), (a[r].z >> 16) | (a[r].w << 16),
+                                       (a[r].w >> 16) | (a4[r] << 16));
+            uint8_t *dst = psdu + (size_t)(f0 + fr) * slot_bytes + y;
+            if (y + 16 <= nc && (((uintptr_t)dst) & 15) == 0) {
+                *(uint4 *)dst = v;
+            } else {
+                const uint32_t w4[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+                for (int i = 0; i < 16; i++)
+                    if (y + i < nc) dst[i] = (uint8_t)(w4[i >> 2] >> (8 * (i & 3)));
             }
         }
-        for (; y < ncopy; y++) slot[y] = (uint8_t)(out[(y + 2) >> 2] >> (8 * ((y + 2) & 3)));
     }
-    if (f < n_frames) write_result(&results[f], fi, live ? (ok ? FOA_ST_OK : FOA_ST_CRC_FAIL) : fi.status);
 }
 
 constexpr int kTbChunk = 48;      // chain-back steps per LDS-DMA chunk (multiple of 6 and 8; two chunks = 48 loads in flight)
@@ -350,6 +420,7 @@ __global__ __launch_bounds__(64) void k_viterbi_finish2(const FrameInfo *__restr
                                                         foa_frame_result *__restrict__ results)
 {
     __shared__ FinishTables tabs;
+    __shared__ FinishWave fwave;
     __shared__ ulonglong2 tbuf[2][kTbChunk / 2][64];     // two chunks of decision words, [piece][lane] x 16 B
     const int lane = threadIdx.x, f = blockIdx.x * 64 + lane;
     finish_tables_init(tabs, lane, 64);
@@ -437,7 +508,7 @@ __global__ __launch_bounds__(64) void k_viterbi_finish2(const FrameInfo *__restr
             which ^= 1;
         }
     }
-    finish_crc_psdu(tabs, fi, live, f, n_frames, out, psdu, slot_bytes, results);
+    finish_crc_psdu(tabs, fwave, fi, live, f, n_frames, decoded, psdu, slot_bytes, results);
 }
 
 inline void launch_viterbi_v2(hipStream_t st, const FrameInfo *info, int nf, const uint32_t *bm, uint64_t *dec, uint32_t *decoded,

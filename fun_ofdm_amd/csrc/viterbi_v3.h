@@ -368,6 +368,7 @@ __global__ __launch_bounds__(64) void k_tb_finish(const FrameInfo *__restrict__ 
                                                   uint8_t *__restrict__ psdu, size_t slot_bytes, foa_frame_result *__restrict__ results)
 {
     __shared__ FinishTables tabs;
+    __shared__ FinishWave fwave;
     __shared__ uint16_t rw[kTbMaxSeg / 16 * 64];
     const int lane = threadIdx.x, f = blockIdx.x * 64 + lane;
     finish_tables_init(tabs, lane, 64);
@@ -378,7 +379,6 @@ __global__ __launch_bounds__(64) void k_tb_finish(const FrameInfo *__restrict__ 
     if (f < n_frames) fi = info[f];
     const bool live = f < n_frames && fi.nsym > 0;
     const int N = live ? fi.nsteps - 6 : 0, nseg = live ? tb_segments(fi.nsteps, S) : 0;
-    uint32_t *out = decoded + fi.dec_off;
 
     int maxseg = nseg;
 #pragma unroll
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(64) void k_tb_finish(const FrameInfo *__restrict__ 
         if (has) s_next = s_k;
     }
     __threadfence();                                                       // re-walked words were written by lane 0
-    finish_crc_psdu(tabs, fi, live, f, n_frames, out, psdu, slot_bytes, results);
+    finish_crc_psdu(tabs, fwave, fi, live, f, n_frames, decoded, psdu, slot_bytes, results);
 }
 
 inline void launch_viterbi_v3(hipStream_t st, const FrameInfo *info, int nf, const uint32_t *bm, uint64_t *dec, uint32_t *decoded,
