@@ -23,8 +23,13 @@
 #include <complex>
 #include <cstdint>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <cstdio>
 #include <deque>
+#include <mutex>
 #include <stdexcept>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -393,6 +398,139 @@ private:
     std::vector<float> buf_;          // interleaved samples from stream index base_ on
     int64_t base_;
     std::deque<entry> pending_;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// The caller of the boundary: fun::receiver without the radio.
+// ---------------------------------------------------------------------------------------------------------------
+// What usrp::get_samples(num_samples, buffer) (src/usrp.cpp:125-130) is to fun::receiver: fills `buffer` with the next
+// num_samples complex<double> samples.  Returning false ends the stream (a radio never does).
+class sample_source {
+public:
+    virtual ~sample_source() {}
+    virtual bool get_samples(int num_samples, std::vector<std::complex<double> > &buffer) = 0;
+};
+
+// Samples held in memory (tests, replays).
+class vector_source : public sample_source {
+public:
+    explicit vector_source(std::vector<std::complex<double> > samples) : s_(std::move(samples)), pos_(0) {}
+    bool get_samples(int num_samples, std::vector<std::complex<double> > &buffer) override
+    {
+        if (pos_ >= s_.size()) return false;
+        buffer.assign((size_t)num_samples, std::complex<double>(0, 0));        // the last call is padded with silence
+        const size_t n = std::min((size_t)num_samples, s_.size() - pos_);
+        std::copy(s_.begin() + pos_, s_.begin() + pos_ + n, buffer.begin());
+        pos_ += n;
+        return true;
+    }
+private:
+    std::vector<std::complex<double> > s_;
+    size_t pos_;
+};
+
+// Raw interleaved I/Q files: "fc32" = complex<float> (GNU Radio / UHD rx_samples_to_file default),
+// "fc64" = complex<double> (UHD's wire format for this reference, src/usrp.cpp:46).
+class file_source : public sample_source {
+public:
+    file_source(const std::string &path, const std::string &format) : f_(std::fopen(path.c_str(), "rb")), fc64_(format == "fc64")
+    {
+        if (!f_) throw std::runtime_error("cannot open " + path);
+        if (format != "fc32" && format != "fc64") throw std::runtime_error("format must be fc32 or fc64");
+    }
+    ~file_source() override { if (f_) std::fclose(f_); }
+    file_source(const file_source &) = delete;
+    file_source &operator=(const file_source &) = delete;
+    bool get_samples(int num_samples, std::vector<std::complex<double> > &buffer) override
+    {
+        buffer.assign((size_t)num_samples, std::complex<double>(0, 0));
+        size_t got;
+        if (fc64_) {
+            got = std::fread(buffer.data(), sizeof(std::complex<double>), (size_t)num_samples, f_);
+        } else {
+            tmp_.resize((size_t)num_samples);
+            got = std::fread(tmp_.data(), sizeof(std::complex<float>), (size_t)num_samples, f_);
+            for (size_t i = 0; i < got; i++) buffer[i] = std::complex<double>(tmp_[i].real(), tmp_[i].imag());
+        }
+        return got > 0;
+    }
+private:
+    std::FILE *f_;
+    bool fc64_;
+    std::vector<std::complex<float> > tmp_;
+};
+
+// fun::receiver (src/receiver.h:35-112, src/receiver.cpp:27-78) over a sample_source instead of the USRP: a thread pulls
+// NUM_RX_SAMPLES at a time, runs them through receiver_chain::process_samples() and hands the packets -- possibly none
+// -- to the callback after every call, exactly like receiver_chain_loop(); pause() returns once the loop is parked
+// between two iterations, resume() lets it run again (the reference's binary semaphore).  Unlike a radio a source
+// can end: the loop then stops and finished() turns true.
+class receiver {
+public:
+    typedef void (*callback_t)(std::vector<std::vector<unsigned char> > packets);
+    receiver(callback_t callback, sample_source *source, int device = 0, int num_rx_samples = 4096)
+        : callback_(callback), source_(source), chain_(device), n_(num_rx_samples), token_(true), stop_(false), finished_(false)
+    {
+        thread_ = std::thread(&receiver::receiver_chain_loop, this);
+    }
+    ~receiver()
+    {
+        stop_ = true;
+        resume();                                   // a paused loop must be able to see stop_
+        if (thread_.joinable()) thread_.join();
+    }
+    receiver(const receiver &) = delete;
+    receiver &operator=(const receiver &) = delete;
+
+    void pause() { take(); }                        // sem_wait(&m_pause)
+    void resume() { give(); }                       // sem_post(&m_pause)
+    bool finished() const { return finished_; }
+    void wait_finished()
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        done_cv_.wait(lk, [this] { return finished_.load(); });
+    }
+
+private:
+    void take()
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [this] { return token_; });
+        token_ = false;
+    }
+    void give()
+    {
+        { std::lock_guard<std::mutex> lk(m_); token_ = true; }
+        cv_.notify_one();
+    }
+    void receiver_chain_loop()
+    {
+        std::vector<std::complex<double> > samples((size_t)n_);
+        while (!stop_) {
+            take();                                 // block while the receiver is paused
+            const bool more = !stop_ && source_->get_samples(n_, samples);
+            if (more) {
+                callback_(chain_.process_samples(samples));
+            } else if (!stop_) {
+                // end of the source: one chunk of silence lets timing_sync settle on the frames that are already complete
+                samples.assign((size_t)std::max(n_, 512), std::complex<double>(0, 0));
+                callback_(chain_.process_samples(samples));
+            }
+            give();
+            if (!more) break;
+        }
+        { std::lock_guard<std::mutex> lk(m_); finished_ = true; }
+        done_cv_.notify_all();
+    }
+    callback_t callback_;
+    sample_source *source_;
+    receiver_chain chain_;
+    int n_;
+    std::mutex m_;
+    std::condition_variable cv_, done_cv_;
+    bool token_;
+    std::atomic<bool> stop_, finished_;
+    std::thread thread_;
 };
 
 }  // namespace fun_amd

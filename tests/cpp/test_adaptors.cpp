@@ -2,8 +2,10 @@
 // Build/run: tests/test_gpu_cpp_adaptors.py (needs a GPU).  Exit code 0 = all checks passed.
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "fun_ofdm_amd/blocks.hpp"
@@ -14,6 +16,15 @@ extern "C" {
 typedef std::vector<std::vector<unsigned char> > payloads_t;
 static int failures = 0;
 #define CHECK(cond, ...) do { if (!(cond)) { failures++; printf("FAIL %s:%d: ", __FILE__, __LINE__); printf(__VA_ARGS__); printf("\n"); } } while (0)
+
+// fun_amd::receiver takes a plain function pointer like fun::receiver does (src/receiver.h:58)
+static payloads_t g_rx_packets;
+static std::atomic<int> g_rx_calls(0);
+static void rx_callback(std::vector<std::vector<unsigned char> > packets)
+{
+    g_rx_calls++;
+    for (auto &p : packets) g_rx_packets.push_back(p);
+}
 
 static unsigned long long rng_state = 88172645463325252ull;
 static double urand() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return (double)(rng_state >> 11) / 9007199254740992.0; }
@@ -141,6 +152,22 @@ int main()
         }
         printf("receiver_chain chunk %zu: %zu payloads, first in call %d\n", cs, got.size(), first_call);
         CHECK(got == want, "process_samples payloads differ (chunk %zu: %zu vs %zu)", cs, got.size(), want.size());
+    }
+    // ---- 3. fun_amd::receiver: source -> process_samples -> callback on every call, pause()/resume() ----
+    {
+        fun_amd::vector_source src(stream);
+        fun_amd::receiver rx(rx_callback, &src);
+        rx.pause();                                   // returns with the loop parked between two iterations
+        const int at_pause = g_rx_calls;
+        std::this_thread::sleep_for(std::chrono::milliseconds(200));
+        CHECK(g_rx_calls == at_pause, "receiver kept running while paused (%d -> %d calls)", at_pause, (int)g_rx_calls);
+        CHECK(!rx.finished(), "receiver finished while paused");
+        rx.resume();
+        rx.wait_finished();
+        const int expect_calls = (int)((stream.size() + 4095) / 4096) + 1;      // one call per 4096 samples + the closing silence
+        printf("receiver: %d callbacks, %zu payloads\n", (int)g_rx_calls, g_rx_packets.size());
+        CHECK(g_rx_calls == expect_calls, "callback count %d, expected %d (it is called after every process_samples)", (int)g_rx_calls, expect_calls);
+        CHECK(g_rx_packets == want, "receiver payloads differ (%zu vs %zu)", g_rx_packets.size(), want.size());
     }
     printf(failures ? "FAILED (%d)\n" : "OK\n", failures);
     return failures ? 1 : 0;
