@@ -1,0 +1,146 @@
+#!/usr/bin/env python3
+"""SURVEY 8d configs 3 and 5 and the PCIe-inclusive figure of config 2, for DESIGN.md (not the judged bench line).
+
+  config 3: the 8 standard rates x 4092-byte payloads, 1000 frames each, 25 dB: device-resident Msamples/s per rate,
+            CRC passes on the GPU and on the CPU oracle (a subset), identical results required
+  config 5: one continuous stream, frames cycling the 8 rates, 1024-byte payloads, zero gap, CFO within +-4 kHz, 25 dB:
+            device pre-sync + decode, Msamples/s
+  config 2 host entry: foa_rx_decode_frames_host (H2D of 8 B/sample + D2H of PSDUs inside the timed region)
+Workloads are built on the device (foa_tx_*).  One JSON object per line."""
+import json
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
+import fun_ofdm_amd as foa                      # noqa: E402
+from fun_ofdm_amd import synth                  # noqa: E402
+from oracle import pyoracle as po               # noqa: E402
+
+dev = torch.device("cuda", 0)
+rx = foa.Receiver(0)
+rx.set_option("record_soft", 0)
+RATES = (0, 2, 3, 5, 6, 8, 9, 10)
+
+
+def timed(fn, reps=5):
+    fn(); rx.sync(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    rx.sync(); torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def config3(n=1000, length=4092):
+    for rate in RATES:
+        pays = synth.splitmix64_bytes(0x0FD3 + rate, n, length)
+        frames = rx.tx_build_frames(torch.from_numpy(pays).to(dev), rate)
+        s = frames.shape[1]
+        pitch = -(-(s + 576) // 4096) * 4096
+        iq = rx.tx_channel(frames, pitch, 176, 25.0, seed=300 + rate)
+        del frames
+        cap = n * pitch // 512 + 64
+        descs = torch.zeros(cap * 48, dtype=torch.uint8, device=dev)
+        ends = torch.zeros(cap, dtype=torch.int64, device=dev)
+        m = rx.sync_dev(iq, descs, ends)
+        psdu = torch.zeros((m, length), dtype=torch.uint8, device=dev)
+        res = torch.zeros((m, 4), dtype=torch.int32, device=dev)
+        dt = timed(lambda: rx.decode_frames_dev(iq, descs[:m * 48], ends[:m], psdu, res))
+        r = res.cpu().numpy()
+        d = descs.cpu().numpy()[:m * 48].view(foa.frame_desc_dtype)
+        real = np.nonzero((d["lts1_pos"] - 360) % pitch == 0)[0]
+        ok = real[r[real, 0] == 0]
+        which = (d["lts1_pos"][ok] - 360) // pitch
+        exact = bool(np.array_equal(psdu.cpu().numpy()[ok], pays[which]))
+        # CPU oracle on the first 64 alignments: same status / PSDUs
+        k = min(m, 64)
+        h_iq = iq[:int(ends[k - 1].item())].cpu().numpy().reshape(-1).view(np.complex64)
+        opsdu, ores = po.decode_batch_f32(h_iq, d[:k], ends[:k].cpu().numpy(), slot_bytes=length, threads=8)
+        same = bool(np.array_equal(ores.view(np.int32).reshape(-1, 4), r[:k]))
+        print(json.dumps({"config": 3, "rate_enum": rate, "frames": n, "payload": length, "frame_samples": int(s), "alignments": int(m),
+                          "frames_found": int(real.size), "crc_ok": int(ok.size), "psdu_bit_exact": exact, "gpu_equals_cpu_on_64": same,
+                          "ms": round(dt * 1e3, 3), "Msamples_per_s_in_frame": round(real.size * s / dt / 1e6, 1)}), flush=True)
+        del iq, psdu, res
+
+
+def config5(n=4000, length=1024):
+    rates = [RATES[i % 8] for i in range(n)]
+    parts, pays_all = [], []
+    for rate in RATES:
+        idx = [i for i in range(n) if rates[i] == rate]
+        pays = synth.splitmix64_bytes(0x0FD5 + rate, len(idx), length)
+        parts.append((idx, rx.tx_build_frames(torch.from_numpy(pays).to(dev), rate)))
+        pays_all.append((idx, pays))
+    # zero gap: concatenate the frames in order into one stream (the channel kernel wants a fixed pitch, so each rate
+    # goes through it with pitch = its own frame length and the pieces are interleaved afterwards)
+    total = sum(p[1].shape[1] * len(p[0]) for p in parts) + 2048
+    stream = torch.zeros((total, 2), dtype=torch.float32, device=dev)
+    offs = np.zeros(n + 1, np.int64)
+    lens = {}
+    for idx, fr in parts:
+        lens.update({i: fr.shape[1] for i in idx})
+    offs[1:] = np.cumsum([lens[i] for i in range(n)])
+    offs += 1024
+    for (idx, fr), rate in zip(parts, RATES):
+        s = fr.shape[1]
+        noisy = rx.tx_channel(fr, s, 0, 25.0, seed=500 + rate, cfo_hz=4000.0).reshape(len(idx), s, 2)
+        for j, i in enumerate(idx):
+            stream[offs[i]:offs[i] + s] = noisy[j]
+    sigma = float(np.sqrt(0.0124 / 2 / 10 ** 2.5))
+    stream[:1024] = torch.randn((1024, 2), device=dev) * sigma
+    stream[offs[n]:] = torch.randn((total - int(offs[n]), 2), device=dev) * sigma
+    cap = n + 4096
+    descs = torch.zeros(cap * 48, dtype=torch.uint8, device=dev)
+    ends = torch.zeros(cap, dtype=torch.int64, device=dev)
+    psdu = torch.zeros((cap, length), dtype=torch.uint8, device=dev)
+    res = torch.zeros((cap, 4), dtype=torch.int32, device=dev)
+    got = [0]
+
+    def run():
+        got[0] = rx.sync_dev(stream, descs, ends)
+        rx.decode_frames_dev(stream, descs[:got[0] * 48], ends[:got[0]], psdu[:got[0]], res[:got[0]])
+    dt = timed(run, reps=3)
+    m = got[0]
+    r = res[:m].cpu().numpy()
+    d = descs.cpu().numpy()[:m * 48].view(foa.frame_desc_dtype)
+    start_of = {int(offs[i]) + 184: i for i in range(n)}
+    ok = [(a, start_of[int(p)]) for a, p in enumerate(d["lts1_pos"]) if int(p) in start_of and r[a, 0] == 0]
+    lookup = {}
+    for idx, pays in pays_all:
+        lookup.update({i: pays[j] for j, i in enumerate(idx)})
+    hp = psdu[:m].cpu().numpy()
+    exact = all(np.array_equal(hp[a], lookup[i]) for a, i in ok)
+    print(json.dumps({"config": 5, "frames": n, "stream_samples": int(total), "alignments": int(m), "frames_ok": len(ok), "psdu_bit_exact": bool(exact),
+                      "ms_sync_plus_decode": round(dt * 1e3, 3), "Msamples_per_s_stream": round(total / dt / 1e6, 1)}), flush=True)
+
+
+def config2_host(n=10000, length=1024):
+    pays = synth.splitmix64_bytes(0x0FD2, n, length)
+    frames = rx.tx_build_frames(torch.from_numpy(pays).to(dev), 10)
+    iq = rx.tx_channel(frames, 4096, 176, 25.0, seed=7919)
+    h_iq = iq.cpu().numpy().reshape(-1).view(np.complex64)
+    del frames, iq
+    descs = foa.find_alignments(h_iq)
+    ends = foa.alignment_ends(descs, h_iq.size)
+    rx.decode_frames_host(h_iq, descs, ends, slot_bytes=length)
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        psdu, res = rx.decode_frames_host(h_iq, descs, ends, slot_bytes=length)
+    dt = (time.perf_counter() - t0) / reps
+    real = np.nonzero((descs["lts1_pos"] - 360) % 4096 == 0)[0]
+    print(json.dumps({"config": "2 through the host-pointer entry (pageable host memory, H2D + D2H inside)", "frames": n, "ms": round(dt * 1e3, 2),
+                      "Msamples_per_s_in_frame": round(real.size * 3520 / dt / 1e6, 1), "frames_ok": int((res[real]["status"] == 0).sum())}), flush=True)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["3", "5", "2h"]
+    if "3" in which:
+        config3()
+    if "5" in which:
+        config5()
+    if "2h" in which:
+        config2_host()
