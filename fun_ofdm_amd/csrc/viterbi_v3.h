@@ -104,8 +104,17 @@ __device__ __forceinline__ uint32_t fwd3_step(uint32_t M, const uint2 w, const F
     const uint32_t s0 = __builtin_amdgcn_readfirstlane(Mn);
     const uint32_t over = ((s0 & 0x00FF00FFu) + 0x002D002Du) & 0x01000100u;
     if (__builtin_expect(over != 0u, 0)) {      // cold: keeps the common path free of taken branches
-        if (over & 0x100u) Mn -= wave_min_u32(Mn & 0xFFFFu) - kBias;
-        if (over >> 16) Mn -= (wave_min_u32(Mn >> 16) - kBias) << 16;
+        // the amount is wave-uniform: subtract the bias on the scalar side so the vector side is one v_sub
+        if (over & 0x100u) {
+            uint32_t adj;
+            asm("s_sub_u32 %0, %1, %2" : "=s"(adj) : "s"(wave_min_u32(Mn & 0xFFFFu)), "s"(kBias) : "scc");
+            Mn -= adj;
+        }
+        if (over >> 16) {
+            uint32_t adj;
+            asm("s_sub_u32 %0, %1, %2\n\ts_lshl_b32 %0, %0, 16" : "=s"(adj) : "s"(wave_min_u32(Mn >> 16)), "s"(kBias) : "scc");
+            Mn -= adj;
+        }
     }
     return Mn;
 }
