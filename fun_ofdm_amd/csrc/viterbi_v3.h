@@ -40,8 +40,8 @@ namespace foa {
 #define FOA_ABL 0        // timing experiments only (tools/ablate.sh): 1 no decision ops, 2 no renormalisation
 #endif
 constexpr int kChunk3 = 48;                  // data steps per forward chunk: 3 decision blocks, 8 phase groups
-constexpr int kTbPieces = 24;                // LDS-DMA instructions per chunk: 8 lane groups x 3 blocks, 1 KiB each
-constexpr int kTbChunkBytes = kTbPieces * 1024;   // LDS: [lane / 8][block][lane % 8] x 128 B
+constexpr int kTbBlockBytes = 8 * 1024;      // LDS of one 16-step decision block of the wave's 64 lanes: [lane / 8][lane % 8] x 128 B
+constexpr int kTbRing = 3;                   // blocks resident per wave: one being walked, two streaming in
 constexpr int kTbMaxSeg = 3072;              // largest segment length (LDS of the re-walk path: 8 B per step)
 
 __device__ __forceinline__ uint32_t pk_sub_wrap(uint32_t a, uint32_t b)
@@ -231,29 +231,29 @@ __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd3(const FrameInfo
 // ---------------------------------------------------------------------------------------------------------
 // chain-back, one lane per segment
 // ---------------------------------------------------------------------------------------------------------
-// LDS holds, per chunk buffer, the three 128-byte decision blocks of every lane's chunk as whole lines:
-// [lane / 8][block][lane % 8][slot] u16.  Eight consecutive lanes of an LDS-DMA instruction fetch the eight 16-byte
-// pieces of ONE line (one block of one segment), so every instruction moves eight full 128-byte lines.  The lane's
-// LDS byte offset carries the complemented slot index in bits 1-6; block and buffer are immediate offsets.  A step
-// is then: read 16 bits, shift the step's bit to its place, v_bfi it in.
-__device__ __forceinline__ uint32_t tb_lane_base(int lane) { return (uint32_t)(lane >> 3) * 3072u + (uint32_t)(lane & 7) * 128u; }
+// LDS holds a ring of three 16-step decision blocks of every lane: [ring slot][lane / 8][lane % 8][slot] u16, whole
+// 128-byte lines.  Eight consecutive lanes of an LDS-DMA instruction fetch the eight 16-byte pieces of ONE line (one
+// block of one segment), so every instruction moves eight full lines.  The lane's LDS byte offset carries the
+// complemented slot index in bits 1-6; the ring slot is an immediate offset.  A step is then: read 16 bits, shift the
+// step's bit to its place, v_bfi it in.  24 KB per wave let six waves share a CU, which is what the kernel's speed
+// hangs on: a lane's walk is one dependent chain of about 200 clocks per step, so time = steps per lane x rounds.
+__device__ __forceinline__ uint32_t tb_lane_base(int lane) { return (uint32_t)(lane >> 3) * 1024u + (uint32_t)(lane & 7) * 128u; }
 __device__ __forceinline__ uint32_t tb_gather(uint32_t a) { return (a >> 1) & 63u; }
 
-// 48 steps of one chunk (data steps 48c+47 .. 48c), decoded bits into w[] (data bit 96u+i at bit 31-(i mod 32) of
-// w[i/32]: the reference's MSB-first byte order once the word is byte-swapped).  UPPER: the chunk is the upper half
-// of its 96-step unit.
-template <int BUF, bool UPPER>
-__device__ __forceinline__ void tb_walk_chunk(const uint8_t *tb, uint32_t &a, uint32_t (&w)[3])
+// 16 steps of block KK (0..5) of a 96-step unit, i.e. data steps 96u + 16 KK + 15 .. 96u + 16 KK, decoded bits into w[]
+// (data bit 96u+i at bit 31-(i mod 32) of w[i/32]: the reference's MSB-first byte order once the word is byte-swapped).
+template <int KK>
+__device__ __forceinline__ void tb_walk_block(const uint8_t *tb, uint32_t &a, uint32_t (&w)[3])
 {
 #pragma unroll
-    for (int j = kChunk3 - 1; j >= 0; j--) {
-        const int blk = j >> 4, bit = j & 15, q = 5 - j % 6, pos = q + 1;
-        const uint32_t v = *(const uint16_t *)(tb + a + (BUF * kTbChunkBytes + blk * 1024));
-        const uint32_t tmp = pos >= bit ? v << (pos - bit) : v >> (bit - pos);
+    for (int jj = 15; jj >= 0; jj--) {
+        const int ju = 16 * KK + jj, q = 5 - ju % 6, pos = q + 1;            // unit starts are multiples of 96: phase = ju mod 6
+        const uint32_t v = *(const uint16_t *)(tb + a + (KK % kTbRing) * kTbBlockBytes);
+        const uint32_t tmp = pos >= jj ? v << (pos - jj) : v >> (jj - pos);
         asm("v_bfi_b32 %0, %1, %2, %0" : "+v"(a) : "s"(1u << pos), "v"(tmp));
-        if (j % 6 == 0) {
+        if (ju % 6 == 0) {
             // the six bits just written are the six data bits of this group, complemented; p bit i = data bit 5-i
-            const int o = 6 * ((UPPER ? 8 : 0) + j / 6), wi = o >> 5, r = o & 31;
+            const int o = ju, wi = o >> 5, r = o & 31;
             const uint32_t p = tb_gather(a) ^ 63u;
             if (r <= 26) {
                 w[wi] |= p << (26 - r);
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(64) void k_tb_walk(const FrameInfo *__restrict__ in
                                                 const int64_t *__restrict__ totals, const uint64_t *__restrict__ dec,
                                                 uint32_t *__restrict__ decoded, uint16_t *__restrict__ tb_state, int S, int L)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t tb[2 * kTbChunkBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t tb[kTbRing * kTbBlockBytes];
     const int lane = threadIdx.x, g = blockIdx.x * 64 + lane;
     const int n_seg = (int)totals[4];
     if (blockIdx.x * 64 >= n_seg) return;
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(64) void k_tb_walk(const FrameInfo *__restrict__ in
     if (live) fi = info[f];
     const int k = g - fi.seg_off, N = fi.nsteps - 6;
     const int n_lo = k * S, n_own = min(n_lo + S, N), n_hi = min(n_lo + S + L, N);
-    const int cnt = live ? (n_hi - n_lo + kChunk3 - 1) / kChunk3 : 0;      // chunks this lane walks, numbered from its bottom
+    const int cnt = live ? (n_hi - n_lo + kChunk3 - 1) / kChunk3 : 0;      // 48-step chunks this lane walks, numbered from its bottom
     const int own = live ? (n_own - n_lo + kChunk3 - 1) / kChunk3 : 0;     // of which the lowest `own` are its own
     const uint8_t *src = live ? (const uint8_t *)(dec + fi.dec_off) + (size_t)(n_lo / kChunk3) * 384 : (const uint8_t *)dec;
     uint32_t *out = decoded + fi.dec_off + n_lo / 32;
@@ -290,9 +290,8 @@ __global__ __launch_bounds__(64) void k_tb_walk(const FrameInfo *__restrict__ in
     uint32_t a = tb_lane_base(lane) + (63u << 1);                          // state 0; true at the frame's end, a guess elsewhere
     uint32_t e = 63u, w[3] = { 0u, 0u, 0u };
 
-    // Fetch roles: in the instruction for lane group gi, this lane moves piece lane % 8 of the blocks of segment lane
-    // 8 gi + lane / 8.  Chunk i of every segment lane -> LDS buffer `which`; a segment lane that has no chunk i gets
-    // its chunk 0 again (always inside its region).
+    // Fetch roles: in the instruction for lane group gi, this lane moves piece lane % 8 of a block of segment lane
+    // 8 gi + lane / 8.  A segment lane that has no chunk i gets its chunk 0 again (always inside its region).
     const uint8_t *fsrc[8];
     int fcnt[8];
 #pragma unroll
@@ -301,47 +300,46 @@ __global__ __launch_bounds__(64) void k_tb_walk(const FrameInfo *__restrict__ in
         fsrc[gi] = (const uint8_t *)__shfl((unsigned long long)(uintptr_t)src, from) + (lane & 7) * 16;
         fcnt[gi] = __shfl(cnt, from);
     }
-    auto fetch = [&](int i, int which) {
-        const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)&tb[which * kTbChunkBytes];
+    // block bk (0..2) of chunk i of every segment lane -> ring slot bk
+    auto fetch = [&](int i, int bk) {
+        const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)&tb[bk * kTbBlockBytes];
 #pragma unroll
         for (int gi = 0; gi < 8; gi++) {
-            const uint8_t *p = fsrc[gi] + (size_t)(i < fcnt[gi] ? i : 0) * 384;
-#pragma unroll
-            for (int blk = 0; blk < 3; blk++) {
-                unsigned keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep)
-                             : "v"(p + 128 * blk), "s"(lds0 + (uint32_t)(gi * 3 + blk) * 1024u)
-                             : "memory");
-            }
+            const uint8_t *p = fsrc[gi] + (size_t)(i < fcnt[gi] ? i : 0) * 384 + 128 * bk;
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(p), "s"(lds0 + (uint32_t)gi * 1024u)
+                         : "memory");
         }
     };
+    // Block KK of unit u is block KK % 3 of chunk 2u + KK / 3.  While it is walked the two blocks below it are in flight
+    // or landed, and the block two below is requested as soon as the ring slot above is free (the block walked before).
+#define FOA_TB_BLOCK(KK)                                                                                   \
+    {                                                                                                      \
+        constexpr int below = (KK) - 2;           /* in-unit index of the block to request, may be negative */ \
+        if (below >= 0) fetch(2 * u + below / 3, below % 3);                                               \
+        else if (u > 0) fetch(2 * (u - 1) + (below + 6) / 3, (below + 6) % 3);                             \
+        if (below >= 0 || u > 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                         \
+        else if ((KK) == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                               \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                              \
+        __builtin_amdgcn_wave_barrier();                                                                   \
+        if ((KK) % 3 == 2 && 2 * u + (KK) / 3 == own - 1) e = tb_gather(a);                                \
+        if (2 * u + (KK) / 3 < cnt) tb_walk_block<(KK)>(tb, a, w);                                         \
+        __builtin_amdgcn_wave_barrier();                                                                   \
+    }
     const int U = (cmax - 1) / 2;                                           // top unit
+    fetch(2 * U + 1, 2);
     fetch(2 * U + 1, 1);
     for (int u = U; u >= 0; u--) {
-        // upper chunk 2u+1 in buffer 1, lower chunk 2u in buffer 0; the next chunk streams in while one is walked
-        fetch(2 * u, 0);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kTbPieces) : "memory");
-        __builtin_amdgcn_wave_barrier();
-        if (2 * u + 1 == own - 1) e = tb_gather(a);
-        if (2 * u + 1 < cnt) tb_walk_chunk<1, true>(tb, a, w);
-        __builtin_amdgcn_wave_barrier();
-        if (u > 0) {
-            fetch(2 * u - 1, 1);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kTbPieces) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (2 * u == own - 1) e = tb_gather(a);
-        if (2 * u < cnt) tb_walk_chunk<0, false>(tb, a, w);
-        __builtin_amdgcn_wave_barrier();
+        FOA_TB_BLOCK(5) FOA_TB_BLOCK(4) FOA_TB_BLOCK(3) FOA_TB_BLOCK(2) FOA_TB_BLOCK(1) FOA_TB_BLOCK(0)
         // own is even except in a frame's last segment, whose chunks above `own` lie beyond the frame's end (zeros)
         if (2 * u < own) {
             out[3 * u] = __builtin_bswap32(w[0]); out[3 * u + 1] = __builtin_bswap32(w[1]); out[3 * u + 2] = __builtin_bswap32(w[2]);
         }
         w[0] = w[1] = w[2] = 0u;
     }
+#undef FOA_TB_BLOCK
     if (live) tb_state[g] = (uint16_t)(e | (tb_gather(a) << 8));
 }
 
