@@ -121,6 +121,7 @@ def main():
     ap.add_argument("--frontend", type=int, default=1, help="0: wave-per-symbol kernel, 1: lane-per-symbol kernel")
     ap.add_argument("--tx", choices=("host", "device"), default="host",
                     help="where the synthetic frames are built: numpy on the host (default) or foa_tx_* on the device")
+    ap.add_argument("--no-pipeline", action="store_true", help="finish of a step on the same stream as the rest (no overlap with the next step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -180,6 +181,7 @@ def main():
     if args.tb_overlap >= 0:
         rx.set_option("tb_overlap", args.tb_overlap)
     rx.set_option("frontend", args.frontend)
+    rx.set_option("pipeline", 0 if args.no_pipeline else 1)
     rx.set_option("record_soft", 0)        # PSDUs are the output; soft bytes are only kept for diagnostics
     rx.reserve(iq.size, m)
     d_iq = torch.from_numpy(iq.view(np.float32).reshape(-1, 2)).to(dev)
@@ -208,16 +210,19 @@ def main():
         dist.barrier()
     kern = {k: 0.0 for k in ("header", "scan", "symbols", "viterbi_fwd", "viterbi_finish", "total")}
     t_start = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         step()
-        if args.steps <= 50:                             # per-kernel HIP-event times (adds one sync per step)
-            for k, v in rx.kernel_ms().items():
+        if args.steps <= 50 and i > 0:                   # per-kernel HIP-event times of the step before: that step is
+            for k, v in rx.kernel_ms(previous=True).items():   # complete, so asking does not stall the one just queued
                 kern[k] += v
     rx.sync()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t_start
+    if args.steps <= 50:
+        for k, v in rx.kernel_ms().items():              # ... and of the last step, after the clock has stopped
+            kern[k] += v
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -284,6 +289,7 @@ def main():
                        "counted_samples": "in-frame only (3520/frame)", "value_all_samples_fed": round(value * PITCH / frame_samples, 1),
                        "x_realtime_20MSps": round(value / 20.0, 1), "psdu_bit_exact": exact, "frames_ok": ok_frames, "frames_found_by_sync_rank0": int(real.size),
                        "alignments_decoded_per_gpu": m, "frontend_dtype": "f64", "viterbi_kernel": args.viterbi, "frontend_kernel": args.frontend,
+                       "steps_pipelined": bool(args.viterbi == 2 and not args.no_pipeline and world == 1),
                        "sharding": ("global frame i on rank i mod %d, one %s gather of PSDU slots to rank 0 per step" % (world, backend)) if world > 1 else "single GPU"},
         }
         if with_sync:

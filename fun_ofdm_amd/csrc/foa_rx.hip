@@ -145,17 +145,9 @@ void foa::build_tables(DeviceTables *t)
     for (int b = -255; b <= 255; b++) t->bm_dif[b + 255] = ((uint32_t)((b + 256) >> 3) << 8) | ((uint32_t)((256 - b) >> 3) << 16);
 }
 
-struct foa_rx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[8] = {};
-    bool have_timing = false;
-    int viterbi_kind = 2;        // 0: lane per state (viterbi_v1.h), 1: packed, serial chain-back (v2), 2: packed, segment chain-back (v3)
-    int tb_segment = 960, tb_overlap = 96;   // v3 chain-back: data steps per segment / run-in steps (multiples of 96)
-    bool record_eq = false;
-    bool record_soft = true;     // keep the depunctured soft bytes (taps, lane-per-state kernel); off = branch metrics only
-    int frontend_kind = 1;       // 1: one lane per symbol (frontend_lps.h), 0: one wave per symbol
-    // workspace
+// Everything one decode call writes between its header kernel and its finish kernel.  There are two sets so that the
+// chain-back of call k (HBM-bound, on the second stream) can run under the front end and forward pass of call k+1.
+struct WorkSet {
     DevBuf<FrameInfo> info;
     DevBuf<double2> hinv;
     DevBuf<int32_t> sym2frame, seg2frame;
@@ -165,12 +157,46 @@ struct foa_rx {
     DevBuf<uint32_t> bm, decoded;
     DevBuf<int64_t> totals;
     DevBuf<double2> eq_sig, eq_data;
+    size_t sym_cap = 0, soft_cap = 0, dec_cap = 0;
+    hipEvent_t ev[7] = {};       // start, after header, after scan, after symbols, end, after the forward pass, start of the finish
+    hipEvent_t fwd_done = nullptr, done = nullptr;
+    bool used = false, have_timing = false, piped = false;
+    void release_all()
+    {
+        info.release(); hinv.release(); sym2frame.release(); seg2frame.release(); tb_state.release(); soft.release(); dec.release(); bm.release();
+        decoded.release(); totals.release(); eq_sig.release(); eq_data.release();
+    }
+};
+
+struct foa_rx {
+    int device = 0;
+    hipStream_t stream = nullptr;      // front end + forward pass (and everything else)
+    hipStream_t stream2 = nullptr;     // chain-back + finish of the pipelined path
+    int viterbi_kind = 2;        // 0: lane per state (viterbi_v1.h), 1: packed, serial chain-back (v2), 2: packed, segment chain-back (v3)
+    int tb_segment = 960, tb_overlap = 96;   // v3 chain-back: data steps per segment / run-in steps (multiples of 96)
+    bool pipeline = true;        // v3: finish of one call overlaps the next call's front end (two work sets, two streams)
+    bool record_eq = false;
+    bool record_soft = true;     // keep the depunctured soft bytes (taps, lane-per-state kernel); off = branch metrics only
+    int frontend_kind = 1;       // 1: one lane per symbol (frontend_lps.h), 0: one wave per symbol, 2: four lanes per symbol
+    WorkSet sets[2];
+    WorkSet *w = &sets[0];       // the set of the most recent decode call
+    WorkSet *prev = nullptr;     // the set of the call before it (kernel times of a call that is certainly complete)
+    // Pipelined path: the chain-back + finish of a call is queued (on stream2) only when the NEXT call has queued its
+    // front end, so that it runs under that call's forward pass (memory-bound next to issue-bound) rather than under its
+    // latency-bound front end; foa_rx_sync and everything that needs results queue it at once.
+    struct Pending {
+        bool valid = false;
+        WorkSet *w = nullptr;
+        int nf = 0, S = 0, L = 0;
+        size_t max_segs = 0, slot_bytes = 0;
+        uint8_t *psdu = nullptr;
+        foa_frame_result *results = nullptr;
+    } pending;
     DevBuf<uint8_t> scratch;     // staging for the host-pointer entry points
     DevBuf<uint32_t> sy_flags;   // device pre-sync workspace
     DevBuf<int32_t> sy_cnt, sy_off, sy_keep, sy_n;
     DevBuf<int64_t> sy_x;
     DevBuf<SyncCand> sy_cand;
-    size_t sym_cap = 0, soft_cap = 0, dec_cap = 0;
     size_t last_frames = 0;
 };
 
@@ -182,17 +208,44 @@ int workspace(foa_rx *rx, size_t n_samples, size_t n_frames)
     size_t soft_cap = 432 * sym_cap + 256 * (n_frames + 1);
     size_t dec_cap = 216 * sym_cap + 192 * (n_frames + 1);
     int rc;
-    if ((rc = rx->info.ensure(n_frames + 1)) || (rc = rx->hinv.ensure((n_frames + 1) * 64)) || (rc = rx->sym2frame.ensure(sym_cap)) ||
-        (rc = rx->soft.ensure(soft_cap)) || (rc = rx->dec.ensure(dec_cap)) || (rc = rx->bm.ensure(dec_cap)) || (rc = rx->decoded.ensure(dec_cap)) ||
-        (rc = rx->totals.ensure(8 + 4 * ((n_frames + kScanBlock - 1) / kScanBlock + 1))))
+    if ((rc = rx->w->info.ensure(n_frames + 1)) || (rc = rx->w->hinv.ensure((n_frames + 1) * 64)) || (rc = rx->w->sym2frame.ensure(sym_cap)) ||
+        (rc = rx->w->soft.ensure(soft_cap)) || (rc = rx->w->dec.ensure(dec_cap)) || (rc = rx->w->bm.ensure(dec_cap)) || (rc = rx->w->decoded.ensure(dec_cap)) ||
+        (rc = rx->w->totals.ensure(8 + 4 * ((n_frames + kScanBlock - 1) / kScanBlock + 1))))
         return rc;
-    if (rx->record_eq && ((rc = rx->eq_sig.ensure((n_frames + 1) * 48)) || (rc = rx->eq_data.ensure(sym_cap * 48)))) return rc;
+    if (rx->record_eq && ((rc = rx->w->eq_sig.ensure((n_frames + 1) * 48)) || (rc = rx->w->eq_data.ensure(sym_cap * 48)))) return rc;
     // chain-back segments: every frame has at most dec_words/segment + 1 of them
     const size_t seg_cap = dec_cap / 96 + n_frames + 64;
-    if ((rc = rx->seg2frame.ensure(seg_cap)) || (rc = rx->tb_state.ensure(seg_cap))) return rc;
+    if ((rc = rx->w->seg2frame.ensure(seg_cap)) || (rc = rx->w->tb_state.ensure(seg_cap))) return rc;
     // capacities handed to the scan are those of the buffers actually allocated
-    rx->sym_cap = rx->sym2frame.n; rx->soft_cap = rx->soft.n; rx->dec_cap = rx->dec.n < rx->bm.n ? rx->dec.n : rx->bm.n;
-    if (rx->record_eq && rx->eq_data.n / 48 < rx->sym_cap) rx->sym_cap = rx->eq_data.n / 48;
+    rx->w->sym_cap = rx->w->sym2frame.n; rx->w->soft_cap = rx->w->soft.n; rx->w->dec_cap = rx->w->dec.n < rx->w->bm.n ? rx->w->dec.n : rx->w->bm.n;
+    if (rx->record_eq && rx->w->eq_data.n / 48 < rx->w->sym_cap) rx->w->sym_cap = rx->w->eq_data.n / 48;
+    return FOA_OK;
+}
+
+// queue the deferred chain-back + finish; after_front_end: the event of the call it should run under (or null: now)
+int flush_pending(foa_rx *rx, hipEvent_t after_front_end)
+{
+    foa_rx::Pending &p = rx->pending;
+    if (!p.valid) return FOA_OK;
+    hipStream_t sb = rx->stream2;
+    HIP_TRY(hipStreamWaitEvent(sb, p.w->fwd_done, 0));
+    if (after_front_end) HIP_TRY(hipStreamWaitEvent(sb, after_front_end, 0));
+    HIP_TRY(hipEventRecord(p.w->ev[6], sb));
+    launch_finish3(sb, p.w->info.p, p.nf, p.w->dec.p, p.w->decoded.p, p.w->seg2frame.p, p.w->totals.p, p.w->tb_state.p, p.max_segs, p.S, p.L, p.psdu,
+                   p.slot_bytes, p.results);
+    HIP_TRY(hipEventRecord(p.w->ev[4], sb));
+    HIP_TRY(hipEventRecord(p.w->done, sb));
+    HIP_TRY(hipGetLastError());
+    p.valid = false;
+    return FOA_OK;
+}
+
+int drain(foa_rx *rx)
+{
+    int rc = flush_pending(rx, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(rx->stream));
+    HIP_TRY(hipStreamSynchronize(rx->stream2));
     return FOA_OK;
 }
 
@@ -225,7 +278,12 @@ int foa_rx_create(foa_rx **out, int device)
     foa_rx *rx = new foa_rx();
     rx->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&rx->stream, hipStreamNonBlocking));
-    for (auto &e : rx->ev) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipStreamCreateWithFlags(&rx->stream2, hipStreamNonBlocking));
+    for (auto &ws : rx->sets) {
+        for (auto &e : ws.ev) HIP_TRY(hipEventCreate(&e));
+        HIP_TRY(hipEventCreateWithFlags(&ws.fwd_done, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ws.done, hipEventDisableTiming));
+    }
     DeviceTables tab;
     build_tables(&tab);
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_tab), &tab, sizeof tab));
@@ -237,12 +295,17 @@ void foa_rx_destroy(foa_rx *rx)
 {
     if (!rx) return;
     (void)hipSetDevice(rx->device);
-    (void)hipStreamSynchronize(rx->stream);
-    rx->info.release(); rx->hinv.release(); rx->sym2frame.release(); rx->soft.release(); rx->dec.release(); rx->bm.release(); rx->decoded.release(); rx->totals.release();
-    rx->eq_sig.release(); rx->eq_data.release(); rx->scratch.release();
+    (void)drain(rx);
+    for (auto &ws : rx->sets) {
+        ws.release_all();
+        for (auto &e : ws.ev) if (e) (void)hipEventDestroy(e);
+        if (ws.fwd_done) (void)hipEventDestroy(ws.fwd_done);
+        if (ws.done) (void)hipEventDestroy(ws.done);
+    }
+    rx->scratch.release();
     rx->sy_flags.release(); rx->sy_cnt.release(); rx->sy_off.release(); rx->sy_keep.release(); rx->sy_n.release(); rx->sy_x.release(); rx->sy_cand.release();
-    for (auto &e : rx->ev) if (e) (void)hipEventDestroy(e);
     if (rx->stream) (void)hipStreamDestroy(rx->stream);
+    if (rx->stream2) (void)hipStreamDestroy(rx->stream2);
     delete rx;
 }
 
@@ -250,7 +313,16 @@ int foa_rx_reserve(foa_rx *rx, size_t n_samples, size_t n_frames)
 {
     if (!rx) return fail(FOA_E_INVALID, "rx is NULL");
     HIP_TRY(hipSetDevice(rx->device));
-    return workspace(rx, n_samples, n_frames);
+    { int rc0 = drain(rx); if (rc0) return rc0; }
+    WorkSet *keep = rx->w;
+    int rc = FOA_OK;
+    for (auto &ws : rx->sets) {                                        // both work sets (the second only matters when pipelining)
+        rx->w = &ws;
+        if ((rc = workspace(rx, n_samples, n_frames))) break;
+        if (!(rx->pipeline && rx->viterbi_kind == 2)) break;
+    }
+    rx->w = keep;
+    return rc;
 }
 
 int foa_rx_set_option(foa_rx *rx, const char *name, int64_t value)
@@ -271,6 +343,7 @@ int foa_rx_set_option(foa_rx *rx, const char *name, int64_t value)
         rx->tb_overlap = (int)value;
         return FOA_OK;
     }
+    if (!strcmp(name, "pipeline")) { rx->pipeline = value != 0; return FOA_OK; }
     if (!strcmp(name, "record_eq")) { rx->record_eq = value != 0; return FOA_OK; }
     if (!strcmp(name, "record_soft")) { rx->record_soft = value != 0; return FOA_OK; }
     if (!strcmp(name, "frontend")) {
@@ -286,8 +359,7 @@ void *foa_rx_stream(foa_rx *rx) { return rx ? (void *)rx->stream : nullptr; }
 int foa_rx_sync(foa_rx *rx)
 {
     if (!rx) return fail(FOA_E_INVALID, "rx is NULL");
-    HIP_TRY(hipStreamSynchronize(rx->stream));
-    return FOA_OK;
+    return drain(rx);
 }
 
 int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, const foa_frame_desc *d_descs, const int64_t *d_ends,
@@ -298,55 +370,78 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
     if (!d_iq || !d_descs || !d_ends || !d_psdu || !d_results) return fail(FOA_E_INVALID, "NULL device pointer");
     if (n_frames > 0x7FFFFFF0u) return fail(FOA_E_INVALID, "too many frames");
     HIP_TRY(hipSetDevice(rx->device));
+    // Two work sets take turns when the finish runs on its own stream: this call's front end and forward pass may then
+    // start while the previous call's chain-back is still reading the other set.
+    const bool piped = rx->pipeline && rx->viterbi_kind == 2;
+    if (!piped) { int rc0 = flush_pending(rx, nullptr); if (rc0) return rc0; }
+    rx->prev = rx->w;
+    if (piped) rx->w = rx->w == &rx->sets[0] ? &rx->sets[1] : &rx->sets[0];
+    if (rx->w->used) HIP_TRY(hipEventSynchronize(rx->w->done));      // the call that last used this set is complete
     int rc = workspace(rx, n_samples, n_frames);
     if (rc) return rc;
     hipStream_t st = rx->stream;
+    if (!piped && rx->prev->used && rx->prev != rx->w) HIP_TRY(hipStreamWaitEvent(st, rx->prev->done, 0));
     const int nf = (int)n_frames;
     const float2 *iq = (const float2 *)d_iq;
-    double2 *eq_sig = rx->record_eq ? rx->eq_sig.p : nullptr, *eq_data = rx->record_eq ? rx->eq_data.p : nullptr;
+    double2 *eq_sig = rx->record_eq ? rx->w->eq_sig.p : nullptr, *eq_data = rx->record_eq ? rx->w->eq_data.p : nullptr;
 
-    HIP_TRY(hipEventRecord(rx->ev[0], st));
-    hipLaunchKernelGGL(k_header, dim3(nf), dim3(64), 0, st, iq, d_descs, d_ends, nf, rx->info.p, rx->hinv.p, eq_sig);
-    HIP_TRY(hipEventRecord(rx->ev[1], st));
-    int64_t caps[1] = { (int64_t)rx->sym_cap };
-    HIP_TRY(hipMemcpyAsync(rx->totals.p + 3, caps, sizeof caps, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(rx->sym2frame.p, 0xFF, rx->sym_cap * sizeof(int32_t), st));
+    HIP_TRY(hipEventRecord(rx->w->ev[0], st));
+    hipLaunchKernelGGL(k_header, dim3(nf), dim3(64), 0, st, iq, d_descs, d_ends, nf, rx->w->info.p, rx->w->hinv.p, eq_sig);
+    HIP_TRY(hipEventRecord(rx->w->ev[1], st));
+    int64_t caps[1] = { (int64_t)rx->w->sym_cap };
+    HIP_TRY(hipMemcpyAsync(rx->w->totals.p + 3, caps, sizeof caps, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(rx->w->sym2frame.p, 0xFF, rx->w->sym_cap * sizeof(int32_t), st));
     // segments of this call: at most (total data steps)/S + one per frame; lanes beyond the real total idle
-    const size_t max_segs = std::min(rx->seg2frame.n, rx->dec_cap / (size_t)rx->tb_segment + n_frames + 1);
-    HIP_TRY(hipMemsetAsync(rx->seg2frame.p, 0xFF, max_segs * sizeof(int32_t), st));
+    const size_t max_segs = std::min(rx->w->seg2frame.n, rx->w->dec_cap / (size_t)rx->tb_segment + n_frames + 1);
+    HIP_TRY(hipMemsetAsync(rx->w->seg2frame.p, 0xFF, max_segs * sizeof(int32_t), st));
     const int n_sb = (nf + kScanBlock - 1) / kScanBlock;
-    int64_t *blk = rx->totals.p + 8;
-    hipLaunchKernelGGL(k_scan_sums, dim3(n_sb), dim3(kScanBlock), 0, st, rx->info.p, nf, rx->tb_segment, blk);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, blk, n_sb, rx->totals.p);
-    hipLaunchKernelGGL(k_scan_apply, dim3(n_sb), dim3(kScanBlock), 0, st, rx->info.p, nf, (int64_t)rx->sym_cap, (int64_t)rx->soft_cap,
-                       (int64_t)rx->dec_cap, rx->tb_segment, blk, rx->sym2frame.p, rx->seg2frame.p);
-    HIP_TRY(hipEventRecord(rx->ev[2], st));
+    int64_t *blk = rx->w->totals.p + 8;
+    hipLaunchKernelGGL(k_scan_sums, dim3(n_sb), dim3(kScanBlock), 0, st, rx->w->info.p, nf, rx->tb_segment, blk);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, blk, n_sb, rx->w->totals.p);
+    hipLaunchKernelGGL(k_scan_apply, dim3(n_sb), dim3(kScanBlock), 0, st, rx->w->info.p, nf, (int64_t)rx->w->sym_cap, (int64_t)rx->w->soft_cap,
+                       (int64_t)rx->w->dec_cap, rx->tb_segment, blk, rx->w->sym2frame.p, rx->w->seg2frame.p);
+    HIP_TRY(hipEventRecord(rx->w->ev[2], st));
     // upper bound on data symbols in n_samples samples; waves beyond the real total exit at once
-    const size_t max_sym = rx->sym_cap;
+    const size_t max_sym = rx->w->sym_cap;
     if (rx->frontend_kind == 2) {
-        uint8_t *soft_out = (rx->record_soft || rx->viterbi_kind == 0) ? rx->soft.p : nullptr;
+        uint8_t *soft_out = (rx->record_soft || rx->viterbi_kind == 0) ? rx->w->soft.p : nullptr;
         hipLaunchKernelGGL(k_data_symbols_q4, dim3((unsigned)((max_sym + 16 * kQ4Waves - 1) / (16 * kQ4Waves))), dim3(64 * kQ4Waves), 0, st, iq,
-                           d_descs, rx->info.p, rx->sym2frame.p, rx->totals.p, rx->hinv.p, soft_out, rx->bm.p, eq_data);
+                           d_descs, rx->w->info.p, rx->w->sym2frame.p, rx->w->totals.p, rx->w->hinv.p, soft_out, rx->w->bm.p, eq_data);
     } else if (rx->frontend_kind == 1) {
-        uint8_t *soft_out = (rx->record_soft || rx->viterbi_kind == 0) ? rx->soft.p : nullptr;
-        hipLaunchKernelGGL(k_data_symbols_lps, dim3((unsigned)((max_sym + 63) / 64)), dim3(64), 0, st, iq, d_descs, rx->info.p, rx->sym2frame.p,
-                           rx->totals.p, rx->hinv.p, soft_out, rx->bm.p, eq_data);
+        uint8_t *soft_out = (rx->record_soft || rx->viterbi_kind == 0) ? rx->w->soft.p : nullptr;
+        hipLaunchKernelGGL(k_data_symbols_lps, dim3((unsigned)((max_sym + 63) / 64)), dim3(64), 0, st, iq, d_descs, rx->w->info.p, rx->w->sym2frame.p,
+                           rx->w->totals.p, rx->w->hinv.p, soft_out, rx->w->bm.p, eq_data);
     } else {
         hipLaunchKernelGGL(k_data_symbols, dim3((unsigned)((max_sym + kSymWaves - 1) / kSymWaves)), dim3(64 * kSymWaves), 0, st, iq, d_descs,
-                           rx->info.p, rx->sym2frame.p, rx->totals.p, rx->hinv.p, rx->soft.p, rx->bm.p, eq_data);
+                           rx->w->info.p, rx->w->sym2frame.p, rx->w->totals.p, rx->w->hinv.p, rx->w->soft.p, rx->w->bm.p, eq_data);
     }
-    HIP_TRY(hipEventRecord(rx->ev[3], st));
-    if (rx->viterbi_kind == 0)
-        hipLaunchKernelGGL(k_viterbi_v1, dim3(nf), dim3(64), 0, st, rx->info.p, nf, rx->soft.p, rx->dec.p, d_psdu, slot_bytes, d_results);
-    else if (rx->viterbi_kind == 1)
-        launch_viterbi_v2(st, rx->info.p, nf, rx->bm.p, rx->dec.p, rx->decoded.p, d_psdu, slot_bytes, d_results, rx->ev[5]);
-    else
-        launch_viterbi_v3(st, rx->info.p, nf, rx->bm.p, rx->dec.p, rx->decoded.p, rx->seg2frame.p, rx->totals.p, rx->tb_state.p, max_segs,
-                          rx->tb_segment, rx->tb_overlap, d_psdu, slot_bytes, d_results, rx->ev[5]);
-    HIP_TRY(hipEventRecord(rx->ev[4], st));
-    if (rx->viterbi_kind == 0) HIP_TRY(hipEventRecord(rx->ev[5], st));
+    HIP_TRY(hipEventRecord(rx->w->ev[3], st));
+    if (piped) {
+        // the previous call's chain-back + finish goes under this call's forward pass
+        if ((rc = flush_pending(rx, rx->w->ev[3]))) return rc;
+        launch_fwd3(st, rx->w->info.p, nf, rx->w->bm.p, rx->w->dec.p);
+        HIP_TRY(hipEventRecord(rx->w->ev[5], st));
+        HIP_TRY(hipEventRecord(rx->w->fwd_done, st));
+        foa_rx::Pending &p = rx->pending;
+        p.valid = true; p.w = rx->w; p.nf = nf; p.S = rx->tb_segment; p.L = rx->tb_overlap; p.max_segs = max_segs; p.slot_bytes = slot_bytes;
+        p.psdu = d_psdu; p.results = d_results;
+    } else {
+        if (rx->viterbi_kind == 0)
+            hipLaunchKernelGGL(k_viterbi_v1, dim3(nf), dim3(64), 0, st, rx->w->info.p, nf, rx->w->soft.p, rx->w->dec.p, d_psdu, slot_bytes, d_results);
+        else if (rx->viterbi_kind == 1)
+            launch_viterbi_v2(st, rx->w->info.p, nf, rx->w->bm.p, rx->w->dec.p, rx->w->decoded.p, d_psdu, slot_bytes, d_results, rx->w->ev[5]);
+        else
+            launch_viterbi_v3(st, rx->w->info.p, nf, rx->w->bm.p, rx->w->dec.p, rx->w->decoded.p, rx->w->seg2frame.p, rx->w->totals.p, rx->w->tb_state.p,
+                              max_segs, rx->tb_segment, rx->tb_overlap, d_psdu, slot_bytes, d_results, rx->w->ev[5]);
+        if (rx->viterbi_kind == 0) HIP_TRY(hipEventRecord(rx->w->ev[5], st));
+        HIP_TRY(hipEventRecord(rx->w->ev[6], st));                     // (not separable from the forward pass on one stream)
+        HIP_TRY(hipEventRecord(rx->w->ev[4], st));
+        HIP_TRY(hipEventRecord(rx->w->done, st));
+    }
     HIP_TRY(hipGetLastError());
-    rx->have_timing = true;
+    rx->w->used = true;
+    rx->w->have_timing = true;
+    rx->w->piped = piped;
     rx->last_frames = n_frames;
     return FOA_OK;
 }
@@ -372,23 +467,39 @@ int foa_rx_decode_frames_host(foa_rx *rx, const float *iq, size_t n_samples, con
     rc = foa_rx_decode_frames_dev(rx, (const float *)(b + o_iq), n_samples, (const foa_frame_desc *)(b + o_desc), (const int64_t *)(b + o_end),
                                   n_frames, b + o_psdu, slot_bytes, (foa_frame_result *)(b + o_res));
     if (rc) return rc;
+    if ((rc = flush_pending(rx, nullptr))) return rc;                   // the finish runs on the second stream
+    HIP_TRY(hipStreamWaitEvent(st, rx->w->done, 0));
     HIP_TRY(hipMemcpyAsync(psdu, b + o_psdu, n_frames * slot_bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(results, b + o_res, n_frames * sizeof(foa_frame_result), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return FOA_OK;
 }
 
+static int kernel_ms_of(foa_rx *rx, WorkSet *w, float out_ms[6])
+{
+    if (!w || !w->have_timing) return fail(FOA_E_STATE, "no such decode call has been made on this handle");
+    if (rx->pending.valid && rx->pending.w == w) { int rc = flush_pending(rx, nullptr); if (rc) return rc; }
+    HIP_TRY(hipEventSynchronize(w->ev[4]));
+    HIP_TRY(hipEventSynchronize(w->ev[5]));
+    for (int i = 0; i < 3; i++) HIP_TRY(hipEventElapsedTime(&out_ms[i], w->ev[i], w->ev[i + 1]));
+    HIP_TRY(hipEventElapsedTime(&out_ms[3], w->ev[3], w->ev[5]));      // forward pass (or the fused v1 kernel)
+    // chain-back + descramble + CRC (0 for v1); on the pipelined path from where the second stream starts on it
+    if (w->piped) HIP_TRY(hipEventElapsedTime(&out_ms[4], w->ev[6], w->ev[4]));
+    else HIP_TRY(hipEventElapsedTime(&out_ms[4], w->ev[5], w->ev[4]));
+    HIP_TRY(hipEventElapsedTime(&out_ms[5], w->ev[0], w->ev[4]));      // whole call, first kernel to last (includes the deferral)
+    return FOA_OK;
+}
+
 int foa_rx_last_kernel_ms(foa_rx *rx, float out_ms[6])
 {
     if (!rx || !out_ms) return fail(FOA_E_INVALID, "NULL argument");
-    if (!rx->have_timing) return fail(FOA_E_STATE, "no decode call has been made on this handle");
-    HIP_TRY(hipEventSynchronize(rx->ev[4]));
-    HIP_TRY(hipEventSynchronize(rx->ev[5]));
-    for (int i = 0; i < 3; i++) HIP_TRY(hipEventElapsedTime(&out_ms[i], rx->ev[i], rx->ev[i + 1]));
-    HIP_TRY(hipEventElapsedTime(&out_ms[3], rx->ev[3], rx->ev[5]));      // forward pass (or the fused v1 kernel)
-    HIP_TRY(hipEventElapsedTime(&out_ms[4], rx->ev[5], rx->ev[4]));      // chain-back + descramble + CRC (0 for v1)
-    HIP_TRY(hipEventElapsedTime(&out_ms[5], rx->ev[0], rx->ev[4]));
-    return FOA_OK;
+    return kernel_ms_of(rx, rx->w, out_ms);
+}
+
+int foa_rx_prev_kernel_ms(foa_rx *rx, float out_ms[6])
+{
+    if (!rx || !out_ms) return fail(FOA_E_INVALID, "NULL argument");
+    return kernel_ms_of(rx, rx->prev, out_ms);
 }
 
 int foa_rx_get_taps(foa_rx *rx, size_t n_frames, double *hinv, double *eq, size_t eq_cap, uint64_t *eq_off, uint8_t *soft, size_t soft_cap,
@@ -399,10 +510,10 @@ int foa_rx_get_taps(foa_rx *rx, size_t n_frames, double *hinv, double *eq, size_
     if (eq && !rx->record_eq) return fail(FOA_E_STATE, "set option record_eq=1 before the decode call to get eq");
     if (soft && !rx->record_soft && rx->viterbi_kind != 0 && rx->frontend_kind != 0) return fail(FOA_E_STATE, "set option record_soft=1 before the decode call to get soft bytes");
     HIP_TRY(hipSetDevice(rx->device));
-    HIP_TRY(hipStreamSynchronize(rx->stream));
+    { int rc0 = drain(rx); if (rc0) return rc0; }
     std::vector<FrameInfo> info(n_frames);
-    HIP_TRY(hipMemcpy(info.data(), rx->info.p, n_frames * sizeof(FrameInfo), hipMemcpyDeviceToHost));
-    if (hinv) HIP_TRY(hipMemcpy(hinv, rx->hinv.p, n_frames * 64 * sizeof(double2), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(info.data(), rx->w->info.p, n_frames * sizeof(FrameInfo), hipMemcpyDeviceToHost));
+    if (hinv) HIP_TRY(hipMemcpy(hinv, rx->w->hinv.p, n_frames * 64 * sizeof(double2), hipMemcpyDeviceToHost));
     DeviceTables tab;
     build_tables(&tab);
     size_t eo = 0, so = 0;
@@ -414,14 +525,14 @@ int foa_rx_get_taps(foa_rx *rx, size_t n_frames, double *hinv, double *eq, size_
         const int nsym = fi.nsym > 0 ? fi.nsym : 0;
         if (eq) {
             if (eo + (size_t)(1 + nsym) * 48 > eq_cap) return fail(FOA_E_INVALID, "eq_cap too small");
-            HIP_TRY(hipMemcpy(eq + 2 * eo, rx->eq_sig.p + f * 48, 48 * sizeof(double2), hipMemcpyDeviceToHost));
-            if (nsym) HIP_TRY(hipMemcpy(eq + 2 * (eo + 48), rx->eq_data.p + (size_t)fi.sym_off * 48, (size_t)nsym * 48 * sizeof(double2), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(eq + 2 * eo, rx->w->eq_sig.p + f * 48, 48 * sizeof(double2), hipMemcpyDeviceToHost));
+            if (nsym) HIP_TRY(hipMemcpy(eq + 2 * (eo + 48), rx->w->eq_data.p + (size_t)fi.sym_off * 48, (size_t)nsym * 48 * sizeof(double2), hipMemcpyDeviceToHost));
         }
         eo += (size_t)(1 + nsym) * 48;
         const size_t sb = nsym ? (size_t)2 * fi.nsteps : 0;
         if (soft && sb) {
             if (so + sb > soft_cap) return fail(FOA_E_INVALID, "soft_cap too small");
-            HIP_TRY(hipMemcpy(soft + so, rx->soft.p + fi.soft_off, sb, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(soft + so, rx->w->soft.p + fi.soft_off, sb, hipMemcpyDeviceToHost));
         }
         so += sb;
     }
@@ -435,13 +546,13 @@ int foa_rx_get_decisions(foa_rx *rx, size_t frame, uint64_t *out, size_t cap, si
     if (!rx || !out || !n_steps) return fail(FOA_E_INVALID, "NULL argument");
     if (frame >= rx->last_frames) return fail(FOA_E_STATE, "frame index beyond the last decode call");
     HIP_TRY(hipSetDevice(rx->device));
-    HIP_TRY(hipStreamSynchronize(rx->stream));
+    { int rc0 = drain(rx); if (rc0) return rc0; }
     FrameInfo fi;
-    HIP_TRY(hipMemcpy(&fi, rx->info.p + frame, sizeof fi, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&fi, rx->w->info.p + frame, sizeof fi, hipMemcpyDeviceToHost));
     const size_t n = fi.nsym > 0 ? (size_t)fi.nsteps : 0;
     *n_steps = n;
     if (n > cap) return fail(FOA_E_INVALID, "cap too small (%zu steps)", n);
-    if (n) HIP_TRY(hipMemcpy(out, rx->dec.p + fi.dec_off, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (n) HIP_TRY(hipMemcpy(out, rx->w->dec.p + fi.dec_off, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return FOA_OK;
 }
 
@@ -556,10 +667,10 @@ int foa_conv_decode(foa_rx *rx, const uint8_t *symbols, uint8_t *data, int data_
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     int rc = rx->scratch.ensure(up(sym_bytes) + up(out_bytes));
     if (rc) return rc;
-    if ((rc = rx->dec.ensure(n_blocks * stride))) return rc;
+    if ((rc = rx->w->dec.ensure(n_blocks * stride))) return rc;
     uint8_t *d_sym = rx->scratch.p, *d_out = rx->scratch.p + up(sym_bytes);
     HIP_TRY(hipMemcpyAsync(d_sym, symbols, sym_bytes, hipMemcpyHostToDevice, rx->stream));
-    hipLaunchKernelGGL(k_conv_decode, dim3((unsigned)n_blocks), dim3(64), 0, rx->stream, d_sym, d_out, data_bits, (int)n_blocks, rx->dec.p, (int)stride);
+    hipLaunchKernelGGL(k_conv_decode, dim3((unsigned)n_blocks), dim3(64), 0, rx->stream, d_sym, d_out, data_bits, (int)n_blocks, rx->w->dec.p, (int)stride);
     HIP_TRY(hipMemcpyAsync(data, d_out, out_bytes, hipMemcpyDeviceToHost, rx->stream));
     HIP_TRY(hipStreamSynchronize(rx->stream));
     return FOA_OK;
@@ -645,6 +756,7 @@ int foa_decode_data_f64(foa_rx *rx, const double *carriers, const uint64_t *carr
     if (!rx || !carriers || !carrier_off || !results || !psdu) return fail(FOA_E_INVALID, "NULL argument");
     if (n_frames == 0) return FOA_OK;
     HIP_TRY(hipSetDevice(rx->device));
+    { int rc0 = drain(rx); if (rc0) return rc0; }                     // this entry point reuses the work set of the batch calls
     DeviceTables tab;
     build_tables(&tab);
     // frame records and offsets on the host (what k_header + k_scan produce in the fused path)
@@ -671,9 +783,9 @@ int foa_decode_data_f64(foa_rx *rx, const double *carriers, const uint64_t *carr
     coff[n_frames] = (int64_t)carrier_off[n_frames];
     const size_t n_sym = sym2frame.size(), n_car = (size_t)carrier_off[n_frames];
     int rc;
-    if ((rc = rx->info.ensure(n_frames + 1)) || (rc = rx->sym2frame.ensure(n_sym + 1)) || (rc = rx->soft.ensure((size_t)soft_off + 256)) ||
-        (rc = rx->dec.ensure((size_t)dec_off + 64)) || (rc = rx->bm.ensure((size_t)dec_off + 64)) || (rc = rx->decoded.ensure((size_t)dec_off + 64)) ||
-        (rc = rx->seg2frame.ensure(seg2frame.size() + 64)) || (rc = rx->tb_state.ensure(seg2frame.size() + 64)) || (rc = rx->totals.ensure(8)))
+    if ((rc = rx->w->info.ensure(n_frames + 1)) || (rc = rx->w->sym2frame.ensure(n_sym + 1)) || (rc = rx->w->soft.ensure((size_t)soft_off + 256)) ||
+        (rc = rx->w->dec.ensure((size_t)dec_off + 64)) || (rc = rx->w->bm.ensure((size_t)dec_off + 64)) || (rc = rx->w->decoded.ensure((size_t)dec_off + 64)) ||
+        (rc = rx->w->seg2frame.ensure(seg2frame.size() + 64)) || (rc = rx->w->tb_state.ensure(seg2frame.size() + 64)) || (rc = rx->w->totals.ensure(8)))
         return rc;
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t c_b = n_car * sizeof(double2), o_b = (n_frames + 1) * sizeof(int64_t), p_b = n_frames * slot_bytes, r_b = n_frames * sizeof(foa_frame_result);
@@ -684,20 +796,20 @@ int foa_decode_data_f64(foa_rx *rx, const double *carriers, const uint64_t *carr
     hipStream_t st = rx->stream;
     HIP_TRY(hipMemcpyAsync(b, carriers, c_b, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(b + up(c_b), coff.data(), o_b, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(rx->info.p, info.data(), n_frames * sizeof(FrameInfo), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(rx->sym2frame.p, sym2frame.data(), n_sym * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(rx->w->info.p, info.data(), n_frames * sizeof(FrameInfo), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(rx->w->sym2frame.p, sym2frame.data(), n_sym * sizeof(int32_t), hipMemcpyHostToDevice, st));
     const int64_t n_segs = (int64_t)seg2frame.size();
-    HIP_TRY(hipMemcpyAsync(rx->seg2frame.p, seg2frame.data(), seg2frame.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(rx->totals.p + 4, &n_segs, sizeof n_segs, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(rx->w->seg2frame.p, seg2frame.data(), seg2frame.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(rx->w->totals.p + 4, &n_segs, sizeof n_segs, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(d_psdu, 0, p_b, st));
     hipLaunchKernelGGL(k_stage_demap, dim3((unsigned)((n_sym + kSymWaves - 1) / kSymWaves)), dim3(64 * kSymWaves), 0, st, (const double2 *)b,
-                       (const int64_t *)(b + up(c_b)), rx->info.p, rx->sym2frame.p, (int)n_sym, rx->soft.p, rx->bm.p);
+                       (const int64_t *)(b + up(c_b)), rx->w->info.p, rx->w->sym2frame.p, (int)n_sym, rx->w->soft.p, rx->w->bm.p);
     if (rx->viterbi_kind == 0)
-        hipLaunchKernelGGL(k_viterbi_v1, dim3((unsigned)n_frames), dim3(64), 0, st, rx->info.p, (int)n_frames, rx->soft.p, rx->dec.p, d_psdu, slot_bytes, d_res);
+        hipLaunchKernelGGL(k_viterbi_v1, dim3((unsigned)n_frames), dim3(64), 0, st, rx->w->info.p, (int)n_frames, rx->w->soft.p, rx->w->dec.p, d_psdu, slot_bytes, d_res);
     else if (rx->viterbi_kind == 1)
-        launch_viterbi_v2(st, rx->info.p, (int)n_frames, rx->bm.p, rx->dec.p, rx->decoded.p, d_psdu, slot_bytes, d_res, nullptr);
+        launch_viterbi_v2(st, rx->w->info.p, (int)n_frames, rx->w->bm.p, rx->w->dec.p, rx->w->decoded.p, d_psdu, slot_bytes, d_res, nullptr);
     else
-        launch_viterbi_v3(st, rx->info.p, (int)n_frames, rx->bm.p, rx->dec.p, rx->decoded.p, rx->seg2frame.p, rx->totals.p, rx->tb_state.p,
+        launch_viterbi_v3(st, rx->w->info.p, (int)n_frames, rx->w->bm.p, rx->w->dec.p, rx->w->decoded.p, rx->w->seg2frame.p, rx->w->totals.p, rx->w->tb_state.p,
                           seg2frame.size(), rx->tb_segment, rx->tb_overlap, d_psdu, slot_bytes, d_res, nullptr);
     HIP_TRY(hipMemcpyAsync(psdu, d_psdu, p_b, hipMemcpyDeviceToHost, st));
     std::vector<foa_frame_result> out(n_frames);

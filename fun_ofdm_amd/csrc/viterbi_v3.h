@@ -411,14 +411,26 @@ __global__ __launch_bounds__(64) void k_tb_finish(const FrameInfo *__restrict__ 
     finish_crc_psdu(tabs, fwave, fi, live, f, n_frames, decoded, psdu, slot_bytes, results);
 }
 
+inline void launch_fwd3(hipStream_t st, const FrameInfo *info, int nf, const uint32_t *bm, uint64_t *dec)
+{
+    hipLaunchKernelGGL(k_viterbi_fwd3, dim3(((nf + 1) / 2 + kFwdWaves - 1) / kFwdWaves), dim3(64 * kFwdWaves), 0, st, info, nf, bm, dec);
+}
+
+inline void launch_finish3(hipStream_t st, const FrameInfo *info, int nf, const uint64_t *dec, uint32_t *decoded, const int32_t *seg2frame,
+                           const int64_t *totals, uint16_t *tb_state, size_t max_segs, int S, int L, uint8_t *psdu, size_t slot_bytes,
+                           foa_frame_result *results)
+{
+    hipLaunchKernelGGL(k_tb_walk, dim3((unsigned)((max_segs + 63) / 64)), dim3(64), 0, st, info, seg2frame, totals, dec, decoded, tb_state, S, L);
+    hipLaunchKernelGGL(k_tb_finish, dim3((nf + 63) / 64), dim3(64), 0, st, info, nf, dec, decoded, tb_state, S, psdu, slot_bytes, results);
+}
+
 inline void launch_viterbi_v3(hipStream_t st, const FrameInfo *info, int nf, const uint32_t *bm, uint64_t *dec, uint32_t *decoded,
                               const int32_t *seg2frame, const int64_t *totals, uint16_t *tb_state, size_t max_segs, int S, int L,
                               uint8_t *psdu, size_t slot_bytes, foa_frame_result *results, hipEvent_t between)
 {
-    hipLaunchKernelGGL(k_viterbi_fwd3, dim3(((nf + 1) / 2 + kFwdWaves - 1) / kFwdWaves), dim3(64 * kFwdWaves), 0, st, info, nf, bm, dec);
+    launch_fwd3(st, info, nf, bm, dec);
     if (between) (void)hipEventRecord(between, st);
-    hipLaunchKernelGGL(k_tb_walk, dim3((unsigned)((max_segs + 63) / 64)), dim3(64), 0, st, info, seg2frame, totals, dec, decoded, tb_state, S, L);
-    hipLaunchKernelGGL(k_tb_finish, dim3((nf + 63) / 64), dim3(64), 0, st, info, nf, dec, decoded, tb_state, S, psdu, slot_bytes, results);
+    launch_finish3(st, info, nf, dec, decoded, seg2frame, totals, tb_state, max_segs, S, L, psdu, slot_bytes, results);
 }
 
 }  // namespace foa

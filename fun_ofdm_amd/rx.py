@@ -109,10 +109,11 @@ class Receiver:
         self.sync()
         return iq
 
-    def kernel_ms(self):
-        """HIP-event durations of the last decode in ms: header, scan, symbols, viterbi_fwd, viterbi_finish, total."""
+    def kernel_ms(self, previous=False):
+        """HIP-event durations of the last decode (or, previous=True, of the one before it, which does not stall a
+        pipelined sequence of calls) in ms: header, scan, symbols, viterbi_fwd, viterbi_finish, total."""
         out = (C.c_float * 6)()
-        check(lib().foa_rx_last_kernel_ms(self._h, out))
+        check((lib().foa_rx_prev_kernel_ms if previous else lib().foa_rx_last_kernel_ms)(self._h, out))
         return dict(zip(("header", "scan", "symbols", "viterbi_fwd", "viterbi_finish", "total"), (float(x) for x in out)))
 
     def taps(self, n_frames, eq=False, soft=True, cap_symbols=None):

@@ -90,6 +90,9 @@ int foa_rx_reserve(foa_rx *rx, size_t n_samples, size_t n_frames);
  *   "tb_segment"  viterbi 2: data steps per chain-back segment, a multiple of 96 in [96, 3072] (default 960)
  *   "tb_overlap"  viterbi 2: run-in steps above a segment, a multiple of 96 in [0, 3072] (default 96); any value gives
  *                 the same result as the serial chain-back, small values cost re-walks
+ *   "pipeline"    viterbi 2: run chain-back + finish on a second stream with a second work set, so that they overlap the
+ *                 front end and forward pass of the next decode call (default 1; results and ordering are unchanged,
+ *                 foa_rx_sync waits for both streams)
  *   "frontend"    0 = one wave per data symbol; 1 = one lane per data symbol (default); 2 = four lanes per data symbol
  *   "record_soft" keep the depunctured soft bytes for foa_rx_get_taps (default 1; 0 saves their HBM writes)
  *   "record_eq"   keep the equalised carriers for foa_rx_get_taps (default 0) */
@@ -126,6 +129,9 @@ void *foa_rx_stream(foa_rx *rx);
  * stream: [0] header (LTS+SIGNAL), [1] offset scan, [2] data-symbol FFT/equalise/demap,
  * [3] Viterbi forward pass, [4] chain-back + descramble + CRC, [5] whole call.  Synchronises. */
 int foa_rx_last_kernel_ms(foa_rx *rx, float out_ms[6]);
+/* The same for the decode call before the most recent one: that call is complete (or nearly) while the most recent one
+ * may still be running, so reading it does not stall a pipelined sequence of calls. */
+int foa_rx_prev_kernel_ms(foa_rx *rx, float out_ms[6]);
 
 /* Intermediates of the most recent decode call, copied to HOST memory (parity tests).
  *   hinv    64 complex doubles (re,im) per frame: channel_est's m_chan_est (channel_est.cpp:53-58)
