@@ -193,18 +193,33 @@ def main():
     d_which = torch.from_numpy(which).to(dev)
     gathered = [None]
 
+    def gather_now():
+        # slots in local frame order (a frame the detector missed leaves a zero slot, like a CRC failure)
+        local = torch.zeros((args.frames, PAYLOAD), dtype=torch.uint8, device=dev)
+        local.index_copy_(0, d_which, d_psdu.index_select(0, d_real))
+        gathered[0] = shard.gather_psdus(local.to(cdev), n_global, rank, world)
+
+    in_flight = [False]
+
     def step():
+        # Queue this step's front end and forward pass; the previous step's chain-back + finish runs under it on the
+        # library's second stream.  With several ranks the previous step's PSDUs are gathered meanwhile (they are final
+        # once wait_previous() returns, and this step's finish is not queued before the next call or sync()).
         rx.decode_frames_dev(d_iq, d_desc, d_ends, d_psdu, d_res)
-        if world > 1:
-            rx.sync()                                    # the PSDUs must exist before the collective reads them
-            # slots in local frame order (a frame the detector missed leaves a zero slot, like a CRC failure)
-            local = torch.zeros((args.frames, PAYLOAD), dtype=torch.uint8, device=dev)
-            local.index_copy_(0, d_which, d_psdu.index_select(0, d_real))
-            gathered[0] = shard.gather_psdus(local.to(cdev), n_global, rank, world)
+        if world > 1 and in_flight[0]:
+            rx.wait_previous()
+            gather_now()
+        in_flight[0] = True
+
+    def finish_steps():
+        rx.sync()
+        if world > 1 and in_flight[0]:
+            gather_now()                                 # the last step's PSDUs
+        in_flight[0] = False
 
     for _ in range(args.warmup):
         step()
-    rx.sync()
+    finish_steps()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -215,7 +230,7 @@ def main():
         if args.steps <= 50 and i > 0:                   # per-kernel HIP-event times of the step before: that step is
             for k, v in rx.kernel_ms(previous=True).items():   # complete, so asking does not stall the one just queued
                 kern[k] += v
-    rx.sync()
+    finish_steps()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -289,7 +304,7 @@ def main():
                        "counted_samples": "in-frame only (3520/frame)", "value_all_samples_fed": round(value * PITCH / frame_samples, 1),
                        "x_realtime_20MSps": round(value / 20.0, 1), "psdu_bit_exact": exact, "frames_ok": ok_frames, "frames_found_by_sync_rank0": int(real.size),
                        "alignments_decoded_per_gpu": m, "frontend_dtype": "f64", "viterbi_kernel": args.viterbi, "frontend_kernel": args.frontend,
-                       "steps_pipelined": bool(args.viterbi == 2 and not args.no_pipeline and world == 1),
+                       "steps_pipelined": bool(args.viterbi == 2 and not args.no_pipeline),
                        "sharding": ("global frame i on rank i mod %d, one %s gather of PSDU slots to rank 0 per step" % (world, backend)) if world > 1 else "single GPU"},
         }
         if with_sync:

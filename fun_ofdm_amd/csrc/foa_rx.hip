@@ -362,6 +362,16 @@ int foa_rx_sync(foa_rx *rx)
     return drain(rx);
 }
 
+int foa_rx_wait_previous(foa_rx *rx)
+{
+    if (!rx) return fail(FOA_E_INVALID, "rx is NULL");
+    WorkSet *p = rx->prev;
+    if (!p || !p->used || p == rx->w) return FOA_OK;
+    if (rx->pending.valid && rx->pending.w == p) { int rc = flush_pending(rx, nullptr); if (rc) return rc; }
+    HIP_TRY(hipEventSynchronize(p->done));
+    return FOA_OK;
+}
+
 int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, const foa_frame_desc *d_descs, const int64_t *d_ends,
                              size_t n_frames, uint8_t *d_psdu, size_t slot_bytes, foa_frame_result *d_results)
 {

@@ -109,6 +109,10 @@ class Receiver:
         self.sync()
         return iq
 
+    def wait_previous(self):
+        """Block until the decode call before the most recent one is complete (see foa_rx_wait_previous)."""
+        check(lib().foa_rx_wait_previous(self._h))
+
     def kernel_ms(self, previous=False):
         """HIP-event durations of the last decode (or, previous=True, of the one before it, which does not stall a
         pipelined sequence of calls) in ms: header, scan, symbols, viterbi_fwd, viterbi_finish, total."""

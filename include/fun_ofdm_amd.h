@@ -122,6 +122,9 @@ int foa_rx_decode_frames_host(foa_rx *rx, const float *iq, size_t n_samples, con
 /* Block until everything queued on the handle's stream has finished. */
 int foa_rx_sync(foa_rx *rx);
 
+/* Blocks until the decode call BEFORE the most recent one is complete (its PSDUs and results are final), without
+ * waiting for the most recent one: with option "pipeline" a caller can consume batch k-1 while batch k is in flight. */
+int foa_rx_wait_previous(foa_rx *rx);
 /* The handle's hipStream_t (as void*) so callers can order their own work against it. */
 void *foa_rx_stream(foa_rx *rx);
 

@@ -395,3 +395,40 @@ def test_device_sync_matches_host_sync(rx, po):
         assert np.array_equal(res, ores.view(np.int32).reshape(-1, 4))
         ok = res[:, 0] == 0
         assert np.array_equal(t_psdu.cpu().numpy()[ok], opsdu[ok]) and ok.sum() >= 30
+
+
+def test_pipelined_calls_keep_their_results_apart(rx, po):
+    """Back-to-back decode calls without a sync in between (the finish of call k runs on a second stream under the
+    forward pass of call k+1, on alternating work sets): every call must produce exactly what it produces alone."""
+    import torch
+    dev = torch.device("cuda", 0)
+    _set_viterbi(rx, VITERBI_KINDS[2])
+    rng = np.random.default_rng(31)
+    cases = []
+    for k in range(5):
+        specs = [(int(rng.integers(0, 11)), int(rng.integers(1, 600))) for _ in range(6 + 3 * k)]
+        iq, pays = _make_stream(po, rng, specs, snr_db=24.0)
+        descs = po.find_alignments_f32(iq)
+        ends = _ends(descs, iq.size)
+        cases.append((iq, descs, ends))
+    rx.set_option("pipeline", 0)
+    alone = [rx.decode_frames_host(iq, d, e) for iq, d, e in cases]
+    rx.set_option("pipeline", 1)
+    bufs = []
+    for iq, d, e in cases:
+        t_iq = torch.from_numpy(iq.view(np.float32).reshape(-1, 2)).to(dev)
+        t_d = torch.from_numpy(d.view(np.uint8).copy()).to(dev)
+        t_e = torch.from_numpy(e).to(dev)
+        t_p = torch.zeros((d.size, 4096), dtype=torch.uint8, device=dev)
+        t_r = torch.zeros((d.size, 4), dtype=torch.int32, device=dev)
+        bufs.append((t_iq, t_d, t_e, t_p, t_r))
+    torch.cuda.synchronize()
+    for rep in range(3):                                   # 15 calls in flight order, no sync between them
+        for b in bufs:
+            rx.decode_frames_dev(*b)
+    rx.sync()
+    for (psdu, res), b in zip(alone, bufs):
+        assert np.array_equal(b[4].cpu().numpy(), res.view(np.int32).reshape(-1, 4))
+        assert np.array_equal(b[3].cpu().numpy(), psdu)
+    ms = rx.kernel_ms()
+    assert ms["viterbi_finish"] > 0 and rx.kernel_ms(previous=True)["viterbi_fwd"] > 0
