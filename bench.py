@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--viterbi", type=int, default=2, help="0: lane per state, 1: packed + serial chain-back, 2: packed + segment chain-back")
     ap.add_argument("--tb-segment", type=int, default=0, help="viterbi 2: data steps per chain-back segment (0: library default)")
     ap.add_argument("--tb-overlap", type=int, default=-1, help="viterbi 2: run-in steps of a segment (-1: library default)")
-    ap.add_argument("--frontend", type=int, default=1, help="0: wave-per-symbol kernel, 1: lane-per-symbol kernel")
+    ap.add_argument("--frontend", type=int, default=-1, help="-1: library default, 0: wave-per-symbol, 1: lane-per-symbol, 2: quad-per-symbol kernel")
     ap.add_argument("--tx", choices=("host", "device"), default="host",
                     help="where the synthetic frames are built: numpy on the host (default) or foa_tx_* on the device")
     ap.add_argument("--no-pipeline", action="store_true", help="finish of a step on the same stream as the rest (no overlap with the next step)")

@@ -159,6 +159,7 @@ struct WorkSet {
     DevBuf<double2> eq_sig, eq_data;
     size_t sym_cap = 0, soft_cap = 0, dec_cap = 0;
     hipEvent_t ev[7] = {};       // start, after header, after scan, after symbols, end, after the forward pass, start of the finish
+    WorkSet *before = nullptr;   // the set of the call queued before this one (pipelined path)
     hipEvent_t fwd_done = nullptr, done = nullptr;
     bool used = false, have_timing = false, piped = false;
     void release_all()
@@ -172,13 +173,15 @@ struct foa_rx {
     int device = 0;
     hipStream_t stream = nullptr;      // front end + forward pass (and everything else)
     hipStream_t stream2 = nullptr;     // chain-back + finish of the pipelined path
+    hipStream_t stream3 = nullptr;     // header + scan + front end of the pipelined path
     int viterbi_kind = 2;        // 0: lane per state (viterbi_v1.h), 1: packed, serial chain-back (v2), 2: packed, segment chain-back (v3)
     int tb_segment = 960, tb_overlap = 96;   // v3 chain-back: data steps per segment / run-in steps (multiples of 96)
     bool pipeline = true;        // v3: finish of one call overlaps the next call's front end (two work sets, two streams)
     bool record_eq = false;
     bool record_soft = true;     // keep the depunctured soft bytes (taps, lane-per-state kernel); off = branch metrics only
-    int frontend_kind = 1;       // 1: one lane per symbol (frontend_lps.h), 0: one wave per symbol, 2: four lanes per symbol
-    WorkSet sets[2];
+    int frontend_kind = -1;      // 1: one lane per symbol (frontend_lps.h), 0: one wave per symbol, 2: four lanes per symbol (frontend_q4.h);
+                                 // -1: by context -- 2 when calls are pipelined (128-VGPR waves fit under the forward pass), else 1
+    WorkSet sets[3];
     WorkSet *w = &sets[0];       // the set of the most recent decode call
     WorkSet *prev = nullptr;     // the set of the call before it (kernel times of a call that is certainly complete)
     // Pipelined path: the chain-back + finish of a call is queued (on stream2) only when the NEXT call has queued its
@@ -246,6 +249,7 @@ int drain(foa_rx *rx)
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(rx->stream));
     HIP_TRY(hipStreamSynchronize(rx->stream2));
+    HIP_TRY(hipStreamSynchronize(rx->stream3));
     return FOA_OK;
 }
 
@@ -279,6 +283,7 @@ int foa_rx_create(foa_rx **out, int device)
     rx->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&rx->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&rx->stream2, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&rx->stream3, hipStreamNonBlocking));
     for (auto &ws : rx->sets) {
         for (auto &e : ws.ev) HIP_TRY(hipEventCreate(&e));
         HIP_TRY(hipEventCreateWithFlags(&ws.fwd_done, hipEventDisableTiming));
@@ -306,6 +311,7 @@ void foa_rx_destroy(foa_rx *rx)
     rx->sy_flags.release(); rx->sy_cnt.release(); rx->sy_off.release(); rx->sy_keep.release(); rx->sy_n.release(); rx->sy_x.release(); rx->sy_cand.release();
     if (rx->stream) (void)hipStreamDestroy(rx->stream);
     if (rx->stream2) (void)hipStreamDestroy(rx->stream2);
+    if (rx->stream3) (void)hipStreamDestroy(rx->stream3);
     delete rx;
 }
 
@@ -347,7 +353,7 @@ int foa_rx_set_option(foa_rx *rx, const char *name, int64_t value)
     if (!strcmp(name, "record_eq")) { rx->record_eq = value != 0; return FOA_OK; }
     if (!strcmp(name, "record_soft")) { rx->record_soft = value != 0; return FOA_OK; }
     if (!strcmp(name, "frontend")) {
-        if (value < 0 || value > 2) return fail(FOA_E_INVALID, "frontend must be 0 (wave per symbol), 1 (lane per symbol) or 2 (quad per symbol)");
+        if (value < -1 || value > 2) return fail(FOA_E_INVALID, "frontend must be -1 (by context), 0 (wave per symbol), 1 (lane per symbol) or 2 (quad per symbol)");
         rx->frontend_kind = (int)value;
         return FOA_OK;
     }
@@ -385,11 +391,13 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
     const bool piped = rx->pipeline && rx->viterbi_kind == 2;
     if (!piped) { int rc0 = flush_pending(rx, nullptr); if (rc0) return rc0; }
     rx->prev = rx->w;
-    if (piped) rx->w = rx->w == &rx->sets[0] ? &rx->sets[1] : &rx->sets[0];
+    if (piped) rx->w = &rx->sets[(int)((rx->w - rx->sets) + 1) % 3];     // three sets: front end k+1 | forward pass k | finish k-1
     if (rx->w->used) HIP_TRY(hipEventSynchronize(rx->w->done));      // the call that last used this set is complete
     int rc = workspace(rx, n_samples, n_frames);
     if (rc) return rc;
-    hipStream_t st = rx->stream;
+    // st: header, scan, front end.  Pipelined, that is the third stream, so that they can run under the forward pass of
+    // the call before (still busy on the first stream) wherever registers and LDS allow.
+    hipStream_t st = piped ? rx->stream3 : rx->stream, st_fwd = rx->stream;
     if (!piped && rx->prev->used && rx->prev != rx->w) HIP_TRY(hipStreamWaitEvent(st, rx->prev->done, 0));
     const int nf = (int)n_frames;
     const float2 *iq = (const float2 *)d_iq;
@@ -413,11 +421,12 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
     HIP_TRY(hipEventRecord(rx->w->ev[2], st));
     // upper bound on data symbols in n_samples samples; waves beyond the real total exit at once
     const size_t max_sym = rx->w->sym_cap;
-    if (rx->frontend_kind == 2) {
+    const int frontend = rx->frontend_kind >= 0 ? rx->frontend_kind : (piped ? 2 : 1);
+    if (frontend == 2) {
         uint8_t *soft_out = (rx->record_soft || rx->viterbi_kind == 0) ? rx->w->soft.p : nullptr;
         hipLaunchKernelGGL(k_data_symbols_q4, dim3((unsigned)((max_sym + 16 * kQ4Waves - 1) / (16 * kQ4Waves))), dim3(64 * kQ4Waves), 0, st, iq,
                            d_descs, rx->w->info.p, rx->w->sym2frame.p, rx->w->totals.p, rx->w->hinv.p, soft_out, rx->w->bm.p, eq_data);
-    } else if (rx->frontend_kind == 1) {
+    } else if (frontend == 1) {
         uint8_t *soft_out = (rx->record_soft || rx->viterbi_kind == 0) ? rx->w->soft.p : nullptr;
         hipLaunchKernelGGL(k_data_symbols_lps, dim3((unsigned)((max_sym + 63) / 64)), dim3(64), 0, st, iq, d_descs, rx->w->info.p, rx->w->sym2frame.p,
                            rx->w->totals.p, rx->w->hinv.p, soft_out, rx->w->bm.p, eq_data);
@@ -429,9 +438,10 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
     if (piped) {
         // the previous call's chain-back + finish goes under this call's forward pass
         if ((rc = flush_pending(rx, rx->w->ev[3]))) return rc;
-        launch_fwd3(st, rx->w->info.p, nf, rx->w->bm.p, rx->w->dec.p);
-        HIP_TRY(hipEventRecord(rx->w->ev[5], st));
-        HIP_TRY(hipEventRecord(rx->w->fwd_done, st));
+        HIP_TRY(hipStreamWaitEvent(st_fwd, rx->w->ev[3], 0));
+        launch_fwd3(st_fwd, rx->w->info.p, nf, rx->w->bm.p, rx->w->dec.p);
+        HIP_TRY(hipEventRecord(rx->w->ev[5], st_fwd));
+        HIP_TRY(hipEventRecord(rx->w->fwd_done, st_fwd));
         foa_rx::Pending &p = rx->pending;
         p.valid = true; p.w = rx->w; p.nf = nf; p.S = rx->tb_segment; p.L = rx->tb_overlap; p.max_segs = max_segs; p.slot_bytes = slot_bytes;
         p.psdu = d_psdu; p.results = d_results;
@@ -452,6 +462,7 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
     rx->w->used = true;
     rx->w->have_timing = true;
     rx->w->piped = piped;
+    rx->w->before = piped ? rx->prev : nullptr;
     rx->last_frames = n_frames;
     return FOA_OK;
 }
@@ -469,7 +480,7 @@ int foa_rx_decode_frames_host(foa_rx *rx, const float *iq, size_t n_samples, con
     int rc = rx->scratch.ensure(total);
     if (rc) return rc;
     uint8_t *b = rx->scratch.p;
-    hipStream_t st = rx->stream;
+    hipStream_t st = (rx->pipeline && rx->viterbi_kind == 2) ? rx->stream3 : rx->stream;      // the stream the front end will run on
     HIP_TRY(hipMemcpyAsync(b + o_iq, iq, n_samples * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(b + o_desc, descs, n_frames * sizeof(foa_frame_desc), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(b + o_end, ends, n_frames * 8, hipMemcpyHostToDevice, st));
@@ -492,7 +503,14 @@ static int kernel_ms_of(foa_rx *rx, WorkSet *w, float out_ms[6])
     HIP_TRY(hipEventSynchronize(w->ev[4]));
     HIP_TRY(hipEventSynchronize(w->ev[5]));
     for (int i = 0; i < 3; i++) HIP_TRY(hipEventElapsedTime(&out_ms[i], w->ev[i], w->ev[i + 1]));
-    HIP_TRY(hipEventElapsedTime(&out_ms[3], w->ev[3], w->ev[5]));      // forward pass (or the fused v1 kernel)
+    // forward pass (or the fused v1 kernel).  Pipelined, the kernel starts when BOTH its front end and the previous call's
+    // forward pass (same stream) are done, so its duration is the shorter of the two intervals -- an extra event in front of
+    // it would be exact too, but costs the stream 1-3 % (measured)
+    HIP_TRY(hipEventElapsedTime(&out_ms[3], w->ev[3], w->ev[5]));
+    if (w->piped && w->before && w->before->piped && w->before->have_timing && hipEventQuery(w->before->ev[5]) == hipSuccess) {
+        float since_prev = 0.f;
+        if (hipEventElapsedTime(&since_prev, w->before->ev[5], w->ev[5]) == hipSuccess && since_prev > 0.f && since_prev < out_ms[3]) out_ms[3] = since_prev;
+    }
     // chain-back + descramble + CRC (0 for v1); on the pipelined path from where the second stream starts on it
     if (w->piped) HIP_TRY(hipEventElapsedTime(&out_ms[4], w->ev[6], w->ev[4]));
     else HIP_TRY(hipEventElapsedTime(&out_ms[4], w->ev[5], w->ev[4]));

@@ -93,7 +93,9 @@ int foa_rx_reserve(foa_rx *rx, size_t n_samples, size_t n_frames);
  *   "pipeline"    viterbi 2: run chain-back + finish on a second stream with a second work set, so that they overlap the
  *                 front end and forward pass of the next decode call (default 1; results and ordering are unchanged,
  *                 foa_rx_sync waits for both streams)
- *   "frontend"    0 = one wave per data symbol; 1 = one lane per data symbol (default); 2 = four lanes per data symbol
+ *   "frontend"    0 = one wave per data symbol; 1 = one lane per data symbol; 2 = four lanes per data symbol;
+ *                 -1 (default) = 2 when calls are pipelined (its 128-VGPR waves run under the previous call's forward
+ *                 pass), else 1 (fastest on its own)
  *   "record_soft" keep the depunctured soft bytes for foa_rx_get_taps (default 1; 0 saves their HBM writes)
  *   "record_eq"   keep the equalised carriers for foa_rx_get_taps (default 0) */
 int foa_rx_set_option(foa_rx *rx, const char *name, int64_t value);

@@ -195,7 +195,7 @@ def test_frontends_vs_oracle(rx, po, frontend):
             for k in range(eq.shape[0]):
                 assert _rel(eq[k], want[k]) < REL_TOL, (f, k)
     finally:
-        rx.set_option("frontend", 1)
+        rx.set_option("frontend", -1)
         rx.set_option("record_eq", 0)
 
 
