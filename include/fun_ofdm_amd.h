@@ -90,9 +90,11 @@ int foa_rx_reserve(foa_rx *rx, size_t n_samples, size_t n_frames);
  *   "tb_segment"  viterbi 2: data steps per chain-back segment, a multiple of 96 in [96, 3072] (default 960)
  *   "tb_overlap"  viterbi 2: run-in steps above a segment, a multiple of 96 in [0, 3072] (default 96); any value gives
  *                 the same result as the serial chain-back, small values cost re-walks
- *   "pipeline"    viterbi 2: run chain-back + finish on a second stream with a second work set, so that they overlap the
- *                 front end and forward pass of the next decode call (default 1; results and ordering are unchanged,
- *                 foa_rx_sync waits for both streams)
+ *   "pipeline"    viterbi 2: consecutive decode calls form a three-stage pipeline (front end | forward pass | chain-back
+ *                 and finish) over three streams and three work sets (default 1).  Results and their order are unchanged;
+ *                 the outputs of a call are final after foa_rx_sync (or, for the call before the most recent one, after
+ *                 foa_rx_wait_previous), and the INPUTS of a call must be complete when it is made and stay untouched
+ *                 until then.  0 = every call runs start to end on the handle's stream.
  *   "frontend"    0 = one wave per data symbol; 1 = one lane per data symbol; 2 = four lanes per data symbol;
  *                 -1 (default) = 2 when calls are pipelined (its 128-VGPR waves run under the previous call's forward
  *                 pass), else 1 (fastest on its own)
@@ -101,8 +103,8 @@ int foa_rx_reserve(foa_rx *rx, size_t n_samples, size_t n_frames);
 int foa_rx_set_option(foa_rx *rx, const char *name, int64_t value);
 
 /*
- * Batch decode with DEVICE pointers; asynchronous on the handle's stream (call foa_rx_sync or read
- * results after your own synchronisation).  Replaces the per-frame work of fft_symbols, channel_est,
+ * Batch decode with DEVICE pointers; asynchronous (call foa_rx_sync before reading the outputs; with option
+ * "pipeline" = 0 the work is on the handle's stream alone and may be ordered against foa_rx_stream).  Replaces the per-frame work of fft_symbols, channel_est,
  * phase_tracker and frame_decoder (files and lines above) for n_frames alignments.
  *   d_iq       n_samples interleaved (re,im) float pairs: the raw stream handed to process_samples,
  *              before timing_sync's rotation (the kernel applies it from the descriptor)
