@@ -432,3 +432,34 @@ def test_pipelined_calls_keep_their_results_apart(rx, po):
         assert np.array_equal(b[3].cpu().numpy(), psdu)
     ms = rx.kernel_ms()
     assert ms["viterbi_finish"] > 0 and rx.kernel_ms(previous=True)["viterbi_fwd"] > 0
+
+
+@pytest.mark.parametrize("seed", [101, 102, 103])
+def test_random_batches_vs_oracle(rx, po, seed):
+    """Randomised batches (rates, lengths incl. 0 and 4095, SNR from hopeless to clean, CFO, gaps, a cut-off last frame),
+    decoded with the defaults (pipelined calls, front end by context) and with short chain-back segments: every alignment
+    must come out exactly as the oracle has it."""
+    rng = np.random.default_rng(seed)
+    for rep in range(3):
+        n = int(rng.integers(20, 60))
+        specs = []
+        for _ in range(n):
+            r = int(rng.integers(0, 11))
+            ln = int(rng.choice([0, 1, 4095, int(rng.integers(2, 400)), int(rng.integers(400, 2000))], p=[0.05, 0.05, 0.03, 0.6, 0.27]))
+            specs.append((r, ln))
+        snr = float(rng.choice([6.0, 14.0, 20.0, 27.0]))
+        iq, pays = _make_stream(po, rng, specs, snr_db=snr, gap=(0, 700), cfo_hz=float(rng.choice([0.0, 2000.0, 4500.0])))
+        if rep == 2:
+            iq = iq[:iq.size - int(rng.integers(500, 3000))]              # the stream ends inside the last frame
+        descs = po.find_alignments_f32(iq)
+        if descs.size == 0:
+            continue
+        ends = _ends(descs, iq.size)
+        opsdu, ores = po.decode_batch_f32(iq, descs, ends, threads=4)
+        for kind in (VITERBI_KINDS[2], (2, 96, 96), VITERBI_KINDS[1]):
+            _set_viterbi(rx, kind)
+            psdu, res = rx.decode_frames_host(iq, descs, ends)
+            assert np.array_equal(res.view(np.int32), ores.view(np.int32)), (seed, rep, kind, snr)
+            ok = res["status"] == 0
+            assert np.array_equal(psdu[ok], opsdu[ok]), (seed, rep, kind)
+    _set_viterbi(rx, VITERBI_KINDS[2])
