@@ -48,13 +48,15 @@ class Receiver:
         check(lib().foa_rx_sync(self._h))
 
     # ---- batch decode, host buffers -------------------------------------------------------------
-    def decode_frames_host(self, iq, descs, ends, slot_bytes=4096):
-        """iq: complex64[n]; descs: frame_desc_dtype[m]; ends: int64[m] -> (psdu uint8[m, slot], results[m])."""
+    def decode_frames_host(self, iq, descs, ends, slot_bytes=4096, psdu_out=None):
+        """iq: complex64[n]; descs: frame_desc_dtype[m]; ends: int64[m] -> (psdu uint8[m, slot], results[m]).
+        psdu_out: optional preallocated uint8[m, slot] to receive the PSDUs."""
         iq = np.ascontiguousarray(iq, np.complex64)
         descs = np.ascontiguousarray(descs, frame_desc_dtype)
         ends = np.ascontiguousarray(ends, np.int64)
         m = descs.size
-        psdu = np.zeros((m, slot_bytes), np.uint8)
+        psdu = np.zeros((m, slot_bytes), np.uint8) if psdu_out is None else psdu_out
+        assert psdu.shape == (m, slot_bytes) and psdu.dtype == np.uint8 and psdu.flags.c_contiguous
         res = np.zeros(m, frame_result_dtype)
         check(lib().foa_rx_decode_frames_host(self._h, _vp(iq), iq.size, _vp(descs), _vp(ends), m, _vp(psdu), slot_bytes, _vp(res)))
         return psdu, res
