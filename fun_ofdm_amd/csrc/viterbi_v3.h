@@ -106,13 +106,15 @@ __device__ __forceinline__ uint32_t fwd3_step(uint32_t M, const uint2 w, const F
     if (__builtin_expect(over != 0u, 0)) {      // cold: keeps the common path free of taken branches
         // the amount is wave-uniform: subtract the bias on the scalar side so the vector side is one v_sub
         if (over & 0x100u) {
+            const uint32_t mn = wave_min_u32(Mn & 0xFFFFu);
             uint32_t adj;
-            asm("s_sub_u32 %0, %1, %2" : "=s"(adj) : "s"(wave_min_u32(Mn & 0xFFFFu)), "s"(kBias) : "scc");
+            asm("s_sub_u32 %0, %1, %2" : "=s"(adj) : "s"(mn), "s"(kBias) : "scc");
             Mn -= adj;
         }
         if (over >> 16) {
+            const uint32_t mn = wave_min_u32(Mn >> 16);
             uint32_t adj;
-            asm("s_sub_u32 %0, %1, %2\n\ts_lshl_b32 %0, %0, 16" : "=s"(adj) : "s"(wave_min_u32(Mn >> 16)), "s"(kBias) : "scc");
+            asm("s_sub_u32 %0, %1, %2\n\ts_lshl_b32 %0, %0, 16" : "=s"(adj) : "s"(mn), "s"(kBias) : "scc");
             Mn -= adj;
         }
     }
@@ -166,8 +168,9 @@ __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd3(const FrameInfo
     const FrameInfo ia = info[fA];
     FrameInfo ib = ia;
     if (fB < n_frames) ib = info[fB];
-    const int TA = ia.nsym > 0 ? ia.nsteps : 0;
-    const int TB = (fB < n_frames && ib.nsym > 0) ? ib.nsteps : 0;
+    // (wave-uniform by construction; saying so lets the compiler keep the loop control and the test counter on the scalar unit)
+    const int TA = __builtin_amdgcn_readfirstlane(ia.nsym > 0 ? ia.nsteps : 0);
+    const int TB = __builtin_amdgcn_readfirstlane((fB < n_frames && ib.nsym > 0) ? ib.nsteps : 0);
     if (max(TA, TB) == 0) return;
     const int NA = max(TA - 6, 0), NB = max(TB - 6, 0), N = max(NA, NB);             // data steps
     const int NAtop = (NA + kChunk3 - 1) / kChunk3 * kChunk3, NBtop = (NB + kChunk3 - 1) / kChunk3 * kChunk3;
