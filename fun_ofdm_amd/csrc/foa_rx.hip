@@ -169,6 +169,20 @@ struct WorkSet {
     }
 };
 
+// One asynchronous host-pointer call (foa_rx_submit_host): device staging for inputs and outputs, page-locked host mirrors
+// of both (the caller's buffers are free again when submit returns; the results wait in ours until they are collected).
+struct HostJob {
+    bool busy = false;
+    uint64_t ticket = 0;
+    DevBuf<uint8_t> dev;
+    uint8_t *pin = nullptr;          // page-locked host buffer, same layout as dev
+    size_t pin_cap = 0;              // its size
+    size_t total = 0, o_psdu = 0, o_res = 0, n_frames = 0, slot_bytes = 0;      // layout of the call in flight
+    hipEvent_t done = nullptr;
+    bool copy_queued = false;
+};
+constexpr int kMaxJobs = 8;
+
 struct foa_rx {
     int device = 0;
     hipStream_t stream = nullptr;      // front end + forward pass (and everything else)
@@ -194,7 +208,11 @@ struct foa_rx {
         size_t max_segs = 0, slot_bytes = 0;
         uint8_t *psdu = nullptr;
         foa_frame_result *results = nullptr;
+        HostJob *job = nullptr;  // submit_host: copy the outputs back once the finish is queued
     } pending;
+    HostJob jobs[kMaxJobs];
+    uint64_t next_ticket = 1;
+    HostJob *attach_job = nullptr;   // set by submit_host around its decode call
     DevBuf<uint8_t> scratch;     // staging for the host-pointer entry points
     DevBuf<uint32_t> sy_flags;   // device pre-sync workspace
     DevBuf<int32_t> sy_cnt, sy_off, sy_keep, sy_n;
@@ -238,6 +256,13 @@ int flush_pending(foa_rx *rx, hipEvent_t after_front_end)
                    p.slot_bytes, p.results);
     HIP_TRY(hipEventRecord(p.w->ev[4], sb));
     HIP_TRY(hipEventRecord(p.w->done, sb));
+    if (p.job) {
+        HostJob &j = *p.job;
+        HIP_TRY(hipMemcpyAsync(j.pin + j.o_psdu, j.dev.p + j.o_psdu, j.total - j.o_psdu, hipMemcpyDeviceToHost, sb));
+        HIP_TRY(hipEventRecord(j.done, sb));
+        j.copy_queued = true;
+        p.job = nullptr;
+    }
     HIP_TRY(hipGetLastError());
     p.valid = false;
     return FOA_OK;
@@ -306,6 +331,11 @@ void foa_rx_destroy(foa_rx *rx)
         for (auto &e : ws.ev) if (e) (void)hipEventDestroy(e);
         if (ws.fwd_done) (void)hipEventDestroy(ws.fwd_done);
         if (ws.done) (void)hipEventDestroy(ws.done);
+    }
+    for (auto &j : rx->jobs) {
+        j.dev.release();
+        if (j.pin) (void)hipHostFree(j.pin);
+        if (j.done) (void)hipEventDestroy(j.done);
     }
     rx->scratch.release();
     rx->sy_flags.release(); rx->sy_cnt.release(); rx->sy_off.release(); rx->sy_keep.release(); rx->sy_n.release(); rx->sy_x.release(); rx->sy_cand.release();
@@ -444,7 +474,7 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
         HIP_TRY(hipEventRecord(rx->w->fwd_done, st_fwd));
         foa_rx::Pending &p = rx->pending;
         p.valid = true; p.w = rx->w; p.nf = nf; p.S = rx->tb_segment; p.L = rx->tb_overlap; p.max_segs = max_segs; p.slot_bytes = slot_bytes;
-        p.psdu = d_psdu; p.results = d_results;
+        p.psdu = d_psdu; p.results = d_results; p.job = rx->attach_job;
     } else {
         if (rx->viterbi_kind == 0)
             hipLaunchKernelGGL(k_viterbi_v1, dim3(nf), dim3(64), 0, st, rx->w->info.p, nf, rx->w->soft.p, rx->w->dec.p, d_psdu, slot_bytes, d_results);
@@ -494,6 +524,80 @@ int foa_rx_decode_frames_host(foa_rx *rx, const float *iq, size_t n_samples, con
     HIP_TRY(hipMemcpyAsync(results, b + o_res, n_frames * sizeof(foa_frame_result), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return FOA_OK;
+}
+
+int foa_rx_submit_host(foa_rx *rx, const float *iq, size_t n_samples, const foa_frame_desc *descs, const int64_t *ends, size_t n_frames,
+                       size_t slot_bytes, uint64_t *ticket)
+{
+    if (!rx || !ticket) return fail(FOA_E_INVALID, "NULL argument");
+    if (n_frames == 0 || !iq || !descs || !ends) return fail(FOA_E_INVALID, "empty call or NULL pointer");
+    HIP_TRY(hipSetDevice(rx->device));
+    HostJob *job = nullptr;
+    for (auto &j : rx->jobs) if (!j.busy) { job = &j; break; }
+    if (!job) return fail(FOA_E_STATE, "%d calls are in flight: collect the oldest first", kMaxJobs);
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_iq = 0, o_desc = o_iq + up(n_samples * 8), o_end = o_desc + up(n_frames * sizeof(foa_frame_desc)), o_psdu = o_end + up(n_frames * 8),
+                 o_res = o_psdu + up(n_frames * slot_bytes), total = o_res + up(n_frames * sizeof(foa_frame_result));
+    int rc = job->dev.ensure(total);
+    if (rc) return rc;
+    if (job->pin_cap < total) {
+        if (job->pin) (void)hipHostFree(job->pin);
+        job->pin = nullptr; job->pin_cap = 0;
+        const size_t want = total + total / 2;
+        HIP_TRY(hipHostMalloc((void **)&job->pin, want, hipHostMallocDefault));
+        job->pin_cap = want;
+    }
+    if (!job->done) HIP_TRY(hipEventCreateWithFlags(&job->done, hipEventDisableTiming));
+    // the caller's buffers are ours only until we return: mirror them, then everything else is asynchronous
+    memcpy(job->pin + o_iq, iq, n_samples * 8);
+    memcpy(job->pin + o_desc, descs, n_frames * sizeof(foa_frame_desc));
+    memcpy(job->pin + o_end, ends, n_frames * 8);
+    const bool piped = rx->pipeline && rx->viterbi_kind == 2;
+    hipStream_t st = piped ? rx->stream3 : rx->stream;
+    uint8_t *b = job->dev.p;
+    HIP_TRY(hipMemcpyAsync(b, job->pin, o_psdu, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(b + o_psdu, 0, n_frames * slot_bytes, st));
+    job->total = total; job->o_psdu = o_psdu; job->o_res = o_res; job->n_frames = n_frames; job->slot_bytes = slot_bytes; job->copy_queued = false;
+    rx->attach_job = piped ? job : nullptr;
+    rc = foa_rx_decode_frames_dev(rx, (const float *)(b + o_iq), n_samples, (const foa_frame_desc *)(b + o_desc), (const int64_t *)(b + o_end), n_frames,
+                                  b + o_psdu, slot_bytes, (foa_frame_result *)(b + o_res));
+    rx->attach_job = nullptr;
+    if (rc) return rc;
+    if (!piped) {
+        HIP_TRY(hipMemcpyAsync(job->pin + o_psdu, b + o_psdu, total - o_psdu, hipMemcpyDeviceToHost, rx->stream));
+        HIP_TRY(hipEventRecord(job->done, rx->stream));
+        job->copy_queued = true;
+    }
+    job->busy = true;
+    job->ticket = rx->next_ticket++;
+    *ticket = job->ticket;
+    return FOA_OK;
+}
+
+int foa_rx_collect(foa_rx *rx, uint64_t ticket, int wait, uint8_t *psdu, foa_frame_result *results)
+{
+    if (!rx || !psdu || !results) return fail(FOA_E_INVALID, "NULL argument");
+    HostJob *job = nullptr;
+    for (auto &j : rx->jobs) if (j.busy && j.ticket == ticket) { job = &j; break; }
+    if (!job) return fail(FOA_E_INVALID, "unknown ticket");
+    HIP_TRY(hipSetDevice(rx->device));
+    if (!job->copy_queued) {
+        // its chain-back + finish is still the pending one: queue it (it would otherwise wait for the next call)
+        if (!(rx->pending.valid && rx->pending.job == job)) return fail(FOA_E_STATE, "internal: job without a pending finish");
+        int rc = flush_pending(rx, nullptr);
+        if (rc) return rc;
+    }
+    if (wait) {
+        HIP_TRY(hipEventSynchronize(job->done));
+    } else {
+        hipError_t e = hipEventQuery(job->done);
+        if (e == hipErrorNotReady) return 0;
+        if (e != hipSuccess) return fail(FOA_E_HIP, "hipEventQuery: %s", hipGetErrorString(e));
+    }
+    memcpy(psdu, job->pin + job->o_psdu, job->n_frames * job->slot_bytes);
+    memcpy(results, job->pin + job->o_res, job->n_frames * sizeof(foa_frame_result));
+    job->busy = false;
+    return 1;
 }
 
 static int kernel_ms_of(foa_rx *rx, WorkSet *w, float out_ms[6])

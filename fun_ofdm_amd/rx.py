@@ -61,6 +61,25 @@ class Receiver:
         check(lib().foa_rx_decode_frames_host(self._h, _vp(iq), iq.size, _vp(descs), _vp(ends), m, _vp(psdu), slot_bytes, _vp(res)))
         return psdu, res
 
+    def submit_host(self, iq, descs, ends, slot_bytes=4096):
+        """Asynchronous decode_frames_host: returns a ticket (foa_rx_submit_host)."""
+        iq = np.ascontiguousarray(iq, np.complex64)
+        descs = np.ascontiguousarray(descs, frame_desc_dtype)
+        ends = np.ascontiguousarray(ends, np.int64)
+        t = C.c_uint64(0)
+        check(lib().foa_rx_submit_host(self._h, _vp(iq), iq.size, _vp(descs), _vp(ends), descs.size, slot_bytes, C.byref(t)))
+        return (int(t.value), descs.size, slot_bytes)
+
+    def collect(self, ticket, wait=True):
+        """-> (psdu, results) of a submit_host ticket, or None if wait=False and it is not complete yet."""
+        t, m, slot_bytes = ticket
+        psdu = np.zeros((m, slot_bytes), np.uint8)
+        res = np.zeros(m, frame_result_dtype)
+        rc = lib().foa_rx_collect(self._h, t, 1 if wait else 0, _vp(psdu), _vp(res))
+        if rc < 0:
+            check(rc)
+        return (psdu, res) if rc == 1 else None
+
     # ---- batch decode, device buffers (torch tensors on this device) ------------------------------
     def decode_frames_dev(self, iq, descs, ends, psdu, results):
         """All arguments are CUDA(HIP) torch tensors already resident in HBM:

@@ -132,6 +132,15 @@ int foa_rx_wait_previous(foa_rx *rx);
 /* The handle's hipStream_t (as void*) so callers can order their own work against it. */
 void *foa_rx_stream(foa_rx *rx);
 
+/* The same with nothing left to wait for: foa_rx_submit_host copies the caller's buffers, queues the transfers and the decode
+ * and returns a ticket; up to 8 calls may be in flight.  foa_rx_collect(ticket, wait, ...) returns 1 and fills psdu
+ * (n_frames * slot_bytes) and results once that call is complete, 0 if it is not yet (only with wait = 0), < 0 on error.
+ * Calls complete in the order they were submitted.  For a stream front end that must not stall on the GPU:
+ * H2D of batch k+1, compute of batch k and D2H of batch k-1 overlap on the library's streams. */
+int foa_rx_submit_host(foa_rx *rx, const float *iq, size_t n_samples, const foa_frame_desc *descs, const int64_t *ends, size_t n_frames,
+                       size_t slot_bytes, uint64_t *ticket);
+int foa_rx_collect(foa_rx *rx, uint64_t ticket, int wait, uint8_t *psdu, foa_frame_result *results);
+
 /* HIP-event durations (ms) of the kernels of the most recent decode call, measured on the handle's
  * stream: [0] header (LTS+SIGNAL), [1] offset scan, [2] data-symbol FFT/equalise/demap,
  * [3] Viterbi forward pass, [4] chain-back + descramble + CRC, [5] whole call.  Synchronises. */

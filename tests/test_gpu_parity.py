@@ -463,3 +463,46 @@ def test_random_batches_vs_oracle(rx, po, seed):
             ok = res["status"] == 0
             assert np.array_equal(psdu[ok], opsdu[ok]), (seed, rep, kind)
     _set_viterbi(rx, VITERBI_KINDS[2])
+
+
+@pytest.mark.parametrize("pipeline", [1, 0])
+def test_async_host_calls(rx, po, pipeline):
+    """foa_rx_submit_host / foa_rx_collect: several calls in flight, the caller's buffers reusable at once, results
+    identical to the synchronous entry point and delivered in submission order."""
+    import time
+    _set_viterbi(rx, VITERBI_KINDS[2])
+    rng = np.random.default_rng(41)
+    cases = []
+    for k in range(6):
+        specs = [(int(rng.integers(0, 11)), int(rng.integers(1, 500))) for _ in range(4 + 2 * k)]
+        iq, pays = _make_stream(po, rng, specs, snr_db=24.0)
+        descs = po.find_alignments_f32(iq)
+        cases.append((iq, descs, _ends(descs, iq.size)))
+    rx.set_option("pipeline", 0)
+    want = [rx.decode_frames_host(iq, d, e) for iq, d, e in cases]
+    rx.set_option("pipeline", pipeline)
+    try:
+        tickets = []
+        for iq, d, e in cases:
+            iq2, d2, e2 = iq.copy(), d.copy(), e.copy()
+            tickets.append(rx.submit_host(iq2, d2, e2))
+            iq2[:] = 0; d2["lts1_pos"] = -1; e2[:] = 0            # the library has its own copy by now
+        # poll the first without blocking until it is there, then take the rest in order
+        t0 = time.time()
+        first = None
+        while first is None and time.time() - t0 < 30:
+            first = rx.collect(tickets[0], wait=False)
+        assert first is not None
+        got = [first] + [rx.collect(t) for t in tickets[1:]]
+        for (psdu, res), (wp, wr) in zip(got, want):
+            assert np.array_equal(res.view(np.int32), wr.view(np.int32))
+            assert np.array_equal(psdu, wp)
+        # more than 8 in flight is refused, and collecting makes room again
+        many = [rx.submit_host(*cases[0]) for _ in range(8)]
+        with pytest.raises(Exception):
+            rx.submit_host(*cases[0])
+        for t in many:
+            psdu, res = rx.collect(t)
+            assert np.array_equal(psdu, want[0][0])
+    finally:
+        rx.set_option("pipeline", 1)
