@@ -301,11 +301,22 @@ private:
 // ---------------------------------------------------------------------------------------------------------------
 class receiver_chain {
 public:
-    explicit receiver_chain(int device = 0) : dev_(device), sync_(nullptr), base_(0)
+    // async_batch_calls = 0: every call decodes what has completed and returns it (synchronous GPU call inside).
+    // async_batch_calls = k > 0: a stream front end that must keep up with the air.  A lone frame takes the
+    // GPU about a millisecond however short it is (its trellis is one serial chain), a batch of thousands hardly longer; so
+    // every k-th call submits everything decodable as ONE asynchronous batch (foa_rx_submit_host: H2D, compute and D2H of
+    // consecutive batches overlap) and every call hands out the payloads of the batches that have finished -- in stream
+    // order, a few calls late, like the reference's five-call latency.  Same payloads as the synchronous mode.
+    explicit receiver_chain(int device = 0, int async_batch_calls = 0)
+        : dev_(device), sync_(nullptr), base_(0), batch_calls_(async_batch_calls), calls_(0)
     {
         check(foa_sync_create(&sync_), "foa_sync_create");
     }
-    ~receiver_chain() { if (sync_) foa_sync_destroy(sync_); }
+    ~receiver_chain()
+    {
+        try { while (!jobs_.empty()) collect_front(true, nullptr); } catch (...) {}
+        if (sync_) foa_sync_destroy(sync_);
+    }
     receiver_chain(const receiver_chain &) = delete;
     receiver_chain &operator=(const receiver_chain &) = delete;
 
@@ -314,21 +325,10 @@ public:
     // returned by the call that delivers its last sample (the reference returns it five calls later).
     std::vector<std::vector<unsigned char> > process_samples(std::vector<std::complex<double> > samples)
     {
+        if (batch_calls_ > 0) return process_async(samples, false);
         std::vector<std::vector<unsigned char> > out;
-        const size_t n = samples.size();
-        if (n == 0) return out;
-        // the device consumes complex<float> (BASELINE north_star); the pre-sync decides on the doubles it was given
-        const size_t o = buf_.size();
-        buf_.resize(o + 2 * n);
-        for (size_t i = 0; i < n; i++) { buf_[o + 2 * i] = (float)samples[i].real(); buf_[o + 2 * i + 1] = (float)samples[i].imag(); }
-        std::vector<foa_frame_desc> found(n / 300 + 8);
-        size_t got = 0;
-        check(foa_sync_push_f64(sync_, reinterpret_cast<const double *>(samples.data()), n, found.data(), found.size(), &got), "foa_sync_push_f64");
-        for (;;) {
-            for (size_t i = 0; i < got; i++) pending_.push_back(entry(found[i]));
-            if (got < found.size()) break;
-            check(foa_sync_push_f64(sync_, nullptr, 0, found.data(), found.size(), &got), "foa_sync_push_f64");
-        }
+        if (samples.empty()) return out;
+        append(samples);
         const int64_t avail = base_ + (int64_t)(buf_.size() / 2);    // stream index one past the newest sample
         const int64_t settled = foa_sync_settled(sync_);             // timing_sync has looked at everything before this
         // which pending alignments can be finished now?  An alignment's extent ends at the next alignment's LTS1
@@ -374,12 +374,91 @@ public:
         return out;
     }
 
+    // Asynchronous mode: everything that can still be decoded, waited for (end of a capture; a radio never ends).
+    std::vector<std::vector<unsigned char> > flush()
+    {
+        if (batch_calls_ > 0) return process_async(std::vector<std::complex<double> >(), true);
+        return std::vector<std::vector<unsigned char> >();
+    }
+
 private:
     struct entry {
         foa_frame_desc d;
         int64_t need_end;     // stream index the frame needs before it can be decoded (0: SIGNAL not decoded yet)
         explicit entry(const foa_frame_desc &x) : d(x), need_end(0) {}
     };
+    struct job { uint64_t ticket; size_t n_frames; };
+    static const int64_t kLongestFrame = 320 + 80 * 1369 + 160;       // samples: 4095 bytes at 6 Mbps, plus timing_sync's look-ahead
+
+    // the device consumes complex<float> (BASELINE north_star); the pre-sync decides on the doubles it was given
+    void append(const std::vector<std::complex<double> > &samples)
+    {
+        const size_t n = samples.size(), o = buf_.size();
+        if (n == 0) return;
+        buf_.resize(o + 2 * n);
+        for (size_t i = 0; i < n; i++) { buf_[o + 2 * i] = (float)samples[i].real(); buf_[o + 2 * i + 1] = (float)samples[i].imag(); }
+        std::vector<foa_frame_desc> found(n / 300 + 8);
+        size_t got = 0;
+        check(foa_sync_push_f64(sync_, reinterpret_cast<const double *>(samples.data()), n, found.data(), found.size(), &got), "foa_sync_push_f64");
+        for (;;) {
+            for (size_t i = 0; i < got; i++) pending_.push_back(entry(found[i]));
+            if (got < found.size()) break;
+            check(foa_sync_push_f64(sync_, nullptr, 0, found.data(), found.size(), &got), "foa_sync_push_f64");
+        }
+    }
+    // oldest batch in flight -> payloads (returns false if it is not finished and wait is false)
+    bool collect_front(bool wait, std::vector<std::vector<unsigned char> > *out)
+    {
+        const job j = jobs_.front();
+        std::vector<unsigned char> psdu(j.n_frames * 4096);
+        std::vector<foa_frame_result> res(j.n_frames);
+        const int rc = foa_rx_collect(dev_.get(), j.ticket, wait ? 1 : 0, psdu.data(), res.data());
+        if (rc < 0) check(rc, "foa_rx_collect");
+        if (rc == 0) return false;
+        jobs_.pop_front();
+        if (out)
+            for (size_t i = 0; i < j.n_frames; i++)
+                if (res[i].status == FOA_ST_OK) out->push_back(std::vector<unsigned char>(psdu.begin() + i * 4096, psdu.begin() + i * 4096 + res[i].length));
+        return true;
+    }
+    std::vector<std::vector<unsigned char> > process_async(const std::vector<std::complex<double> > &samples, bool final)
+    {
+        std::vector<std::vector<unsigned char> > out;
+        append(samples);
+        while (!jobs_.empty() && collect_front(false, &out)) {}
+        calls_++;
+        if (final || calls_ % batch_calls_ == 0) {
+            const int64_t avail = base_ + (int64_t)(buf_.size() / 2), settled = foa_sync_settled(sync_);
+            // An alignment goes out once its extent is final: the next alignment is known (fft_symbols re-aligns there), or
+            // so much stream has passed that neither its frame nor a later tag can reach back into it.  (Its length is not
+            // known here -- SIGNAL is decoded on the device -- so the newest alignment of a burst waits for that.)
+            std::vector<foa_frame_desc> rel;
+            std::vector<int64_t> rel_end;
+            size_t take = 0;
+            for (; take < pending_.size(); take++) {
+                const bool has_next = take + 1 < pending_.size();
+                const int64_t lts1 = pending_[take].d.lts1_pos;
+                if (!has_next && !final && (avail - lts1 < kLongestFrame || settled - 8 < lts1 + kLongestFrame)) break;
+                rel.push_back(pending_[take].d);
+                rel_end.push_back(has_next ? pending_[take + 1].d.lts1_pos : avail);
+            }
+            if (!rel.empty()) {
+                // the batch only needs the samples from just before its first alignment to its last end
+                const int64_t lo = std::max(base_, std::min(rel.front().lts1_pos, rel.front().rot_start) - 16), hi = rel_end.back();
+                for (size_t i = 0; i < rel.size(); i++) { rel[i].lts1_pos -= lo; rel[i].rot_start -= lo; rel_end[i] -= lo; }
+                while (jobs_.size() >= 6) collect_front(true, &out);
+                job j;
+                j.n_frames = rel.size();
+                check(foa_rx_submit_host(dev_.get(), buf_.data() + 2 * (lo - base_), (size_t)(hi - lo), rel.data(), rel_end.data(), rel.size(), 4096, &j.ticket),
+                      "foa_rx_submit_host");
+                jobs_.push_back(j);
+                pending_.erase(pending_.begin(), pending_.begin() + take);
+            }
+        }
+        if (final) while (!jobs_.empty()) collect_front(true, &out);
+        trim();
+        return out;
+    }
     // drop samples nothing can refer to any more: before the oldest pending alignment, and before what a future
     // alignment could reach back to (timing_sync places LTS1 at most 160+8 samples before the point it has reached)
     void trim()
@@ -398,6 +477,9 @@ private:
     std::vector<float> buf_;          // interleaved samples from stream index base_ on
     int64_t base_;
     std::deque<entry> pending_;
+    int batch_calls_;
+    long calls_;
+    std::deque<job> jobs_;
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -468,8 +550,8 @@ private:
 class receiver {
 public:
     typedef void (*callback_t)(std::vector<std::vector<unsigned char> > packets);
-    receiver(callback_t callback, sample_source *source, int device = 0, int num_rx_samples = 4096)
-        : callback_(callback), source_(source), chain_(device), n_(num_rx_samples), token_(true), stop_(false), finished_(false)
+    receiver(callback_t callback, sample_source *source, int device = 0, int num_rx_samples = 4096, int async_batch_calls = 0)
+        : callback_(callback), source_(source), chain_(device, async_batch_calls), n_(num_rx_samples), token_(true), stop_(false), finished_(false)
     {
         thread_ = std::thread(&receiver::receiver_chain_loop, this);
     }
@@ -515,6 +597,8 @@ private:
                 // end of the source: one chunk of silence lets timing_sync settle on the frames that are already complete
                 samples.assign((size_t)std::max(n_, 512), std::complex<double>(0, 0));
                 callback_(chain_.process_samples(samples));
+                std::vector<std::vector<unsigned char> > rest = chain_.flush();          // asynchronous chain: what is still in flight
+                if (!rest.empty()) callback_(rest);
             }
             give();
             if (!more) break;

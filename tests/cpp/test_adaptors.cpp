@@ -153,6 +153,22 @@ int main()
         printf("receiver_chain chunk %zu: %zu payloads, first in call %d\n", cs, got.size(), first_call);
         CHECK(got == want, "process_samples payloads differ (chunk %zu: %zu vs %zu)", cs, got.size(), want.size());
     }
+    // ---- 2b. receiver_chain in asynchronous batches: the same payloads, in order, a few calls later ----
+    for (int k : { 1, 3, 8 }) {
+        fun_amd::receiver_chain rc(0, k);
+        payloads_t got;
+        int calls_with_output = 0;
+        for (size_t x = 0; x < stream.size(); x += chunk) {
+            payloads_t r = rc.process_samples(std::vector<std::complex<double> >(stream.begin() + x, stream.begin() + x + chunk));
+            if (!r.empty()) calls_with_output++;
+            for (auto &p : r) got.push_back(p);
+        }
+        payloads_t rest = rc.flush();
+        for (auto &p : rest) got.push_back(p);
+        printf("receiver_chain async every %d calls: %zu payloads (%zu from flush), %d calls returned some\n", k, got.size(), rest.size(), calls_with_output);
+        CHECK(got == want, "asynchronous process_samples payloads differ (batch %d: %zu vs %zu)", k, got.size(), want.size());
+    }
+
     // ---- 3. fun_amd::receiver: source -> process_samples -> callback on every call, pause()/resume() ----
     {
         fun_amd::vector_source src(stream);

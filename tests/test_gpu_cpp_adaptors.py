@@ -34,10 +34,11 @@ def test_sim_cli_over_iq_file(tmp_path):
                     "-L", libdir, "-lfun_ofdm_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lpthread", "-o", exe], check=True)
     pays = synth.splitmix64_bytes(0xC11, 24, 300)
     iq, _ = synth.make_stream(synth.build_frames(pays, 8), 4096, 200, 25.0, seed=9)
-    for fmt, data in (("fc32", iq.astype(np.complex64)), ("fc64", iq.astype(np.complex128))):
+    for fmt, data, extra in (("fc32", iq.astype(np.complex64), []), ("fc64", iq.astype(np.complex128), []),
+                             ("fc32", iq.astype(np.complex64), ["--async", "4"])):
         src, out = str(tmp_path / ("cap." + fmt)), str(tmp_path / ("psdus." + fmt))
         data.tofile(src)
-        r = subprocess.run([exe, src, "--format", fmt, "--out", out, "--chunk", "4096"], capture_output=True, text=True, timeout=600)
+        r = subprocess.run([exe, src, "--format", fmt, "--out", out, "--chunk", "4096"] + extra, capture_output=True, text=True, timeout=600)
         print(r.stdout, r.stderr)
         assert r.returncode == 0, r.stdout + r.stderr
         raw = open(out, "rb").read()
