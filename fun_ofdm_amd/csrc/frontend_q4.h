@@ -54,6 +54,61 @@ __device__ __forceinline__ void q4_butterfly(cpx a, cpx b, cpx c, cpx d, cpx &y0
     y0 = cadd(t0, u); y1 = cadd(t1, v1); y2 = cadd(t0, cadd(cneg(b), cneg(d))); y3 = cadd(t1, v3);
 }
 
+// Equalise + derotate this lane's data carriers, demap them, scatter the soft bytes into the symbol's depunctured order and
+// turn them into branch-metric words.  BPSC > 0: bits per carrier known at compile time (rr / rate wave-uniform); 0: generic.
+template <int BPSC>
+__device__ __forceinline__ void q4_emit(Q4Shared &sh, Q4Wave &ws, const cpx (&X)[16], cpx rot, const double2 *__restrict__ h, const RateRow &rr, int rate,
+                                        int qd, int m, bool valid, int64_t w, int64_t my_out, const FrameInfo &fi, int k,
+                                        uint8_t *__restrict__ soft, uint32_t *__restrict__ bm, double2 *__restrict__ eq_tap)
+{
+    // the symbol's depunctured soft bytes start as erasures (puncturer.cpp:94-102)
+    {
+        const uint4 fill = make_uint4(0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu);
+#pragma unroll
+        for (int i = 0; i < 7; i++) *(uint4 *)&ws.soft[qd][112 * m + 16 * i] = fill;
+    }
+    wave_lds_sync();
+    const int bpsc = BPSC > 0 ? BPSC : rr.bpsc, nb = bpsc == 1 ? 1 : bpsc / 2;
+    const uint16_t *pos = sh.pos[rate];
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int s_idx = (16 * j + 4 * m + a + 32) & 63;
+            const int di = sh.dindex[s_idx];
+            if (di < 0) continue;
+            const double2 hh = h[s_idx];
+            const cpx zc = cmul(cmul(cpx{ hh.x, hh.y }, X[4 * a + j]), rot);
+            if (eq_tap && valid) eq_tap[(size_t)w * 48 + di] = make_double2(zc.x, zc.y);
+            const uint32_t li = qam_lookup(sh.qam, zc.x, rr.scale_d), lq = bpsc > 1 ? qam_lookup(sh.qam, zc.y, rr.scale_d) : 0u;
+#pragma unroll
+            for (int b = 0; b < 6; b++) {
+                if (b < bpsc) {
+                    const uint32_t byte = b < nb ? (li >> (8 * b)) & 255u : (lq >> (8 * (b - nb))) & 255u;
+                    ws.soft[qd][pos[di * bpsc + b]] = (uint8_t)byte;             // interleaver.cpp:33-36, puncturer.cpp:112-118
+                }
+            }
+        }
+    }
+    wave_lds_sync();
+    // ---- four trellis steps (8 soft bytes) per lane and trip -> branch-metric words (viterbi.cpp:242-247) ----
+    uint8_t *soft_dst = (soft && valid) ? soft + fi.soft_off + (int64_t)(k - 1) * 2 * rr.dbps : nullptr;
+    const int ngroups = rr.dbps / 4;
+    for (int g4 = m; g4 < ngroups; g4 += 4) {
+        const uint2 sb = *(const uint2 *)&ws.soft[qd][8 * g4];
+        uint32_t wd[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const uint32_t pair = (t < 2 ? sb.x : sb.y) >> (16 * (t & 1));
+            const uint32_t s0 = pair & 255u, s1 = (pair >> 8) & 255u;
+            wd[t] = sh.bm_sum[s0 + s1] | sh.bm_dif[s0 + 255u - s1];
+        }
+        if (valid) *(uint4 *)(bm + my_out + 4 * g4) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+        if (soft_dst) *(uint2 *)(soft_dst + 8 * g4) = sb;
+    }
+}
+
 __global__ __launch_bounds__(64 * kQ4Waves) __attribute__((amdgpu_waves_per_eu(FOA_Q4_WPE, 8)))
 void k_data_symbols_q4(const float2 *__restrict__ iq, const foa_frame_desc *__restrict__ descs, const FrameInfo *__restrict__ info,
                        const int32_t *__restrict__ sym2frame, const int64_t *__restrict__ totals, const double2 *__restrict__ hinv,
@@ -146,50 +201,19 @@ void k_data_symbols_q4(const float2 *__restrict__ iq, const foa_frame_desc *__re
     }
     const cpx rot = unit_conj(pe);
 
-    // the symbol's depunctured soft bytes start as erasures (puncturer.cpp:94-102)
-    {
-        const uint4 fill = make_uint4(0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu);
-#pragma unroll
-        for (int i = 0; i < 7; i++) *(uint4 *)&ws.soft[qd][112 * m + 16 * i] = fill;
-    }
-    wave_lds_sync();
-    const int bpsc = rr.bpsc, nb = bpsc == 1 ? 1 : bpsc / 2;
-#pragma unroll
-    for (int a = 0; a < 4; a++) {
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int s_idx = (16 * j + 4 * m + a + 32) & 63;
-            const int di = sh.dindex[s_idx];
-            if (di < 0) continue;
-            const double2 hh = h[s_idx];
-            const cpx zc = cmul(cmul(cpx{ hh.x, hh.y }, X[4 * a + j]), rot);
-            if (eq_tap && valid) eq_tap[(size_t)w * 48 + di] = make_double2(zc.x, zc.y);
-            const uint32_t li = qam_lookup(sh.qam, zc.x, rr.scale_d), lq = bpsc > 1 ? qam_lookup(sh.qam, zc.y, rr.scale_d) : 0u;
-#pragma unroll
-            for (int b = 0; b < 6; b++) {
-                if (b < bpsc) {
-                    const uint32_t byte = b < nb ? (li >> (8 * b)) & 255u : (lq >> (8 * (b - nb))) & 255u;
-                    ws.soft[qd][sh.pos[rate][di * bpsc + b]] = (uint8_t)byte;      // interleaver.cpp:33-36, puncturer.cpp:112-118
-                }
-            }
+    // ---- soft demapping, scatter into depunctured order, branch metrics: per modulation when the wave's sixteen symbols
+    // share a rate (the usual case: loop bounds and table rows are then scalar), generically otherwise ----
+    const int rate_u = __builtin_amdgcn_readfirstlane(rate);
+    if (__all(rate == rate_u)) {
+        const RateRow ru = g_tab.rates[rate_u];
+        switch (ru.bpsc) {
+        case 1: q4_emit<1>(sh, ws, X, rot, h, ru, rate_u, qd, m, valid, w, my_out, fi, k, soft, bm, eq_tap); break;
+        case 2: q4_emit<2>(sh, ws, X, rot, h, ru, rate_u, qd, m, valid, w, my_out, fi, k, soft, bm, eq_tap); break;
+        case 4: q4_emit<4>(sh, ws, X, rot, h, ru, rate_u, qd, m, valid, w, my_out, fi, k, soft, bm, eq_tap); break;
+        default: q4_emit<6>(sh, ws, X, rot, h, ru, rate_u, qd, m, valid, w, my_out, fi, k, soft, bm, eq_tap); break;
         }
-    }
-    wave_lds_sync();
-    // ---- four trellis steps (8 soft bytes) per lane and trip -> branch-metric words (viterbi.cpp:242-247) ----
-    uint8_t *soft_dst = (soft && valid) ? soft + fi.soft_off + (int64_t)(k - 1) * 2 * rr.dbps : nullptr;
-    const int ngroups = rr.dbps / 4;
-    for (int g4 = m; g4 < ngroups; g4 += 4) {
-        const uint2 sb = *(const uint2 *)&ws.soft[qd][8 * g4];
-        uint32_t wd[4];
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const uint32_t pair = (t < 2 ? sb.x : sb.y) >> (16 * (t & 1));
-            const uint32_t s0 = pair & 255u, s1 = (pair >> 8) & 255u;
-            wd[t] = sh.bm_sum[s0 + s1] | sh.bm_dif[s0 + 255u - s1];
-        }
-        if (valid) *(uint4 *)(bm + my_out + 4 * g4) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
-        if (soft_dst) *(uint2 *)(soft_dst + 8 * g4) = sb;
+    } else {
+        q4_emit<0>(sh, ws, X, rot, h, rr, rate, qd, m, valid, w, my_out, fi, k, soft, bm, eq_tap);
     }
 }
 
