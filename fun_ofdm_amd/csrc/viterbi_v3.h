@@ -174,8 +174,12 @@ __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd3(const FrameInfo
     if (max(TA, TB) == 0) return;
     const int NA = max(TA - 6, 0), NB = max(TB - 6, 0), N = max(NA, NB);             // data steps
     const int NAtop = (NA + kChunk3 - 1) / kChunk3 * kChunk3, NBtop = (NB + kChunk3 - 1) / kChunk3 * kChunk3;
-    const uint32_t *bmA = bm + ia.dec_off, *bmB = bm + ib.dec_off;
-    uint16_t *dA = (uint16_t *)(dec + ia.dec_off), *dB = (uint16_t *)(dec + ib.dec_off);
+    auto uniform64 = [](int64_t v) {
+        return (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)v));
+    };
+    const int64_t offA = uniform64(ia.dec_off), offB = uniform64(ib.dec_off);     // scalar bases: addresses become base + lane
+    const uint32_t *bmA = bm + offA, *bmB = bm + offB;
+    uint16_t *dA = (uint16_t *)(dec + offA), *dB = (uint16_t *)(dec + offB);
     const Fwd3Lane c = fwd3_lane_init(lane);
     uint32_t M = lane == 0 ? kBias2 : kBias2 + 0x003F003Fu;               // viterbi.cpp:71-78 (label 0 = slot 0)
     uint32_t acc[3] = { 0u, 0u, 0u };
