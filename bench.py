@@ -224,19 +224,27 @@ def main():
     if world > 1:
         dist.barrier()
     kern = {k: 0.0 for k in ("header", "scan", "symbols", "viterbi_fwd", "viterbi_finish", "total")}
+    timing_age = 2 if (args.steps <= 50 and args.viterbi == 2 and not args.no_pipeline and world == 1) else 1
     t_start = time.perf_counter()
     for i in range(args.steps):
         step()
-        if args.steps <= 50 and i > 0:                   # per-kernel HIP-event times of the step before: that step is
-            for k, v in rx.kernel_ms(previous=True).items():   # complete, so asking does not stall the one just queued
+        if timing_age == 2:
+            if i > 1:                                    # per-kernel HIP-event times of the step two back: complete for sure,
+                for k, v in rx.kernel_ms(age=2).items():  # so the host is not held up (the next call's front end must be
+                    kern[k] += v                         # queued while this step's forward pass is still running)
+        elif args.steps <= 50 and i > 0:
+            for k, v in rx.kernel_ms(previous=True).items():
                 kern[k] += v
     finish_steps()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t_start
-    if args.steps <= 50:
-        for k, v in rx.kernel_ms().items():              # ... and of the last step, after the clock has stopped
+    if args.steps <= 50:                                 # ... and of the last step(s), after the clock has stopped
+        if timing_age == 2 and args.steps > 1:
+            for k, v in rx.kernel_ms(previous=True).items():
+                kern[k] += v
+        for k, v in rx.kernel_ms().items():
             kern[k] += v
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)

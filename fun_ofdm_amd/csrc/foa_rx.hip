@@ -428,6 +428,10 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
     // st: header, scan, front end.  Pipelined, that is the third stream, so that they can run under the forward pass of
     // the call before (still busy on the first stream) wherever registers and LDS allow.
     hipStream_t st = piped ? rx->stream3 : rx->stream, st_fwd = rx->stream;
+    // Under one forward pass first the chain-back of the call before, then the front end of the call after: both at once
+    // slow each other and the forward pass down more than they gain (measured: 1.50 against 1.43 ms per step; letting only
+    // the light header and scan run alongside the chain-back is no better: 1.52).
+    if (piped && rx->prev->before && rx->prev->before->used && rx->prev->before != rx->w) HIP_TRY(hipStreamWaitEvent(st, rx->prev->before->done, 0));
     if (!piped && rx->prev->used && rx->prev != rx->w) HIP_TRY(hipStreamWaitEvent(st, rx->prev->done, 0));
     const int nf = (int)n_frames;
     const float2 *iq = (const float2 *)d_iq;
@@ -632,6 +636,16 @@ int foa_rx_prev_kernel_ms(foa_rx *rx, float out_ms[6])
 {
     if (!rx || !out_ms) return fail(FOA_E_INVALID, "NULL argument");
     return kernel_ms_of(rx, rx->prev, out_ms);
+}
+
+int foa_rx_kernel_ms_age(foa_rx *rx, int age, float out_ms[6])
+{
+    if (!rx || !out_ms) return fail(FOA_E_INVALID, "NULL argument");
+    if (age < 0 || age > 2) return fail(FOA_E_INVALID, "age must be 0, 1 or 2");
+    WorkSet *w = rx->w;
+    for (int i = 0; i < age && w; i++) w = w->before;                // the pipelined calls link their work sets
+    if (age > 0 && (!w || w == rx->w)) return fail(FOA_E_STATE, "no decode call of that age (calls must be pipelined)");
+    return kernel_ms_of(rx, w, out_ms);
 }
 
 int foa_rx_get_taps(foa_rx *rx, size_t n_frames, double *hinv, double *eq, size_t eq_cap, uint64_t *eq_off, uint8_t *soft, size_t soft_cap,

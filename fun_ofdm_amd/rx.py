@@ -134,11 +134,15 @@ class Receiver:
         """Block until the decode call before the most recent one is complete (see foa_rx_wait_previous)."""
         check(lib().foa_rx_wait_previous(self._h))
 
-    def kernel_ms(self, previous=False):
-        """HIP-event durations of the last decode (or, previous=True, of the one before it, which does not stall a
-        pipelined sequence of calls) in ms: header, scan, symbols, viterbi_fwd, viterbi_finish, total."""
+    def kernel_ms(self, previous=False, age=None):
+        """HIP-event durations of the last decode (previous=True: of the one before it; age=2: of the one before that,
+        which is certainly complete in a pipelined sequence of calls) in ms: header, scan, symbols, viterbi_fwd,
+        viterbi_finish, total."""
         out = (C.c_float * 6)()
-        check((lib().foa_rx_prev_kernel_ms if previous else lib().foa_rx_last_kernel_ms)(self._h, out))
+        if age is not None:
+            check(lib().foa_rx_kernel_ms_age(self._h, int(age), out))
+        else:
+            check((lib().foa_rx_prev_kernel_ms if previous else lib().foa_rx_last_kernel_ms)(self._h, out))
         return dict(zip(("header", "scan", "symbols", "viterbi_fwd", "viterbi_finish", "total"), (float(x) for x in out)))
 
     def taps(self, n_frames, eq=False, soft=True, cap_symbols=None):

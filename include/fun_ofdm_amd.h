@@ -148,6 +148,10 @@ int foa_rx_last_kernel_ms(foa_rx *rx, float out_ms[6]);
 /* The same for the decode call before the most recent one: that call is complete (or nearly) while the most recent one
  * may still be running, so reading it does not stall a pipelined sequence of calls. */
 int foa_rx_prev_kernel_ms(foa_rx *rx, float out_ms[6]);
+/* ... and for the call `age` calls back (0 = most recent, 1 = previous, 2 = the one before: with pipelined calls that one is
+ * certainly complete, so asking never delays the host, which matters because the next call's front end runs under the
+ * forward pass that is on the GPU now). */
+int foa_rx_kernel_ms_age(foa_rx *rx, int age, float out_ms[6]);
 
 /* Intermediates of the most recent decode call, copied to HOST memory (parity tests).
  *   hinv    64 complex doubles (re,im) per frame: channel_est's m_chan_est (channel_est.cpp:53-58)
