@@ -13,10 +13,11 @@
 //     terms live in lanes 1 and 2 and are broadcast so that every lane adds them in the reference's order;
 //   * soft bytes are scattered into the symbol's depunctured order in LDS ((carrier, bit) -> position table per
 //     rate), and each lane turns 4 consecutive trellis steps at a time into branch-metric words: 16-byte stores.
-// 128 VGPRs, four waves per SIMD.  Measured (config 2): 0.52 ms against 0.34 ms for the lane-per-symbol kernel, and the
-// time does not move with occupancy (2, 3 or 4 waves per SIMD): the fp64 butterflies issue at about 8 clocks per wave
-// instruction and the quad layout spends 2 024 VALU instructions per 16 symbols where lane-per-symbol spends 4 400 per
-// 64, so it is selectable (option "frontend" = 2) and covered by the parity suite, but not the default.
+// 128 VGPRs, four waves per SIMD.  Measured alone (config 2): 0.46 ms against 0.33 ms for the lane-per-symbol kernel (the
+// fp64 butterflies issue at about 8 clocks per wave instruction and the quad layout spends 1 640 VALU instructions per 16
+// symbols where lane-per-symbol spends 4 400 per 64).  Its place is the pipelined path: 128-VGPR waves fit next to the
+// forward pass of the previous call (172 of a SIMD's 512 VGPRs are free there), 512-VGPR waves do not, so there it is the
+// default front end (option "frontend" = -1) and the lane-per-symbol kernel is the default when calls run in line.
 #pragma once
 
 #include "frontend_lps.h"
