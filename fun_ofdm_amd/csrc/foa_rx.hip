@@ -195,7 +195,7 @@ struct foa_rx {
     bool record_soft = true;     // keep the depunctured soft bytes (taps, lane-per-state kernel); off = branch metrics only
     int frontend_kind = -1;      // 1: one lane per symbol (frontend_lps.h), 0: one wave per symbol, 2: four lanes per symbol (frontend_q4.h);
                                  // -1: by context -- 2 when calls are pipelined (128-VGPR waves fit under the forward pass), else 1
-    WorkSet sets[3];
+    WorkSet sets[4];             // three are in use at any time (below); the fourth keeps the call before them readable (timings)
     WorkSet *w = &sets[0];       // the set of the most recent decode call
     WorkSet *prev = nullptr;     // the set of the call before it (kernel times of a call that is certainly complete)
     // Pipelined path: the chain-back + finish of a call is queued (on stream2) only when the NEXT call has queued its
@@ -421,7 +421,7 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
     const bool piped = rx->pipeline && rx->viterbi_kind == 2;
     if (!piped) { int rc0 = flush_pending(rx, nullptr); if (rc0) return rc0; }
     rx->prev = rx->w;
-    if (piped) rx->w = &rx->sets[(int)((rx->w - rx->sets) + 1) % 3];     // three sets: front end k+1 | forward pass k | finish k-1
+    if (piped) rx->w = &rx->sets[(int)((rx->w - rx->sets) + 1) % 4];     // in use: front end k+1 | forward pass k | finish k-1
     if (rx->w->used) HIP_TRY(hipEventSynchronize(rx->w->done));      // the call that last used this set is complete
     int rc = workspace(rx, n_samples, n_frames);
     if (rc) return rc;
