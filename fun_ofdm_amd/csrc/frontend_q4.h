@@ -74,12 +74,17 @@ __device__ __forceinline__ void q4_emit(Q4Shared &sh, Q4Wave &ws, const cpx (&X)
 #pragma unroll
     for (int a = 0; a < 4; a++) {
         __builtin_amdgcn_sched_barrier(0);
+        // the four taps of this round first, whether or not the bin carries data: one memory round trip per round instead of
+        // one per bin (inside the `data carrier?` branch every load would be waited for on the spot)
+        double2 hh4[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) hh4[j] = h[(16 * j + 4 * m + a + 32) & 63];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int s_idx = (16 * j + 4 * m + a + 32) & 63;
             const int di = sh.dindex[s_idx];
             if (di < 0) continue;
-            const double2 hh = h[s_idx];
+            const double2 hh = hh4[j];
             const cpx zc = cmul(cmul(cpx{ hh.x, hh.y }, X[4 * a + j]), rot);
             if (eq_tap && valid) eq_tap[(size_t)w * 48 + di] = make_double2(zc.x, zc.y);
             const uint32_t li = qam_lookup(sh.qam, zc.x, rr.scale_d), lq = bpsc > 1 ? qam_lookup(sh.qam, zc.y, rr.scale_d) : 0u;
