@@ -161,9 +161,6 @@ __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd3(const FrameInfo
                                                                  const uint32_t *__restrict__ bm, uint64_t *__restrict__ dec)
 {
     __shared__ uint4 bml_all[kFwdWaves][4 * kChunk3];
-    // The forward passes of consecutive calls are the critical path of the pipeline; the front end and the
-    // chain-back of neighbouring calls that share the SIMDs take the issue slots these waves leave.
-    __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint4 *bml = bml_all[wave];
     const int fA = 2 * (blockIdx.x * kFwdWaves + wave), fB = fA + 1;
