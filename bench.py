@@ -187,44 +187,54 @@ def main():
     d_iq = torch.from_numpy(iq.view(np.float32).reshape(-1, 2)).to(dev)
     d_desc = torch.from_numpy(descs.view(np.uint8).copy()).to(dev)
     d_ends = torch.from_numpy(ends).to(dev)
-    d_psdu = torch.zeros((m, PAYLOAD), dtype=torch.uint8, device=dev)
-    d_res = torch.zeros((m, 4), dtype=torch.int32, device=dev)
+    # three output sets in rotation: with several ranks the PSDUs of step k-2 are gathered while step k is being queued and
+    # step k-1's chain-back has yet to run, so consecutive steps must not share their output buffers
+    n_out = 3 if world > 1 else 1
+    out_psdu = [torch.zeros((m, PAYLOAD), dtype=torch.uint8, device=dev) for _ in range(n_out)]
+    out_res = [torch.zeros((m, 4), dtype=torch.int32, device=dev) for _ in range(n_out)]
+    d_psdu, d_res = out_psdu[0], out_res[0]
     d_real = torch.from_numpy(real).to(dev)
     d_which = torch.from_numpy(which).to(dev)
     gathered = [None]
 
-    def gather_now():
+    def gather_now(buf):
         # slots in local frame order (a frame the detector missed leaves a zero slot, like a CRC failure)
         local = torch.zeros((args.frames, PAYLOAD), dtype=torch.uint8, device=dev)
-        local.index_copy_(0, d_which, d_psdu.index_select(0, d_real))
+        local.index_copy_(0, d_which, buf.index_select(0, d_real))
         gathered[0] = shard.gather_psdus(local.to(cdev), n_global, rank, world)
 
-    in_flight = [False]
+    issued = [0]          # steps queued since the last finish_steps()
+    done = [0]            # of which gathered
 
     def step():
         # Queue this step's front end and forward pass; the previous step's chain-back + finish runs under it on the
-        # library's second stream.  With several ranks the previous step's PSDUs are gathered meanwhile (they are final
-        # once wait_previous() returns, and this step's finish is not queued before the next call or sync()).
-        rx.decode_frames_dev(d_iq, d_desc, d_ends, d_psdu, d_res)
-        if world > 1 and in_flight[0]:
-            rx.wait_previous()
-            gather_now()
-        in_flight[0] = True
+        # library's second stream.  With several ranks the PSDUs of the step two back are gathered meanwhile: that step is
+        # complete by now, so the host is not held up and the next step's front end is queued in time.
+        k = issued[0]
+        rx.decode_frames_dev(d_iq, d_desc, d_ends, out_psdu[k % n_out], out_res[k % n_out])
+        issued[0] = k + 1
+        if world > 1 and k - done[0] >= 2:
+            rx.wait_age(2)
+            gather_now(out_psdu[done[0] % n_out])
+            done[0] += 1
 
     def finish_steps():
         rx.sync()
-        if world > 1 and in_flight[0]:
-            gather_now()                                 # the last step's PSDUs
-        in_flight[0] = False
+        while world > 1 and done[0] < issued[0]:         # the last two steps' PSDUs
+            gather_now(out_psdu[done[0] % n_out])
+            done[0] += 1
+        last = (issued[0] - 1) % n_out if issued[0] else 0
+        issued[0] = done[0] = 0
+        return out_psdu[last], out_res[last]
 
     for _ in range(args.warmup):
         step()
-    finish_steps()
+    d_psdu, d_res = finish_steps()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     kern = {k: 0.0 for k in ("header", "scan", "symbols", "viterbi_fwd", "viterbi_finish", "total")}
-    timing_age = 2 if (args.steps <= 50 and args.viterbi == 2 and not args.no_pipeline and world == 1) else 1
+    timing_age = 2 if (args.steps <= 50 and args.viterbi == 2 and not args.no_pipeline) else 1
     t_start = time.perf_counter()
     for i in range(args.steps):
         step()
@@ -235,7 +245,7 @@ def main():
         elif args.steps <= 50 and i > 0:
             for k, v in rx.kernel_ms(previous=True).items():
                 kern[k] += v
-    finish_steps()
+    d_psdu, d_res = finish_steps()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

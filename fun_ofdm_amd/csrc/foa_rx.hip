@@ -398,15 +398,20 @@ int foa_rx_sync(foa_rx *rx)
     return drain(rx);
 }
 
-int foa_rx_wait_previous(foa_rx *rx)
+int foa_rx_wait_age(foa_rx *rx, int age)
 {
     if (!rx) return fail(FOA_E_INVALID, "rx is NULL");
-    WorkSet *p = rx->prev;
-    if (!p || !p->used || p == rx->w) return FOA_OK;
-    if (rx->pending.valid && rx->pending.w == p) { int rc = flush_pending(rx, nullptr); if (rc) return rc; }
-    HIP_TRY(hipEventSynchronize(p->done));
+    if (age < 0 || age > 2) return fail(FOA_E_INVALID, "age must be 0, 1 or 2");
+    WorkSet *w = rx->w;
+    if (age == 1 && !(rx->pipeline && rx->viterbi_kind == 2)) w = rx->prev;      // calls in line: the same set again
+    else for (int i = 0; i < age && w; i++) w = w->before;
+    if (!w || !w->used || (age > 0 && w == rx->w)) return FOA_OK;       // no such call: nothing to wait for
+    if (rx->pending.valid && rx->pending.w == w) { int rc = flush_pending(rx, nullptr); if (rc) return rc; }
+    HIP_TRY(hipEventSynchronize(w->done));
     return FOA_OK;
 }
+
+int foa_rx_wait_previous(foa_rx *rx) { return foa_rx_wait_age(rx, 1); }
 
 int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, const foa_frame_desc *d_descs, const int64_t *d_ends,
                              size_t n_frames, uint8_t *d_psdu, size_t slot_bytes, foa_frame_result *d_results)

@@ -134,6 +134,10 @@ class Receiver:
         """Block until the decode call before the most recent one is complete (see foa_rx_wait_previous)."""
         check(lib().foa_rx_wait_previous(self._h))
 
+    def wait_age(self, age):
+        """Block until the decode call `age` calls back is complete (see foa_rx_wait_age)."""
+        check(lib().foa_rx_wait_age(self._h, int(age)))
+
     def kernel_ms(self, previous=False, age=None):
         """HIP-event durations of the last decode (previous=True: of the one before it; age=2: of the one before that,
         which is certainly complete in a pipelined sequence of calls) in ms: header, scan, symbols, viterbi_fwd,

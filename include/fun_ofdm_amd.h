@@ -129,6 +129,10 @@ int foa_rx_sync(foa_rx *rx);
 /* Blocks until the decode call BEFORE the most recent one is complete (its PSDUs and results are final), without
  * waiting for the most recent one: with option "pipeline" a caller can consume batch k-1 while batch k is in flight. */
 int foa_rx_wait_previous(foa_rx *rx);
+/* The same for the call `age` calls back (0 = the most recent, i.e. everything; 1 = previous; 2 = the one before: in a
+ * pipelined sequence that one is complete by the time the most recent call has been queued, so this does not hold the
+ * host up -- and a host that is held up queues the next call's front end late). */
+int foa_rx_wait_age(foa_rx *rx, int age);
 /* The handle's hipStream_t (as void*) so callers can order their own work against it. */
 void *foa_rx_stream(foa_rx *rx);
 
