@@ -910,7 +910,7 @@ int foa_decode_data_f64(foa_rx *rx, const double *carriers, const uint64_t *carr
     { int rc0 = drain(rx); if (rc0) return rc0; }                     // this entry point reuses the work set of the batch calls
     DeviceTables tab;
     build_tables(&tab);
-    // frame records and offsets on the host (what k_header + k_scan produce in the fused path)
+    // frame records and offsets on the host (what k_header + the k_scan_* kernels produce in the fused path)
     std::vector<FrameInfo> info(n_frames);
     std::vector<int32_t> sym2frame, seg2frame;
     std::vector<int64_t> coff(n_frames + 1);

@@ -4,7 +4,8 @@
 // channel_est.cpp:77-81, phase_tracker.cpp:83-99, modulator.cpp:108-164 / qam.h:110-125, interleaver.cpp:28-38,
 // puncturer.cpp:78-123), same operation order (so the results are bit-identical to that kernel), but each lane
 // owns a whole symbol: the 64 samples, the radix-4 butterflies and the 48 equalised carriers live in its own
-// registers.  Nothing is exchanged between lanes, nothing is computed 64-fold redundantly, and there is no LDS;
+// registers.  Nothing is exchanged between lanes and nothing is computed 64-fold redundantly (LDS only stages the coalesced
+// loads and stores and holds the demapping / branch-metric tables);
 // per symbol this issues roughly 1/10 of the instructions of the wave-per-symbol kernel.  All indices
 // (butterfly wiring, subcarrier order, interleaver and puncturing positions) are compile-time constants of the
 // unrolled code, selected per rate by a wave-uniform switch (lanes of other rates, if any, wait their turn).

@@ -13,9 +13,9 @@
 //   * A VGPR carries the two frames' metrics as u16 halves biased by 0xFF00: `v_pk_add_u16 ... clamp`
 //     saturates at 0xFFFF exactly where `_mm_adds_epu8` saturates at 255; min/compare are bias-invariant.
 //   * Branch metrics arrive precomputed (one dword m00,m01,m10,m11 per step and frame, written by
-//     k_data_symbols); a lane selects its butterfly's Branchtab class with one v_perm_b32.
-//   * The 64 decision bits of a step are the lane mask of one v_cmp per frame and leave through the scalar
-//     data cache collected with v_writelane and stored 480 B at a time.  Bit p of the word of step t says
+//     the front end); a lane selects its butterfly's Branchtab class with one v_perm_b32.
+//   * The 64 decision bits of a step are the lane mask of one v_cmp per frame; the mask is parked in lane J of a
+//     VGPR pair (plain v_mov under a one-lane EXEC) and a chunk of 60 steps leaves as one coalesced store.  Bit p of the word of step t says
 //     "slot p's survivor came from the pair's HIGH slot", which is all the chain-back needs:
 //         p <- (p & ~(1<<q)) | (bit << q).
 //   * Renormalisation (about every 9th step per frame) reduces with DPP inside rows and four v_readlane.
@@ -186,7 +186,7 @@ __device__ __forceinline__ uint32_t fwd2_group(uint32_t M, const uint2 *bml, con
     return M;
 }
 
-// a full chunk of kChunk = 60 steps, completely unrolled so that every v_writelane has a constant lane
+// a full chunk of kChunk = 60 steps, completely unrolled so that every decision word is parked in a constant lane
 template <bool SA, bool SB>
 __device__ __forceinline__ uint32_t fwd2_chunk(uint32_t M, const uint2 *bml, const Fwd2Lane &c, DecAcc &accA, DecAcc &accB, int lane)
 {
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd2(const FrameInfo
         if (t0 + lane < TA && lane < nn) dA[t0 + lane] = ((uint64_t)accA.hi << 32) | accA.lo;
         if (t0 + lane < TB && lane < nn) dB[t0 + lane] = ((uint64_t)accB.hi << 32) | accB.lo;
     }
-    // the chain-back kernel reads whole 24-step blocks: the words after a frame's last step, up to the end of its
+    // the chain-back kernel reads whole 48-step chunks: the words after a frame's last step, up to the end of its
     // region (dec_words(T)), must read as "no decision" (zero keeps the walk in slot 0)
     for (int i = TA + lane; i < dec_words(TA); i += 64) dA[i] = 0;
     if (TB > 0)
