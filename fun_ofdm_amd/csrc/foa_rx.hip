@@ -445,18 +445,14 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
     HIP_TRY(hipEventRecord(rx->w->ev[0], st));
     hipLaunchKernelGGL(k_header, dim3(nf), dim3(64), 0, st, iq, d_descs, d_ends, nf, rx->w->info.p, rx->w->hinv.p, eq_sig);
     HIP_TRY(hipEventRecord(rx->w->ev[1], st));
-    int64_t caps[1] = { (int64_t)rx->w->sym_cap };
-    HIP_TRY(hipMemcpyAsync(rx->w->totals.p + 3, caps, sizeof caps, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(rx->w->sym2frame.p, 0xFF, rx->w->sym_cap * sizeof(int32_t), st));
     // segments of this call: at most (total data steps)/S + one per frame; lanes beyond the real total idle
     const size_t max_segs = std::min(rx->w->seg2frame.n, rx->w->dec_cap / (size_t)rx->tb_segment + n_frames + 1);
-    HIP_TRY(hipMemsetAsync(rx->w->seg2frame.p, 0xFF, max_segs * sizeof(int32_t), st));
     const int n_sb = (nf + kScanBlock - 1) / kScanBlock;
     int64_t *blk = rx->w->totals.p + 8;
     hipLaunchKernelGGL(k_scan_sums, dim3(n_sb), dim3(kScanBlock), 0, st, rx->w->info.p, nf, rx->tb_segment, blk);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, blk, n_sb, rx->w->totals.p);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, blk, n_sb, (int64_t)rx->w->sym_cap, rx->w->totals.p);
     hipLaunchKernelGGL(k_scan_apply, dim3(n_sb), dim3(kScanBlock), 0, st, rx->w->info.p, nf, (int64_t)rx->w->sym_cap, (int64_t)rx->w->soft_cap,
-                       (int64_t)rx->w->dec_cap, rx->tb_segment, blk, rx->w->sym2frame.p, rx->w->seg2frame.p);
+                       (int64_t)rx->w->dec_cap, rx->tb_segment, (int64_t)rx->w->seg2frame.n, blk, rx->w->sym2frame.p, rx->w->seg2frame.p);
     HIP_TRY(hipEventRecord(rx->w->ev[2], st));
     // upper bound on data symbols in n_samples samples; waves beyond the real total exit at once
     const size_t max_sym = rx->w->sym_cap;

@@ -454,8 +454,9 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_sums(const FrameInfo *__res
 }
 
 // pass 2: exclusive scan of the block sums in place, grand totals -> totals[0..2] and totals[4]  (one block)
-__global__ __launch_bounds__(1024) void k_scan_blocks(int64_t *__restrict__ blk, int n_blocks, int64_t *__restrict__ totals)
+__global__ __launch_bounds__(1024) void k_scan_blocks(int64_t *__restrict__ blk, int n_blocks, int64_t sym_cap, int64_t *__restrict__ totals)
 {
+    if (threadIdx.x == 0) totals[3] = sym_cap;            // read by the data-symbol kernels next to totals[0]
     __shared__ int64_t wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (int i = 0; i < 4; i++) {
@@ -480,7 +481,7 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(int64_t *__restrict__ blk,
             if (j < n_blocks) blk[(size_t)i * n_blocks + j] = carry + before + x - v;
             carry += all;
         }
-        if (tid == 0) totals[i < 3 ? i : 4] = carry;          // totals[3] is the caller's symbol capacity
+        if (tid == 0) totals[i < 3 ? i : 4] = carry;          // totals[3] is the symbol capacity (above)
     }
 }
 
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(int64_t *__restrict__ blk,
 // and segment -> frame maps (so that the data-symbol and chain-back kernels find their frame without a search;
 // frames are short: <= 1368 symbols)
 __global__ __launch_bounds__(kScanBlock) void k_scan_apply(FrameInfo *__restrict__ info, int n_frames, int64_t sym_cap, int64_t soft_cap,
-                                                           int64_t dec_cap, int seg_steps, const int64_t *__restrict__ blk,
+                                                           int64_t dec_cap, int seg_steps, int64_t seg_cap, const int64_t *__restrict__ blk,
                                                            int32_t *__restrict__ sym2frame, int32_t *__restrict__ seg2frame)
 {
     __shared__ int64_t part[4][kScanBlock / 64];
@@ -501,15 +502,17 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_apply(FrameInfo *__restrict
                   c = ex.v[2] + blk[(size_t)2 * gridDim.x + blockIdx.x], d = ex.v[3] + blk[(size_t)3 * gridDim.x + blockIdx.x];
     const int nsym = (int)q.v[0];
     info[f].seg_off = (int32_t)d;
+    const int ns = (int)q.v[3];
     if (nsym > 0 && (a + nsym > sym_cap || b + q.v[1] > soft_cap || c + q.v[2] > dec_cap)) {
-        // keeps its slots in the numbering (they stay unused: sym2frame / seg2frame = -1 there)
+        // keeps its slots in the numbering; they are marked unused (as far as the maps reach)
         info[f].status = FOA_ST_NO_SPACE; info[f].nsteps = -nsym; info[f].nsym = 0;
+        for (int k = 0; k < nsym; k++) if (a + k < sym_cap) sym2frame[a + k] = -1;
+        for (int k = 0; k < ns; k++) if (d + k < seg_cap) seg2frame[d + k] = -1;
         return;
     }
     info[f].sym_off = (int32_t)a; info[f].soft_off = b; info[f].dec_off = c;
     for (int k = 0; k < nsym; k++) sym2frame[a + k] = f;
-    const int ns = (int)q.v[3];
-    for (int k = 0; k < ns; k++) seg2frame[d + k] = f;
+    for (int k = 0; k < ns; k++) if (d + k < seg_cap) seg2frame[d + k] = f;
 }
 
 // =================================================================================================
