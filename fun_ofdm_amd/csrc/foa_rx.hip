@@ -160,7 +160,7 @@ struct WorkSet {
     size_t sym_cap = 0, soft_cap = 0, dec_cap = 0;
     hipEvent_t ev[7] = {};       // start, after header, after scan, after symbols, end, after the forward pass, start of the finish
     WorkSet *before = nullptr;   // the set of the call queued before this one (pipelined path)
-    hipEvent_t fwd_done = nullptr, done = nullptr;
+    hipEvent_t fwd_done = nullptr, done = nullptr, walk_done = nullptr;
     bool used = false, have_timing = false, piped = false;
     void release_all()
     {
@@ -253,7 +253,7 @@ int flush_pending(foa_rx *rx, hipEvent_t after_front_end)
     if (after_front_end) HIP_TRY(hipStreamWaitEvent(sb, after_front_end, 0));
     HIP_TRY(hipEventRecord(p.w->ev[6], sb));
     launch_finish3(sb, p.w->info.p, p.nf, p.w->dec.p, p.w->decoded.p, p.w->seg2frame.p, p.w->totals.p, p.w->tb_state.p, p.max_segs, p.S, p.L, p.psdu,
-                   p.slot_bytes, p.results);
+                   p.slot_bytes, p.results, p.w->walk_done);
     HIP_TRY(hipEventRecord(p.w->ev[4], sb));
     HIP_TRY(hipEventRecord(p.w->done, sb));
     if (p.job) {
@@ -313,6 +313,7 @@ int foa_rx_create(foa_rx **out, int device)
         for (auto &e : ws.ev) HIP_TRY(hipEventCreate(&e));
         HIP_TRY(hipEventCreateWithFlags(&ws.fwd_done, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&ws.done, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ws.walk_done, hipEventDisableTiming));
     }
     DeviceTables tab;
     build_tables(&tab);
@@ -331,6 +332,7 @@ void foa_rx_destroy(foa_rx *rx)
         for (auto &e : ws.ev) if (e) (void)hipEventDestroy(e);
         if (ws.fwd_done) (void)hipEventDestroy(ws.fwd_done);
         if (ws.done) (void)hipEventDestroy(ws.done);
+        if (ws.walk_done) (void)hipEventDestroy(ws.walk_done);
     }
     for (auto &j : rx->jobs) {
         j.dev.release();
@@ -433,10 +435,12 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
     // st: header, scan, front end.  Pipelined, that is the third stream, so that they can run under the forward pass of
     // the call before (still busy on the first stream) wherever registers and LDS allow.
     hipStream_t st = piped ? rx->stream3 : rx->stream, st_fwd = rx->stream;
-    // Under one forward pass first the chain-back of the call before, then the front end of the call after: both at once
-    // slow each other and the forward pass down more than they gain (measured: 1.50 against 1.43 ms per step; letting only
-    // the light header and scan run alongside the chain-back is no better: 1.52).
-    if (piped && rx->prev->before && rx->prev->before->used && rx->prev->before != rx->w) HIP_TRY(hipStreamWaitEvent(st, rx->prev->before->done, 0));
+    // Under one forward pass first the chain-back walk of the call before, then the front end of the call after: the two
+    // heavy guests at once slow each other and the forward pass down more than they gain (measured: 1.50 against 1.43 ms per
+    // step; letting only the light header and scan run alongside the walk is no better: 1.52).  The stitch/CRC kernel
+    // behind the walk is light and latency-bound, so the front end does not wait for that one.
+    if (piped && rx->prev->before && rx->prev->before->used && rx->prev->before->piped && rx->prev->before != rx->w)
+        HIP_TRY(hipStreamWaitEvent(st, rx->prev->before->walk_done, 0));
     if (!piped && rx->prev->used && rx->prev != rx->w) HIP_TRY(hipStreamWaitEvent(st, rx->prev->done, 0));
     const int nf = (int)n_frames;
     const float2 *iq = (const float2 *)d_iq;

@@ -425,9 +425,10 @@ inline void launch_fwd3(hipStream_t st, const FrameInfo *info, int nf, const uin
 
 inline void launch_finish3(hipStream_t st, const FrameInfo *info, int nf, const uint64_t *dec, uint32_t *decoded, const int32_t *seg2frame,
                            const int64_t *totals, uint16_t *tb_state, size_t max_segs, int S, int L, uint8_t *psdu, size_t slot_bytes,
-                           foa_frame_result *results)
+                           foa_frame_result *results, hipEvent_t walk_done = nullptr)
 {
     hipLaunchKernelGGL(k_tb_walk, dim3((unsigned)((max_segs + 63) / 64)), dim3(64), 0, st, info, seg2frame, totals, dec, decoded, tb_state, S, L);
+    if (walk_done) (void)hipEventRecord(walk_done, st);
     hipLaunchKernelGGL(k_tb_finish, dim3((nf + 63) / 64), dim3(64), 0, st, info, nf, dec, decoded, tb_state, S, psdu, slot_bytes, results);
 }
 
