@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Reduce the two rocprofv3 --pmc passes of tools/profile_round.sh to HBM bytes per launch and kernel."""
+"""Reduce the rocprofv3 --pmc passes of tools/profile_round.sh to per-launch, per-kernel figures (HBM bytes, SQ issue, LDS, L2)."""
 import csv
 import glob
 import json
@@ -49,4 +49,21 @@ for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_IN
 if sq:
     json.dump({"command": "rocprofv3 --pmc SQ_* (own pass) -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline " + " ".join(args),
                "frames_per_gpu": frames, "per_launch": sq}, open(os.path.join(out, tag + "_pmc_sq.json"), "w"), indent=1)
+lds = {}
+for sub, names in (("pl", ("SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_ADDR_CONFLICT", "SQ_LDS_UNALIGNED_STALL")),
+                   ("pc", ("TCC_HIT_sum", "TCC_MISS_sum"))):
+    for c in names:
+        for k, v in per_kernel(sub, c).items():
+            if k.startswith("k_"):
+                lds.setdefault(k, {})[c] = round(v, 1)
+for k, d in lds.items():
+    if d.get("SQ_LDS_IDX_ACTIVE"):
+        d["lds_bank_conflict_frac"] = round(d.get("SQ_LDS_BANK_CONFLICT", 0.0) / d["SQ_LDS_IDX_ACTIVE"], 4)
+    if "TCC_HIT_sum" in d and d["TCC_HIT_sum"] + d.get("TCC_MISS_sum", 0.0) > 0:
+        d["l2_hit_frac"] = round(d["TCC_HIT_sum"] / (d["TCC_HIT_sum"] + d["TCC_MISS_sum"]), 4)
+if lds:
+    json.dump({"command": "rocprofv3 --pmc SQ_LDS_* | TCC_HIT_sum TCC_MISS_sum (own passes) -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline " + " ".join(args),
+               "frames_per_gpu": frames,
+               "notes": "lds_bank_conflict_frac = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE (extra cycles over all LDS-array cycles); l2_hit_frac = TCC_HIT / (TCC_HIT + TCC_MISS), MI355X_MICROARCH.md L2 section",
+               "per_launch": lds}, open(os.path.join(out, tag + "_pmc_lds_l2.json"), "w"), indent=1)
 print(json.dumps(kern, indent=1))
