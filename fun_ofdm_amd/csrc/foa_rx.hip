@@ -718,32 +718,34 @@ int foa_rx_sync_dev(foa_rx *rx, const float *d_iq, size_t n_samples, foa_frame_d
     const int n_blocks = (int)((n_words + kSyncBlockWords - 1) / kSyncBlockWords);
     const int32_t ccap = (int32_t)std::min<size_t>(n_samples / 64 + 64, 0x7FFFFFF0u);
     int rc;
-    if ((rc = rx->sy_flags.ensure((size_t)n_words)) || (rc = rx->sy_cnt.ensure((size_t)n_blocks)) || (rc = rx->sy_off.ensure((size_t)n_blocks)) ||
+    if ((rc = rx->sy_flags.ensure((size_t)n_words)) || (rc = rx->sy_cnt.ensure((size_t)std::max(n_blocks, (ccap + 255) / 256))) ||
+        (rc = rx->sy_off.ensure((size_t)std::max(n_blocks, (ccap + 255) / 256))) ||
         (rc = rx->sy_x.ensure((size_t)ccap)) || (rc = rx->sy_cand.ensure((size_t)ccap)) || (rc = rx->sy_keep.ensure((size_t)ccap)) || (rc = rx->sy_n.ensure(8)))
         return rc;
-    hipStream_t st = rx->stream;
+    // With calls pipelined this stage goes where the next call's front end goes: on the third stream, under the forward
+    // pass of the decode call in flight (its own scratch is touched by nothing else; the descriptors it writes are read by
+    // the header and data-symbol kernels of the next decode call, which follow on the same stream).
+    hipStream_t st = rx->pipeline ? rx->stream3 : rx->stream;
     const float2 *iq = (const float2 *)d_iq;
-    hipLaunchKernelGGL(k_sync_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, iq, n, rx->sy_flags.p);
+    hipLaunchKernelGGL(k_sync_flags, dim3((unsigned)((n + kFlagSamples - 1) / kFlagSamples)), dim3(256), 0, st, iq, n, rx->sy_flags.p);
     hipLaunchKernelGGL(k_sync_sts_end, dim3(n_blocks), dim3(kSyncBlockWords), 0, st, rx->sy_flags.p, n_words, 0, rx->sy_cnt.p, rx->sy_off.p, rx->sy_x.p, ccap);
     hipLaunchKernelGGL(k_sync_scan, dim3(1), dim3(1024), 0, st, rx->sy_cnt.p, n_blocks, rx->sy_off.p, rx->sy_n.p);
     hipLaunchKernelGGL(k_sync_sts_end, dim3(n_blocks), dim3(kSyncBlockWords), 0, st, rx->sy_flags.p, n_words, 1, rx->sy_cnt.p, rx->sy_off.p, rx->sy_x.p, ccap);
-    // one wave per candidate; the candidate count lives on the device, so launch for the capacity that can occur in
-    // practice (an STS_END needs 17 samples) and let surplus waves exit -- but first learn the count to keep the grid small
-    int32_t ncand = 0;
-    HIP_TRY(hipMemcpyAsync(&ncand, rx->sy_n.p, sizeof ncand, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    if (ncand > ccap) return fail(FOA_E_NOMEM, "too many STS_END candidates (%d)", ncand);
-    if (ncand == 0) return FOA_OK;
-    hipLaunchKernelGGL(k_sync_lts, dim3(ncand), dim3(64), 0, st, iq, n, rx->sy_x.p, rx->sy_n.p, ccap, rx->sy_cand.p);
-    hipLaunchKernelGGL(k_sync_keep, dim3((ncand + 255) / 256), dim3(256), 0, st, rx->sy_cand.p, rx->sy_n.p, ccap, rx->sy_keep.p);
-    hipLaunchKernelGGL(k_sync_finish, dim3(1), dim3(1024), 0, st, rx->sy_cand.p, rx->sy_keep.p, rx->sy_n.p, ccap, n, d_descs, d_ends,
-                       (int32_t)std::min<size_t>(cap, 0x7FFFFFF0u), rx->sy_n.p + 2);
-    int32_t nout[2] = { 0, 0 };
-    HIP_TRY(hipMemcpyAsync(nout, rx->sy_n.p + 2, sizeof nout, hipMemcpyDeviceToHost, st));
+    // one wave per candidate; the count stays on the device: fixed grids stride over it (k_sync_finish reports overflow)
+    const int lts_grid = (int)std::min<int64_t>(ccap, 16384);
+    hipLaunchKernelGGL(k_sync_lts, dim3(lts_grid), dim3(64), 0, st, iq, n, rx->sy_x.p, rx->sy_n.p, ccap, rx->sy_cand.p);
+    const int kb = (ccap + 255) / 256;       // blocks of the keep / emit stage; their counts reuse the STS_END stage's count buffers
+    hipLaunchKernelGGL(k_sync_keep, dim3(kb), dim3(256), 0, st, rx->sy_cand.p, rx->sy_n.p, ccap, rx->sy_keep.p, rx->sy_cnt.p);
+    hipLaunchKernelGGL(k_sync_scan, dim3(1), dim3(1024), 0, st, rx->sy_cnt.p, kb, rx->sy_off.p, rx->sy_n.p + 3);
+    hipLaunchKernelGGL(k_sync_emit, dim3(kb), dim3(256), 0, st, rx->sy_cand.p, rx->sy_keep.p, rx->sy_n.p, ccap, rx->sy_off.p, rx->sy_n.p + 3, n, d_descs, d_ends,
+                       (int32_t)std::min<size_t>(cap, 0x7FFFFFF0u));
+    int32_t cnt[4] = { 0, 0, 0, 0 };         // [0] STS_END candidates, [3] alignments found
+    HIP_TRY(hipMemcpyAsync(cnt, rx->sy_n.p, sizeof cnt, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipGetLastError());
-    if ((size_t)nout[1] > cap) return fail(FOA_E_INVALID, "cap too small: %d alignments found", nout[1]);
-    *n_found = (size_t)nout[0];
+    if (cnt[0] > ccap) return fail(FOA_E_NOMEM, "too many STS_END candidates (%d)", cnt[0]);
+    if ((size_t)cnt[3] > cap) return fail(FOA_E_INVALID, "cap too small: %d alignments found", cnt[3]);
+    *n_found = (size_t)cnt[3];
     return FOA_OK;
 }
 

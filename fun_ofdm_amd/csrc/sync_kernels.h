@@ -13,7 +13,7 @@
 //   k_sync_lts       timing_sync.cpp:69-113 per candidate: 96 x 64-tap cross-correlation with the LTS (same summation
 //                    order as the reference), the five strongest peaks above 0.9, the 64-apart test against the
 //                    strongest, the phase of timing_sync.cpp:113.
-//   k_sync_finish    tags written by an earlier hit can overwrite a later STS_END (timing_sync.cpp:105-106); drop those,
+//   k_sync_keep/emit tags written by an earlier hit can overwrite a later STS_END (timing_sync.cpp:105-106); drop those,
 //                    compact in stream order, chain the "previous phasor", derive the per-alignment end.
 #pragma once
 
@@ -32,32 +32,53 @@ struct SyncCand {
 
 __device__ __forceinline__ cpx widen(float2 v) { return cpx{ (double)v.x, (double)v.y }; }
 
-// flags[w] bit i = (|corr_sum| / pow_sum > 0.9) at sample 32*w + i.  One thread per sample: the 16 products of its
-// window are summed directly (neighbouring lanes read neighbouring samples, so the 32 loads per lane are coalesced and
-// served by L1), a wave's 64 verdicts leave as one ballot.
+constexpr int kFlagSamples = 1024;   // samples per block of k_sync_flags
+
+// flags[w] bit i = (|corr_sum| / pow_sum > 0.9) at sample 32*w + i.
+// The window of sample i holds the products of positions i-15 .. i, and a product belongs to sixteen windows: each
+// block forms the products of its 1024 + 15 positions once (three doubles each, in LDS) and every thread then adds
+// its sixteen in the order the direct sum used (oldest first), so the sums are the same doubles as before at 54
+// instead of 192 fp64 operations per sample.  |S| / P > 0.9 is decided on S.S against 0.81 P.P wherever that is clear by a
+// margin of 1e-9 (the rounding of hypot and of the division is 1e-15); only the rest takes hypot() and the division.
+// A wave's 64 verdicts leave as one ballot.
 __global__ __launch_bounds__(256) void k_sync_flags(const float2 *__restrict__ iq, int64_t n, uint32_t *__restrict__ flags)
 {
 #pragma clang fp contract(off)
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;        // grid covers a multiple of 64 samples
+    __shared__ double pr[kFlagSamples + 16], pi[kFlagSamples + 16], pw[kFlagSamples + 16];
+    const int t = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * kFlagSamples;
     auto at = [&](int64_t k) -> cpx { return (k >= 0 && k < n) ? widen(iq[k]) : cpx{ 0.0, 0.0 }; };
-    cpx S = { 0.0, 0.0 };
-    double P = 0.0;
-    cpx x[32];
-#pragma unroll
-    for (int k = 0; k < 32; k++) x[k] = at(i - 31 + k);                      // x[31] = sample i, x[15] = sample i-16
-#pragma unroll
-    for (int k = 0; k < 16; k++) {                                           // oldest product first, like a running sum would hold them
-        const cpx a = x[16 + k], b = x[k];
-        S.x += a.x * b.x + a.y * b.y;                                        // a * conj(b)
-        S.y += a.y * b.x - a.x * b.y;
-        P += a.x * a.x + a.y * a.y;
+    for (int s = t; s < kFlagSamples + 15; s += 256) {                      // slot s = position base - 15 + s
+        const int64_t j = base - 15 + s;
+        const cpx a = at(j), b = at(j - 16);
+        pr[s] = a.x * b.x + a.y * b.y;                                       // a * conj(b)
+        pi[s] = a.y * b.x - a.x * b.y;
+        pw[s] = a.x * a.x + a.y * a.y;
     }
-    const double corr = hypot(S.x, S.y) / P;
-    const uint64_t m = __ballot(i < n && corr > 0.9);
-    const int lane = threadIdx.x & 63;
-    const int64_t w = i >> 5;
-    if (lane == 0 && i < n) flags[w] = (uint32_t)m;
-    if (lane == 32 && i < n) flags[w] = (uint32_t)(m >> 32);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kFlagSamples / 256; r++) {
+        const int s0 = t + 256 * r;                                          // sample base + s0: slots s0 .. s0 + 15
+        const int64_t i = base + s0;
+        cpx S = { 0.0, 0.0 };
+        double P = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {                                       // oldest product first, like a running sum would hold them
+            S.x += pr[s0 + k];
+            S.y += pi[s0 + k];
+            P += pw[s0 + k];
+        }
+        const double q = S.x * S.x + S.y * S.y, lim = 0.81 * (P * P);
+        bool above;
+        if (q > lim * (1.0 + 1e-9)) above = true;
+        else if (q < lim * (1.0 - 1e-9) || P == 0.0) above = false;         // no power: 0/0 or NaN/0, never above
+        else above = hypot(S.x, S.y) / P > 0.9;                              // too close to call (or not finite): the reference's expression
+        const uint64_t m = __ballot(i < n && above);
+        const int lane = t & 63;
+        const int64_t w = i >> 5;
+        if (lane == 0 && i < n) flags[w] = (uint32_t)m;
+        if (lane == 32 && i < n) flags[w] = (uint32_t)(m >> 32);
+    }
 }
 
 // STS_END candidates of one block of flag words: count (pass 0) or write in order at offsets[block] (pass 1)
@@ -100,22 +121,39 @@ __global__ __launch_bounds__(kSyncBlockWords) void k_sync_sts_end(const uint32_t
     }
 }
 
+// exclusive scan of a block's 1024 per-thread values (in LDS part[]); returns the thread's offset, total in *total
+__device__ __forceinline__ int block1024_exclusive_scan(int v, int32_t *part, int *total)
+{
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(x, o);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) part[wv] = x;
+    __syncthreads();
+    int before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) {
+        const int pv = part[w];
+        if (w < wv) before += pv;
+        all += pv;
+    }
+    *total = all;
+    return before + x - v;
+}
+
 // exclusive scan of block counts (one block); total -> out_total[0]
 __global__ __launch_bounds__(1024) void k_sync_scan(const int32_t *__restrict__ cnt, int n_blocks, int32_t *__restrict__ off, int32_t *__restrict__ out_total)
 {
-    __shared__ int32_t part[1024];
+    __shared__ int32_t part[16];
     const int t = threadIdx.x, per = (n_blocks + 1023) / 1024, lo = t * per, hi = min(lo + per, n_blocks);
     int s = 0;
     for (int i = lo; i < hi; i++) s += cnt[i];
-    part[t] = s;
-    __syncthreads();
-    if (t == 0) {
-        int run = 0;
-        for (int i = 0; i < 1024; i++) { int v = part[i]; part[i] = run; run += v; }
-        out_total[0] = run;
-    }
-    __syncthreads();
-    s = part[t];
+    int total;
+    s = block1024_exclusive_scan(s, part, &total);
+    if (t == 0) out_total[0] = total;
     for (int i = lo; i < hi; i++) { off[i] = s; s += cnt[i]; }
 }
 
@@ -135,20 +173,27 @@ __global__ __launch_bounds__(64) void k_sync_lts(const float2 *__restrict__ iq, 
                                                   int32_t cap, SyncCand *__restrict__ out)
 {
 #pragma clang fp contract(off)
-    const int c = blockIdx.x, lane = threadIdx.x;
-    if (c >= min(*n_cand, cap)) return;
-    const int64_t x = cand_x[c];
+    const int lane = threadIdx.x, nc = min(*n_cand, cap);
     auto at = [&](int64_t i) -> cpx { return (i >= 0 && i < n) ? widen(iq[i]) : cpx{ 0.0, 0.0 }; };
+    // the candidate count lives on the device: a fixed grid strides over it, so the host need not learn it in between
+    __shared__ double2 win[160];                          // samples x .. x+159 of the candidate, widened once
+    for (int c = blockIdx.x; c < nc; c += gridDim.x) {
+    const int64_t x = cand_x[c];
+    __syncthreads();                                      // (one wave) the window of the candidate before is no longer read
+    for (int i = lane; i < 160; i += 64) { const cpx a = at(x + i); win[i] = make_double2(a.x, a.y); }
+    __syncthreads();
     // corr_norm for p = x + lane and (lanes < 32) p = x + 64 + lane
     double v[2] = { -1.0, -1.0 };
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         if (h == 1 && lane >= 32) break;
-        const int64_t p = x + 64 * h + lane;
+        const int p = 64 * h + lane;                      // relative to x
         cpx corr = { 0.0, 0.0 };
         double power = 0.0;
+#pragma unroll 8
         for (int s = 0; s < 64; s++) {
-            const cpx a = at(p + s);
+            const double2 aw = win[p + s];
+            const cpx a = { aw.x, aw.y };
             const cpx m = cmul(a, cpx{ g_tab.lts_conj_re[s], g_tab.lts_conj_im[s] });
             corr.x += m.x; corr.y += m.y;
             power += a.x * a.x + a.y * a.y;
@@ -183,59 +228,62 @@ __global__ __launch_bounds__(64) void k_sync_lts(const float2 *__restrict__ iq, 
         break;
     }
     if (lane == 0) out[c] = o;
+    }
 }
 
-// keep[c] = found and not overwritten by the tags of one of the four candidates before it
-__global__ void k_sync_keep(const SyncCand *__restrict__ cand, const int32_t *__restrict__ n_cand, int32_t cap, int32_t *__restrict__ keep)
+// keep[c] = found and not overwritten by the tags of one of the four candidates before it; block_count[b] = kept in block b
+__global__ __launch_bounds__(256) void k_sync_keep(const SyncCand *__restrict__ cand, const int32_t *__restrict__ n_cand, int32_t cap, int32_t *__restrict__ keep,
+                                                   int32_t *__restrict__ block_count)
 {
+    __shared__ int32_t wsum[4];
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     const int nc = min(*n_cand, cap);
-    if (c >= nc) return;
-    int k = cand[c].found;
-    for (int b = 1; b <= 4 && c - b >= 0 && k; b++) {
-        const SyncCand &e = cand[c - b];
-        if (e.found && (cand[c].x == e.lts1_pos || cand[c].x == e.lts1_pos + 64)) k = 0;
+    int k = 0;
+    if (c < nc) {
+        k = cand[c].found;
+        for (int b = 1; b <= 4 && c - b >= 0 && k; b++) {
+            const SyncCand &e = cand[c - b];
+            if (e.found && (cand[c].x == e.lts1_pos || cand[c].x == e.lts1_pos + 64)) k = 0;
+        }
+        keep[c] = k;
     }
-    keep[c] = k;
+    const int in_wave = __popcll(__ballot(k != 0));
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = in_wave;
+    __syncthreads();
+    if (threadIdx.x == 0) block_count[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-// ordered compaction of kept candidates -> descriptors; one block (candidates are few: one per frame or so)
-__global__ __launch_bounds__(1024) void k_sync_finish(const SyncCand *__restrict__ cand, const int32_t *__restrict__ keep, const int32_t *__restrict__ n_cand,
-                                                       int32_t cap, int64_t n_samples, foa_frame_desc *__restrict__ descs, int64_t *__restrict__ ends,
-                                                       int32_t desc_cap, int32_t *__restrict__ n_out)
+// ordered compaction of the kept candidates -> descriptors.  block_off[] = exclusive scan of k_sync_keep's counts,
+// *n_kept = their total.  A kept candidate finds its neighbours in the kept sequence by walking keep[] (nearly every
+// candidate is kept, so the walks are one or two steps): the phasor before it (timing_sync.cpp:113 applies the rotation
+// found at one LTS until the next) and the start of the alignment after it, which is where its own ends.
+__global__ __launch_bounds__(256) void k_sync_emit(const SyncCand *__restrict__ cand, const int32_t *__restrict__ keep, const int32_t *__restrict__ n_cand,
+                                                   int32_t cap, const int32_t *__restrict__ block_off, const int32_t *__restrict__ n_kept, int64_t n_samples,
+                                                   foa_frame_desc *__restrict__ descs, int64_t *__restrict__ ends, int32_t desc_cap)
 {
-    __shared__ int32_t part[1024];
+    __shared__ int32_t wsum[4];
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int nc = min(*n_cand, cap);
-    const int t = threadIdx.x, per = (nc + 1023) / 1024, lo = t * per, hi = min(lo + per, nc);
-    int s = 0;
-    for (int i = lo; i < hi; i++) s += keep[i];
-    part[t] = s;
+    const int k = c < nc ? keep[c] : 0;
+    const uint64_t m = __ballot(k != 0);
+    if (lane == 0) wsum[wv] = __popcll(m);
     __syncthreads();
-    if (t == 0) {
-        int run = 0;
-        for (int i = 0; i < 1024; i++) { int v = part[i]; part[i] = run; run += v; }
-        n_out[0] = min(run, desc_cap);
-        n_out[1] = run;
-    }
-    __syncthreads();
-    int pos = part[t];
-    for (int i = lo; i < hi; i++) {
-        if (!keep[i]) continue;
-        if (pos < desc_cap) {
-            foa_frame_desc d;
-            d.lts1_pos = cand[i].lts1_pos; d.rot_start = cand[i].x; d.c = cand[i].c; d.s = cand[i].s;
-            d.c_prev = 1.0; d.s_prev = 0.0;              // fixed up below
-            descs[pos] = d;
-        }
-        pos++;
-    }
-    __syncthreads();
-    __threadfence_block();
-    const int total = min(n_out[1], desc_cap);
-    for (int k = t; k < total; k += 1024) {
-        if (k > 0) { descs[k].c_prev = descs[k - 1].c; descs[k].s_prev = descs[k - 1].s; }
-        ends[k] = k + 1 < total ? descs[k + 1].lts1_pos : n_samples;
-    }
+    if (!k) return;
+    int pos = block_off[blockIdx.x] + __popcll(m & ((1ull << lane) - 1));
+    for (int w = 0; w < wv; w++) pos += wsum[w];
+    if (pos >= desc_cap) return;
+    const int total = min(*n_kept, desc_cap);
+    foa_frame_desc d;
+    d.lts1_pos = cand[c].lts1_pos; d.rot_start = cand[c].x; d.c = cand[c].c; d.s = cand[c].s;
+    d.c_prev = 1.0; d.s_prev = 0.0;
+    for (int j = c - 1; j >= 0; j--)
+        if (keep[j]) { d.c_prev = cand[j].c; d.s_prev = cand[j].s; break; }
+    descs[pos] = d;
+    int64_t e = n_samples;
+    if (pos + 1 < total)
+        for (int j = c + 1; j < nc; j++)
+            if (keep[j]) { e = cand[j].lts1_pos; break; }
+    ends[pos] = e;
 }
 
 }  // namespace foa
