@@ -397,6 +397,64 @@ def test_device_sync_matches_host_sync(rx, po):
         assert np.array_equal(t_psdu.cpu().numpy()[ok], opsdu[ok]) and ok.sum() >= 30
 
 
+def test_device_sync_edge_inputs(rx):
+    """Streams too short to hold a window, all-zero input (0/0 everywhere: never above threshold) and noise only:
+    the device stage agrees with the host restatement and writes nothing it should not."""
+    import torch
+    import fun_ofdm_amd as foa
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(5)
+    cases = [np.zeros(5000, np.complex64)]
+    for n in (1, 17, 100, 1023, 1024, 1025, 4097):
+        cases.append(((rng.normal(size=n) + 1j * rng.normal(size=n)) * 0.05).astype(np.complex64))
+    for s in cases:
+        want = foa.find_alignments(s)
+        t_iq = torch.from_numpy(s.view(np.float32).reshape(-1, 2)).to(dev)
+        t_desc = torch.full((64 * 48,), 0xA5, dtype=torch.uint8, device=dev)
+        t_ends = torch.full((64,), -7, dtype=torch.int64, device=dev)
+        n = rx.sync_dev(t_iq, t_desc, t_ends)
+        assert n == want.size, (s.size, n, want.size)
+        got = t_desc.cpu().numpy()
+        assert np.array_equal(got[:n * 48].view(foa.frame_desc_dtype)["lts1_pos"], want["lts1_pos"])
+        assert (got[n * 48:] == 0xA5).all() and (t_ends.cpu().numpy()[n:] == -7).all()
+
+
+def test_device_sync_between_pipelined_decode_calls(rx, po):
+    """sync k+1 is queued while decode k is still in flight (it runs on the third stream under that call's forward
+    pass): descriptors, PSDUs and results of every round equal those of the same round run alone."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(91)
+    streams = []
+    for k in range(4):
+        specs = [(int(rng.integers(0, 11)), int(rng.integers(1, 700))) for _ in range(8 + 2 * k)]
+        iq, _ = _make_stream(po, rng, specs, snr_db=25.0)
+        streams.append(iq)
+    def run(piped):
+        rx.set_option("pipeline", 1 if piped else 0)
+        outs = []
+        for iq in streams:
+            t_iq = torch.from_numpy(iq.view(np.float32).reshape(-1, 2)).to(dev)
+            cap = iq.size // 300 + 16
+            t_desc = torch.zeros(cap * 48, dtype=torch.uint8, device=dev)
+            t_ends = torch.zeros(cap, dtype=torch.int64, device=dev)
+            n = rx.sync_dev(t_iq, t_desc, t_ends)
+            t_psdu = torch.zeros((n, 4096), dtype=torch.uint8, device=dev)
+            t_res = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+            rx.decode_frames_dev(t_iq, t_desc[:n * 48], t_ends[:n], t_psdu, t_res)
+            if not piped:
+                rx.sync()
+            outs.append((t_iq, t_desc, t_ends, t_psdu, t_res, n))
+        rx.sync()
+        return [(o[5], o[1].cpu().numpy(), o[2].cpu().numpy(), o[3].cpu().numpy(), o[4].cpu().numpy()) for o in outs]
+    alone, piped = run(False), run(True)
+    rx.set_option("pipeline", 1)
+    for a, b in zip(alone, piped):
+        assert a[0] == b[0] and a[0] >= 6
+        for x, y in zip(a[1:], b[1:]):
+            assert np.array_equal(x, y)
+
+
 def test_pipelined_calls_keep_their_results_apart(rx, po):
     """Back-to-back decode calls without a sync in between (the finish of call k runs on a second stream under the
     forward pass of call k+1, on alternating work sets): every call must produce exactly what it produces alone."""
