@@ -50,6 +50,33 @@ __device__ __forceinline__ uint32_t pk_sub_wrap(uint32_t a, uint32_t b)
     return __builtin_bit_cast(uint32_t, r);
 }
 
+#ifndef FOA_MIN16
+#define FOA_MIN16 1
+#endif
+// Smallest metric of one frame of the packed register, wave-uniform.  High half: the unsigned 32-bit minimum of the packed
+// words has the smallest high half in its high half, so the register goes into the reduction as it is and the shift happens
+// on the scalar side.  Low half: v_min_u16 compares low halves only and takes the DPP operand like v_min_u32 does, so no
+// mask is needed either.  (s_nop: a DPP operand written by the instruction before needs two wait states; the compiler
+// does not look into an asm block.)
+__device__ __forceinline__ uint32_t wave_min_hi16(uint32_t v) { return wave_min_u32(v) >> 16; }
+__device__ __forceinline__ uint32_t wave_min_lo16(uint32_t v)
+{
+#if FOA_MIN16
+    uint32_t r;
+    asm("s_nop 1\n\t"
+        "v_min_u16_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_min_u16_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_min_u16_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_min_u16_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_min_u16_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_min_u16_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+        : "=&v"(r) : "v"(v));
+    return __builtin_amdgcn_readlane(r, 63) & 0xFFFFu;
+#else
+    return wave_min_u32(v & 0xFFFFu);
+#endif
+}
+
 struct Fwd3Lane {
     uint32_t ofs[6];      // byte offset of this lane's variant inside a step's 64-byte staging entry: 16 cls + 8 side
 };
@@ -106,13 +133,13 @@ __device__ __forceinline__ uint32_t fwd3_step(uint32_t M, const uint2 w, const F
     if (__builtin_expect(over != 0u, 0)) {      // cold: keeps the common path free of taken branches
         // the amount is wave-uniform: subtract the bias on the scalar side so the vector side is one v_sub
         if (over & 0x100u) {
-            const uint32_t mn = wave_min_u32(Mn & 0xFFFFu);
+            const uint32_t mn = wave_min_lo16(Mn);
             uint32_t adj;
             asm("s_sub_u32 %0, %1, %2" : "=s"(adj) : "s"(mn), "s"(kBias) : "scc");
             Mn -= adj;
         }
         if (over >> 16) {
-            const uint32_t mn = wave_min_u32(Mn >> 16);
+            const uint32_t mn = wave_min_hi16(Mn);
             uint32_t adj;
             asm("s_sub_u32 %0, %1, %2\n\ts_lshl_b32 %0, %0, 16" : "=s"(adj) : "s"(mn), "s"(kBias) : "scc");
             Mn -= adj;
