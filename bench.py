@@ -211,6 +211,10 @@ def main():
         # library's second stream.  With several ranks the PSDUs of the step two back are gathered meanwhile: that step is
         # complete by now, so the host is not held up and the next step's front end is queued in time.
         k = issued[0]
+        if world > 1 and done[0] > 0:
+            # this call will overwrite the output set whose gather was queued one step ago (on torch's stream, which the
+            # library's streams are not ordered against): make sure that one is through.  It has had a whole step.
+            torch.cuda.current_stream().synchronize()
         rx.decode_frames_dev(d_iq, d_desc, d_ends, out_psdu[k % n_out], out_res[k % n_out])
         issued[0] = k + 1
         if world > 1 and k - done[0] >= 2:
