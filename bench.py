@@ -123,6 +123,7 @@ def main():
                     help="where the synthetic frames are built: numpy on the host (default) or foa_tx_* on the device")
     ap.add_argument("--no-pipeline", action="store_true", help="finish of a step on the same stream as the rest (no overlap with the next step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sync-leg", action="store_true", help="skip the extra leg with the device pre-sync (profiling: keeps its launches out of the kernel averages)")
     args = ap.parse_args()
 
     import torch
@@ -267,7 +268,7 @@ def main():
 
     # ---- extra leg (not `value`): the same pass preceded by frame_detector + timing_sync on the device ----
     with_sync = None
-    if world == 1:
+    if world == 1 and not args.no_sync_leg:
         cap = iq.size // 300 + 16
         s_desc = torch.zeros(cap * 48, dtype=torch.uint8, device=dev)
         s_ends = torch.zeros(cap, dtype=torch.int64, device=dev)
