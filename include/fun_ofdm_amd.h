@@ -173,7 +173,7 @@ int foa_rx_get_taps(foa_rx *rx, size_t n_frames, double *hinv, double *eq, size_
  * fun_ofdm_amd/csrc/viterbi_v3.h). */
 int foa_rx_get_decisions(foa_rx *rx, size_t frame, uint64_t *out, size_t cap, size_t *n_steps);
 
-/* ---- pre-sync (host side for now; SURVEY 8f #1 moves it onto the device) ---- */
+/* ---- pre-sync: on the host (streaming) and on the device (whole resident streams), SURVEY 8f #1 ---- */
 
 /* Streaming frame_detector + timing_sync (src/frame_detector.cpp:41-93, src/timing_sync.cpp:51-139):
  * consumes the raw stream in chunks of any size and reports one descriptor per LTS1/LTS2 tag pair,
@@ -192,7 +192,11 @@ int64_t foa_sync_settled(const foa_sync *s);
  * pointers, capacity cap) in stream order and returns the number of alignments in *n_found (synchronises).  The decisions
  * are the reference's up to floating-point ties: windowed sums are formed directly instead of by the reference's
  * ever-drifting running sums, so a threshold decision can differ when the normalised correlation is within ~1e-15 of
- * 0.9. */
+ * 0.9.  d_iq must be complete when the call is made (like the input of foa_rx_decode_frames_dev: with
+ * calls pipelined the stage runs on the library's third stream, under the forward pass of a decode call in flight, and
+ * is not ordered behind foa_rx_stream()); d_descs / d_ends may be handed to the next decode call straight away.
+ * FOA_E_INVALID if more than cap alignments are found, FOA_E_NOMEM if the stream holds more STS_END candidates than
+ * one per 64 samples. */
 int foa_rx_sync_dev(foa_rx *rx, const float *d_iq, size_t n_samples, foa_frame_desc *d_descs, int64_t *d_ends, size_t cap, size_t *n_found);
 
 /* ---- stage-level entry points (one per replaced fun::block, for the per-block adaptors) ---- */
