@@ -158,9 +158,10 @@ struct WorkSet {
     DevBuf<int64_t> totals;
     DevBuf<double2> eq_sig, eq_data;
     size_t sym_cap = 0, soft_cap = 0, dec_cap = 0;
-    hipEvent_t ev[7] = {};       // start, after header, after scan, after symbols, end, after the forward pass, start of the finish
+    hipEvent_t ev[8] = {};       // start, after header, after scan, after symbols, end, after the forward pass, start of the finish,
+                                 // start of the forward pass (pipelined path)
     WorkSet *before = nullptr;   // the set of the call queued before this one (pipelined path)
-    hipEvent_t fwd_done = nullptr, done = nullptr, walk_done = nullptr;
+    hipEvent_t done = nullptr, walk_done = nullptr;
     bool used = false, have_timing = false, piped = false;
     void release_all()
     {
@@ -188,6 +189,7 @@ struct foa_rx {
     hipStream_t stream = nullptr;      // front end + forward pass (and everything else)
     hipStream_t stream2 = nullptr;     // chain-back + finish of the pipelined path
     hipStream_t stream3 = nullptr;     // header + scan + front end of the pipelined path
+    hipStream_t stream4 = nullptr;     // forward passes of every other pipelined call (the rest are on `stream`)
     int viterbi_kind = 2;        // 0: lane per state (viterbi_v1.h), 1: packed, serial chain-back (v2), 2: packed, segment chain-back (v3)
     int tb_segment = 960, tb_overlap = 96;   // v3 chain-back: data steps per segment / run-in steps (multiples of 96)
     bool pipeline = true;        // v3: finish of one call overlaps the next call's front end (two work sets, two streams)
@@ -249,7 +251,8 @@ int flush_pending(foa_rx *rx, hipEvent_t after_front_end)
     foa_rx::Pending &p = rx->pending;
     if (!p.valid) return FOA_OK;
     hipStream_t sb = rx->stream2;
-    HIP_TRY(hipStreamWaitEvent(sb, p.w->fwd_done, 0));
+    HIP_TRY(hipStreamWaitEvent(sb, p.w->ev[5], 0));          // its forward pass (the timing event doubles as the dependency:
+                                                              // every packet between two forward passes costs the first stream microseconds)
     if (after_front_end) HIP_TRY(hipStreamWaitEvent(sb, after_front_end, 0));
     HIP_TRY(hipEventRecord(p.w->ev[6], sb));
     launch_finish3(sb, p.w->info.p, p.nf, p.w->dec.p, p.w->decoded.p, p.w->seg2frame.p, p.w->totals.p, p.w->tb_state.p, p.max_segs, p.S, p.L, p.psdu,
@@ -275,6 +278,7 @@ int drain(foa_rx *rx)
     HIP_TRY(hipStreamSynchronize(rx->stream));
     HIP_TRY(hipStreamSynchronize(rx->stream2));
     HIP_TRY(hipStreamSynchronize(rx->stream3));
+    HIP_TRY(hipStreamSynchronize(rx->stream4));
     return FOA_OK;
 }
 
@@ -309,9 +313,9 @@ int foa_rx_create(foa_rx **out, int device)
     HIP_TRY(hipStreamCreateWithFlags(&rx->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&rx->stream2, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&rx->stream3, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&rx->stream4, hipStreamNonBlocking));
     for (auto &ws : rx->sets) {
         for (auto &e : ws.ev) HIP_TRY(hipEventCreate(&e));
-        HIP_TRY(hipEventCreateWithFlags(&ws.fwd_done, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&ws.done, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&ws.walk_done, hipEventDisableTiming));
     }
@@ -330,7 +334,6 @@ void foa_rx_destroy(foa_rx *rx)
     for (auto &ws : rx->sets) {
         ws.release_all();
         for (auto &e : ws.ev) if (e) (void)hipEventDestroy(e);
-        if (ws.fwd_done) (void)hipEventDestroy(ws.fwd_done);
         if (ws.done) (void)hipEventDestroy(ws.done);
         if (ws.walk_done) (void)hipEventDestroy(ws.walk_done);
     }
@@ -344,6 +347,7 @@ void foa_rx_destroy(foa_rx *rx)
     if (rx->stream) (void)hipStreamDestroy(rx->stream);
     if (rx->stream2) (void)hipStreamDestroy(rx->stream2);
     if (rx->stream3) (void)hipStreamDestroy(rx->stream3);
+    if (rx->stream4) (void)hipStreamDestroy(rx->stream4);
     delete rx;
 }
 
@@ -434,7 +438,10 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
     if (rc) return rc;
     // st: header, scan, front end.  Pipelined, that is the third stream, so that they can run under the forward pass of
     // the call before (still busy on the first stream) wherever registers and LDS allow.
-    hipStream_t st = piped ? rx->stream3 : rx->stream, st_fwd = rx->stream;
+    // Forward passes of consecutive calls take turns on two streams: nothing orders one behind the other (each has its own
+    // work set), so the next one starts the moment its front end is done, into the tail of the one before, instead of
+    // ~20 us after it (end-of-kernel release, event packets, dispatch): 1.345 -> 1.316 ms per step at config 2.
+    hipStream_t st = piped ? rx->stream3 : rx->stream, st_fwd = (piped && ((rx->w - rx->sets) & 1)) ? rx->stream4 : rx->stream;
     // Under one forward pass first the chain-back walk of the call before, then the front end of the call after: the two
     // heavy guests at once slow each other and the forward pass down more than they gain (measured: 1.50 against 1.43 ms per
     // step; letting only the light header and scan run alongside the walk is no better: 1.52).  The stitch/CRC kernel
@@ -478,9 +485,9 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
         // the previous call's chain-back + finish goes under this call's forward pass
         if ((rc = flush_pending(rx, rx->w->ev[3]))) return rc;
         HIP_TRY(hipStreamWaitEvent(st_fwd, rx->w->ev[3], 0));
+        HIP_TRY(hipEventRecord(rx->w->ev[7], st_fwd));          // start of the forward pass (this stream idles every other step: free)
         launch_fwd3(st_fwd, rx->w->info.p, nf, rx->w->bm.p, rx->w->dec.p);
         HIP_TRY(hipEventRecord(rx->w->ev[5], st_fwd));
-        HIP_TRY(hipEventRecord(rx->w->fwd_done, st_fwd));
         foa_rx::Pending &p = rx->pending;
         p.valid = true; p.w = rx->w; p.nf = nf; p.S = rx->tb_segment; p.L = rx->tb_overlap; p.max_segs = max_segs; p.slot_bytes = slot_bytes;
         p.psdu = d_psdu; p.results = d_results; p.job = rx->attach_job;
@@ -616,14 +623,10 @@ static int kernel_ms_of(foa_rx *rx, WorkSet *w, float out_ms[6])
     HIP_TRY(hipEventSynchronize(w->ev[4]));
     HIP_TRY(hipEventSynchronize(w->ev[5]));
     for (int i = 0; i < 3; i++) HIP_TRY(hipEventElapsedTime(&out_ms[i], w->ev[i], w->ev[i + 1]));
-    // forward pass (or the fused v1 kernel).  Pipelined, the kernel starts when BOTH its front end and the previous call's
-    // forward pass (same stream) are done, so its duration is the shorter of the two intervals -- an extra event in front of
-    // it would be exact too, but costs the stream 1-3 % (measured)
-    HIP_TRY(hipEventElapsedTime(&out_ms[3], w->ev[3], w->ev[5]));
-    if (w->piped && w->before && w->before->piped && w->before->have_timing && hipEventQuery(w->before->ev[5]) == hipSuccess) {
-        float since_prev = 0.f;
-        if (hipEventElapsedTime(&since_prev, w->before->ev[5], w->ev[5]) == hipSuccess && since_prev > 0.f && since_prev < out_ms[3]) out_ms[3] = since_prev;
-    }
+    // forward pass (or the fused v1 kernel).  Pipelined, it has its own start event: consecutive forward passes overlap by
+    // design (two streams), so this is the launch's own duration, like a kernel trace reports it, not the step's share.
+    if (w->piped) HIP_TRY(hipEventElapsedTime(&out_ms[3], w->ev[7], w->ev[5]));
+    else HIP_TRY(hipEventElapsedTime(&out_ms[3], w->ev[3], w->ev[5]));
     // chain-back + descramble + CRC (0 for v1); on the pipelined path from where the second stream starts on it
     if (w->piped) HIP_TRY(hipEventElapsedTime(&out_ms[4], w->ev[6], w->ev[4]));
     else HIP_TRY(hipEventElapsedTime(&out_ms[4], w->ev[5], w->ev[4]));

@@ -11,8 +11,8 @@ out=gpurun_out/prof_$tag; rm -rf $out; mkdir -p $out
 # (--no-sync-leg: the extra leg with the device pre-sync launches the same kernels again under different sharing; left in,
 #  they would enter the per-kernel averages that are compared with bench.py's live HIP-event times.  The second trace is
 #  the full default command and is kept for the pre-sync kernels.)
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-sync-leg "$@" > $out/${tag}_bench_under_rocprof.json 2> $out/kt.log
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/kf -o kf -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline "$@" > /dev/null 2> $out/kf.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-sync-leg "$@" > $out/${tag}_bench_under_rocprof.json 2> $out/kt.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kf -o kf -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline "$@" > /dev/null 2> $out/kf.log
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pf -o pf -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > /dev/null 2> $out/pf.log
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pw -o pw -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > /dev/null 2> $out/pw.log
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVES --output-format csv -d $out/ps -o ps -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > /dev/null 2> $out/ps.log
