@@ -227,6 +227,39 @@ def test_truncated_and_degenerate_inputs(rx, po, golden):
     assert tuple(res[0]) == tuple(o_res)
 
 
+def test_overlapping_alignments_exhaust_the_workspace(po):
+    """The workspace of a call is sized from its sample count.  Descriptors that claim the same samples several times over
+    need more than that: the frames that still fit decode as usual, the rest come back FOA_ST_NO_SPACE (with their symbol
+    count), nothing is written out of bounds, and the handle works normally afterwards."""
+    import fun_ofdm_amd as foa
+    rng = np.random.default_rng(12)
+    r = foa.Receiver(0)                       # a fresh handle: its buffers are exactly as large as this call needs
+    try:
+        for pipeline in (1, 0):
+            r.set_option("pipeline", pipeline)
+            iq, pays = _make_stream(po, rng, [(0, 100)], snr_db=30.0, gap=(150, 151))
+            d1 = po.find_alignments_f32(iq)
+            assert d1.size == 1
+            for copies in (2, 3, 7, 300):
+                descs = np.repeat(d1, copies)
+                ends = np.full(copies, iq.size, np.int64)
+                psdu, res = r.decode_frames_host(iq, descs, ends)
+                st = res["status"]
+                assert st[0] == foa.ST_OK and psdu[0, :100].tobytes() == pays[0].tobytes()
+                fit = int((st == foa.ST_OK).sum())
+                assert 1 <= fit < copies and (st[:fit] == foa.ST_OK).all() and (st[fit:] == foa.ST_NO_SPACE).all()
+                assert all(psdu[k, :100].tobytes() == pays[0].tobytes() for k in range(fit))
+                assert (res["num_symbols"] == res["num_symbols"][0]).all() and (res["rate"] == 0).all() and (res["length"] == 100).all()
+            # and a normal call on the same handle
+            iq2, pays2 = _make_stream(po, rng, [(10, 300), (5, 77)], snr_db=30.0)
+            d2 = po.find_alignments_f32(iq2)
+            psdu2, res2 = r.decode_frames_host(iq2, d2, _ends(d2, iq2.size))
+            assert (res2["status"] == foa.ST_OK).all()
+            assert psdu2[0, :300].tobytes() == pays2[0].tobytes() and psdu2[1, :77].tobytes() == pays2[1].tobytes()
+    finally:
+        r.close()
+
+
 def test_rotation_switch_inside_lts(rx, po, golden):
     """rot_start after lts1_pos: the first samples of the LTS window use the previous phasor
     (timing_sync.cpp:105,124: the tag may sit up to 8 samples before the STS_END sample)."""
