@@ -22,8 +22,7 @@ struct FrameInfo {
     int64_t soft_off;    // byte offset of this frame's depunctured soft bytes
     int64_t dec_off;     // offset (in 8-byte words) of this frame's decision words
     int32_t seg_off;     // first chain-back segment's index in the call-wide segment numbering (viterbi_v3.h)
-    int32_t nsym0;       // nsym as the header decode set it; never changed afterwards (k_scan_one sums it while other
-                         // blocks may already be marking frames that do not fit)
+    int32_t reserved_;
 };
 
 // rates.h:52-196 as a device table

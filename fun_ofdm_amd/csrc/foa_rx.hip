@@ -459,8 +459,11 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
     // segments of this call: at most (total data steps)/S + one per frame; lanes beyond the real total idle
     const size_t max_segs = std::min(rx->w->seg2frame.n, rx->w->dec_cap / (size_t)rx->tb_segment + n_frames + 1);
     const int n_sb = (nf + kScanBlock - 1) / kScanBlock;
-    hipLaunchKernelGGL(k_scan_one, dim3(n_sb), dim3(kScanBlock), 0, st, rx->w->info.p, nf, (int64_t)rx->w->sym_cap, (int64_t)rx->w->soft_cap,
-                       (int64_t)rx->w->dec_cap, rx->tb_segment, (int64_t)rx->w->seg2frame.n, rx->w->totals.p, rx->w->sym2frame.p, rx->w->seg2frame.p);
+    int64_t *blk = rx->w->totals.p + 8;
+    hipLaunchKernelGGL(k_scan_sums, dim3(n_sb), dim3(kScanBlock), 0, st, rx->w->info.p, nf, rx->tb_segment, blk);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, blk, n_sb, (int64_t)rx->w->sym_cap, rx->w->totals.p);
+    hipLaunchKernelGGL(k_scan_apply, dim3(n_sb), dim3(kScanBlock), 0, st, rx->w->info.p, nf, (int64_t)rx->w->sym_cap, (int64_t)rx->w->soft_cap,
+                       (int64_t)rx->w->dec_cap, rx->tb_segment, (int64_t)rx->w->seg2frame.n, blk, rx->w->sym2frame.p, rx->w->seg2frame.p);
     HIP_TRY(hipEventRecord(rx->w->ev[2], st));
     // upper bound on data symbols in n_samples samples; waves beyond the real total exit at once
     const size_t max_sym = rx->w->sym_cap;
@@ -925,7 +928,7 @@ int foa_decode_data_f64(foa_rx *rx, const double *carriers, const uint64_t *carr
         FrameInfo &fi = info[f];
         fi.status = FOA_ST_CRC_FAIL; fi.rate = rate; fi.length = len; fi.nsym = nsym; fi.sym_off = (int32_t)sym2frame.size();
         fi.nsteps = nsym * dbps; fi.soft_off = soft_off; fi.dec_off = dec_off;
-        fi.seg_off = (int32_t)seg2frame.size(); fi.nsym0 = nsym;
+        fi.seg_off = (int32_t)seg2frame.size(); fi.reserved_ = 0;
         seg2frame.insert(seg2frame.end(), (size_t)tb_segments(fi.nsteps, rx->tb_segment), (int32_t)f);
         soft_off += ((int64_t)2 * fi.nsteps + 255) & ~(int64_t)255;
         dec_off += dec_words(fi.nsteps);

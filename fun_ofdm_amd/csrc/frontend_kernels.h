@@ -348,7 +348,7 @@ __global__ __launch_bounds__(64) void k_header(const float2 *__restrict__ iq, co
     const int64_t end = ends[f], p = d.lts1_pos;
     FrameInfo fi;
     fi.status = FOA_ST_HEADER_FAIL; fi.rate = -1; fi.length = 0; fi.nsym = 0; fi.sym_off = 0; fi.nsteps = 0;
-    fi.soft_off = 0; fi.dec_off = 0; fi.seg_off = 0; fi.nsym0 = 0;
+    fi.soft_off = 0; fi.dec_off = 0;
     if (p < 0 || p + 208 > end) {                     // LTS or SIGNAL window cut off
         fi.status = FOA_ST_TRUNCATED;
         if (lane == 0) info[f] = fi;
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(64) void k_header(const float2 *__restrict__ iq, co
         if (rate >= 0) {
             fi.rate = rate; fi.length = length;
             if (p + 144 + 80 * (int64_t)nsym + 64 > end) { fi.status = FOA_ST_TRUNCATED; fi.nsteps = -nsym; }   // nsym still reported
-            else { fi.status = FOA_ST_CRC_FAIL; fi.nsym = fi.nsym0 = nsym; fi.nsteps = nsym * g_tab.rates[rate].dbps; }   // pending until the CRC is checked
+            else { fi.status = FOA_ST_CRC_FAIL; fi.nsym = nsym; fi.nsteps = nsym * g_tab.rates[rate].dbps; }   // pending until the CRC is checked
         }
         info[f] = fi;
     }
@@ -398,9 +398,21 @@ __host__ __device__ constexpr int64_t dec_words(int64_t nsteps) { return nsteps 
 // chain-back segments of a frame (viterbi_v3.h): its nsteps - 6 data steps in pieces of seg_steps
 __host__ __device__ constexpr int tb_segments(int nsteps, int seg_steps) { return nsteps > 6 ? (nsteps - 6 + seg_steps - 1) / seg_steps : 0; }
 
+// Three small kernels instead of one block: a single CU's memory pipeline (one 64-line request per wave instruction)
+// made the one-block version the 50 us tail of a 2 ms call.  One thread per frame throughout.
 constexpr int kScanBlock = 256;
 
 struct ScanQ { int64_t v[4]; };          // data symbols, soft bytes (256-aligned), decision words, chain-back segments
+
+__device__ __forceinline__ ScanQ scan_quantities(const FrameInfo *info, int f, int n_frames, int seg_steps)
+{
+    ScanQ q = { { 0, 0, 0, 0 } };
+    if (f < n_frames) {
+        const int nsym = info[f].nsym, nsteps = nsym > 0 ? info[f].nsteps : 0;
+        q.v[0] = nsym; q.v[1] = ((int64_t)2 * nsteps + 255) & ~(int64_t)255; q.v[2] = dec_words(nsteps); q.v[3] = tb_segments(nsteps, seg_steps);
+    }
+    return q;
+}
 
 // exclusive scan over the block's threads; totals in tot[] (valid in every thread)
 __device__ __forceinline__ ScanQ block_exclusive_scan(const ScanQ &q, int64_t (&tot)[4], int64_t (*part)[kScanBlock / 64])
@@ -432,13 +444,62 @@ __device__ __forceinline__ ScanQ block_exclusive_scan(const ScanQ &q, int64_t (&
     return r;
 }
 
-// offsets into the frame record of frame f (frames that do not fit are marked FOA_ST_NO_SPACE), and its entries of the
-// symbol -> frame and segment -> frame maps (so that the data-symbol and chain-back kernels find their frame without a
-// search; frames are short: <= 1368 symbols).  q: the frame's quantities, a..d: their exclusive prefix sums.
-__device__ __forceinline__ void scan_apply_frame(FrameInfo *__restrict__ info, int f, const ScanQ &q, int64_t a, int64_t b, int64_t c, int64_t d,
-                                                 int64_t sym_cap, int64_t soft_cap, int64_t dec_cap, int64_t seg_cap,
-                                                 int32_t *__restrict__ sym2frame, int32_t *__restrict__ seg2frame)
+// pass 1: per-block sums -> blk[4][n_blocks]
+__global__ __launch_bounds__(kScanBlock) void k_scan_sums(const FrameInfo *__restrict__ info, int n_frames, int seg_steps, int64_t *__restrict__ blk)
 {
+    __shared__ int64_t part[4][kScanBlock / 64];
+    int64_t tot[4];
+    block_exclusive_scan(scan_quantities(info, blockIdx.x * kScanBlock + threadIdx.x, n_frames, seg_steps), tot, part);
+    if (threadIdx.x < 4) blk[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = tot[threadIdx.x];
+}
+
+// pass 2: exclusive scan of the block sums in place, grand totals -> totals[0..2] and totals[4]  (one block)
+__global__ __launch_bounds__(1024) void k_scan_blocks(int64_t *__restrict__ blk, int n_blocks, int64_t sym_cap, int64_t *__restrict__ totals)
+{
+    if (threadIdx.x == 0) totals[3] = sym_cap;            // read by the data-symbol kernels next to totals[0]
+    __shared__ int64_t wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = 0; i < 4; i++) {
+        int64_t carry = 0;
+        for (int base = 0; base < n_blocks; base += 1024) {
+            const int j = base + tid;
+            const int64_t v = j < n_blocks ? blk[(size_t)i * n_blocks + j] : 0;
+            int64_t x = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int64_t y = __shfl_up(x, o);
+                if (lane >= o) x += y;
+            }
+            __syncthreads();
+            if (lane == 63) wsum[wv] = x;
+            __syncthreads();
+            int64_t before = 0, all = 0;
+            for (int w = 0; w < 16; w++) {
+                if (w < wv) before += wsum[w];
+                all += wsum[w];
+            }
+            if (j < n_blocks) blk[(size_t)i * n_blocks + j] = carry + before + x - v;
+            carry += all;
+        }
+        if (tid == 0) totals[i < 3 ? i : 4] = carry;          // totals[3] is the symbol capacity (above)
+    }
+}
+
+// pass 3: offsets into the frame records (frames that do not fit are marked FOA_ST_NO_SPACE), and the symbol -> frame
+// and segment -> frame maps (so that the data-symbol and chain-back kernels find their frame without a search;
+// frames are short: <= 1368 symbols)
+__global__ __launch_bounds__(kScanBlock) void k_scan_apply(FrameInfo *__restrict__ info, int n_frames, int64_t sym_cap, int64_t soft_cap,
+                                                           int64_t dec_cap, int seg_steps, int64_t seg_cap, const int64_t *__restrict__ blk,
+                                                           int32_t *__restrict__ sym2frame, int32_t *__restrict__ seg2frame)
+{
+    __shared__ int64_t part[4][kScanBlock / 64];
+    const int f = blockIdx.x * kScanBlock + threadIdx.x;
+    const ScanQ q = scan_quantities(info, f, n_frames, seg_steps);
+    int64_t tot[4];
+    const ScanQ ex = block_exclusive_scan(q, tot, part);
+    if (f >= n_frames) return;
+    const int64_t a = ex.v[0] + blk[blockIdx.x], b = ex.v[1] + blk[(size_t)gridDim.x + blockIdx.x],
+                  c = ex.v[2] + blk[(size_t)2 * gridDim.x + blockIdx.x], d = ex.v[3] + blk[(size_t)3 * gridDim.x + blockIdx.x];
     const int nsym = (int)q.v[0];
     info[f].seg_off = (int32_t)d;
     const int ns = (int)q.v[3];
@@ -452,51 +513,6 @@ __device__ __forceinline__ void scan_apply_frame(FrameInfo *__restrict__ info, i
     info[f].sym_off = (int32_t)a; info[f].soft_off = b; info[f].dec_off = c;
     for (int k = 0; k < nsym; k++) sym2frame[a + k] = f;
     for (int k = 0; k < ns; k++) if (d + k < seg_cap) seg2frame[d + k] = f;
-}
-
-// One launch, one thread per frame: every block first adds up the quantities of ALL frames before its own -- redundant,
-// but a few hundred pipelined loads per thread from L2 and no communication between blocks --, then scans its own 256
-// and applies.  (The stage sits on the chain walk -> header -> scan -> data symbols -> forward pass that sets the
-// pipelined step; as three dependent launches of microsecond kernels -- block sums, scan of the sums, apply -- it cost
-// that chain more in kernel boundaries than in work.  The first version, a single block, had a single CU's memory
-// pipeline as its limit: 50 us.)  It reads nsym0, which nobody writes after the header kernel, so it does not matter
-// that other blocks are already marking frames that do not fit.
-
-__device__ __forceinline__ ScanQ scan_quantities0(const FrameInfo *info, int f, int n_frames, int seg_steps)
-{
-    ScanQ q = { { 0, 0, 0, 0 } };
-    if (f < n_frames) {
-        const int nsym = info[f].nsym0, nsteps = nsym > 0 ? nsym * g_tab.rates[info[f].rate].dbps : 0;
-        q.v[0] = nsym; q.v[1] = ((int64_t)2 * nsteps + 255) & ~(int64_t)255; q.v[2] = dec_words(nsteps); q.v[3] = tb_segments(nsteps, seg_steps);
-    }
-    return q;
-}
-
-__global__ __launch_bounds__(kScanBlock) void k_scan_one(FrameInfo *__restrict__ info, int n_frames, int64_t sym_cap, int64_t soft_cap, int64_t dec_cap,
-                                                         int seg_steps, int64_t seg_cap, int64_t *__restrict__ totals, int32_t *__restrict__ sym2frame,
-                                                         int32_t *__restrict__ seg2frame)
-{
-    __shared__ int64_t part[4][kScanBlock / 64];
-    const int first = blockIdx.x * kScanBlock, f = first + threadIdx.x;
-    ScanQ acc = { { 0, 0, 0, 0 } };
-#pragma unroll 4
-    for (int g = threadIdx.x; g < first; g += kScanBlock) {
-        const ScanQ q = scan_quantities0(info, g, n_frames, seg_steps);
-#pragma unroll
-        for (int i = 0; i < 4; i++) acc.v[i] += q.v[i];
-    }
-    int64_t before[4], tot[4];
-    block_exclusive_scan(acc, before, part);              // before[] = the sums over all threads = over all frames before this block
-    __syncthreads();                                       // part[] is used again
-    const ScanQ q = scan_quantities0(info, f, n_frames, seg_steps);
-    const ScanQ ex = block_exclusive_scan(q, tot, part);
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
-        totals[0] = before[0] + tot[0]; totals[1] = before[1] + tot[1]; totals[2] = before[2] + tot[2]; totals[4] = before[3] + tot[3];
-        totals[3] = sym_cap;                               // read by the data-symbol kernels next to totals[0]
-    }
-    if (f >= n_frames) return;
-    scan_apply_frame(info, f, q, before[0] + ex.v[0], before[1] + ex.v[1], before[2] + ex.v[2], before[3] + ex.v[3], sym_cap, soft_cap, dec_cap, seg_cap,
-                     sym2frame, seg2frame);
 }
 
 // =================================================================================================
