@@ -84,7 +84,9 @@ class Receiver:
     def decode_frames_dev(self, iq, descs, ends, psdu, results):
         """All arguments are CUDA(HIP) torch tensors already resident in HBM:
         iq complex64[n] (or float32[n,2]); descs uint8[m*48] (frame_desc_dtype bytes); ends int64[m];
-        psdu uint8[m, slot]; results int32[m, 4].  Asynchronous on the handle's stream."""
+        psdu uint8[m, slot]; results int32[m, 4].  Asynchronous on the handle's streams, which are NOT ordered against
+        torch's: whatever torch still has queued on these tensors must be through before the call (a host-side
+        synchronize of torch's stream here would cost the pipelined loop 3-8 %, so it is left to the caller)."""
         n = iq.numel() if iq.is_complex() else iq.numel() // 2
         m = ends.numel()
         assert descs.numel() * descs.element_size() == m * frame_desc_dtype.itemsize
