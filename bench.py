@@ -198,10 +198,15 @@ def main():
     d_which = torch.from_numpy(which).to(dev)
     gathered = [None]
 
-    def gather_now(buf):
+    read_done = [None] * n_out
+
+    def gather_now(i):
         # slots in local frame order (a frame the detector missed leaves a zero slot, like a CRC failure)
+        buf = out_psdu[i]
         local = torch.zeros((args.frames, PAYLOAD), dtype=torch.uint8, device=dev)
         local.index_copy_(0, d_which, buf.index_select(0, d_real))
+        read_done[i] = torch.cuda.Event()
+        read_done[i].record()
         gathered[0] = shard.gather_psdus(local.to(cdev), n_global, rank, world)
 
     issued = [0]          # steps queued since the last finish_steps()
@@ -212,21 +217,23 @@ def main():
         # library's second stream.  With several ranks the PSDUs of the step two back are gathered meanwhile: that step is
         # complete by now, so the host is not held up and the next step's front end is queued in time.
         k = issued[0]
-        if world > 1 and done[0] > 0:
-            # this call will overwrite the output set whose gather was queued one step ago (on torch's stream, which the
-            # library's streams are not ordered against): make sure that one is through.  It has had a whole step.
-            torch.cuda.current_stream().synchronize()
+        if read_done[k % n_out] is not None:
+            # this call will overwrite an output set that a gather has read (on torch's stream, which the library's streams
+            # are not ordered against): wait for that read -- one event, queued a step ago; a synchronize of torch's stream
+            # would do too, but on this runtime it waits for the library's streams as well and costs the loop 3-8 %
+            read_done[k % n_out].synchronize()
+            read_done[k % n_out] = None
         rx.decode_frames_dev(d_iq, d_desc, d_ends, out_psdu[k % n_out], out_res[k % n_out])
         issued[0] = k + 1
         if world > 1 and k - done[0] >= 2:
             rx.wait_age(2)
-            gather_now(out_psdu[done[0] % n_out])
+            gather_now(done[0] % n_out)
             done[0] += 1
 
     def finish_steps():
         rx.sync()
         while world > 1 and done[0] < issued[0]:         # the last two steps' PSDUs
-            gather_now(out_psdu[done[0] % n_out])
+            gather_now(done[0] % n_out)
             done[0] += 1
         last = (issued[0] - 1) % n_out if issued[0] else 0
         issued[0] = done[0] = 0
