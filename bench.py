@@ -350,6 +350,13 @@ def main():
                                "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": pmc_traffic(fwd_kernel, args.frames),
                                "algorithmic_bytes_per_launch": int(alg_bytes), "avg_kernel_ms": round(kms["viterbi_fwd"], 4),
                                "note": "bound by VALU issue, not by HBM (SURVEY 8d): see valu_issue and DESIGN.md 4"}
+            if out["config"]["steps_pipelined"]:
+                # consecutive forward passes run on two streams and overlap at their ends, so a launch lasts longer than a
+                # step: the launch duration (what a kernel trace reports, used above) counts the shared time twice
+                step_ms = elapsed / args.steps * 1e3
+                out["roofline"]["launches_overlap"] = {"ms_per_step": round(step_ms, 4),
+                                                       "achieved_at_step_rate": round(alg_bytes / (step_ms * 1e-3) / 1e9, 2),
+                                                       "frac_at_step_rate": round(alg_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)}
             # the limit that actually binds: a wave64 VALU instruction holds its SIMD for 4 clocks -> 1024 SIMDs x 2.4 GHz / 4
             nv = pmc_valu(fwd_kernel, args.frames)
             if nv:

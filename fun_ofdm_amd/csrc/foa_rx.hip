@@ -196,7 +196,7 @@ struct foa_rx {
     bool record_eq = false;
     bool record_soft = true;     // keep the depunctured soft bytes (taps, lane-per-state kernel); off = branch metrics only
     int frontend_kind = -1;      // 1: one lane per symbol (frontend_lps.h), 0: one wave per symbol, 2: four lanes per symbol (frontend_q4.h);
-                                 // -1: by context -- 2 when calls are pipelined (128-VGPR waves fit under the forward pass), else 1
+                                 // -1: the default, 2
     WorkSet sets[4];             // three are in use at any time (below); the fourth keeps the call before them readable (timings)
     WorkSet *w = &sets[0];       // the set of the most recent decode call
     WorkSet *prev = nullptr;     // the set of the call before it (kernel times of a call that is certainly complete)
@@ -467,7 +467,7 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
     HIP_TRY(hipEventRecord(rx->w->ev[2], st));
     // upper bound on data symbols in n_samples samples; waves beyond the real total exit at once
     const size_t max_sym = rx->w->sym_cap;
-    const int frontend = rx->frontend_kind >= 0 ? rx->frontend_kind : (piped ? 2 : 1);
+    const int frontend = rx->frontend_kind >= 0 ? rx->frontend_kind : 2;
     if (frontend == 2) {
         uint8_t *soft_out = (rx->record_soft || rx->viterbi_kind == 0) ? rx->w->soft.p : nullptr;
         hipLaunchKernelGGL(k_data_symbols_q4, dim3((unsigned)((max_sym + 16 * kQ4Waves - 1) / (16 * kQ4Waves))), dim3(64 * kQ4Waves), 0, st, iq,

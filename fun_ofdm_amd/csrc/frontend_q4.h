@@ -13,21 +13,25 @@
 //     terms live in lanes 1 and 2 and are broadcast so that every lane adds them in the reference's order;
 //   * soft bytes are scattered into the symbol's depunctured order in LDS ((carrier, bit) -> position table per
 //     rate), and each lane turns 4 consecutive trellis steps at a time into branch-metric words: 16-byte stores.
-// 128 VGPRs, four waves per SIMD.  Measured alone (config 2): 0.46 ms against 0.33 ms for the lane-per-symbol kernel (the
-// fp64 butterflies issue at about 8 clocks per wave instruction and the quad layout spends 1 640 VALU instructions per 16
-// symbols where lane-per-symbol spends 4 400 per 64).  Its place is the pipelined path: 128-VGPR waves fit next to the
-// forward pass of the previous call (172 of a SIMD's 512 VGPRs are free there), 512-VGPR waves do not, so there it is the
-// default front end (option "frontend" = -1) and the lane-per-symbol kernel is the default when calls run in line.
+// Measured alone (config 2): 0.31 ms against 0.34 ms for the lane-per-symbol kernel, although the fp64 butterflies issue at
+// about 6 clocks per wave instruction and the quad layout spends 1 640 VALU instructions per 16 symbols where
+// lane-per-symbol spends 4 400 per 64: its waves are small (<= 176 VGPRs against 512), so several share a SIMD and hide each
+// other's latencies, and they fit next to the forward pass of the previous call in the pipelined path.  It is the default
+// front end (option "frontend" = -1); the lane-per-symbol and wave-per-symbol kernels stay selectable and in the parity suite.
 #pragma once
 
 #include "frontend_lps.h"
 
 namespace foa {
 
-#ifndef FOA_Q4_WPE
-#define FOA_Q4_WPE 4
+#ifndef FOA_Q4_WAVES
+#define FOA_Q4_WAVES 4
 #endif
-constexpr int kQ4Waves = 5;                  // waves per block: 14 KB of tables + 7 KB per wave = 50 KB, three blocks per CU
+constexpr int kQ4Waves = FOA_Q4_WAVES;       // waves per block: FOUR, one per SIMD (14 KB of tables + 7 KB per wave = 42 KB of LDS).
+                                             // With five (a block's waves go round the SIMDs, so the fifth doubles up on one) the
+                                             // kernel alone took 0.447 ms instead of 0.308 and the pipelined step 1.32 ms instead
+                                             // of 1.21 (2, 3, 6 waves per block: 1.23; 8: 1.28).  The register budget does not
+                                             // matter (128 ... 256 VGPRs: 1.20-1.23 ms).
 
 struct Q4Wave {                              // LDS private to one wave
     union {
@@ -115,7 +119,7 @@ __device__ __forceinline__ void q4_emit(Q4Shared &sh, Q4Wave &ws, const cpx (&X)
     }
 }
 
-__global__ __launch_bounds__(64 * kQ4Waves) __attribute__((amdgpu_waves_per_eu(FOA_Q4_WPE, 8)))
+__global__ __launch_bounds__(64 * kQ4Waves)
 void k_data_symbols_q4(const float2 *__restrict__ iq, const foa_frame_desc *__restrict__ descs, const FrameInfo *__restrict__ info,
                        const int32_t *__restrict__ sym2frame, const int64_t *__restrict__ totals, const double2 *__restrict__ hinv,
                        uint8_t *__restrict__ soft, uint32_t *__restrict__ bm, double2 *__restrict__ eq_tap)
@@ -124,7 +128,10 @@ void k_data_symbols_q4(const float2 *__restrict__ iq, const foa_frame_desc *__re
     // In the pipelined path this kernel and the chain-back run one after the other under a neighbouring call's forward pass
     // and together take longer than it does, so this one gets the issue slots first (measured: 1.41 -> 1.38 ms per step;
     // raising the chain-back kernels as well gives 1.40, raising the forward pass instead 1.41).
-    __builtin_amdgcn_s_setprio(2);
+#ifndef FOA_Q4_PRIO
+#define FOA_Q4_PRIO 2
+#endif
+    __builtin_amdgcn_s_setprio(FOA_Q4_PRIO);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, qd = lane >> 2, m = lane & 3;
     for (int i = tid; i < 641; i += 64 * kQ4Waves) sh.qam[i] = g_tab.qam_lut[i];
     for (int i = tid; i < 511; i += 64 * kQ4Waves) { sh.bm_sum[i] = g_tab.bm_sum[i]; sh.bm_dif[i] = g_tab.bm_dif[i]; }

@@ -221,7 +221,10 @@ __device__ __forceinline__ uint32_t fwd2_step_dyn(uint32_t M, int j, bool sa, bo
 #undef FOA_DYN
 }
 
-constexpr int kFwdWaves = 4;     // waves (frame pairs) per workgroup: whole workgroups spread evenly over a CU's four SIMDs
+#ifndef FOA_FWD_WAVES
+#define FOA_FWD_WAVES 4
+#endif
+constexpr int kFwdWaves = FOA_FWD_WAVES;     // waves (frame pairs) per workgroup: whole workgroups spread evenly over a CU's four SIMDs
 
 __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd2(const FrameInfo *__restrict__ info, int n_frames,
                                                                  const uint32_t *__restrict__ bm, uint64_t *__restrict__ dec)

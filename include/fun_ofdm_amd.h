@@ -96,8 +96,8 @@ int foa_rx_reserve(foa_rx *rx, size_t n_samples, size_t n_frames);
  *                 foa_rx_wait_previous), and the INPUTS of a call must be complete when it is made and stay untouched
  *                 until then.  0 = every call runs start to end on the handle's stream.
  *   "frontend"    0 = one wave per data symbol; 1 = one lane per data symbol; 2 = four lanes per data symbol;
- *                 -1 (default) = 2 when calls are pipelined (its 128-VGPR waves run under the previous call's forward
- *                 pass), else 1 (fastest on its own)
+ *                 -1 (default) = 2 (fastest alone, and its small waves run under the previous call's forward pass when
+ *                 calls are pipelined); all three give bit-identical results
  *   "record_soft" keep the depunctured soft bytes for foa_rx_get_taps (default 1; 0 saves their HBM writes)
  *   "record_eq"   keep the equalised carriers for foa_rx_get_taps (default 0) */
 int foa_rx_set_option(foa_rx *rx, const char *name, int64_t value);
