@@ -252,7 +252,7 @@ int flush_pending(foa_rx *rx, hipEvent_t after_front_end)
     if (!p.valid) return FOA_OK;
     hipStream_t sb = rx->stream2;
     HIP_TRY(hipStreamWaitEvent(sb, p.w->ev[5], 0));          // its forward pass (the timing event doubles as the dependency:
-                                                              // every packet between two forward passes costs the first stream microseconds)
+                                                              // every packet between two forward passes costs their streams microseconds)
     if (after_front_end) HIP_TRY(hipStreamWaitEvent(sb, after_front_end, 0));
     HIP_TRY(hipEventRecord(p.w->ev[6], sb));
     launch_finish3(sb, p.w->info.p, p.nf, p.w->dec.p, p.w->decoded.p, p.w->seg2frame.p, p.w->totals.p, p.w->tb_state.p, p.max_segs, p.S, p.L, p.psdu,
@@ -437,7 +437,7 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
     int rc = workspace(rx, n_samples, n_frames);
     if (rc) return rc;
     // st: header, scan, front end.  Pipelined, that is the third stream, so that they can run under the forward pass of
-    // the call before (still busy on the first stream) wherever registers and LDS allow.
+    // the call before (still busy on its own stream) wherever registers and LDS allow.
     // Forward passes of consecutive calls take turns on two streams: nothing orders one behind the other (each has its own
     // work set), so the next one starts the moment its front end is done, into the tail of the one before, instead of
     // ~20 us after it (end-of-kernel release, event packets, dispatch): 1.345 -> 1.316 ms per step at config 2.
