@@ -133,14 +133,17 @@ void k_data_symbols_q4(const float2 *__restrict__ iq, const foa_frame_desc *__re
 #endif
     __builtin_amdgcn_s_setprio(FOA_Q4_PRIO);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, qd = lane >> 2, m = lane & 3;
+    const int64_t total = min(totals[0], totals[3]);
+    if ((int64_t)blockIdx.x * kQ4Waves * 16 >= total) return;       // the grid is sized by an upper bound: surplus blocks leave at once
     for (int i = tid; i < 641; i += 64 * kQ4Waves) sh.qam[i] = g_tab.qam_lut[i];
     for (int i = tid; i < 511; i += 64 * kQ4Waves) { sh.bm_sum[i] = g_tab.bm_sum[i]; sh.bm_dif[i] = g_tab.bm_dif[i]; }
-    for (int i = tid; i < kNumRates * 288; i += 64 * kQ4Waves) sh.pos[i / 288][i % 288] = g_tab.sym_pos[i / 288][i % 288];
+    static_assert(sizeof(sh.pos) == sizeof(g_tab.sym_pos) && sizeof(sh.pos) % 4 == 0 && offsetof(DeviceTables, sym_pos) % 4 == 0 &&
+                  offsetof(Q4Shared, pos) % 4 == 0, "position tables are copied as dwords");
+    for (int i = tid; i < (int)(sizeof(sh.pos) / 4); i += 64 * kQ4Waves) ((uint32_t *)sh.pos)[i] = ((const uint32_t *)g_tab.sym_pos)[i];
     if (tid < 64) { sh.tw[tid] = make_double2(g_tab.tw_re[tid], g_tab.tw_im[tid]); sh.dindex[tid] = g_tab.data_index[tid]; }
     __syncthreads();
     Q4Wave &ws = sh.w[wave];
 
-    const int64_t total = min(totals[0], totals[3]);
     const int64_t w0 = ((int64_t)blockIdx.x * kQ4Waves + wave) * 16, w = w0 + qd;      // this quad's symbol slot
     if (w0 >= total) return;                                       // whole wave idle (wave-uniform; no block sync below)
     const int fq = w < total ? sym2frame[w] : -1;
