@@ -9,10 +9,17 @@ over one batch of 10 000 synthetic 54 Mbps frames (1024-byte payloads, AWGN 25 d
 For N > 1 every rank decodes its own 10 000-frame shard (weak scaling; frames are independent, so the
 data path has no collective) and the decoded PSDUs are gathered to rank 0 over RCCL inside the step.
 Rank 0 prints ONE JSON line.
+
+Launch: under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` every process is one rank
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment).  Started plainly with --gpus N > 1, this process
+starts the N ranks itself as fresh child processes -- before torch or the GPU has been touched -- and exits with
+their status.  --gpus must equal WORLD_SIZE when both are given.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,96 +29,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 RATE, PAYLOAD, SNR_DB, PITCH, LEAD = 10, 1024, 25.0, 4096, 176
+FRAME_SAMPLES = 320 + 80 * 40
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+N_SIMD = 256 * 4                # 256 CUs x 4 SIMDs
+SEED_BASE = 0x0FD2              # SURVEY 8d: payload of global frame i = splitmix64(SEED_BASE + i)
+# Forward pass, SURVEY 8d "algorithmic ops": per trellis step 64 states x (2 saturating adds + 1 min + 1 compare) + 32 branch metrics
+ALG_LANE_OPS_PER_STEP = 256 + 32
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-SEED_BASE = 0x0FD2              # SURVEY 8d: payload of global frame i = splitmix64(SEED_BASE + i)
-
-
-def make_workload(frame_ids, noise_seed):
-    """Synthetic frames for the given global frame ids -> (iq complex64[n*PITCH], payloads uint8[n, PAYLOAD])."""
-    from fun_ofdm_amd import synth
-    n_frames = len(frame_ids)
-    seed_base = noise_seed
-    pays = synth.splitmix64_bytes(SEED_BASE, n_frames, PAYLOAD, ids=frame_ids)
-    iq = np.empty(n_frames * PITCH, np.complex64)
-    step = 500
-    for a in range(0, n_frames, step):
-        b = min(n_frames, a + step)
-        fr = synth.build_frames(pays[a:b], RATE)
-        part, _ = synth.make_stream(fr, PITCH, LEAD, SNR_DB, seed=seed_base * 1000003 + a)
-        iq[a * PITCH:b * PITCH] = part
-    return iq, pays
-
-
-def cpu_baseline(iq, descs, ends, pays, budget_s=15.0):
-    """The oracle (a port of the reference's per-frame path: fft_symbols..frame_decoder on one
-    alignment) timed on this host's cores on a bounded sample of the same workload."""
-    from oracle import pyoracle as po
-    cores = os.cpu_count() or 1
-    n = min(descs.size, 64 * cores)
-    # size the sample from a quick probe so that the leg stays near budget_s
-    t0 = time.perf_counter()
-    po.decode_batch_f32(iq, descs[:cores], ends[:cores], slot_bytes=PAYLOAD, threads=cores)
-    probe = time.perf_counter() - t0
-    n = int(min(descs.size, max(cores, cores * budget_s / max(probe, 1e-3))))
-    n_samp = int(ends[n - 1])
-    t0 = time.perf_counter()
-    psdu, res = po.decode_batch_f32(iq[:n_samp], descs[:n], ends[:n], slot_bytes=PAYLOAD, threads=cores)
-    dt = time.perf_counter() - t0
-    real = np.nonzero((descs["lts1_pos"][:n] - (LEAD + 184)) % PITCH == 0)[0]
-    in_frame = real.size * (320 + 80 * 40)
-    out = dict(value=in_frame / dt / 1e6, unit="Msamples/s", cores=cores, kind="port",
-               sample="%d of the workload's alignments (%d frames, %d samples fed), oracle fo_decode_batch_f32 on %d threads, %.1f s"
-                      % (n, real.size, n_samp, cores, dt))
-    # the reference's own structure for comparison (SURVEY 8d): process_samples() over six block threads + the caller,
-    # 4096-sample chunks, pre-sync included -- one chain, on a few hundred frames
-    try:
-        nf = min(len(pays), 400)
-        chain = po.ReceiverChain(threaded=True)
-        t0 = time.perf_counter()
-        got = chain.run_stream(iq[:nf * PITCH], chunk=4096)
-        dt_c = time.perf_counter() - t0
-        out["reference_structure"] = {"value": round(nf * (320 + 80 * 40) / dt_c / 1e6, 2), "unit": "Msamples/s", "threads": 7,
-                                      "sample": "%d frames through the oracle's receiver_chain (frame_detector .. frame_decoder as "
-                                                "six block threads, 4096-sample calls), %d payloads out, %.1f s" % (nf, len(got), dt_c)}
-    except Exception as e:                                # the headline baseline above does not depend on this leg
-        out["reference_structure"] = {"error": str(e)}
-    return out, psdu, res, n
-
-
-def pmc_traffic(kernel, frames):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/), if they were taken on
-    this workload size; PMC counters cannot be read from inside the timed process."""
-    best = None
-    pdir = os.path.join(ROOT, "profiles")
-    for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
-        if name.endswith("_pmc_hbm.json"):
-            d = json.load(open(os.path.join(pdir, name)))
-            if d.get("frames_per_gpu") == frames and kernel in d.get("kernels", {}):
-                best = d["kernels"][kernel]["hbm_bytes_per_launch"]
-    return best
-
-
-def pmc_valu(kernel, frames):
-    """VALU instructions per launch of `kernel` from the committed SQ counter pass (profiles/*_pmc_sq.json)."""
-    pdir = os.path.join(ROOT, "profiles")
-    best = None
-    for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
-        if name.endswith("_pmc_sq.json"):
-            d = json.load(open(os.path.join(pdir, name)))
-            if d.get("frames_per_gpu") == frames and kernel in d.get("per_launch", {}):
-                best = d["per_launch"][kernel].get("SQ_INSTS_VALU")
-    return best
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node (default: WORLD_SIZE, else 1)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=10000, help="frames per GPU (BASELINE config 2: 10000)")
@@ -124,35 +56,171 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="finish of a step on the same stream as the rest (no overlap with the next step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sync-leg", action="store_true", help="skip the extra leg with the device pre-sync (profiling: keeps its launches out of the kernel averages)")
-    args = ap.parse_args()
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the legs that are not `value`: host-pointer entry (H2D + D2H inside), config 3 rate sweep, config 5 stream")
+    ap.add_argument("--legs-frames", type=int, default=1000, help="frames per rate of the config-3 leg")
+    return ap.parse_args(argv)
 
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n, argv):
+    """Start n rank processes of this script (fresh interpreters: nothing here has imported torch or touched the GPU)
+    and return the worst exit status.  Rank 0 inherits stdout, so its JSON line is this process's output."""
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in alive:                       # a rank failed: the others would wait in a collective for ever
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def make_workload(frame_ids, noise_seed):
+    """Synthetic frames for the given global frame ids -> (iq complex64[n*PITCH], payloads uint8[n, PAYLOAD])."""
+    from fun_ofdm_amd import synth
+    n_frames = len(frame_ids)
+    pays = synth.splitmix64_bytes(SEED_BASE, n_frames, PAYLOAD, ids=frame_ids)
+    iq = np.empty(n_frames * PITCH, np.complex64)
+    step = 500
+    for a in range(0, n_frames, step):
+        b = min(n_frames, a + step)
+        fr = synth.build_frames(pays[a:b], RATE)
+        part, _ = synth.make_stream(fr, PITCH, LEAD, SNR_DB, seed=noise_seed * 1000003 + a)
+        iq[a * PITCH:b * PITCH] = part
+    return iq, pays
+
+
+def cpu_baseline(iq, descs, ends, pays, budget_s=15.0):
+    """The oracle (a port of the reference's per-frame path: fft_symbols..frame_decoder on one
+    alignment) timed on this host's cores on a bounded sample of the same workload."""
+    from oracle import pyoracle as po
+    cores = os.cpu_count() or 1
+    # size the sample from a quick probe so that the leg stays near budget_s
+    t0 = time.perf_counter()
+    po.decode_batch_f32(iq, descs[:cores], ends[:cores], slot_bytes=PAYLOAD, threads=cores)
+    probe = time.perf_counter() - t0
+    n = int(min(descs.size, max(cores, cores * budget_s / max(probe, 1e-3))))
+    n_samp = int(ends[n - 1])
+    t0 = time.perf_counter()
+    psdu, res = po.decode_batch_f32(iq[:n_samp], descs[:n], ends[:n], slot_bytes=PAYLOAD, threads=cores)
+    dt = time.perf_counter() - t0
+    real = np.nonzero((descs["lts1_pos"][:n] - (LEAD + 184)) % PITCH == 0)[0]
+    in_frame = real.size * FRAME_SAMPLES
+    out = dict(value=in_frame / dt / 1e6, unit="Msamples/s", cores=cores, kind="port",
+               sample="%d of the workload's alignments (%d frames, %d samples fed), oracle fo_decode_batch_f32 on %d threads, %.1f s"
+                      % (n, real.size, n_samp, cores, dt),
+               note="a port: the reference itself needs FFTW3 and Boost, which this image does not have (oracle/Makefile builds "
+                    "the ten reference translation units that need neither and the port is pinned against them)")
+    # the reference's own structure for comparison (SURVEY 8d): process_samples() over six block threads + the caller,
+    # 4096-sample chunks, pre-sync included -- one chain, on a few hundred frames
+    try:
+        nf = min(len(pays), 400)
+        chain = po.ReceiverChain(threaded=True)
+        t0 = time.perf_counter()
+        got = chain.run_stream(iq[:nf * PITCH], chunk=4096)
+        dt_c = time.perf_counter() - t0
+        out["reference_structure"] = {"value": round(nf * FRAME_SAMPLES / dt_c / 1e6, 2), "unit": "Msamples/s", "threads": 7,
+                                      "sample": "%d frames through the oracle's receiver_chain (frame_detector .. frame_decoder as "
+                                                "six block threads, 4096-sample calls), %d payloads out, %.1f s" % (nf, len(got), dt_c)}
+    except Exception as e:                                # the headline baseline above does not depend on this leg
+        out["reference_structure"] = {"error": str(e)}
+    return out, psdu, res, n
+
+
+def _profile_json(suffix, key, kernel, frames, field):
+    """Latest profiles/*<suffix> entry for `kernel` taken at this workload size (PMC counters cannot be read from inside
+    the timed process; tools/profile_round.sh takes them with rocprofv3 in separate passes)."""
+    pdir = os.path.join(ROOT, "profiles")
+    best = None
+    for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if name.endswith(suffix):
+            d = json.load(open(os.path.join(pdir, name)))
+            if d.get("frames_per_gpu") == frames and kernel in d.get(key, {}):
+                v = d[key][kernel].get(field)
+                if v is not None:
+                    best = (v, name)
+    return best
+
+
+def valu_clocks_per_instr():
+    """Clocks of SIMD time one wave64 VALU instruction of the forward pass's mix costs, measured by tools/probe_issue.hip on
+    this part (profiles/*_probe_issue.json).  The issue roof follows from it: 1024 SIMDs x f / clocks."""
+    pdir = os.path.join(ROOT, "profiles")
+    best = None
+    for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if name.endswith("_probe_issue.json"):
+            best = (json.load(open(os.path.join(pdir, name))), name)
+    return best
+
+
+class _CpuEvent:
+    def record(self):
+        pass
+
+    def synchronize(self):
+        pass
+
+
+def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=False):
+    """One rank of the benchmark.  make_receiver / on_cpu: test hooks (tests/test_bench_gloo.py runs this host logic at
+    world 2 over gloo on CPU tensors with a stand-in for the receiver handle)."""
     import torch
     import torch.distributed as dist
     import fun_ofdm_amd as foa
+    from fun_ofdm_amd import shard, synth
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # FOA_BENCH_BACKEND=gloo lets the N>1 code path be exercised on a box with fewer GPUs than ranks (ranks then
-    # share devices and the gather goes through host memory); the real runs use nccl (= RCCL over xGMI).
-    backend = os.environ.get("FOA_BENCH_BACKEND", "nccl")
-    dev_index = local_rank % max(torch.cuda.device_count(), 1)
-    dev = torch.device("cuda", dev_index)
-    torch.cuda.set_device(dev)
-    if world > 1:
+    n_dev = 0 if on_cpu else torch.cuda.device_count()        # (counting devices does not initialise the GPU)
+    if backend is None:
+        backend = os.environ.get("FOA_BENCH_BACKEND")
+    if backend is None:
+        # RCCL wants one device per rank; with fewer devices than ranks (one-GPU box) the ranks share devices and the
+        # gather goes through host memory over gloo -- the same host code path, stated in the output line
+        backend = "nccl" if (n_dev >= world and not on_cpu) else "gloo"
+    if on_cpu:
+        dev = torch.device("cpu")
+        dev_index = 0
+    else:
+        dev_index = local_rank % max(n_dev, 1)
+        dev = torch.device("cuda", dev_index)
+        torch.cuda.set_device(dev)
+
+    def dev_sync():
+        if not on_cpu:
+            torch.cuda.synchronize()
+
+    if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
     cdev = dev if backend == "nccl" else torch.device("cpu")       # where collective tensors live
 
     t0 = time.perf_counter()
-    from fun_ofdm_amd import shard, synth
     n_global = args.frames * world
     my_ids = shard.local_frame_ids(n_global, rank, world).numpy()       # global frame i -> rank i mod G
-    if args.tx == "device":
+    if args.tx == "device" and not on_cpu:
         # frame_builder + channel on the device (SURVEY 8f #2); the samples come back once for the host-side checks
         gen = foa.Receiver(dev_index)
         pays = synth.splitmix64_bytes(SEED_BASE, len(my_ids), PAYLOAD, ids=my_ids)
@@ -170,12 +238,11 @@ def main():
     real = np.nonzero((descs["lts1_pos"] - (LEAD + 184)) % PITCH == 0)[0]
     which = (descs["lts1_pos"][real] - (LEAD + 184)) // PITCH          # local frame index of each alignment that sits on a frame
     if rank == 0:
-        log("[bench] rank0: %d frames generated in %.1f s, sync found %d alignments (%d on frames) in %.1f s"
-            % (args.frames, t1 - t0, descs.size, real.size, t2 - t1))
+        log("[bench] rank0 of %d (%s): %d frames generated in %.1f s, sync found %d alignments (%d on frames) in %.1f s"
+            % (world, backend, args.frames, t1 - t0, descs.size, real.size, t2 - t1))
     m = descs.size
-    frame_samples = 320 + 80 * 40
 
-    rx = foa.Receiver(dev_index)
+    rx = make_receiver(dev_index) if make_receiver else foa.Receiver(dev_index)
     rx.set_option("viterbi", args.viterbi)
     if args.tb_segment > 0:
         rx.set_option("tb_segment", args.tb_segment)
@@ -193,21 +260,21 @@ def main():
     n_out = 3 if world > 1 else 1
     out_psdu = [torch.zeros((m, PAYLOAD), dtype=torch.uint8, device=dev) for _ in range(n_out)]
     out_res = [torch.zeros((m, 4), dtype=torch.int32, device=dev) for _ in range(n_out)]
-    d_psdu, d_res = out_psdu[0], out_res[0]
     d_real = torch.from_numpy(real).to(dev)
     d_which = torch.from_numpy(which).to(dev)
     gathered = [None]
-
     read_done = [None] * n_out
+    n_gathers = [0]
 
     def gather_now(i):
         # slots in local frame order (a frame the detector missed leaves a zero slot, like a CRC failure)
         buf = out_psdu[i]
         local = torch.zeros((args.frames, PAYLOAD), dtype=torch.uint8, device=dev)
         local.index_copy_(0, d_which, buf.index_select(0, d_real))
-        read_done[i] = torch.cuda.Event()
+        read_done[i] = _CpuEvent() if on_cpu else torch.cuda.Event()
         read_done[i].record()
         gathered[0] = shard.gather_psdus(local.to(cdev), n_global, rank, world)
+        n_gathers[0] += 1
 
     issued = [0]          # steps queued since the last finish_steps()
     done = [0]            # of which gathered
@@ -242,32 +309,36 @@ def main():
     for _ in range(args.warmup):
         step()
     d_psdu, d_res = finish_steps()
-    torch.cuda.synchronize()
+    dev_sync()
     if world > 1:
         dist.barrier()
+    piped = bool(args.viterbi == 2 and not args.no_pipeline)
     kern = {k: 0.0 for k in ("header", "scan", "symbols", "viterbi_fwd", "viterbi_finish", "total")}
-    timing_age = 2 if (args.steps <= 50 and args.viterbi == 2 and not args.no_pipeline) else 1
+    kern_n = 0
+    n_gathers[0] = 0
     t_start = time.perf_counter()
     for i in range(args.steps):
         step()
-        if timing_age == 2:
-            if i > 1:                                    # per-kernel HIP-event times of the step two back: complete for sure,
-                for k, v in rx.kernel_ms(age=2).items():  # so the host is not held up (the next call's front end must be
-                    kern[k] += v                         # queued while this step's forward pass is still running)
-        elif args.steps <= 50 and i > 0:
-            for k, v in rx.kernel_ms(previous=True).items():
+        # per-kernel HIP-event times of the step two back: complete for sure, so the host is not held up (the next call's
+        # front end must be queued while this step's forward pass is still running).  Calls in line (--no-pipeline, other
+        # kernels) keep one event set per call, and reading it would stall the loop at every step: they are read after it.
+        if piped and args.steps <= 50 and i > 1:
+            for k, v in rx.kernel_ms(age=2).items():
                 kern[k] += v
+            kern_n += 1
     d_psdu, d_res = finish_steps()
-    torch.cuda.synchronize()
+    dev_sync()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t_start
     if args.steps <= 50:                                 # ... and of the last step(s), after the clock has stopped
-        if timing_age == 2 and args.steps > 1:
+        if piped and args.steps > 1:
             for k, v in rx.kernel_ms(previous=True).items():
                 kern[k] += v
+            kern_n += 1
         for k, v in rx.kernel_ms().items():
             kern[k] += v
+        kern_n += 1
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -275,7 +346,7 @@ def main():
 
     # ---- extra leg (not `value`): the same pass preceded by frame_detector + timing_sync on the device ----
     with_sync = None
-    if world == 1 and not args.no_sync_leg:
+    if world == 1 and not args.no_sync_leg and not on_cpu:
         cap = iq.size // 300 + 16
         s_desc = torch.zeros(cap * 48, dtype=torch.uint8, device=dev)
         s_ends = torch.zeros(cap, dtype=torch.int64, device=dev)
@@ -291,8 +362,9 @@ def main():
         torch.cuda.synchronize()
         dt_s = (time.perf_counter() - t_s) / 10
         same_sync = n_found == m and bool(torch.equal(s_psdu, d_psdu)) and bool(torch.equal(s_res, d_res))
-        with_sync = {"Msamples_per_s": round(args.frames * frame_samples / dt_s / 1e6, 1), "ms_per_step": round(dt_s * 1e3, 4),
+        with_sync = {"Msamples_per_s": round(args.frames * FRAME_SAMPLES / dt_s / 1e6, 1), "ms_per_step": round(dt_s * 1e3, 4),
                      "alignments": int(n_found), "same_results_as_host_sync": same_sync}
+        del s_desc, s_ends, s_psdu, s_res
 
     # ---- correctness of what was timed: every frame decodes to its payload, bit-exact ----
     res = d_res.cpu().numpy()
@@ -303,7 +375,6 @@ def main():
     # its CRC at 25 dB; the CPU receiver fails the same ones -- checked against the oracle below)
     # (the reference's detector may also miss a frame: such a frame is reported, not counted as exact or inexact)
     exact = bool(np.array_equal(psdu[real][okm], pays[which][okm])) and np.unique(which).size == real.size
-    n_frames_total = n_global
     if world > 1:
         flag = torch.tensor([1 if exact else 0], dtype=torch.int32, device=cdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -318,10 +389,12 @@ def main():
             all_pays = synth.splitmix64_bytes(SEED_BASE, n_global, PAYLOAD)
             nz = g.any(axis=1)                           # frames whose CRC failed leave their slot zeroed
             exact = exact and bool(np.array_equal(g[nz], all_pays[nz])) and int(nz.sum()) == ok_frames
+            exact = exact and n_gathers[0] == args.steps     # one gather per timed step, all inside the timed region
 
+    out = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        in_frame = n_frames_total * frame_samples
+        in_frame = n_global * FRAME_SAMPLES
         value = in_frame / (elapsed / args.steps) / 1e6
         out = {
             "metric": "RX Msamples/s @20 MHz, 54 Mbps 64-QAM r=3/4; PSDU bit-exact vs CPU",
@@ -330,54 +403,232 @@ def main():
             "dtype": "u8", "data": "synthetic" if args.tx == "host" else "synthetic (built on the device: foa_tx_build_frames_dev + foa_tx_channel_dev)",
             "config": {"workload": "BASELINE configs[1]: %d frames/GPU x 1024-byte PSDU payload, 64-QAM r=3/4 (54 Mbps), AWGN 25 dB"
                                    % args.frames,
-                       "frames_per_gpu": args.frames, "frame_samples": frame_samples, "slot_pitch_samples": PITCH,
-                       "counted_samples": "in-frame only (3520/frame)", "value_all_samples_fed": round(value * PITCH / frame_samples, 1),
+                       "frames_per_gpu": args.frames, "frame_samples": FRAME_SAMPLES, "slot_pitch_samples": PITCH,
+                       "counted_samples": "in-frame only (3520/frame)", "value_all_samples_fed": round(value * PITCH / FRAME_SAMPLES, 1),
                        "x_realtime_20MSps": round(value / 20.0, 1), "psdu_bit_exact": exact, "frames_ok": ok_frames, "frames_found_by_sync_rank0": int(real.size),
                        "alignments_decoded_per_gpu": m, "frontend_dtype": "f64", "viterbi_kernel": args.viterbi, "frontend_kernel": args.frontend,
-                       "steps_pipelined": bool(args.viterbi == 2 and not args.no_pipeline),
-                       "sharding": ("global frame i on rank i mod %d, one %s gather of PSDU slots to rank 0 per step" % (world, backend)) if world > 1 else "single GPU"},
+                       "steps_pipelined": piped,
+                       "sharding": ("global frame i on rank i mod %d, one %s gather of PSDU slots to rank 0 per step%s"
+                                    % (world, "RCCL" if backend == "nccl" else backend,
+                                       "" if backend == "nccl" else " (ranks share %d device(s); host-memory gather)" % max(n_dev, 1))) if world > 1 else "single GPU"},
         }
         if with_sync:
             out["config"]["incl_device_pre_sync"] = with_sync
-        if args.steps <= 50:
-            kms = {k: v / args.steps for k, v in kern.items()}
-            # dominant kernel: the Viterbi forward pass.  Algorithmic bytes per frame: one branch-metric dword
-            # in and 64 decision bits out per trellis step (39 symbols x 216 steps).
-            alg_bytes = real.size * 39 * 216 * (4 + 8)
-            ach = alg_bytes / (kms["viterbi_fwd"] * 1e-3) / 1e9
-            fwd_kernel = {0: "k_viterbi_v1", 1: "k_viterbi_fwd2", 2: "k_viterbi_fwd3"}[args.viterbi]
-            out["roofline"] = {"bound": "hbm", "kernel": fwd_kernel, "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                               "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": pmc_traffic(fwd_kernel, args.frames),
-                               "algorithmic_bytes_per_launch": int(alg_bytes), "avg_kernel_ms": round(kms["viterbi_fwd"], 4),
-                               "note": "bound by VALU issue, not by HBM (SURVEY 8d): see valu_issue and DESIGN.md 4"}
-            if out["config"]["steps_pipelined"]:
-                # consecutive forward passes run on two streams and overlap at their ends, so a launch lasts longer than a
-                # step: the launch duration (what a kernel trace reports, used above) counts the shared time twice
-                step_ms = elapsed / args.steps * 1e3
-                out["roofline"]["launches_overlap"] = {"ms_per_step": round(step_ms, 4),
-                                                       "achieved_at_step_rate": round(alg_bytes / (step_ms * 1e-3) / 1e9, 2),
-                                                       "frac_at_step_rate": round(alg_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)}
-            # the limit that actually binds: a wave64 VALU instruction holds its SIMD for 4 clocks -> 1024 SIMDs x 2.4 GHz / 4
-            nv = pmc_valu(fwd_kernel, args.frames)
-            if nv:
-                peak_gi = 1024 * 2.4 / 4.0
-                ach_gi = nv / (kms["viterbi_fwd"] * 1e-3) / 1e9
-                out["roofline"]["valu_issue"] = {"achieved": round(ach_gi, 1), "peak": round(peak_gi, 1), "unit": "G wave-instr/s",
-                                                 "frac": round(ach_gi / peak_gi, 4), "valu_instr_per_launch": int(nv),
-                                                 "source": "SQ_INSTS_VALU, profiles/*_pmc_sq.json; duration live from HIP events"}
+        if args.steps <= 50 and kern_n and not on_cpu:
+            kms = {k: v / kern_n for k, v in kern.items()}
+            out["roofline"] = roofline(args, kms, real.size, ms_per_step, piped)
             out["kernel_ms"] = {k: round(v, 4) for k, v in kms.items()}
-        if not args.no_cpu_baseline:
-            cb, opsdu, ores, n_cb = cpu_baseline(iq, descs, ends, pays)
-            out["cpu_baseline"] = cb
-            same = bool(np.array_equal(ores.view(np.int32).reshape(-1, 4), res[:n_cb]))
-            okm = res[:n_cb, 0] == 0
-            same = same and bool(np.array_equal(opsdu[okm], psdu[:n_cb][okm]))
-            out["config"]["gpu_equals_cpu_on_sample"] = same
-            out["config"]["cpu_sample_alignments"] = int(n_cb)
-            out["config"]["psdu_bit_exact"] = bool(exact and same)
-        print(json.dumps(out), flush=True)
+    if rank == 0 and not args.no_extra_legs and world == 1 and not on_cpu:
+        out["legs"] = extra_legs(args, rx, dev, iq, descs, ends, real, psdu, res)
+    if rank == 0 and not args.no_cpu_baseline:
+        cb, opsdu, ores, n_cb = cpu_baseline(iq, descs, ends, pays)
+        out["cpu_baseline"] = cb
+        same = bool(np.array_equal(ores.view(np.int32).reshape(-1, 4), res[:n_cb]))
+        okc = res[:n_cb, 0] == 0
+        same = same and bool(np.array_equal(opsdu[okc], psdu[:n_cb][okc]))
+        out["config"]["gpu_equals_cpu_on_sample"] = same
+        out["config"]["cpu_sample_alignments"] = int(n_cb)
+        out["config"]["psdu_bit_exact"] = bool(exact and same)
     rx.close()
+    return out
+
+
+def roofline(args, kms, n_real, ms_per_step, piped):
+    """The dominant kernel is the Viterbi forward pass and what binds it is VALU issue, not HBM:
+    `bound`/`achieved`/`peak`/`frac` describe that roof; the HBM figures the contract also asks for are the `hbm` object."""
+    fwd_kernel = {0: "k_viterbi_v1", 1: "k_viterbi_fwd2", 2: "k_viterbi_fwd3"}[args.viterbi]
+    t_k = kms["viterbi_fwd"] * 1e-3                      # average launch duration, live from HIP events on the kernel's own stream
+    steps = n_real * 39 * 216                            # trellis steps per launch (frames found x 39 symbols x 216)
+    alg_ops = steps * ALG_LANE_OPS_PER_STEP              # SURVEY 8d: (256 + 32) lane-ops per step
+    probe = valu_clocks_per_instr()
+    clk = probe[0]["forward_mix_clk_per_wave_instr"] if probe else 4.0
+    f_ghz = probe[0]["shader_clock_ghz"] if probe else 2.4
+    # one wave64 VALU instruction = 64 lane-ops and holds its SIMD for `clk` clocks
+    peak_lane = N_SIMD * f_ghz * 1e9 * 64.0 / clk        # lane-ops/s the part can issue with this instruction mix
+    ach_lane = alg_ops / t_k
+    r = {"bound": "valu", "kernel": fwd_kernel, "achieved": round(ach_lane / 1e12, 3), "peak": round(peak_lane / 1e12, 3), "unit": "T lane-ops/s",
+         "frac": round(ach_lane / peak_lane, 4),
+         "definition": "algorithmic integer lane-ops (SURVEY 8d: 64 states x (2 saturating adds + min + compare) + 32 branch metrics = 288 per "
+                       "trellis step) x %d steps per launch / average launch duration; peak = 1024 SIMDs x %.2f GHz x 64 lanes / %.2f clocks per "
+                       "wave64 instruction of this kernel's mix (%s)" % (steps, f_ghz, clk, probe[1] if probe else "no probe file: 4 assumed"),
+         "algorithmic_ops_per_launch": int(alg_ops), "avg_kernel_ms": round(kms["viterbi_fwd"], 4)}
+    nv = _profile_json("_pmc_sq.json", "per_launch", fwd_kernel, args.frames, "SQ_INSTS_VALU")
+    if nv:
+        peak_gi = N_SIMD * f_ghz / clk
+        ach_gi = nv[0] / t_k / 1e9
+        r["valu_issue"] = {"achieved": round(ach_gi, 1), "peak": round(peak_gi, 1), "unit": "G wave-instr/s", "frac": round(ach_gi / peak_gi, 4),
+                           "valu_instr_per_launch": int(nv[0]), "source": "SQ_INSTS_VALU, profiles/%s; duration live from HIP events" % nv[1]}
+    # HBM: algorithmic bytes of this kernel = one branch-metric word in, 64 decision bits out per trellis step
+    alg_bytes = steps * (4 + 8)
+    tr = _profile_json("_pmc_hbm.json", "kernels", fwd_kernel, args.frames, "hbm_bytes_per_launch")
+    r["traffic"] = tr[0] if tr else None
+    r["hbm"] = {"achieved": round(alg_bytes / t_k / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(alg_bytes / t_k / 1e9 / HBM_PEAK_GBPS, 5),
+                "algorithmic_bytes_per_launch": int(alg_bytes), "traffic_source": tr[1] if tr else None,
+                "stage_bytes_survey_8d": int(n_real * 39 * (288 + 27)),
+                "note": "12 B per step is what this kernel's interface moves (4-byte metric word in, 8 bytes of decisions out); SURVEY 8d's "
+                        "figure for a fused Viterbi stage is 288 B in + 27 B out per symbol (stage_bytes_survey_8d): decisions and metric "
+                        "words crossing HBM are 8.2 x that"}
+    if piped:
+        # consecutive forward passes run on two streams and overlap at their ends, so a launch lasts longer than a step: the
+        # launch duration (what a kernel trace reports, used above) counts the shared time twice
+        r["launches_overlap"] = {"ms_per_step": round(ms_per_step, 4), "frac_at_step_rate": round(alg_ops / (ms_per_step * 1e-3) / peak_lane, 4),
+                                 "evidence": "profiles/*_kernel_trace_excerpt.csv: forward passes alternate on two queues and overlap"}
+    return r
+
+
+def extra_legs(args, rx, dev, iq, descs, ends, real, psdu_dev_path, res_dev_path):
+    """Driver-run figures that are NOT `value`: (ii) config 2 end to end through the host-pointer entry, config 3
+    per rate, config 5 as one stream with device pre-sync.  Workloads of configs 3 and 5 are built on the device."""
+    import torch
+    import fun_ofdm_amd as foa
+    from fun_ofdm_amd import synth
+    from oracle import pyoracle as po                    # checker only (a bounded subset per leg), never timed
+    legs = {}
+    STD = (0, 2, 3, 5, 6, 8, 9, 10)
+
+    def timed(fn, reps):
+        for _ in range(4):                               # once per rotating work set of the library: each sizes its buffers on first use
+            fn()
+        rx.sync(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        rx.sync(); torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    # ---- config 2 end to end: pageable host memory in, H2D of 8 B/sample + D2H of the PSDUs inside the timed region ----
+    try:
+        hp = np.zeros((descs.size, PAYLOAD), np.uint8)
+        rx.decode_frames_host(iq, descs, ends, slot_bytes=PAYLOAD, psdu_out=hp)
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            _, hres = rx.decode_frames_host(iq, descs, ends, slot_bytes=PAYLOAD, psdu_out=hp)
+        dt = (time.perf_counter() - t0) / reps
+        legs["end_to_end_host_pointers"] = {
+            "Msamples_per_s": round(real.size * FRAME_SAMPLES / dt / 1e6, 1), "ms_per_call": round(dt * 1e3, 3),
+            "what": "foa_rx_decode_frames_host on the config-2 batch: H2D of %d MB + decode + D2H of the PSDUs, synchronous" % (iq.nbytes >> 20),
+            "same_results_as_device_path": bool(np.array_equal(hres.view(np.int32).reshape(-1, 4), res_dev_path) and np.array_equal(hp, psdu_dev_path))}
+    except Exception as e:
+        legs["end_to_end_host_pointers"] = {"error": str(e)}
+
+    # ---- config 3: the 8 standard rates x 4092-byte payloads (PSDU incl. CRC = 4096 bytes, SURVEY fact 6) ----
+    try:
+        n, length, rows = args.legs_frames, 4092, []
+        for rate in STD:
+            pays = synth.splitmix64_bytes(0x0FD3 + rate, n, length)
+            frames = rx.tx_build_frames(torch.from_numpy(pays).to(dev), rate)
+            s = frames.shape[1]
+            pitch = -(-(s + 576) // 4096) * 4096
+            d_iq = rx.tx_channel(frames, pitch, 176, 25.0, seed=300 + rate)
+            del frames
+            cap = n * pitch // 512 + 64
+            d_desc = torch.zeros(cap * 48, dtype=torch.uint8, device=dev)
+            d_end = torch.zeros(cap, dtype=torch.int64, device=dev)
+            m = rx.sync_dev(d_iq, d_desc, d_end)
+            d_psdu = torch.zeros((m, length), dtype=torch.uint8, device=dev)
+            d_res = torch.zeros((m, 4), dtype=torch.int32, device=dev)
+            dt = timed(lambda: rx.decode_frames_dev(d_iq, d_desc[:m * 48], d_end[:m], d_psdu, d_res), 5)
+            r = d_res.cpu().numpy()
+            d = d_desc.cpu().numpy()[:m * 48].view(foa.frame_desc_dtype)
+            on = np.nonzero((d["lts1_pos"] - 360) % pitch == 0)[0]
+            ok = on[r[on, 0] == 0]
+            exact = bool(np.array_equal(d_psdu.cpu().numpy()[ok], pays[(d["lts1_pos"][ok] - 360) // pitch]))
+            k = min(m, 16)                               # CPU oracle on the first alignments: same status and PSDUs
+            e = d_end[:k].cpu().numpy()
+            h_iq = d_iq[:int(e[-1])].cpu().numpy().reshape(-1).view(np.complex64)
+            opsdu, ores = po.decode_batch_f32(h_iq, d[:k], e, slot_bytes=length, threads=min(16, os.cpu_count() or 1))
+            same = bool(np.array_equal(ores.view(np.int32).reshape(-1, 4), r[:k]))
+            okk = r[:k, 0] == 0
+            same = same and bool(np.array_equal(opsdu[okk], d_psdu[:k].cpu().numpy()[okk]))
+            rows.append({"rate_enum": rate, "mbps": foa.RATE_MBPS[rate], "frame_samples": int(s), "frames_found": int(on.size), "crc_ok": int(ok.size),
+                         "psdu_bit_exact": exact, "gpu_equals_cpu_on_%d" % k: same, "ms": round(dt * 1e3, 3),
+                         "Msamples_per_s": round(on.size * s / dt / 1e6, 1)})
+            del d_iq, d_psdu, d_res, d_desc, d_end
+        legs["config3_rate_sweep"] = {"frames_per_rate": n, "payload_bytes": length, "snr_db": 25.0, "counted_samples": "in-frame", "rates": rows}
+    except Exception as e:
+        legs["config3_rate_sweep"] = {"error": str(e)}
+
+    # ---- config 5: one continuous stream, frames cycling the 8 rates back to back, CFO within +-4 kHz, pre-sync on the device ----
+    try:
+        n, length = 4000, 1024
+        rates = [STD[i % 8] for i in range(n)]
+        parts, lookup, lens = [], {}, {}
+        for rate in STD:
+            idx = [i for i in range(n) if rates[i] == rate]
+            pays = synth.splitmix64_bytes(0x0FD5 + rate, len(idx), length)
+            fr = rx.tx_build_frames(torch.from_numpy(pays).to(dev), rate)
+            parts.append((idx, fr, rate))
+            lookup.update({i: pays[j] for j, i in enumerate(idx)})
+            lens.update({i: fr.shape[1] for i in idx})
+        total = sum(lens.values()) + 2048
+        stream = torch.zeros((total, 2), dtype=torch.float32, device=dev)
+        offs = np.zeros(n + 1, np.int64)
+        offs[1:] = np.cumsum([lens[i] for i in range(n)])
+        offs += 1024
+        for idx, fr, rate in parts:
+            s = fr.shape[1]
+            noisy = rx.tx_channel(fr, s, 0, 25.0, seed=500 + rate, cfo_hz=4000.0).reshape(len(idx), s, 2)
+            dst = torch.from_numpy(offs[idx]).to(dev)[:, None] + torch.arange(s, device=dev)[None, :]
+            stream[dst.reshape(-1)] = noisy.reshape(-1, 2)
+        del parts
+        sigma = float(np.sqrt(0.0124 / 2 / 10 ** 2.5))
+        stream[:1024] = torch.randn((1024, 2), device=dev) * sigma
+        stream[int(offs[n]):] = torch.randn((total - int(offs[n]), 2), device=dev) * sigma
+        cap = n + 4096
+        d_desc = torch.zeros(cap * 48, dtype=torch.uint8, device=dev)
+        d_end = torch.zeros(cap, dtype=torch.int64, device=dev)
+        d_psdu = torch.zeros((cap, length), dtype=torch.uint8, device=dev)
+        d_res = torch.zeros((cap, 4), dtype=torch.int32, device=dev)
+        got = [0]
+        torch.cuda.synchronize()
+
+        def go():
+            got[0] = rx.sync_dev(stream, d_desc, d_end)
+            rx.decode_frames_dev(stream, d_desc[:got[0] * 48], d_end[:got[0]], d_psdu[:got[0]], d_res[:got[0]])
+        dt = timed(go, 3)
+        m = got[0]
+        r = d_res[:m].cpu().numpy()
+        d = d_desc.cpu().numpy()[:m * 48].view(foa.frame_desc_dtype)
+        start_of = {int(offs[i]) + 184: i for i in range(n)}
+        okl = [(a, start_of[int(p)]) for a, p in enumerate(d["lts1_pos"]) if int(p) in start_of and r[a, 0] == 0]
+        hp = d_psdu[:m].cpu().numpy()
+        exact = all(np.array_equal(hp[a], lookup[i]) for a, i in okl)
+        k = min(m, 64)
+        e = d_end[:k].cpu().numpy()
+        h_iq = stream[:int(e[-1])].cpu().numpy().reshape(-1).view(np.complex64)
+        hd = po.find_alignments_f32(h_iq)
+        hd = hd[:k] if hd.size >= k else hd
+        same = hd.size == k and bool(np.array_equal(hd["lts1_pos"], d["lts1_pos"][:k]))
+        opsdu, ores = po.decode_batch_f32(h_iq, d[:k], e, slot_bytes=length, threads=min(16, os.cpu_count() or 1))
+        same = same and bool(np.array_equal(ores.view(np.int32).reshape(-1, 4), r[:k]))
+        legs["config5_stream"] = {"frames": n, "stream_samples": int(total), "alignments": int(m), "frames_ok": len(okl), "psdu_bit_exact": bool(exact),
+                                  "gpu_equals_cpu_on_first_%d" % k: same, "ms_sync_plus_decode": round(dt * 1e3, 3),
+                                  "Msamples_per_s": round(total / dt / 1e6, 1), "counted_samples": "whole stream",
+                                  "what": "mixed 8 rates back to back, 1024-byte payloads, CFO uniform in +-4 kHz, 25 dB; foa_rx_sync_dev + foa_rx_decode_frames_dev"}
+    except Exception as e:
+        legs["config5_stream"] = {"error": str(e)}
+    return legs
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and (args.gpus or 1) > 1:
+        sys.exit(launch_ranks(args.gpus, argv))
+    world = int(env_world or 1)
+    if args.gpus is not None and args.gpus != world:
+        log("bench.py: --gpus %d but WORLD_SIZE=%d: start it as `python bench.py --gpus N` or under torch.distributed.run "
+            "with --nproc-per-node equal to --gpus" % (args.gpus, world))
+        sys.exit(2)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    out = run(args, rank, world, local_rank)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if world > 1:
+        import torch.distributed as dist
         dist.destroy_process_group()
 
 

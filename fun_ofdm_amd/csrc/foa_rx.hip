@@ -454,7 +454,7 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
     double2 *eq_sig = rx->record_eq ? rx->w->eq_sig.p : nullptr, *eq_data = rx->record_eq ? rx->w->eq_data.p : nullptr;
 
     HIP_TRY(hipEventRecord(rx->w->ev[0], st));
-    hipLaunchKernelGGL(k_header, dim3(nf), dim3(64), 0, st, iq, d_descs, d_ends, nf, rx->w->info.p, rx->w->hinv.p, eq_sig);
+    hipLaunchKernelGGL(k_header, dim3(nf), dim3(64), 0, st, iq, d_descs, d_ends, (int64_t)n_samples, nf, rx->w->info.p, rx->w->hinv.p, eq_sig);
     HIP_TRY(hipEventRecord(rx->w->ev[1], st));
     // segments of this call: at most (total data steps)/S + one per frame; lanes beyond the real total idle
     const size_t max_segs = std::min(rx->w->seg2frame.n, rx->w->dec_cap / (size_t)rx->tb_segment + n_frames + 1);
@@ -728,7 +728,7 @@ int foa_rx_sync_dev(foa_rx *rx, const float *d_iq, size_t n_samples, foa_frame_d
     // With calls pipelined this stage goes where the next call's front end goes: on the third stream, under the forward
     // pass of the decode call in flight (its own scratch is touched by nothing else; the descriptors it writes are read by
     // the header and data-symbol kernels of the next decode call, which follow on the same stream).
-    hipStream_t st = rx->pipeline ? rx->stream3 : rx->stream;
+    hipStream_t st = (rx->pipeline && rx->viterbi_kind == 2) ? rx->stream3 : rx->stream;      // the predicate of the decode path
     const float2 *iq = (const float2 *)d_iq;
     hipLaunchKernelGGL(k_sync_flags, dim3((unsigned)((n + kFlagSamples - 1) / kFlagSamples)), dim3(256), 0, st, iq, n, rx->sy_flags.p);
     hipLaunchKernelGGL(k_sync_sts_end, dim3(n_blocks), dim3(kSyncBlockWords), 0, st, rx->sy_flags.p, n_words, 0, rx->sy_cnt.p, rx->sy_off.p, rx->sy_x.p, ccap);
@@ -802,6 +802,7 @@ int foa_fft_forward_f64(foa_rx *rx, double *vectors, size_t n_vec)
     if (!rx || !vectors) return fail(FOA_E_INVALID, "NULL argument");
     if (n_vec == 0) return FOA_OK;
     HIP_TRY(hipSetDevice(rx->device));
+    { int rc0 = drain(rx); if (rc0) return rc0; }                     // rx->scratch may still be read by a call in flight
     size_t bytes = n_vec * 64 * sizeof(double2);
     int rc = rx->scratch.ensure(bytes);
     if (rc) return rc;
@@ -817,18 +818,61 @@ int foa_conv_decode(foa_rx *rx, const uint8_t *symbols, uint8_t *data, int data_
     if (!rx || !symbols || !data) return fail(FOA_E_INVALID, "NULL argument");
     if (data_bits < 1 || data_bits > 8 * (kMaxDecodedBytes - 8)) return fail(FOA_E_INVALID, "data_bits out of range");
     if (n_blocks == 0) return FOA_OK;
+    if (n_blocks > 0xFFFFu) return fail(FOA_E_INVALID, "at most 65535 blocks per call");
     HIP_TRY(hipSetDevice(rx->device));
-    const size_t nsteps = (size_t)data_bits + 6, sym_bytes = n_blocks * 2 * nsteps, out_bytes = n_blocks * (size_t)((data_bits + 7) / 8);
-    const size_t stride = (nsteps + 63) & ~(size_t)63;
+    { int rc0 = drain(rx); if (rc0) return rc0; }                     // this entry point reuses the work set of the batch calls
+    const size_t nsteps = (size_t)data_bits + 6, sym_bytes = n_blocks * 2 * nsteps, nbytes = (size_t)((data_bits + 7) / 8), out_bytes = n_blocks * nbytes;
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     int rc = rx->scratch.ensure(up(sym_bytes) + up(out_bytes));
     if (rc) return rc;
-    if ((rc = rx->w->dec.ensure(n_blocks * stride))) return rc;
     uint8_t *d_sym = rx->scratch.p, *d_out = rx->scratch.p + up(sym_bytes);
-    HIP_TRY(hipMemcpyAsync(d_sym, symbols, sym_bytes, hipMemcpyHostToDevice, rx->stream));
-    hipLaunchKernelGGL(k_conv_decode, dim3((unsigned)n_blocks), dim3(64), 0, rx->stream, d_sym, d_out, data_bits, (int)n_blocks, rx->w->dec.p, (int)stride);
-    HIP_TRY(hipMemcpyAsync(data, d_out, out_bytes, hipMemcpyDeviceToHost, rx->stream));
-    HIP_TRY(hipStreamSynchronize(rx->stream));
+    hipStream_t st = rx->stream;
+    HIP_TRY(hipMemcpyAsync(d_sym, symbols, sym_bytes, hipMemcpyHostToDevice, st));
+    if (rx->viterbi_kind == 0) {
+        const size_t stride = (nsteps + 63) & ~(size_t)63;
+        if ((rc = rx->w->dec.ensure(n_blocks * stride))) return rc;
+        hipLaunchKernelGGL(k_conv_decode, dim3((unsigned)n_blocks), dim3(64), 0, st, d_sym, d_out, data_bits, (int)n_blocks, rx->w->dec.p, (int)stride);
+    } else {
+        // The kernels of the batch path (option "viterbi" = 1: k_viterbi_fwd2 + k_viterbi_finish2; 2: k_viterbi_fwd3 + k_tb_walk +
+        // k_tb_finish), fed the way the front end feeds them: one frame record and one region of branch-metric words per block.
+        // viterbi.cpp:209 drops an odd last step: its decision word stays zero (viterbi.cpp:193-194), so the chain-back reads
+        // bit data_bits-1 as 0 and stays in state 0 -- the same as decoding one bit less and appending a zero.
+        const int T = 2 * (int)(nsteps / 2), N = T - 6;
+        HIP_TRY(hipMemsetAsync(d_out, 0, out_bytes, st));
+        if (N > 0) {
+            std::vector<FrameInfo> info(n_blocks);
+            std::vector<int32_t> seg2frame;
+            const int64_t words = dec_words(T);
+            const int nseg = tb_segments(T, rx->tb_segment);
+            for (size_t b = 0; b < n_blocks; b++) {
+                FrameInfo &fi = info[b];
+                fi.status = FOA_ST_CRC_FAIL; fi.rate = 0; fi.length = 0; fi.nsym = 1; fi.sym_off = 0; fi.nsteps = T; fi.soft_off = 0;
+                fi.dec_off = (int64_t)b * words; fi.seg_off = (int32_t)(b * (size_t)nseg); fi.reserved_ = 0;
+                seg2frame.insert(seg2frame.end(), (size_t)nseg, (int32_t)b);
+            }
+            const size_t total = n_blocks * (size_t)words + 64;
+            if ((rc = rx->w->info.ensure(n_blocks + 1)) || (rc = rx->w->dec.ensure(total)) || (rc = rx->w->bm.ensure(total)) || (rc = rx->w->decoded.ensure(total)) ||
+                (rc = rx->w->seg2frame.ensure(seg2frame.size() + 64)) || (rc = rx->w->tb_state.ensure(seg2frame.size() + 64)) || (rc = rx->w->totals.ensure(8)))
+                return rc;
+            HIP_TRY(hipMemcpyAsync(rx->w->info.p, info.data(), n_blocks * sizeof(FrameInfo), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(rx->w->seg2frame.p, seg2frame.data(), seg2frame.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            const int64_t n_segs = (int64_t)seg2frame.size();
+            HIP_TRY(hipMemcpyAsync(rx->w->totals.p + 4, &n_segs, sizeof n_segs, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_conv_bm, dim3((unsigned)((T + 255) / 256), (unsigned)n_blocks), dim3(256), 0, st, d_sym, 2 * nsteps, T, rx->w->info.p, rx->w->bm.p);
+            if (rx->viterbi_kind == 1)
+                launch_viterbi_v2(st, rx->w->info.p, (int)n_blocks, rx->w->bm.p, rx->w->dec.p, rx->w->decoded.p, nullptr, 0, nullptr, nullptr);
+            else
+                launch_viterbi_v3(st, rx->w->info.p, (int)n_blocks, rx->w->bm.p, rx->w->dec.p, rx->w->decoded.p, rx->w->seg2frame.p, rx->w->totals.p,
+                                  rx->w->tb_state.p, seg2frame.size(), rx->tb_segment, rx->tb_overlap, nullptr, 0, nullptr, nullptr);
+            hipLaunchKernelGGL(k_conv_pack, dim3((unsigned)((nbytes + 255) / 256), (unsigned)n_blocks), dim3(256), 0, st, rx->w->decoded.p, rx->w->info.p,
+                               (N + 7) / 8, (int)nbytes, d_out);
+            HIP_TRY(hipStreamSynchronize(st));        // the host vectors above are the copies' sources
+            rx->last_frames = 0;                      // the workspace no longer describes a decode_frames call
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(data, d_out, out_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
     return FOA_OK;
 }
 
@@ -837,6 +881,7 @@ int foa_channel_estimate_f64(foa_rx *rx, const double *lts_pairs, double *hinv, 
     if (!rx || !lts_pairs || !hinv) return fail(FOA_E_INVALID, "NULL argument");
     if (n == 0) return FOA_OK;
     HIP_TRY(hipSetDevice(rx->device));
+    { int rc0 = drain(rx); if (rc0) return rc0; }                     // rx->scratch may still be read by a call in flight
     const size_t in_b = n * 128 * sizeof(double2), out_b = n * 64 * sizeof(double2);
     int rc = rx->scratch.ensure(in_b + out_b);
     if (rc) return rc;
@@ -855,6 +900,7 @@ int foa_equalize_f64(foa_rx *rx, double *vectors, size_t n_vec, const double *hi
     for (size_t i = 0; i < n_vec; i++)
         if (hinv_index[i] < 0 || (size_t)hinv_index[i] >= n_hinv) return fail(FOA_E_INVALID, "hinv_index[%zu] out of range", i);
     HIP_TRY(hipSetDevice(rx->device));
+    { int rc0 = drain(rx); if (rc0) return rc0; }                     // rx->scratch may still be read by a call in flight
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t v_b = n_vec * 64 * sizeof(double2), h_b = n_hinv * 64 * sizeof(double2), i_b = n_vec * sizeof(int32_t);
     int rc = rx->scratch.ensure(up(v_b) + up(h_b) + up(i_b));
@@ -875,6 +921,7 @@ int foa_phase_track_f64(foa_rx *rx, const double *vectors, const int32_t *symbol
     if (!rx || !vectors || !symbol_count || !out48) return fail(FOA_E_INVALID, "NULL argument");
     if (n_vec == 0) return FOA_OK;
     HIP_TRY(hipSetDevice(rx->device));
+    { int rc0 = drain(rx); if (rc0) return rc0; }                     // rx->scratch may still be read by a call in flight
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t v_b = n_vec * 64 * sizeof(double2), c_b = n_vec * sizeof(int32_t), o_b = n_vec * 48 * sizeof(double2);
     int rc = rx->scratch.ensure(up(v_b) + up(c_b) + up(o_b));
@@ -894,6 +941,7 @@ int foa_decode_header_f64(foa_rx *rx, const double *carriers48, size_t n, foa_fr
     if (!rx || !carriers48 || !results) return fail(FOA_E_INVALID, "NULL argument");
     if (n == 0) return FOA_OK;
     HIP_TRY(hipSetDevice(rx->device));
+    { int rc0 = drain(rx); if (rc0) return rc0; }                     // rx->scratch may still be read by a call in flight
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t c_b = n * 48 * sizeof(double2), r_b = n * sizeof(foa_frame_result);
     int rc = rx->scratch.ensure(up(c_b) + up(r_b));

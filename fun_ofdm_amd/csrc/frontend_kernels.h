@@ -336,8 +336,8 @@ __device__ __forceinline__ void emit_symbol_soft(cpx z, int di, const RateRow &r
 // One wave (64 threads) per block, one block per frame.
 // =================================================================================================
 __global__ __launch_bounds__(64) void k_header(const float2 *__restrict__ iq, const foa_frame_desc *__restrict__ descs,
-                                               const int64_t *__restrict__ ends, int n_frames, FrameInfo *__restrict__ info,
-                                               double2 *__restrict__ hinv, double2 *__restrict__ eq_tap)
+                                               const int64_t *__restrict__ ends, int64_t n_samples, int n_frames,
+                                               FrameInfo *__restrict__ info, double2 *__restrict__ hinv, double2 *__restrict__ eq_tap)
 {
     __shared__ cpx lds[64];
     __shared__ uint8_t dem[48];
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(64) void k_header(const float2 *__restrict__ iq, co
     const int f = blockIdx.x, lane = threadIdx.x;
     if (f >= n_frames) return;
     const foa_frame_desc d = descs[f];
-    const int64_t end = ends[f], p = d.lts1_pos;
+    const int64_t end = min(ends[f], n_samples), p = d.lts1_pos;      // nothing is read beyond the stream, whatever the caller's ends say
     FrameInfo fi;
     fi.status = FOA_ST_HEADER_FAIL; fi.rate = -1; fi.length = 0; fi.nsym = 0; fi.sym_off = 0; fi.nsteps = 0;
     fi.soft_off = 0; fi.dec_off = 0;

@@ -84,6 +84,29 @@ __global__ __launch_bounds__(64) void k_stage_header(const double2 *__restrict__
     }
 }
 
+// viterbi::conv_decode through the packed kernels (foa_conv_decode with option "viterbi" = 1 or 2): the soft bytes of
+// block blockIdx.y -> one branch-metric dword per trellis step in the block's region, exactly what the front end hands
+// the forward pass (viterbi.cpp:242-247 per Branchtab class; emit_symbol_soft).
+__global__ __launch_bounds__(256) void k_conv_bm(const uint8_t *__restrict__ symbols, size_t sym_stride, int T, const FrameInfo *__restrict__ info,
+                                                 uint32_t *__restrict__ bm)
+{
+    const int b = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    const uint8_t *sp = symbols + (size_t)b * sym_stride + 2 * (size_t)t;
+    const uint32_t s0 = sp[0], s1 = sp[1], n0 = s0 ^ 255u, n1 = s1 ^ 255u;
+    bm[info[b].dec_off + t] = ((s0 + s1 + 1u) >> 3) | (((s0 + n1 + 1u) >> 3) << 8) | (((n0 + s1 + 1u) >> 3) << 16) | (((n0 + n1 + 1u) >> 3) << 24);
+}
+
+// ... and the decoded bytes (MSB-first, as the chain-back kernels leave them) of every block, packed
+__global__ __launch_bounds__(256) void k_conv_pack(const uint32_t *__restrict__ decoded, const FrameInfo *__restrict__ info, int nbytes_have, int nbytes_out,
+                                                   uint8_t *__restrict__ data)
+{
+    const int b = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= nbytes_out) return;
+    const uint8_t *src = (const uint8_t *)(decoded + info[b].dec_off);
+    data[(size_t)b * nbytes_out + x] = x < nbytes_have ? src[x] : (uint8_t)0;
+}
+
 // front half of ppdu::decode_data (ppdu.cpp:238-244) from derotated carriers: one wave per data symbol
 __global__ __launch_bounds__(64 * kSymWaves) void k_stage_demap(const double2 *__restrict__ carriers, const int64_t *__restrict__ car_off,
                                                                 const FrameInfo *__restrict__ info, const int32_t *__restrict__ sym2frame,

@@ -59,10 +59,9 @@ __device__ __forceinline__ int finish_frame_wave(const FrameInfo &fi, DecAt dec_
         ok = given == c;
     }
     ok = __builtin_amdgcn_readfirstlane(ok);
-    if (ok) {                                              // ppdu.cpp:283-285
-        int ncopy = min((size_t)len, slot_bytes);
-        for (int x = lane; x < ncopy; x += 64) psdu_slot[x] = decoded[2 + x];
-    }
+    if (ok && (size_t)len > slot_bytes) return 2;          // a payload longer than the caller's slot is reported, never cut short
+    if (ok)                                                // ppdu.cpp:283-285
+        for (int x = lane; x < len; x += 64) psdu_slot[x] = decoded[2 + x];
     return ok;
 }
 
@@ -128,7 +127,7 @@ __global__ __launch_bounds__(64) void k_viterbi_v1(const FrameInfo *__restrict__
     int ok = finish_frame_wave(
         fi, [&](int base, int l) -> uint64_t { return base + l < T ? dp[base + l] : 0ull; }, decoded, crc_tab,
         psdu + (size_t)f * slot_bytes, slot_bytes, lane);
-    if (lane == 0) write_result(&results[f], fi, ok ? FOA_ST_OK : FOA_ST_CRC_FAIL);
+    if (lane == 0) write_result(&results[f], fi, ok == 2 ? FOA_ST_NO_SPACE : ok ? FOA_ST_OK : FOA_ST_CRC_FAIL);
 }
 
 

@@ -369,11 +369,12 @@ __device__ __forceinline__ void finish_crc_psdu(const FinishTables &t, FinishWav
         wave_lds_sync();
     }
     const bool ok = live && (crc ^ 0xFFFFFFFFu) == given;
-    if (f < n_frames) write_result(&results[f], fi, live ? (ok ? FOA_ST_OK : FOA_ST_CRC_FAIL) : fi.status);
+    const bool fits = (size_t)len <= slot_bytes;                           // a payload longer than the caller's slot is reported, never cut short
+    if (f < n_frames) write_result(&results[f], fi, live ? (ok ? (fits ? FOA_ST_OK : FOA_ST_NO_SPACE) : FOA_ST_CRC_FAIL) : fi.status);
 
     // payload = descrambled bytes [2, 2+len) (ppdu.cpp:283-285), only for frames whose CRC matched: 16 bytes per lane,
     // payload bytes 64 c + 16 pc .. + 15 of frame 16 r + sub = bytes 2 .. 17 of the five words from 16 c + 4 pc on
-    const int ncopy = ok ? (int)min((size_t)len, slot_bytes) : 0;
+    const int ncopy = ok && fits ? len : 0;
     fw.ncopy[lane] = ncopy;
     int maxc = ncopy;
 #pragma unroll
@@ -511,6 +512,7 @@ __global__ __launch_bounds__(64) void k_viterbi_finish2(const FrameInfo *__restr
             which ^= 1;
         }
     }
+    if (psdu == nullptr) return;                                           // foa_conv_decode: the decoded bits are the result
     finish_crc_psdu(tabs, fwave, fi, live, f, n_frames, decoded, psdu, slot_bytes, results);
 }
 

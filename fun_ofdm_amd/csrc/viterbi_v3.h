@@ -442,6 +442,7 @@ __global__ __launch_bounds__(64) void k_tb_finish(const FrameInfo *__restrict__ 
         if (has) s_next = s_k;
     }
     __threadfence();                                                       // re-walked words were written by lane 0
+    if (psdu == nullptr) return;                                           // foa_conv_decode: the decoded bits are the result
     finish_crc_psdu(tabs, fwave, fi, live, f, n_frames, decoded, psdu, slot_bytes, results);
 }
 

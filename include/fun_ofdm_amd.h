@@ -46,7 +46,8 @@ enum {
     FOA_ST_HEADER_FAIL = 1,  /* SIGNAL parity or rate check failed (ppdu.cpp:187-203) */
     FOA_ST_CRC_FAIL = 2,     /* ppdu.cpp:272-279 */
     FOA_ST_TRUNCATED = 3,    /* not enough samples before `end` for the symbols SIGNAL announces */
-    FOA_ST_NO_SPACE = 4      /* workspace exhausted (overlapping frame ranges) */
+    FOA_ST_NO_SPACE = 4      /* workspace exhausted (overlapping frame ranges), or the CRC matched but the payload is longer
+                              * than slot_bytes (nothing is copied) */
 };
 
 /* One alignment = one LTS1/LTS2 tag pair produced by timing_sync (src/timing_sync.cpp:98-113).

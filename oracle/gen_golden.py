@@ -62,6 +62,40 @@ def viterbi_kat(rng):
     e = np.clip(po.conv_encode(d, nb).astype(float) * 255 + rng.normal(0, 70, 2 * (nb + 6)), 0, 255).astype(np.uint8)
     e[2::6] = 127; e[4::6] = 127
     add(e, nb)
+    return _pack_kat(syms, bits, outs)
+
+
+def viterbi_long_kat(rng):
+    """Saturation / renormalisation corner cases at the trellis lengths of BASELINE configs 2 and 3,
+    through the real SSE decoder: constant soft bytes, uniform garbage, alternating extremes, a codeword with every second
+    pair erased, an inverted codeword.  (tests/test_gpu_parity.py feeds them to every GPU Viterbi kernel.)"""
+    R = po.Ref
+    syms, bits, outs = [], [], []
+
+    def add(s, nb):
+        syms.append(np.ascontiguousarray(s, np.uint8)); bits.append(nb); outs.append(R.conv_decode(s, nb))
+
+    for nb in (8418, 32826):
+        n = 2 * (nb + 6)
+        for val in (0, 255, 127, 128, 1, 254):
+            add(np.full(n, val, np.uint8), nb)
+        add(rng.integers(0, 256, n, dtype=np.uint8), nb)
+        add(np.where(np.arange(n) % 2 == 0, 0, 255), nb)
+        add(np.where((np.arange(n) // 2) % 2 == 0, 0, 255), nb)
+        add(np.arange(n) * 7 % 256, nb)
+        d = rng.integers(0, 256, (nb + 13) // 8 + 1, dtype=np.uint8)
+        code = po.conv_encode(d, nb).astype(np.uint8) * 255
+        half = code.copy()
+        half.reshape(-1, 2)[1::2] = 127
+        add(half, nb)
+        add(255 - code, nb)
+        noisy = np.clip(code.astype(float) + rng.normal(0, 110, n), 0, 255).astype(np.uint8)     # marginal: many renormalisations
+        noisy[2::6] = 127; noisy[4::6] = 127
+        add(noisy, nb)
+    return _pack_kat(syms, bits, outs)
+
+
+def _pack_kat(syms, bits, outs):
     off = np.cumsum([0] + [s.size for s in syms])
     ooff = np.cumsum([0] + [o.size for o in outs])
     return dict(symbols=np.concatenate(syms), sym_off=off, data_bits=np.array(bits), decoded=np.concatenate(outs), dec_off=ooff)
@@ -189,18 +223,23 @@ def frames(rng):
 def main():
     os.makedirs(OUT, exist_ok=True)
     po.build(ref=True)
-    manifest = {}
+    only = set(sys.argv[1:])                 # optional: regenerate just the named files
+    mpath = os.path.join(OUT, "MANIFEST.json")
+    manifest = json.load(open(mpath)) if (only and os.path.exists(mpath)) else {}
     for fname, fn, seed, prov in (
         ("viterbi_ref.npz", viterbi_kat, 101, "real reference viterbi::conv_decode (SSE) via oracle/_ref"),
+        ("viterbi_long_ref.npz", viterbi_long_kat, 105, "real reference viterbi::conv_decode (SSE) via oracle/_ref: corner cases at 8418 / 32826 data bits"),
         ("codec_ref.npz", codec_kat, 102, "real reference modulator/interleaver/puncturer/viterbi::conv_encode/symbol_mapper/tables via oracle/_ref"),
         ("blocks_ref.npz", blocks_kat, 103, "real reference frame_detector/timing_sync/channel_est/phase_tracker via oracle/_ref (fft_symbols: oracle)"),
         ("frames.npz", frames, 104, "oracle restatement (fo_oracle.c), itself pinned against the *_ref fixtures"),
     ):
+        if only and fname not in only:
+            continue
         print(fname)
         data = fn(np.random.default_rng(seed))
         np.savez_compressed(os.path.join(OUT, fname), **data)
         manifest[fname] = dict(seed=seed, provenance=prov, generator="oracle/gen_golden.py")
-    with open(os.path.join(OUT, "MANIFEST.json"), "w") as f:
+    with open(mpath, "w") as f:
         json.dump(manifest, f, indent=1)
     print({f: os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT)})
 

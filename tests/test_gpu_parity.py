@@ -48,21 +48,38 @@ def test_library_is_native_and_loaded():
     assert foa.lib().foa_device_count() >= 1
 
 
-@pytest.mark.parametrize("kind", [0, 1])
+@pytest.mark.parametrize("kind", VITERBI_KINDS, ids=_kind_id)
 def test_conv_decode_matches_reference_sse_vectors(rx, golden, kind):
-    """GPU Viterbi fed the bytes the REAL reference decoder was fed: bit-exact (incl. garbage)."""
-    rx.set_option("viterbi", kind)
+    """Every Viterbi kernel of the batch path -- foa_conv_decode runs the one option "viterbi" selects, the production
+    k_viterbi_fwd3 / k_tb_walk / k_tb_finish included -- fed the bytes the REAL reference decoder (viterbi.cpp:208-457,
+    :108-146, compiled SSE) was fed: bit-exact, garbage / constant / erasure inputs included."""
+    _set_viterbi(rx, kind)
     g = golden.viterbi_ref
     for i, nb in enumerate(g["data_bits"]):
         s = g["symbols"][g["sym_off"][i]:g["sym_off"][i + 1]]
         want = g["decoded"][g["dec_off"][i]:g["dec_off"][i + 1]]
         got = rx.conv_decode(s, int(nb))[0]
         assert np.array_equal(got, want), "KAT %d (data_bits %d)" % (i, nb)
+    gl = golden.viterbi_long_ref            # corner cases at the trellis lengths of configs 2 and 3, real SSE outputs
+    for i, nb in enumerate(gl["data_bits"]):
+        s = gl["symbols"][gl["sym_off"][i]:gl["sym_off"][i + 1]]
+        got = rx.conv_decode(s, int(nb))[0]
+        assert np.array_equal(got, gl["decoded"][gl["dec_off"][i]:gl["dec_off"][i + 1]]), "long KAT %d (data_bits %d)" % (i, nb)
+    # all of them in one call as well (several blocks share a wave in the packed kernels): group by size
+    for nb in sorted(set(int(x) for x in g["data_bits"])):
+        idx = [i for i, x in enumerate(g["data_bits"]) if int(x) == nb]
+        s = np.concatenate([g["symbols"][g["sym_off"][i]:g["sym_off"][i + 1]] for i in idx])
+        got = rx.conv_decode(s, nb, len(idx))
+        for k, i in enumerate(idx):
+            assert np.array_equal(got[k], g["decoded"][g["dec_off"][i]:g["dec_off"][i + 1]]), (nb, k)
+    _set_viterbi(rx, VITERBI_KINDS[2])
 
 
-def test_conv_decode_random_vs_oracle(rx, po):
+@pytest.mark.parametrize("kind", VITERBI_KINDS, ids=_kind_id)
+def test_conv_decode_random_vs_oracle(rx, po, kind):
+    _set_viterbi(rx, kind)
     rng = np.random.default_rng(21)
-    for nb in (2, 10, 58, 64, 122, 130, 1000, 8418, 32826):
+    for nb in (1, 2, 7, 10, 58, 64, 91, 122, 130, 1000, 1001, 8418, 32826):
         nblk = 5 if nb < 5000 else 2
         n = 2 * (nb + 6)
         s = rng.integers(0, 256, nblk * n, dtype=np.uint8)
@@ -73,6 +90,47 @@ def test_conv_decode_random_vs_oracle(rx, po):
         got = rx.conv_decode(s, nb, nblk)
         for b in range(nblk):
             assert np.array_equal(got[b], po.conv_decode(s[b * n:(b + 1) * n], nb)), (nb, b)
+    _set_viterbi(rx, VITERBI_KINDS[2])
+
+
+# chain-back segmentations of the production kernels for the saturation / renormalisation corner cases below
+SEGMENTATIONS = [(2, S, L) for S in (96, 960, 3072) for L in (0, 96)]
+
+
+def _real_sse_decoder(po):
+    """The REAL reference decoder (oracle/_ref, built from /root/reference in the dev container; the prebuilt library
+    travels to the GPU box) if it is there, else None."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(po.__file__)), "_ref", "libfun_ofdm_ref.so")
+    return po.Ref.conv_decode if os.path.exists(path) else None
+
+
+@pytest.mark.parametrize("kind", [(0, 0, 0), (1, 0, 0)] + SEGMENTATIONS, ids=_kind_id)
+def test_conv_decode_saturation_corner_cases(rx, po, kind):
+    """Where the uint8 saturation, the state-0 renormalisation rule and the tie rule decide the output:
+    constant soft bytes (0, 255, 127 = erasures everywhere, 128), uniformly random bytes, alternating extremes, a clean
+    codeword and a codeword with every second pair erased, at 18 (SIGNAL), 8418 (config 2) and 32826 (config 3) data bits."""
+    _set_viterbi(rx, kind)
+    rng = np.random.default_rng(77)
+    for nb in (18, 8418, 32826):
+        n = 2 * (nb + 6)
+        d = rng.integers(0, 256, (nb + 13) // 8 + 1, dtype=np.uint8)
+        code = po.conv_encode(d, nb).astype(np.uint8) * 255
+        half = code.copy()
+        half.reshape(-1, 2)[1::2] = 127
+        ramp = (np.arange(n) * 7 % 256).astype(np.uint8)
+        alt = np.where(np.arange(n) % 2 == 0, 0, 255).astype(np.uint8)
+        alt4 = np.where((np.arange(n) // 2) % 2 == 0, 0, 255).astype(np.uint8)
+        blocks = [np.full(n, v, np.uint8) for v in (0, 255, 127, 128, 1, 254)] + [rng.integers(0, 256, n, dtype=np.uint8) for _ in range(3)] + \
+                 [alt, alt4, ramp, code, half, 255 - code]
+        s = np.concatenate(blocks)
+        got = rx.conv_decode(s, nb, len(blocks))
+        real = _real_sse_decoder(po)
+        for b, blk in enumerate(blocks):
+            assert np.array_equal(got[b], po.conv_decode(blk, nb)), (nb, b)
+            if real is not None:
+                assert np.array_equal(got[b], real(blk, nb)), ("vs the compiled reference", nb, b)
+    _set_viterbi(rx, VITERBI_KINDS[2])
 
 
 def test_fft_forward_vs_oracle(rx, po):

@@ -9,8 +9,10 @@ import numpy as np
 import pytest
 
 
-def test_viterbi_matches_reference_sse(po, golden):
-    g = golden.viterbi_ref
+@pytest.mark.parametrize("which", ["viterbi_ref", "viterbi_long_ref"])
+def test_viterbi_matches_reference_sse(po, golden, which):
+    """viterbi_long_ref: constant / garbage / alternating / half-erased blocks at 8418 and 32826 data bits (configs 2, 3)."""
+    g = getattr(golden, which)
     for i, nb in enumerate(g["data_bits"]):
         s = g["symbols"][g["sym_off"][i]:g["sym_off"][i + 1]]
         want = g["decoded"][g["dec_off"][i]:g["dec_off"][i + 1]]

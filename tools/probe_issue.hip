@@ -1,48 +1,135 @@
-// Issue-throughput probe: how many clocks of SIMD time does one wave64 instruction of each kind cost on
-// gfx950 when 8 waves per SIMD keep the pipes full?  (8192 waves, each loops over 8 independent chains.)
+// Issue-cost probe for gfx950: how many SHADER CLOCKS of one SIMD does one wave64 instruction of each class cost, with
+// W = 1, 2, 4, 8 waves resident per SIMD (1024 SIMDs x W single-wave workgroups, every wave running 8 independent
+// dependency chains)?  Answers the question DESIGN.md 4 hangs on: is the VALU issue roof of the forward pass
+// 1024 SIMDs x f / 2 (MI355X_MICROARCH.md: SIMD-32, v_fma_f32 issues over 2 cycles) or / 4, for the instruction
+// classes the kernel is made of (v_pk_add_u16 clamp, v_pk_min_u16, v_pk_sub_u16, v_mov_b32_dpp, v_permlane32_swap,
+// v_permlane16_swap, v_bfi_b32, v_lshrrev_b32, v_readfirstlane_b32, ds_read_b64)?
+// Clocks come from s_memtime inside the kernel (tick = shader cycle, MI355X_MICROARCH.md), so the figure does not
+// depend on an assumed frequency; the effective frequency itself is reported as ticks / wall time (HIP events).
+//   hipcc --offload-arch=gfx950 -O3 -o probe_issue.bin tools/probe_issue.hip && ./probe_issue.bin
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdio>
-typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
-#define REP 2048
+#include <vector>
+
+#define REP 8192
+
+enum { V_ADD, V_FMA, V_PK_ADD_CLAMP, V_PK_MIN, V_PK_SUB, V_DPP_QUAD, V_DPP_ROW, V_PERMLANE32, V_PERMLANE16, V_BFI, V_LSHR, V_READFIRST, DS_READ_B64, V_FMA_F64, MIX_FWD, MIX_FWD_CHAIN };
+
 template <int V>
-__global__ __launch_bounds__(64) void k(unsigned *out, unsigned seed)
+__global__ __launch_bounds__(256) void k(unsigned long long *out, unsigned seed, int rep)
 {
+    __shared__ unsigned long long lds[256 * 8];
     unsigned r[8];
     for (int i = 0; i < 8; i++) r[i] = threadIdx.x * 2654435761u + seed + i;
-    unsigned long long sacc = 0;
-    for (int it = 0; it < REP; it++) {
+    for (int i = 0; i < 8; i++) lds[threadIdx.x * 8 + i] = r[i];
+    unsigned sacc = 0;
+    double d[8];
+    for (int i = 0; i < 8; i++) d[i] = (double)r[i];
+    __syncthreads();
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < rep; it++) {
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            if (V == 0) r[i] = r[i] + 0x9E3779B9u;                                                      // v_add_u32
-            if (V == 1) r[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_add_sat(__builtin_bit_cast(ushort2_t, r[i]), __builtin_bit_cast(ushort2_t, 0x00030005u)));   // v_pk_add_u16 clamp
-            if (V == 2) r[i] = __builtin_amdgcn_perm(r[i], r[(i + 1) & 7], 0x07020500u);               // v_perm_b32
-            if (V == 3) r[i] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)r[i], 0xA0, 0xF, 0xF, true);   // v_mov_dpp
-            if (V == 4) { auto s = __builtin_amdgcn_permlane32_swap(r[i], r[(i + 1) & 7], false, false); r[i] = s[0]; r[(i + 1) & 7] = s[1]; }
-            if (V == 5) sacc += __ballot((r[i] & 0xFFFFu) <= (r[(i + 1) & 7] & 0xFFFFu)), r[i] += 1;   // v_cmp_sdwa (+v_add) (+s_add)
-            if (V == 6) asm volatile("v_writelane_b32 %0, %1, 7" : "+v"(r[i]) : "s"(seed));
-            if (V == 7) r[i] ^= r[(i + 1) & 7];                                                         // v_xor
-            if (V == 8) asm volatile("s_nop 0");
-            if (V == 9) asm volatile("s_add_u32 %0, %0, 3" : "+s"(seed));
+            if (V == V_ADD) asm volatile("v_add_u32 %0, %0, %1" : "+v"(r[i]) : "v"(seed));
+            if (V == V_FMA) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(r[i]) : "v"(seed));
+            if (V == V_PK_ADD_CLAMP) asm volatile("v_pk_add_u16 %0, %0, %1 clamp" : "+v"(r[i]) : "v"(seed));
+            if (V == V_PK_MIN) asm volatile("v_pk_min_u16 %0, %0, %1" : "+v"(r[i]) : "v"(r[(i + 1) & 7]));
+            if (V == V_PK_SUB) asm volatile("v_pk_sub_u16 %0, %0, %1" : "+v"(r[i]) : "v"(seed));
+            if (V == V_DPP_QUAD) asm volatile("v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(r[i]));
+            if (V == V_DPP_ROW) asm volatile("v_mov_b32_dpp %0, %0 row_shr:8 row_mask:0xf bank_mask:0xc" : "+v"(r[i]));
+            if (V == V_PERMLANE32) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(r[i]), "+v"(r[(i + 1) & 7]));
+            if (V == V_PERMLANE16) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(r[i]), "+v"(r[(i + 1) & 7]));
+            if (V == V_BFI) asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(r[i]) : "s"(0x00010001u << i), "v"(r[(i + 1) & 7]));
+            if (V == V_LSHR) asm volatile("v_lshrrev_b32 %0, 3, %0" : "+v"(r[i]));
+            if (V == V_READFIRST) { unsigned s; asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(s) : "v"(r[i])); sacc += s; }
+            if (V == DS_READ_B64) { unsigned long long v; asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"((threadIdx.x * 8 + i) * 8)); r[i] ^= (unsigned)v; }
+            if (V == V_FMA_F64) asm volatile("v_fma_f64 %0, %0, %0, %0" : "+v"(d[i]));
+            if (V == MIX_FWD) {
+                // one forward-pass step of viterbi_v3.h as an instruction multiset: 2 DPP moves, 2 clamped adds, sub, shift, bfi, min, readfirstlane
+                unsigned lo, hi, x, y, t, s;
+                asm volatile("v_mov_b32_dpp %0, %2 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                             "v_mov_b32_dpp %1, %2 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf"
+                             : "=&v"(lo), "=&v"(hi) : "v"(r[i]));
+                asm volatile("v_pk_add_u16 %0, %2, %4 clamp\n\tv_pk_add_u16 %1, %3, %4 clamp" : "=&v"(x), "=&v"(y) : "v"(lo), "v"(hi), "v"(seed));
+                asm volatile("v_pk_sub_u16 %0, %1, %2\n\tv_lshrrev_b32 %0, 3, %0" : "=&v"(t) : "v"(x), "v"(y));
+                asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(r[(i + 1) & 7]) : "s"(0x00010001u), "v"(t));
+                asm volatile("v_pk_min_u16 %0, %1, %2" : "=v"(r[i]) : "v"(x), "v"(y));
+                asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(s) : "v"(r[i]));
+                sacc += s;
+            }
+            if (V == MIX_FWD_CHAIN) {
+                // the same nine instructions as ONE dependent chain per wave (r[0] -> r[0]), the renormalisation test's scalar
+                // compare-and-branch included: what a lone frame pair's step looks like to the SIMD
+                unsigned lo, hi, x, y, t, s;
+                asm volatile("v_mov_b32_dpp %0, %2 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                             "v_mov_b32_dpp %1, %2 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf"
+                             : "=&v"(lo), "=&v"(hi) : "v"(r[0]));
+                asm volatile("v_pk_add_u16 %0, %2, %4 clamp\n\tv_pk_add_u16 %1, %3, %4 clamp" : "=&v"(x), "=&v"(y) : "v"(lo), "v"(hi), "v"(seed));
+                asm volatile("v_pk_sub_u16 %0, %1, %2\n\tv_lshrrev_b32 %0, 3, %0" : "=&v"(t) : "v"(x), "v"(y));
+                asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(r[1]) : "s"(0x00010001u), "v"(t));
+                asm volatile("v_pk_min_u16 %0, %1, %2" : "=v"(r[0]) : "v"(x), "v"(y));
+                asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(s) : "v"(r[0]));
+                if (__builtin_expect(((s & 0x00FF00FFu) + 0x002D002Du) & 0x01000100u, 0)) r[0] -= 0x00010001u;
+            }
         }
     }
-    unsigned a = (unsigned)sacc + seed;
-    for (int i = 0; i < 8; i++) a += r[i];
-    out[blockIdx.x * 64 + threadIdx.x] = a;
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    unsigned a = sacc + seed;
+    for (int i = 0; i < 8; i++) a += r[i] + (unsigned)d[i];
+    if ((threadIdx.x & 63) == 0) { const int w = blockIdx.x * 4 + (threadIdx.x >> 6); out[2 * w] = t1 - t0; out[2 * w + 1] = a; }
 }
-template <int V> void run(const char *name, unsigned *d, double per_iter_instr)
+
+template <int V> void run(const char *name, unsigned long long *d, double per_iter_instr, int rep = REP)
 {
-    const int nblk = 256 * 4 * 8;
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    float ms = 0;
-    for (int it = 0; it < 3; it++) { hipEventRecord(e0); k<V><<<nblk, 64>>>(d, 7); hipEventRecord(e1); hipDeviceSynchronize(); hipEventElapsedTime(&ms, e0, e1); }
-    double instr_per_simd = 8.0 * REP * 8 * per_iter_instr;      // 8 waves per SIMD
-    printf("%-34s %8.3f ms   %6.2f ns per wave-instr per SIMD (= %5.2f clk @2.4GHz)\n", name, ms, ms * 1e6 / instr_per_simd, ms * 1e6 / instr_per_simd * 2.4);
+    for (int W : { 1, 2, 4, 5, 8 }) {
+        const int nblk = 256 * 4 * W;      // waves
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        float ms = 0;
+        std::vector<unsigned long long> h(2 * nblk);
+        for (int it = 0; it < 3; it++) {
+            hipEventRecord(e0);
+            k<V><<<nblk / 4, 256>>>(d, 7, rep);
+            hipEventRecord(e1);
+            hipDeviceSynchronize();
+            hipEventElapsedTime(&ms, e0, e1);
+        }
+        hipMemcpy(h.data(), d, 2 * nblk * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        std::vector<unsigned long long> t(nblk);
+        for (int i = 0; i < nblk; i++) t[i] = h[2 * i];
+        std::sort(t.begin(), t.end());
+        const double instr_per_wave = (double)rep * 8 * per_iter_instr, med = (double)t[nblk / 2], mx = (double)t[nblk - 1];
+        // clocks of SIMD time per wave-instruction = a wave's elapsed ticks / (waves sharing the SIMD x its instructions)
+        printf("%-30s W=%d  %8.3f ms  median wave %10.0f ticks  -> %5.2f clk per wave-instr per SIMD (slowest wave %5.2f);  %5.2f GHz (slowest wave's ticks / wall)\n",
+               name, W, ms, med, med / (W * instr_per_wave), mx / (W * instr_per_wave), mx / (ms * 1e6));
+    }
 }
+
 int main()
 {
-    unsigned *d; hipMalloc(&d, 256 * 4 * 8 * 64 * 4);
-    run<0>("v_add_u32", d, 1); run<7>("v_xor_b32", d, 1); run<1>("v_pk_add_u16 clamp", d, 1); run<2>("v_perm_b32", d, 1);
-    run<3>("v_mov_b32_dpp", d, 1); run<4>("v_permlane32_swap (+movs?)", d, 1); run<5>("v_cmp_sdwa + v_add + s_add64", d, 3);
-    run<6>("v_writelane_b32", d, 1); run<8>("s_nop 0", d, 1); run<9>("s_add_u32", d, 1);
+    unsigned long long *d;
+    hipMalloc(&d, 2 * 256 * 4 * 8 * sizeof(unsigned long long));
+    for (int i = 0; i < 200; i++) k<V_FMA><<<2048, 256>>>(d, 7, 2048);      // bring the clocks up before the first row
+    hipDeviceSynchronize();
+    hipDeviceProp_t p;
+    hipGetDeviceProperties(&p, 0);
+    printf("%s  CUs %d  clockRate %d kHz\n", p.gcnArchName, p.multiProcessorCount, p.clockRate);
+    run<V_ADD>("v_add_u32", d, 1);
+    run<V_FMA>("v_fma_f32", d, 1);
+    run<V_PK_ADD_CLAMP>("v_pk_add_u16 clamp", d, 1);
+    run<V_PK_MIN>("v_pk_min_u16", d, 1);
+    run<V_PK_SUB>("v_pk_sub_u16", d, 1);
+    run<V_DPP_QUAD>("v_mov_b32_dpp quad_perm", d, 1);
+    run<V_DPP_ROW>("v_mov_b32_dpp row_shr:8", d, 1);
+    run<V_PERMLANE32>("v_permlane32_swap_b32", d, 1);
+    run<V_PERMLANE16>("v_permlane16_swap_b32", d, 1);
+    run<V_BFI>("v_bfi_b32", d, 1);
+    run<V_LSHR>("v_lshrrev_b32", d, 1);
+    run<V_READFIRST>("v_readfirstlane_b32 (+s_add)", d, 1);
+    run<DS_READ_B64>("ds_read_b64 (+v_xor)", d, 1, 1024);
+    run<V_FMA_F64>("v_fma_f64", d, 1);
+    run<MIX_FWD>("forward-step mix (9 VALU)", d, 9, 2048);
+    run<MIX_FWD_CHAIN>("forward mix, one chain/wave", d, 9, 2048);
     return 0;
 }
