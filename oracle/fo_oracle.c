@@ -246,12 +246,16 @@ void fo_scramble(const uint8_t *in, uint8_t *out, size_t n)
 /* viterbi.cpp:39-62: masks {121,91} on sr = (sr<<1)|bit, bits taken MSB first */
 void fo_conv_encode(const uint8_t *data, uint8_t *symbols, int data_bits)
 {
-    int sr = 0, idx = 0;
+    /* (the reference shifts a signed int for the whole block, viterbi.cpp:53 -- overflow after 31 bits; only the low seven
+     * bits are ever used, so an unsigned register gives the same symbols without the undefined behaviour: UBSan run,
+     * tools/run_sanitizers.sh) */
+    unsigned sr = 0;
+    int idx = 0;
     for (int i = 0; i < data_bits + 6; i++) {
-        int bit = (data[i / 8] >> (7 - (i % 8))) & 1;
+        unsigned bit = (data[i / 8] >> (7 - (i % 8))) & 1u;
         sr = (sr << 1) | bit;
-        symbols[idx++] = (uint8_t)fo_parity((unsigned)(sr & 121));
-        symbols[idx++] = (uint8_t)fo_parity((unsigned)(sr & 91));
+        symbols[idx++] = (uint8_t)fo_parity(sr & 121u);
+        symbols[idx++] = (uint8_t)fo_parity(sr & 91u);
     }
 }
 

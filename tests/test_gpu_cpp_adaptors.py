@@ -52,3 +52,75 @@ def test_sim_cli_over_iq_file(tmp_path):
         assert len(got) >= 22 and all(g in sent for g in got)
         assert [sent.index(g) for g in got] == sorted(sent.index(g) for g in got)      # stream order
         assert ("%d packets" % len(got)) in r.stdout
+
+
+def _collision_stream(po, case, seed, ga=0.15, snr=40.0):
+    """A weak 6 Mbps frame A (300 bytes, 8640 samples) with a second, nominal-level frame B (12 Mbps, 100 bytes) starting in the
+    middle of A's data symbols -- B's SIGNAL intact ("valid"), garbled ("invalid") or B absent ("none") -- then a clean frame C."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    pay = [rng.integers(0, 256, n, dtype=np.uint8) for n in (300, 100, 100)]
+    A, B, C = po.build_frame(pay[0], 0) * ga, po.build_frame(pay[1], 3), po.build_frame(pay[2], 8)
+    if case == "invalid":
+        B = B.copy()
+        B[320:400] = B[320:400][::-1] * 1j
+    s = np.zeros(400 + A.size + 600 + C.size + 500, complex)
+    s[400:400 + A.size] += A
+    off = 400 + 320 + 80 * 40 + 37
+    if case != "none":
+        s[off:off + B.size] += B
+    s[400 + A.size + 600:400 + A.size + 600 + C.size] += C
+    s = s + (rng.normal(size=s.size) + 1j * rng.normal(size=s.size)) * np.sqrt(0.0124 / 2 / 10 ** (snr / 10))
+    return s.astype(np.complex64), [p.tobytes() for p in pay]
+
+
+def test_second_preamble_inside_a_frame(tmp_path, po):
+    """frame_decoder.cpp:52-76: a preamble that arrives before the current frame ends.  With a valid SIGNAL the reference
+    abandons the frame it was collecting and starts the new one; with an invalid SIGNAL it keeps filling the old frame (from
+    the re-aligned symbol windows, fft_symbols.cpp:41-50), which then fails its CRC.  Either way the old frame is never
+    delivered.  The batch path reports it as FOA_ST_TRUNCATED (its extent ends at the next alignment) -- a status the
+    reference has no word for -- and must deliver exactly the reference chain's ordered payload list; so must
+    fun_amd::receiver_chain::process_samples in both of its modes."""
+    import numpy as np
+    import fun_ofdm_amd as foa
+    exe = str(tmp_path / "foa_sim")
+    libdir = os.path.dirname(foa.library_path())
+    subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "examples", "foa_sim.cpp"), "-I", os.path.join(ROOT, "include"),
+                    "-L", libdir, "-lfun_ofdm_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lpthread", "-o", exe], check=True)
+    rx = foa.Receiver(0)
+    seen = set()
+    try:
+        for seed in (5, 7):
+            for case in ("valid", "invalid", "none"):
+                iq, pays = _collision_stream(po, case, seed)
+                want = po.ReceiverChain().run_stream(iq.astype(np.complex128))          # the reference-shaped chain (oracle)
+                names = [{pays[0]: "A", pays[1]: "B", pays[2]: "C"}.get(x, "?") for x in want]
+                assert names == {"valid": ["B", "C"], "invalid": ["C"], "none": ["A", "C"]}[case], (seed, case, names)
+                # batch path: per-alignment results as the oracle's alignment decoder has them, payload list as the chain's
+                descs = foa.find_alignments(iq)
+                assert descs.tobytes() == po.find_alignments_f32(iq).tobytes()
+                ends = foa.alignment_ends(descs, iq.size)
+                psdu, res = rx.decode_frames_host(iq, descs, ends)
+                opsdu, ores = po.decode_batch_f32(iq, descs, ends)
+                assert np.array_equal(res.view(np.int32), ores.view(np.int32)), (seed, case)
+                got = [psdu[f, :res[f]["length"]].tobytes() for f in range(descs.size) if res[f]["status"] == foa.ST_OK]
+                assert got == want, (seed, case)
+                if case != "none":
+                    assert descs.size == 3 and res[0]["status"] == foa.ST_TRUNCATED and res[0]["rate"] == 0 and res[0]["length"] == 300
+                    assert res[1]["status"] == (foa.ST_OK if case == "valid" else foa.ST_HEADER_FAIL)
+                seen.add((case, tuple(int(x) for x in res["status"])))
+                # fun_amd::receiver_chain (synchronous and in asynchronous batches) over the same capture
+                src, out = str(tmp_path / "cap.fc32"), str(tmp_path / "psdus")
+                iq.tofile(src)
+                for extra in ([], ["--async", "2"]):
+                    r = subprocess.run([exe, src, "--format", "fc32", "--out", out, "--chunk", "4096"] + extra, capture_output=True, text=True, timeout=300)
+                    assert r.returncode == 0, r.stdout + r.stderr
+                    raw, recs, o = open(out, "rb").read(), [], 0
+                    while o < len(raw):
+                        n = int.from_bytes(raw[o:o + 4], "little")
+                        recs.append(raw[o + 4:o + 4 + n])
+                        o += 4 + n
+                    assert recs == want, (seed, case, extra)
+    finally:
+        rx.close()
+    assert len(seen) >= 3

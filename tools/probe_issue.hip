@@ -5,14 +5,14 @@
 // classes the kernel is made of (v_pk_add_u16 clamp, v_pk_min_u16, v_pk_sub_u16, v_mov_b32_dpp, v_permlane32_swap,
 // v_permlane16_swap, v_bfi_b32, v_lshrrev_b32, v_readfirstlane_b32, ds_read_b64)?
 // Clocks come from s_memtime inside the kernel (tick = shader cycle, MI355X_MICROARCH.md), so the figure does not
-// depend on an assumed frequency; the effective frequency itself is reported as ticks / wall time (HIP events).
+// depend on an assumed frequency; the effective frequency itself is reported as window ticks / wall time (HIP events).
 //   hipcc --offload-arch=gfx950 -O3 -o probe_issue.bin tools/probe_issue.hip && ./probe_issue.bin
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
 #include <vector>
 
-#define REP 8192
+#define REP 1500        // window = REP x 1000 shader clocks (~0.65 ms)
 
 enum { V_ADD, V_FMA, V_PK_ADD_CLAMP, V_PK_MIN, V_PK_SUB, V_DPP_QUAD, V_DPP_ROW, V_PERMLANE32, V_PERMLANE16, V_BFI, V_LSHR, V_READFIRST, DS_READ_B64, V_FMA_F64, MIX_FWD, MIX_FWD_CHAIN };
 
@@ -27,8 +27,14 @@ __global__ __launch_bounds__(256) void k(unsigned long long *out, unsigned seed,
     double d[8];
     for (int i = 0; i < 8; i++) d[i] = (double)r[i];
     __syncthreads();
-    const unsigned long long t0 = __builtin_readcyclecounter();
-    for (int it = 0; it < rep; it++) {
+    // Fixed WINDOW instead of fixed work: under the SIMD's oldest-first arbitration waves with equal work finish at very
+    // different times and the tail runs at reduced occupancy; here every wave issues until `rep` x 1000 ticks have passed and
+    // reports how far it got, so the occupancy is W from the first tick to the last.
+    const unsigned long long t0 = __builtin_readcyclecounter(), window = (unsigned long long)rep * 1000ull;
+    unsigned long long t1 = t0;
+    unsigned done = 0;
+    for (; t1 - t0 < window; t1 = __builtin_readcyclecounter(), done++) {
+      for (int it = 0; it < 8; it++) {
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             if (V == V_ADD) asm volatile("v_add_u32 %0, %0, %1" : "+v"(r[i]) : "v"(seed));
@@ -73,44 +79,47 @@ __global__ __launch_bounds__(256) void k(unsigned long long *out, unsigned seed,
                 if (__builtin_expect(((s & 0x00FF00FFu) + 0x002D002Du) & 0x01000100u, 0)) r[0] -= 0x00010001u;
             }
         }
+      }
     }
-    const unsigned long long t1 = __builtin_readcyclecounter();
     unsigned a = sacc + seed;
     for (int i = 0; i < 8; i++) a += r[i] + (unsigned)d[i];
-    if ((threadIdx.x & 63) == 0) { const int w = blockIdx.x * 4 + (threadIdx.x >> 6); out[2 * w] = t1 - t0; out[2 * w + 1] = a; }
+    if ((threadIdx.x & 63) == 0) { const int w = blockIdx.x * 4 + (threadIdx.x >> 6); out[3 * w] = t1 - t0; out[3 * w + 1] = done; out[3 * w + 2] = a; }
 }
 
 template <int V> void run(const char *name, unsigned long long *d, double per_iter_instr, int rep = REP)
 {
     for (int W : { 1, 2, 4, 5, 8 }) {
-        const int nblk = 256 * 4 * W;      // waves
+        const int nw = 256 * 4 * W;      // waves
         hipEvent_t e0, e1;
         hipEventCreate(&e0); hipEventCreate(&e1);
         float ms = 0;
-        std::vector<unsigned long long> h(2 * nblk);
-        for (int it = 0; it < 3; it++) {
+        std::vector<unsigned long long> h(3 * nw);
+        for (int it = 0; it < 2; it++) {
             hipEventRecord(e0);
-            k<V><<<nblk / 4, 256>>>(d, 7, rep);
+            k<V><<<nw / 4, 256>>>(d, 7, rep);
             hipEventRecord(e1);
             hipDeviceSynchronize();
             hipEventElapsedTime(&ms, e0, e1);
         }
-        hipMemcpy(h.data(), d, 2 * nblk * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-        std::vector<unsigned long long> t(nblk);
-        for (int i = 0; i < nblk; i++) t[i] = h[2 * i];
-        std::sort(t.begin(), t.end());
-        const double instr_per_wave = (double)rep * 8 * per_iter_instr, med = (double)t[nblk / 2], mx = (double)t[nblk - 1];
-        // clocks of SIMD time per wave-instruction = a wave's elapsed ticks / (waves sharing the SIMD x its instructions)
-        printf("%-30s W=%d  %8.3f ms  median wave %10.0f ticks  -> %5.2f clk per wave-instr per SIMD (slowest wave %5.2f);  %5.2f GHz (slowest wave's ticks / wall)\n",
-               name, W, ms, med, med / (W * instr_per_wave), mx / (W * instr_per_wave), mx / (ms * 1e6));
+        hipMemcpy(h.data(), d, 3 * nw * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        double ticks = 0, instr = 0, lo = 1e30, hi = 0;
+        for (int i = 0; i < nw; i++) {
+            ticks += (double)h[3 * i];
+            const double n = (double)h[3 * i + 1] * 8 * 8 * per_iter_instr;       // trips x 8 reps x 8 chains x instructions
+            instr += n; lo = std::min(lo, n); hi = std::max(hi, n);
+        }
+        // SIMD clocks per wave-instruction = window / (instructions the SIMD's W waves issued in it)
+        const double per_simd = instr / (256.0 * 4), window = ticks / nw;
+        printf("%-30s W=%d  %7.3f ms  %5.2f clk per wave-instr per SIMD   (a wave issues one per %5.1f clk; slowest / fastest wave %4.2f)  %4.2f GHz\n", name, W, ms,
+               window / per_simd, window / (instr / nw), lo / hi, window / (ms * 1e6));
     }
 }
 
 int main()
 {
     unsigned long long *d;
-    hipMalloc(&d, 2 * 256 * 4 * 8 * sizeof(unsigned long long));
-    for (int i = 0; i < 200; i++) k<V_FMA><<<2048, 256>>>(d, 7, 2048);      // bring the clocks up before the first row
+    hipMalloc(&d, 3 * 256 * 4 * 8 * sizeof(unsigned long long));
+    for (int i = 0; i < 200; i++) k<V_FMA><<<2048, 256>>>(d, 7, 100);      // bring the clocks up before the first row
     hipDeviceSynchronize();
     hipDeviceProp_t p;
     hipGetDeviceProperties(&p, 0);
@@ -127,9 +136,9 @@ int main()
     run<V_BFI>("v_bfi_b32", d, 1);
     run<V_LSHR>("v_lshrrev_b32", d, 1);
     run<V_READFIRST>("v_readfirstlane_b32 (+s_add)", d, 1);
-    run<DS_READ_B64>("ds_read_b64 (+v_xor)", d, 1, 1024);
+    run<DS_READ_B64>("ds_read_b64 (+v_xor)", d, 1);
     run<V_FMA_F64>("v_fma_f64", d, 1);
-    run<MIX_FWD>("forward-step mix (9 VALU)", d, 9, 2048);
-    run<MIX_FWD_CHAIN>("forward mix, one chain/wave", d, 9, 2048);
+    run<MIX_FWD>("forward-step mix (9 VALU)", d, 9);
+    run<MIX_FWD_CHAIN>("forward mix, one chain/wave", d, 9);
     return 0;
 }
