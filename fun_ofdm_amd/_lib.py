@@ -51,6 +51,14 @@ _SIGS = {
     "foa_tx_channel_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_double, C.c_double,
                                      C.c_uint64, C.c_void_p]),
     "foa_rx_sync_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "foa_stream_create": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),
+    "foa_stream_destroy": (None, [C.c_void_p]),
+    "foa_stream_push_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "foa_stream_push_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "foa_stream_flush": (C.c_int, [C.c_void_p]),
+    "foa_stream_ready": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "foa_stream_take": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "foa_stream_stats": (C.c_int, [C.c_void_p, C.c_void_p]),
     "foa_sync_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "foa_sync_destroy": (None, [C.c_void_p]),
     "foa_sync_push_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),

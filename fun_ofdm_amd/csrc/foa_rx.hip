@@ -752,7 +752,11 @@ int foa_rx_sync_dev(foa_rx *rx, const float *d_iq, size_t n_samples, foa_frame_d
     return FOA_OK;
 }
 
+void foa_stream_destroy(struct foa_stream *s);
+
 }  // extern "C" (reopened below)
+
+#include "stream_engine.h"
 
 // ---- host-side pre-sync ---------------------------------------------------------------------------
 struct foa_sync {

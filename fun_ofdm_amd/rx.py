@@ -186,6 +186,59 @@ class Receiver:
         return out
 
 
+class Stream:
+    """process_samples() entirely on the device (foa_stream_*): push samples, get the payloads of finished batches."""
+
+    def __init__(self, receiver, batch_samples, narrow_threads=0):
+        self._rx = receiver
+        self._h = C.c_void_p()
+        check(lib().foa_stream_create(receiver._h, int(batch_samples), int(narrow_threads), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().foa_stream_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def push(self, iq):
+        iq = np.ascontiguousarray(iq)
+        if iq.dtype == np.complex64:
+            check(lib().foa_stream_push_f32(self._h, _vp(iq), iq.size))
+        else:
+            iq = iq.astype(np.complex128, copy=False)
+            check(lib().foa_stream_push_f64(self._h, _vp(iq), iq.size))
+        return self.take()
+
+    def flush(self):
+        check(lib().foa_stream_flush(self._h))
+        return self.take(wait=True)
+
+    def take(self, wait=False):
+        """Payloads (bytes objects, stream order) of every batch that has finished (wait: of every batch submitted)."""
+        out = []
+        while True:
+            n, nb = C.c_size_t(0), C.c_size_t(0)
+            rc = lib().foa_stream_ready(self._h, 1 if wait else 0, C.byref(n), C.byref(nb))
+            if rc < 0:
+                check(rc)
+            if rc == 0:
+                return out
+            buf = np.zeros(max(nb.value, 1), np.uint8)
+            lens = np.zeros(max(n.value, 1), np.uint32)
+            check(lib().foa_stream_take(self._h, _vp(buf), _vp(lens)))
+            o = 0
+            for k in range(n.value):
+                out.append(buf[o:o + int(lens[k])].tobytes())
+                o += int(lens[k])
+
+    def stats(self):
+        a = np.zeros(8, np.uint64)
+        check(lib().foa_stream_stats(self._h, _vp(a)))
+        return dict(ok=int(a[0]), header_fail=int(a[1]), crc_fail=int(a[2]), truncated=int(a[3]), no_space=int(a[4]), alignments=int(a[5]),
+                    batches=int(a[6]), samples=int(a[7]))
+
+
 class Sync:
     """Streaming frame_detector + timing_sync on the host (foa_sync_*): push raw samples, get alignment
     descriptors with stream-absolute positions."""

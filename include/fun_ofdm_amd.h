@@ -193,12 +193,46 @@ int64_t foa_sync_settled(const foa_sync *s);
  * pointers, capacity cap) in stream order and returns the number of alignments in *n_found (synchronises).  The decisions
  * are the reference's up to floating-point ties: windowed sums are formed directly instead of by the reference's
  * ever-drifting running sums, so a threshold decision can differ when the normalised correlation is within ~1e-15 of
- * 0.9.  d_iq must be complete when the call is made (like the input of foa_rx_decode_frames_dev: with
+ * 0.9 -- and the reference's running sums never quite forget a huge sample: after a glitch of >= ~1e10 times the
+ * signal amplitude its frame_detector tags residue artefacts for the rest of the stream (circular_accumulator.h:88-95), which
+ * this stage does not reproduce (it finds the real frames only; foa_sync_push_* reproduces the reference there as well;
+ * tests/test_gpu_parity.py::test_device_sync_large_dynamic_range).  d_iq must be complete when the call is made (like the input of foa_rx_decode_frames_dev: with
  * calls pipelined the stage runs on the library's third stream, under the forward pass of a decode call in flight, and
  * is not ordered behind foa_rx_stream()); d_descs / d_ends may be handed to the next decode call straight away.
  * FOA_E_INVALID if more than cap alignments are found, FOA_E_NOMEM if the stream holds more STS_END candidates than
  * one per 64 samples. */
 int foa_rx_sync_dev(foa_rx *rx, const float *d_iq, size_t n_samples, foa_frame_desc *d_descs, int64_t *d_ends, size_t cap, size_t *n_found);
+
+/* ---- process_samples() entirely on the device (SURVEY 8f #1 + #3): a stream engine over the calls above ------------
+ *
+ * What fun::receiver_chain::process_samples() does call by call (src/receiver_chain.cpp:106-126: frame_detector ->
+ * timing_sync -> fft_symbols -> channel_est -> phase_tracker -> frame_decoder on a 4096-sample chunk, state carried from
+ * call to call), done batch by batch on the GPU: pushed samples collect in page-locked memory; every `batch_samples`
+ * samples one batch goes out -- H2D, foa_rx_sync_dev over the batch plus the 112 640 samples before it, foa_rx_decode_frames_dev
+ * for the alignments whose STS_END lies in the batch's share of the stream, D2H of the PSDUs -- asynchronously, several
+ * batches in flight; finished batches hand out their CRC-passing payloads in stream order.  Consecutive batches overlap by
+ * more than the longest frame, so a frame is decoded exactly once, by the batch that holds all of it, and the pre-sync
+ * sees the same samples around every decision as a single pass over the whole stream would (fun_ofdm_amd/csrc/
+ * stream_engine.h).  The payload list equals the reference chain's (tests/test_gpu_stream.py); latency is one batch.
+ * One engine per handle at a time; the handle's other entry points must not be used while a stream is open. */
+typedef struct foa_stream foa_stream;
+/* batch_samples in [4096, 2^28]; narrow_threads: helper threads for the double -> float narrowing of
+ * foa_stream_push_f64 (0 = the calling thread alone; used for pushes of >= 32768 samples). */
+int foa_stream_create(foa_rx *rx, size_t batch_samples, int narrow_threads, foa_stream **out);
+void foa_stream_destroy(foa_stream *s);
+/* The next n_samples of the stream (interleaved re,im).  Returns when they are copied; submits a batch whenever one is full
+ * (which may wait for the oldest batch in flight when all buffers are in use). */
+int foa_stream_push_f32(foa_stream *s, const float *iq, size_t n_samples);
+int foa_stream_push_f64(foa_stream *s, const double *iq, size_t n_samples);
+/* End of the stream: submits what is left, the frames after the last batch boundary included.  No pushes afterwards. */
+int foa_stream_flush(foa_stream *s);
+/* 1 if the oldest submitted batch is complete (then *n_payloads / *n_bytes describe its CRC-passing payloads), 0 if it is
+ * not (wait = 0) or if no batch is outstanding, < 0 on error.  wait = 1 blocks until the oldest batch is complete. */
+int foa_stream_ready(foa_stream *s, int wait, size_t *n_payloads, size_t *n_bytes);
+/* The payloads of the batch foa_stream_ready reported, back to back in stream order, and their lengths; releases it. */
+int foa_stream_take(foa_stream *s, uint8_t *payloads, uint32_t *lengths);
+/* out[0..4]: alignments per FOA_ST_* status so far (taken batches), [5] alignments submitted, [6] batches, [7] samples pushed */
+int foa_stream_stats(const foa_stream *s, uint64_t out[8]);
 
 /* ---- stage-level entry points (one per replaced fun::block, for the per-block adaptors) ---- */
 

@@ -307,14 +307,21 @@ public:
     // every k-th call submits everything decodable as ONE asynchronous batch (foa_rx_submit_host: H2D, compute and D2H of
     // consecutive batches overlap) and every call hands out the payloads of the batches that have finished -- in stream
     // order, a few calls late, like the reference's five-call latency.  Same payloads as the synchronous mode.
-    explicit receiver_chain(int device = 0, int async_batch_calls = 0)
-        : dev_(device), sync_(nullptr), base_(0), batch_calls_(async_batch_calls), calls_(0)
+    // device_batch_samples = B > 0: the whole of process_samples() on the device (foa_stream_*, SURVEY 8f #1 + #3): samples are
+    // only narrowed to float on the host (narrow_threads helpers for large calls); every B samples one batch is uploaded,
+    // pre-synchronised (frame_detector + timing_sync kernels), decoded and its payloads fetched, asynchronously; a call
+    // returns the payloads of the batches that have finished, in stream order (latency: one batch; flush() at the end of a
+    // capture).  Same payloads as the other modes.  This is the mode for sample rates far above real time.
+    explicit receiver_chain(int device = 0, int async_batch_calls = 0, size_t device_batch_samples = 0, int narrow_threads = 0)
+        : dev_(device), sync_(nullptr), base_(0), batch_calls_(async_batch_calls), calls_(0), stream_(nullptr), device_batch_(device_batch_samples),
+          narrow_threads_(narrow_threads)
     {
-        check(foa_sync_create(&sync_), "foa_sync_create");
+        if (device_batch_ == 0) check(foa_sync_create(&sync_), "foa_sync_create");
     }
     ~receiver_chain()
     {
         try { while (!jobs_.empty()) collect_front(true, nullptr); } catch (...) {}
+        if (stream_) foa_stream_destroy(stream_);
         if (sync_) foa_sync_destroy(sync_);
     }
     receiver_chain(const receiver_chain &) = delete;
@@ -325,6 +332,7 @@ public:
     // returned by the call that delivers its last sample (the reference returns it five calls later).
     std::vector<std::vector<unsigned char> > process_samples(std::vector<std::complex<double> > samples)
     {
+        if (device_batch_ > 0) return process_device(samples, false);
         if (batch_calls_ > 0) return process_async(samples, false);
         std::vector<std::vector<unsigned char> > out;
         if (samples.empty()) return out;
@@ -377,6 +385,7 @@ public:
     // Asynchronous mode: everything that can still be decoded, waited for (end of a capture; a radio never ends).
     std::vector<std::vector<unsigned char> > flush()
     {
+        if (device_batch_ > 0) return process_device(std::vector<std::complex<double> >(), true);
         if (batch_calls_ > 0) return process_async(std::vector<std::complex<double> >(), true);
         return std::vector<std::vector<unsigned char> >();
     }
@@ -459,10 +468,35 @@ private:
         trim();
         return out;
     }
+    // everything on the device: push, then hand out whatever has finished (final: flush and wait for all of it)
+    std::vector<std::vector<unsigned char> > process_device(const std::vector<std::complex<double> > &samples, bool final)
+    {
+        std::vector<std::vector<unsigned char> > out;
+        if (!stream_) check(foa_stream_create(dev_.get(), device_batch_, narrow_threads_, &stream_), "foa_stream_create");
+        if (!samples.empty()) check(foa_stream_push_f64(stream_, reinterpret_cast<const double *>(samples.data()), samples.size()), "foa_stream_push_f64");
+        if (final) check(foa_stream_flush(stream_), "foa_stream_flush");
+        for (;;) {
+            size_t n = 0, bytes = 0;
+            const int rc = foa_stream_ready(stream_, final ? 1 : 0, &n, &bytes);
+            if (rc < 0) check(rc, "foa_stream_ready");
+            if (rc == 0) break;
+            take_bytes_.resize(bytes ? bytes : 1);
+            take_len_.resize(n ? n : 1);
+            check(foa_stream_take(stream_, take_bytes_.data(), take_len_.data()), "foa_stream_take");
+            size_t o = 0;
+            for (size_t i = 0; i < n; i++) {
+                out.push_back(std::vector<unsigned char>(take_bytes_.begin() + o, take_bytes_.begin() + o + take_len_[i]));
+                o += take_len_[i];
+            }
+        }
+        if (final) { foa_stream_destroy(stream_); stream_ = nullptr; }     // a new stream starts with the next call
+        return out;
+    }
     // drop samples nothing can refer to any more: before the oldest pending alignment, and before what a future
     // alignment could reach back to (timing_sync places LTS1 at most 160+8 samples before the point it has reached)
     void trim()
     {
+        if (!sync_) return;
         const int64_t settled = foa_sync_settled(sync_);
         int64_t keep_from = settled - 400;
         if (!pending_.empty()) keep_from = std::min(keep_from, pending_.front().d.lts1_pos - 16);
@@ -480,6 +514,11 @@ private:
     int batch_calls_;
     long calls_;
     std::deque<job> jobs_;
+    foa_stream *stream_;              // device mode
+    size_t device_batch_;
+    int narrow_threads_;
+    std::vector<unsigned char> take_bytes_;
+    std::vector<uint32_t> take_len_;
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -550,8 +589,10 @@ private:
 class receiver {
 public:
     typedef void (*callback_t)(std::vector<std::vector<unsigned char> > packets);
-    receiver(callback_t callback, sample_source *source, int device = 0, int num_rx_samples = 4096, int async_batch_calls = 0)
-        : callback_(callback), source_(source), chain_(device, async_batch_calls), n_(num_rx_samples), token_(true), stop_(false), finished_(false)
+    receiver(callback_t callback, sample_source *source, int device = 0, int num_rx_samples = 4096, int async_batch_calls = 0,
+             size_t device_batch_samples = 0, int narrow_threads = 0)
+        : callback_(callback), source_(source), chain_(device, async_batch_calls, device_batch_samples, narrow_threads), n_(num_rx_samples), token_(true),
+          stop_(false), finished_(false)
     {
         thread_ = std::thread(&receiver::receiver_chain_loop, this);
     }

@@ -87,6 +87,18 @@ int main()
         for (auto &p : rest) got.push_back(p);
         CHECK(got == want, "asynchronous process_samples payloads differ (batch %d: %zu vs %zu)", k, got.size(), want.size());
     }
+    {   // device mode of the chain (the engine behind foa_stream_* is the stub's; the wrapper's buffers and loops are real)
+        fun_amd::receiver_chain rc(0, 0, 65536, 2);
+        payloads_t got;
+        for (size_t x = 0; x < stream.size(); x += 4096) {
+            const size_t n = std::min((size_t)4096, stream.size() - x);
+            payloads_t r = rc.process_samples(std::vector<std::complex<double> >(stream.begin() + x, stream.begin() + x + n));
+            for (auto &p : r) got.push_back(p);
+        }
+        payloads_t rest = rc.flush();
+        for (auto &p : rest) got.push_back(p);
+        CHECK(got == want, "device-mode process_samples payloads differ (%zu vs %zu)", got.size(), want.size());
+    }
     for (int async_calls : { 0, 4 }) {
         g_rx_packets.clear();
         g_rx_calls = 0;

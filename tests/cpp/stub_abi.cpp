@@ -81,6 +81,56 @@ int foa_sync_push_f32(foa_sync *s, const float *iq, size_t n, foa_frame_desc *ou
 int foa_sync_push_f64(foa_sync *s, const double *iq, size_t n, foa_frame_desc *out, size_t cap, size_t *n_out) { return sync_push(s, iq, n, out, cap, n_out); }
 int64_t foa_sync_settled(const foa_sync *s) { return s ? s->impl.settled() : 0; }
 
+// foa_stream_*: the wrapper logic of fun_amd::receiver_chain's device mode is what runs here; the engine itself (batches on the
+// GPU) is replaced by "collect everything, pre-sync on the host and decode with the oracle at the flush"
+struct foa_stream {
+    std::vector<float> iq;
+    std::vector<std::vector<uint8_t> > out;
+    bool flushed = false, delivered = false;
+};
+int foa_stream_create(foa_rx *, size_t batch, int, foa_stream **out) { if (batch < 4096) return FOA_E_INVALID; *out = new foa_stream(); return FOA_OK; }
+void foa_stream_destroy(foa_stream *s) { delete s; }
+int foa_stream_push_f32(foa_stream *s, const float *iq, size_t n) { if (s->flushed) return FOA_E_STATE; s->iq.insert(s->iq.end(), iq, iq + 2 * n); return FOA_OK; }
+int foa_stream_push_f64(foa_stream *s, const double *iq, size_t n)
+{
+    if (s->flushed) return FOA_E_STATE;
+    for (size_t i = 0; i < 2 * n; i++) s->iq.push_back((float)iq[i]);
+    return FOA_OK;
+}
+int foa_stream_flush(foa_stream *s)
+{
+    if (s->flushed) return FOA_OK;
+    s->flushed = true;
+    const size_t n = s->iq.size() / 2;
+    std::vector<foa_frame_desc> d(n / 300 + 64);
+    const size_t m = fo_find_alignments_f32(s->iq.data(), (int64_t)n, (fo_frame_desc *)d.data(), d.size());
+    std::vector<int64_t> ends(m);
+    for (size_t i = 0; i < m; i++) ends[i] = i + 1 < m ? d[i + 1].lts1_pos : (int64_t)n;
+    std::vector<uint8_t> psdu(m * 4096 + 1);
+    std::vector<foa_frame_result> res(m + 1);
+    if (m) fo_decode_batch_f32(s->iq.data(), (int64_t)n, (const fo_frame_desc *)d.data(), ends.data(), m, psdu.data(), 4096, (fo_frame_result *)res.data(), 2);
+    for (size_t i = 0; i < m; i++)
+        if (res[i].status == FOA_ST_OK) s->out.push_back(std::vector<uint8_t>(psdu.begin() + i * 4096, psdu.begin() + i * 4096 + res[i].length));
+    return FOA_OK;
+}
+int foa_stream_ready(foa_stream *s, int, size_t *n_payloads, size_t *n_bytes)
+{
+    *n_payloads = 0; *n_bytes = 0;
+    if (!s->flushed || s->delivered) return 0;
+    *n_payloads = s->out.size();
+    for (auto &p : s->out) *n_bytes += p.size();
+    return 1;
+}
+int foa_stream_take(foa_stream *s, uint8_t *payloads, uint32_t *lengths)
+{
+    if (!s->flushed || s->delivered) return FOA_E_STATE;
+    size_t o = 0;
+    for (size_t i = 0; i < s->out.size(); i++) { if (!s->out[i].empty()) memcpy(payloads + o, s->out[i].data(), s->out[i].size()); lengths[i] = (uint32_t)s->out[i].size(); o += s->out[i].size(); }
+    s->delivered = true;
+    return FOA_OK;
+}
+int foa_stream_stats(const foa_stream *, uint64_t out[8]) { memset(out, 0, 8 * sizeof(uint64_t)); return FOA_OK; }
+
 // the per-block adaptors are not part of this run; their entry points only have to link
 int foa_fft_forward_f64(foa_rx *, double *, size_t) { return FOA_E_NO_DEVICE; }
 int foa_channel_estimate_f64(foa_rx *, const double *, double *, size_t) { return FOA_E_NO_DEVICE; }

@@ -510,6 +510,54 @@ def test_device_sync_edge_inputs(rx):
         assert (got[n * 48:] == 0xA5).all() and (t_ends.cpu().numpy()[n:] == -7).all()
 
 
+def test_device_sync_large_dynamic_range(rx, po):
+    """One huge sample (an ADC glitch) in front of normal frames.  frame_detector's running sums (circular_accumulator.h:88-95:
+    sum -= old; sum += new) never forget such a sample exactly -- after 1e10 or more the residue of the cancelled power term
+    makes the reference tag spurious plateaus for the rest of the stream, on top of the real frames.  The device stage forms
+    every 16-term window directly, so the glitch is gone once it has left the window: it finds the real frames and none of
+    the residue's artefacts.  That difference is deliberate and documented (include/fun_ofdm_amd.h); a caller
+    that needs the reference's decisions bit for bit on such input uses foa_sync_push_*, which equals the reference here
+    too.  Up to a dynamic range of ~1e6 in amplitude the two agree exactly."""
+    import torch
+    import fun_ofdm_amd as foa
+    from fun_ofdm_amd import synth
+    dev = torch.device("cuda", 0)
+    pays = synth.splitmix64_bytes(77, 6, 200)
+    iq, _ = synth.make_stream(synth.build_frames(pays, 8), 4096, 300, 25.0, seed=3)
+    clean = foa.find_alignments(iq)
+    real = clean["lts1_pos"]
+    assert real.size == 6
+
+    def device(stream):
+        t_iq = torch.from_numpy(stream.view(np.float32).reshape(-1, 2)).to(dev)
+        cap = stream.size // 300 + 16
+        t_desc = torch.zeros(cap * 48, dtype=torch.uint8, device=dev)
+        t_ends = torch.zeros(cap, dtype=torch.int64, device=dev)
+        n = rx.sync_dev(t_iq, t_desc, t_ends)
+        return t_desc.cpu().numpy()[:n * 48].view(foa.frame_desc_dtype), t_iq, t_desc, t_ends, n
+
+    for val in (30.0, 1e4, 1e10, 1e30):
+        g = iq.copy()
+        g[100] = val
+        host = foa.find_alignments(g)
+        assert host.tobytes() == po.find_alignments_f32(g).tobytes()          # the host restatement is the reference's behaviour
+        got, t_iq, t_desc, t_ends, n = device(g)
+        assert set(real) <= set(host["lts1_pos"])
+        if val <= 1e4:
+            assert np.array_equal(got["lts1_pos"], host["lts1_pos"]) and np.array_equal(got["rot_start"], host["rot_start"])
+        else:
+            assert host.size > real.size                                       # the reference's residue artefacts ...
+            assert np.array_equal(got["lts1_pos"], real)                       # ... which the windowed sums do not have
+        # and the frames decode from the device-made descriptors
+        t_psdu = torch.zeros((n, 256), dtype=torch.uint8, device=dev)
+        t_res = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+        rx.decode_frames_dev(t_iq, t_desc[:n * 48], t_ends[:n], t_psdu, t_res)
+        rx.sync()
+        res, psdu = t_res.cpu().numpy(), t_psdu.cpu().numpy()
+        on = [int(np.nonzero(got["lts1_pos"] == p)[0][0]) for p in real]
+        assert all(res[a, 0] == 0 and psdu[a, :200].tobytes() == pays[k].tobytes() for k, a in enumerate(on))
+
+
 def test_device_sync_between_pipelined_decode_calls(rx, po):
     """sync k+1 is queued while decode k is still in flight (it runs on the third stream under that call's forward
     pass): descriptors, PSDUs and results of every round equal those of the same round run alone."""

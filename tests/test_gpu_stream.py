@@ -1,0 +1,151 @@
+"""receiver_chain::process_samples() entirely on the device (foa_stream_*, fun_ofdm_amd/csrc/stream_engine.h): the stream is cut
+into overlapping batches, every batch is pre-synchronised and decoded by the kernels of the batch path.  The ordered payload
+list must equal the reference-shaped chain's (oracle) whatever the batch size and however the pushes are cut -- frames that
+straddle one or several batch boundaries, back-to-back frames, long silences and a second preamble inside a frame included."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _stream(po, rng, specs, snr_db=25.0, gap=(0, 700), cfo_hz=0.0):
+    parts, pays = [np.zeros(200, complex)], []
+    for rate, ln in specs:
+        pay = rng.integers(0, 256, ln, dtype=np.uint8)
+        f = po.build_frame(pay, rate)
+        if cfo_hz:
+            f = f * np.exp(2j * np.pi * rng.uniform(-cfo_hz, cfo_hz) * np.arange(f.size) / 20e6)
+        f = f * np.exp(1j * rng.uniform(0, 2 * np.pi))
+        parts += [f, np.zeros(int(rng.integers(*gap)), complex)]
+        pays.append(pay.tobytes())
+    parts.append(np.zeros(600, complex))
+    s = np.concatenate(parts)
+    sigma = np.sqrt(0.0124 / (2 * 10 ** (snr_db / 10)))
+    return (s + (rng.normal(size=s.size) + 1j * rng.normal(size=s.size)) * sigma).astype(np.complex64), pays
+
+
+@pytest.fixture(scope="module")
+def rx():
+    import fun_ofdm_amd as foa
+    r = foa.Receiver(0)
+    yield r
+    r.close()
+
+
+@pytest.fixture(scope="module")
+def mixed(po):
+    rng = np.random.default_rng(61)
+    specs = [(int(rng.integers(0, 11)), int(rng.integers(1, 900))) for _ in range(40)]
+    specs += [(0, 4095), (10, 1024), (2, 3000), (10, 0), (5, 1), (0, 2047), (9, 4095)]      # 109 840-sample frames: longer than most batches
+    iq, pays = _stream(po, rng, specs, snr_db=22.0, cfo_hz=3000.0)
+    want = po.ReceiverChain().run_stream(iq.astype(np.complex128))
+    assert len(want) >= 40
+    return iq, pays, want
+
+
+@pytest.mark.parametrize("batch,chunk", [(4096, 4096), (4096, 1000), (20000, 4096), (65536, 7777), (1 << 18, 4096), (1 << 22, 100000)])
+def test_stream_engine_equals_reference_chain(rx, mixed, batch, chunk):
+    import fun_ofdm_amd as foa
+    iq, pays, want = mixed
+    st = foa.Stream(rx, batch)
+    got = []
+    try:
+        for a in range(0, iq.size, chunk):
+            got += st.push(iq[a:a + chunk])
+        got += st.flush()
+        stats = st.stats()
+    finally:
+        st.close()
+    assert got == want, (batch, chunk, len(got), len(want))
+    assert stats["samples"] == iq.size and stats["ok"] == len(want) and stats["batches"] == iq.size // batch + 1
+
+
+def test_stream_engine_double_input_and_helper_threads(rx, mixed):
+    """foa_stream_push_f64 (what process_samples hands over) with the narrowing spread over helper threads."""
+    import fun_ofdm_amd as foa
+    iq, pays, want = mixed
+    wide = iq.astype(np.complex128)
+    st = foa.Stream(rx, 1 << 17, narrow_threads=3)
+    try:
+        got = st.push(wide[:50000]) + st.push(wide[50000:50001]) + st.push(wide[50001:]) + st.flush()
+    finally:
+        st.close()
+    assert got == want
+
+
+def test_stream_engine_back_to_back_and_silence(rx, po):
+    """Zero-gap frames (config 5 shape) across many small batches, then a silence longer than several batches, then more."""
+    import fun_ofdm_amd as foa
+    rng = np.random.default_rng(62)
+    a, _ = _stream(po, rng, [((0, 2, 3, 5, 6, 8, 9, 10)[i % 8], 1024) for i in range(16)], gap=(0, 1), cfo_hz=4000.0)
+    b, _ = _stream(po, rng, [(10, 300), (0, 50)], gap=(0, 300))
+    sigma = np.sqrt(0.0124 / (2 * 10 ** 2.5))
+    quiet = ((rng.normal(size=300000) + 1j * rng.normal(size=300000)) * sigma).astype(np.complex64)
+    iq = np.concatenate([a, quiet, b])
+    want = po.ReceiverChain().run_stream(iq.astype(np.complex128))
+    assert len(want) >= 16
+    for batch in (8192, 50000):
+        st = foa.Stream(rx, batch)
+        try:
+            got = st.push(iq) + st.flush()
+        finally:
+            st.close()
+        assert got == want, batch
+
+
+def test_stream_engine_second_preamble_inside_a_frame(rx, po):
+    from test_gpu_cpp_adaptors import _collision_stream
+    import fun_ofdm_amd as foa
+    for case in ("valid", "invalid", "none"):
+        iq, pays = _collision_stream(po, case, 5)
+        want = po.ReceiverChain().run_stream(iq.astype(np.complex128))
+        for batch in (4096, 1 << 20):
+            st = foa.Stream(rx, batch)
+            try:
+                got = st.push(iq) + st.flush()
+            finally:
+                st.close()
+            assert got == want, (case, batch)
+
+
+def test_stream_engine_api_edges(rx):
+    import fun_ofdm_amd as foa
+    with pytest.raises(foa.FoaError):
+        foa.Stream(rx, 100)                                 # batch too small
+    st = foa.Stream(rx, 4096)
+    try:
+        assert st.take() == [] and st.flush() == []         # an empty stream delivers nothing
+        with pytest.raises(foa.FoaError):
+            st.push(np.zeros(10, np.complex64))             # no pushes after the flush
+    finally:
+        st.close()
+    # the handle is usable as before once the stream is closed
+    psdu, res = rx.decode_frames_host(np.zeros(5000, np.complex64), np.zeros(0, foa.frame_desc_dtype), np.zeros(0, np.int64))
+    assert psdu.shape[0] == 0
+
+
+def test_process_samples_device_mode_through_the_cpp_chain(tmp_path, po, mixed):
+    """fun_amd::receiver / receiver_chain with device_batch_samples > 0 (examples/foa_sim --device-batch): the same ordered
+    payloads as the reference chain, from an fc32 and an fc64 capture, with and without the in-memory preload loop."""
+    import fun_ofdm_amd as foa
+    iq, pays, want = mixed
+    exe = str(tmp_path / "foa_sim")
+    libdir = os.path.dirname(foa.library_path())
+    subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "examples", "foa_sim.cpp"), "-I", os.path.join(ROOT, "include"),
+                    "-L", libdir, "-lfun_ofdm_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lpthread", "-o", exe], check=True)
+    for fmt, data, extra in (("fc32", iq, ["--device-batch", "30000"]), ("fc64", iq.astype(np.complex128), ["--device-batch", "262144", "--narrow-threads", "2"]),
+                             ("fc32", iq, ["--device-batch", "100000", "--preload", "--chunk", "65536", "--narrow-threads", "2"])):
+        src, out = str(tmp_path / ("cap." + fmt)), str(tmp_path / ("psdus." + fmt))
+        data.tofile(src)
+        r = subprocess.run([exe, src, "--format", fmt, "--out", out] + extra, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        raw, recs, o = open(out, "rb").read(), [], 0
+        while o < len(raw):
+            n = int.from_bytes(raw[o:o + 4], "little")
+            recs.append(raw[o + 4:o + 4 + n])
+            o += 4 + n
+        assert recs == want, (fmt, extra, len(recs), len(want))
