@@ -55,6 +55,7 @@ _SIGS = {
     "foa_stream_destroy": (None, [C.c_void_p]),
     "foa_stream_push_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "foa_stream_push_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "foa_stream_push_f64_owned": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "foa_stream_flush": (C.c_int, [C.c_void_p]),
     "foa_stream_ready": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "foa_stream_take": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

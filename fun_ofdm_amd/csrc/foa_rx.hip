@@ -753,6 +753,7 @@ int foa_rx_sync_dev(foa_rx *rx, const float *d_iq, size_t n_samples, foa_frame_d
 }
 
 void foa_stream_destroy(struct foa_stream *s);
+int foa_stream_push_f64_owned(struct foa_stream *s, const double *iq, size_t n_samples, void (*release)(void *), void *ctx);
 
 }  // extern "C" (reopened below)
 

@@ -22,14 +22,12 @@
 // Batches are queued through the same asynchronous job slots as foa_rx_submit_host (pinned mirrors, D2H behind the
 // finish kernel), so H2D of batch k+1, the kernels of batch k and the D2H of batch k-1 overlap, and results come out in
 // stream order.  The double -> float narrowing of process_samples' complex<double> input is the only per-sample work the
-// host does; above 32 Ki samples per call it is spread over a few worker threads.
+// host does.  Threads (stream_core.h): the caller only assigns samples their place in page-locked staging memory; helper
+// threads narrow them (a caller that hands its buffer over, as process_samples' by-value vector allows, does not even wait
+// for that); one submitter thread makes every GPU call while the stream is open.
 #pragma once
 
-#include <atomic>
-#include <condition_variable>
-#include <deque>
-#include <mutex>
-#include <thread>
+#include "stream_core.h"
 
 namespace foa {
 
@@ -37,73 +35,13 @@ constexpr int64_t kStreamLongest = 110592;          // >= 320 + 80 * 1369 (4095 
 constexpr int64_t kStreamCarry = kStreamLongest + 2048;
 constexpr int kStreamBufs = 4;                      // device sample buffers / pinned staging buffers in rotation
 
-// a few persistent threads that narrow double -> float (or copy floats) into the pinned staging buffer
-class NarrowPool {
-public:
-    explicit NarrowPool(int threads) : stop_(false), gen_(0), left_(0)
-    {
-        for (int i = 0; i < threads; i++) th_.emplace_back([this, i] { loop(i); });
-    }
-    ~NarrowPool()
-    {
-        { std::lock_guard<std::mutex> lk(m_); stop_ = true; gen_++; }
-        cv_.notify_all();
-        for (auto &t : th_) t.join();
-    }
-    int size() const { return (int)th_.size(); }
-    // dst[0 .. 2n) = (float) src[0 .. 2n); the caller takes a share too
-    void run(float *dst, const double *src, size_t n)
-    {
-        const int parts = size() + 1;
-        const size_t per = ((n + parts - 1) / parts + 15) & ~(size_t)15;
-        { std::lock_guard<std::mutex> lk(m_); dst_ = dst; src_ = src; n_ = n; per_ = per; left_ = size(); gen_++; }
-        cv_.notify_all();
-        narrow(dst, src, 0, std::min(per, n));
-        std::unique_lock<std::mutex> lk(m_);
-        done_.wait(lk, [this] { return left_ == 0; });
-    }
-    static void narrow(float *dst, const double *src, size_t lo, size_t hi)
-    {
-        for (size_t i = 2 * lo; i < 2 * hi; i++) dst[i] = (float)src[i];
-    }
-
-private:
-    void loop(int i)
-    {
-        uint64_t seen = 0;
-        for (;;) {
-            float *dst; const double *src; size_t n, per;
-            {
-                std::unique_lock<std::mutex> lk(m_);
-                cv_.wait(lk, [&] { return gen_ != seen; });
-                seen = gen_;
-                if (stop_) return;
-                dst = dst_; src = src_; n = n_; per = per_;
-            }
-            const size_t lo = std::min(n, per * (size_t)(i + 1)), hi = std::min(n, per * (size_t)(i + 2));
-            narrow(dst, src, lo, hi);
-            { std::lock_guard<std::mutex> lk(m_); left_--; }
-            done_.notify_one();
-        }
-    }
-    std::vector<std::thread> th_;
-    std::mutex m_;
-    std::condition_variable cv_, done_;
-    bool stop_;
-    uint64_t gen_;
-    int left_;
-    float *dst_ = nullptr;
-    const double *src_ = nullptr;
-    size_t n_ = 0, per_ = 0;
-};
-
 }  // namespace foa
 
-struct foa_stream {
+// The GPU side of one stream: everything here except staging() runs on the core's submitter thread.
+struct StreamGpu {
     foa_rx *rx = nullptr;
     int64_t B = 0;                                   // batch_samples
-    size_t slot = 4096;
-    // rotating buffers
+    size_t slot_bytes = 4096;
     float *pin[foa::kStreamBufs] = {};               // page-locked staging, B float2 each
     DevBuf<float> dev[foa::kStreamBufs];             // (C + B) float2 each
     hipEvent_t in_done[foa::kStreamBufs] = {};       // H2D + carry copy of the buffer's batch are through
@@ -111,157 +49,153 @@ struct foa_stream {
     DevBuf<uint8_t> d_desc[foa::kStreamBufs];
     DevBuf<int64_t> d_ends[foa::kStreamBufs];
     size_t desc_cap = 0;
-    // stream state
-    int64_t pushed = 0;                              // samples accepted so far
-    int64_t fill = 0;                                // samples in the staging buffer of the batch being filled
-    int64_t n_batches = 0;                           // batches submitted
+    int64_t submitted_samples = 0;                   // samples in the batches submitted so far
+    int64_t n_batches = 0;
     int64_t cut_prev = 0;                            // STS_END positions below this have been dealt with
     double prev_c = 1.0, prev_s = 0.0;               // phasor of the last alignment decoded (timing_sync's m_phase_acc)
-    struct InFlight { uint64_t ticket; size_t n_frames; int buf; };
-    std::deque<InFlight> flight;                     // batches whose results have not been taken yet (stream order)
-    // finished batches, unpacked (CRC-passing payloads back to back), oldest first
-    struct Ready { std::vector<uint8_t> bytes; std::vector<uint32_t> len; };
-    std::deque<Ready> ready;
+    struct InFlight { uint64_t handle, ticket; size_t n_frames; };
+    std::deque<InFlight> flight;
+    uint64_t next_handle = 1;
     std::vector<uint8_t> tmp_psdu;
     std::vector<foa_frame_result> tmp_res;
-    bool finished = false;                           // foa_stream_flush has been called: the stream is over
-    uint64_t status_count[5] = { 0, 0, 0, 0, 0 };
-    uint64_t alignments = 0;
-    foa::NarrowPool *pool = nullptr;
     std::vector<foa_frame_desc> h_desc;
+    std::atomic<uint64_t> status_count[5], alignments;
+    std::mutex err_m;
+    std::string err_text;                            // text of the first error raised on the submitter thread
+
+    StreamGpu() { for (auto &c : status_count) c.store(0); alignments.store(0); }
+    float *staging(int slot) { return pin[slot]; }
+
+    int keep_error(int rc)
+    {
+        std::lock_guard<std::mutex> lk(err_m);
+        if (err_text.empty()) err_text = g_err;
+        return rc;
+    }
+
+    // queue batch `n_batches`: n_new samples wait in staging slot `slot`
+    int submit(int slot, int64_t n_new, bool final, uint64_t *handle)
+    {
+        const int rc = submit_impl(slot, n_new, final, handle);
+        return rc ? keep_error(rc) : 0;
+    }
+    int submit_impl(int k, int64_t n_new, bool final, uint64_t *handle)
+    {
+        const int64_t C = foa::kStreamCarry, L = foa::kStreamLongest;
+        const int kp = (k + foa::kStreamBufs - 1) % foa::kStreamBufs;
+        const int64_t n_buf = C + n_new, pushed = submitted_samples + n_new;
+        const int64_t start = pushed - n_new - C;                    // stream index of the buffer's first sample
+        HIP_TRY(hipSetDevice(rx->device));
+        float *d = dev[k].p;
+        if (n_batches == 0) HIP_TRY(hipMemsetAsync(d, 0, (size_t)C * 8, st_in));                    // silence before the stream
+        else HIP_TRY(hipMemcpyAsync(d, dev[kp].p + 2 * B, (size_t)C * 8, hipMemcpyDeviceToDevice, st_in));   // (every batch but the last is full)
+        if (n_new) HIP_TRY(hipMemcpyAsync(d + 2 * C, pin[k], (size_t)n_new * 8, hipMemcpyHostToDevice, st_in));
+        HIP_TRY(hipEventRecord(in_done[k], st_in));
+        const bool piped = rx->pipeline && rx->viterbi_kind == 2;
+        hipStream_t st = piped ? rx->stream3 : rx->stream;          // pre-sync and front end run there
+        HIP_TRY(hipStreamWaitEvent(st, in_done[k], 0));
+        size_t found = 0;
+        int rc = foa_rx_sync_dev(rx, d, (size_t)n_buf, (foa_frame_desc *)d_desc[k].p, d_ends[k].p, desc_cap, &found);
+        if (rc) return rc;
+        // (foa_rx_sync_dev has waited for its stream, hence for the H2D: the staging slot is free again when this returns)
+        // which of them are this batch's: STS_END sample in [cut_prev, cut)
+        const int64_t cut = final ? pushed + 1 : pushed - L;
+        size_t i0 = 0, i1 = 0;
+        if (found) {
+            h_desc.resize(found);
+            HIP_TRY(hipMemcpy(h_desc.data(), d_desc[k].p, found * sizeof(foa_frame_desc), hipMemcpyDeviceToHost));
+            while (i0 < found && start + h_desc[i0].rot_start < cut_prev) i0++;
+            i1 = i0;
+            while (i1 < found && start + h_desc[i1].rot_start < cut) i1++;
+        }
+        const size_t m = i1 - i0;
+        InFlight fl;
+        fl.handle = next_handle++; fl.n_frames = m; fl.ticket = 0;
+        if (m) {
+            // timing_sync's phasor before the first alignment of the batch: the one the last decoded alignment set
+            foa_frame_desc &first = h_desc[i0];
+            first.c_prev = prev_c; first.s_prev = prev_s;
+            HIP_TRY(hipMemcpyAsync(d_desc[k].p + i0 * sizeof(foa_frame_desc), &first, sizeof first, hipMemcpyHostToDevice, st));
+            prev_c = h_desc[i1 - 1].c; prev_s = h_desc[i1 - 1].s;
+            // outputs go through a job slot of the asynchronous host entry (page-locked mirror, D2H behind the finish kernel)
+            HostJob *job = nullptr;
+            for (auto &j : rx->jobs) if (!j.busy) { job = &j; break; }
+            if (!job) return fail(FOA_E_STATE, "internal: no free job slot");
+            auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+            const size_t o_res = up(m * slot_bytes), total = o_res + up(m * sizeof(foa_frame_result));
+            if ((rc = job->dev.ensure(total))) return rc;
+            if (job->pin_cap < total) {
+                if (job->pin) (void)hipHostFree(job->pin);
+                job->pin = nullptr; job->pin_cap = 0;
+                const size_t want = total + total / 2;
+                HIP_TRY(hipHostMalloc((void **)&job->pin, want, hipHostMallocDefault));
+                job->pin_cap = want;
+            }
+            if (!job->done) HIP_TRY(hipEventCreateWithFlags(&job->done, hipEventDisableTiming));
+            HIP_TRY(hipMemsetAsync(job->dev.p, 0, m * slot_bytes, st));
+            job->total = total; job->o_psdu = 0; job->o_res = o_res; job->n_frames = m; job->slot_bytes = slot_bytes; job->copy_queued = false;
+            rx->attach_job = piped ? job : nullptr;
+            rc = foa_rx_decode_frames_dev(rx, d, (size_t)n_buf, (const foa_frame_desc *)d_desc[k].p + i0, d_ends[k].p + i0, m, job->dev.p, slot_bytes,
+                                          (foa_frame_result *)(job->dev.p + o_res));
+            rx->attach_job = nullptr;
+            if (rc) return rc;
+            if (!piped) {
+                HIP_TRY(hipMemcpyAsync(job->pin, job->dev.p, total, hipMemcpyDeviceToHost, rx->stream));
+                HIP_TRY(hipEventRecord(job->done, rx->stream));
+                job->copy_queued = true;
+            }
+            job->busy = true;
+            job->ticket = rx->next_ticket++;
+            fl.ticket = job->ticket;
+            alignments.fetch_add(m);
+        }
+        flight.push_back(fl);
+        *handle = fl.handle;
+        cut_prev = cut;
+        submitted_samples = pushed;
+        n_batches++;
+        return FOA_OK;
+    }
+
+    // the batch behind `handle` (always the oldest in flight): 1 = complete, payloads unpacked; 0 = not yet
+    int collect(uint64_t handle, bool wait, foa::StreamReady *out)
+    {
+        if (flight.empty() || flight.front().handle != handle) return keep_error(fail(FOA_E_STATE, "internal: batches collected out of order"));
+        const InFlight f = flight.front();
+        if (f.n_frames) {
+            (void)hipSetDevice(rx->device);
+            tmp_psdu.resize(f.n_frames * slot_bytes);
+            tmp_res.resize(f.n_frames);
+            const int rc = foa_rx_collect(rx, f.ticket, wait ? 1 : 0, tmp_psdu.data(), tmp_res.data());
+            if (rc < 0) { flight.pop_front(); return keep_error(rc); }
+            if (rc == 0) return 0;
+            for (size_t i = 0; i < f.n_frames; i++) {
+                const foa_frame_result &r = tmp_res[i];
+                if (r.status >= 0 && r.status < 5) status_count[r.status].fetch_add(1);
+                if (r.status != FOA_ST_OK) continue;
+                out->len.push_back((uint32_t)r.length);
+                out->bytes.insert(out->bytes.end(), tmp_psdu.begin() + i * slot_bytes, tmp_psdu.begin() + i * slot_bytes + r.length);
+            }
+        }
+        flight.pop_front();
+        return 1;
+    }
+};
+
+struct foa_stream {
+    StreamGpu gpu;
+    foa::StreamCore<StreamGpu> *core = nullptr;
+    foa::StreamReady ready;                          // the batch foa_stream_ready reported and foa_stream_take has not yet taken
+    bool have_ready = false;
 };
 
 namespace {
 
-// Take the oldest batch in flight out of its job slot (wait = block until it is complete).  1 = taken, 0 = not yet.
-int stream_collect_oldest(foa_stream *s, int wait)
+// an error raised on the submitter thread, reported on the caller's
+int stream_fail(foa_stream *s, int rc)
 {
-    if (s->flight.empty()) return 0;
-    const foa_stream::InFlight f = s->flight.front();
-    foa_stream::Ready out;
-    if (f.n_frames) {
-        s->tmp_psdu.resize(f.n_frames * s->slot);
-        s->tmp_res.resize(f.n_frames);
-        const int rc = foa_rx_collect(s->rx, f.ticket, wait, s->tmp_psdu.data(), s->tmp_res.data());
-        if (rc <= 0) return rc;
-        for (size_t i = 0; i < f.n_frames; i++) {
-            const foa_frame_result &r = s->tmp_res[i];
-            if (r.status >= 0 && r.status < 5) s->status_count[r.status]++;
-            if (r.status != FOA_ST_OK) continue;
-            out.len.push_back((uint32_t)r.length);
-            out.bytes.insert(out.bytes.end(), s->tmp_psdu.begin() + i * s->slot, s->tmp_psdu.begin() + i * s->slot + r.length);
-        }
-    }
-    s->flight.pop_front();
-    s->ready.push_back(std::move(out));
-    return 1;
-}
-
-// Queue the batch in the staging buffer (fill samples; final = the stream ends here: decode everything that is left).
-int stream_submit(foa_stream *s, bool final)
-{
-    foa_rx *rx = s->rx;
-    const int64_t C = foa::kStreamCarry, L = foa::kStreamLongest;
-    const int k = (int)(s->n_batches % foa::kStreamBufs), kp = (int)((s->n_batches + foa::kStreamBufs - 1) % foa::kStreamBufs);
-    const int64_t n_new = s->fill, n_buf = C + n_new;
-    const int64_t start = s->pushed - n_new - C;                   // stream index of the buffer's first sample
-    // the buffer (and its descriptor arrays) may still be read by the batch that used it four batches ago
-    while ((int)s->flight.size() >= foa::kStreamBufs - 1 || (int)s->flight.size() >= kMaxJobs - 1) {
-        const int rc = stream_collect_oldest(s, 1);                // (its payloads wait in s->ready until they are taken)
-        if (rc < 0) return rc;
-    }
-    HIP_TRY(hipSetDevice(rx->device));
-    float *d = s->dev[k].p;
-    if (s->n_batches == 0) HIP_TRY(hipMemsetAsync(d, 0, (size_t)C * 8, s->st_in));                 // silence before the stream
-    else HIP_TRY(hipMemcpyAsync(d, s->dev[kp].p + 2 * s->B, (size_t)C * 8, hipMemcpyDeviceToDevice, s->st_in));   // (every batch but the last is full)
-    if (n_new) HIP_TRY(hipMemcpyAsync(d + 2 * C, s->pin[k], (size_t)n_new * 8, hipMemcpyHostToDevice, s->st_in));
-    HIP_TRY(hipEventRecord(s->in_done[k], s->st_in));
-    const bool piped = rx->pipeline && rx->viterbi_kind == 2;
-    HIP_TRY(hipStreamWaitEvent(piped ? rx->stream3 : rx->stream, s->in_done[k], 0));                // pre-sync and front end follow there
-    size_t found = 0;
-    int rc = foa_rx_sync_dev(rx, d, (size_t)n_buf, (foa_frame_desc *)s->d_desc[k].p, s->d_ends[k].p, s->desc_cap, &found);
-    if (rc) return rc;
-    // which of them are this batch's: STS_END sample in [cut_prev, cut)
-    const int64_t cut = final ? s->pushed + 1 : s->pushed - L;
-    size_t i0 = 0, i1 = 0;
-    if (found) {
-        s->h_desc.resize(found);
-        HIP_TRY(hipMemcpy(s->h_desc.data(), s->d_desc[k].p, found * sizeof(foa_frame_desc), hipMemcpyDeviceToHost));
-        while (i0 < found && start + s->h_desc[i0].rot_start < s->cut_prev) i0++;
-        i1 = i0;
-        while (i1 < found && start + s->h_desc[i1].rot_start < cut) i1++;
-    }
-    const size_t m = i1 - i0;
-    foa_stream::InFlight fl;
-    fl.n_frames = m; fl.buf = k; fl.ticket = 0;
-    if (m) {
-        // timing_sync's phasor before the first alignment of the batch: the one the last decoded alignment set
-        foa_frame_desc &first = s->h_desc[i0];
-        first.c_prev = s->prev_c; first.s_prev = s->prev_s;
-        HIP_TRY(hipMemcpyAsync(s->d_desc[k].p + i0 * sizeof(foa_frame_desc), &first, sizeof first, hipMemcpyHostToDevice, piped ? rx->stream3 : rx->stream));
-        s->prev_c = s->h_desc[i1 - 1].c; s->prev_s = s->h_desc[i1 - 1].s;
-        // outputs go through a job slot of the asynchronous host entry (page-locked mirror, D2H behind the finish kernel)
-        HostJob *job = nullptr;
-        for (auto &j : rx->jobs) if (!j.busy) { job = &j; break; }
-        if (!job) return fail(FOA_E_STATE, "internal: no free job slot");
-        auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-        const size_t o_res = up(m * s->slot), total = o_res + up(m * sizeof(foa_frame_result));
-        if ((rc = job->dev.ensure(total))) return rc;
-        if (job->pin_cap < total) {
-            if (job->pin) (void)hipHostFree(job->pin);
-            job->pin = nullptr; job->pin_cap = 0;
-            const size_t want = total + total / 2;
-            HIP_TRY(hipHostMalloc((void **)&job->pin, want, hipHostMallocDefault));
-            job->pin_cap = want;
-        }
-        if (!job->done) HIP_TRY(hipEventCreateWithFlags(&job->done, hipEventDisableTiming));
-        HIP_TRY(hipMemsetAsync(job->dev.p, 0, m * s->slot, piped ? rx->stream3 : rx->stream));
-        job->total = total; job->o_psdu = 0; job->o_res = o_res; job->n_frames = m; job->slot_bytes = s->slot; job->copy_queued = false;
-        rx->attach_job = piped ? job : nullptr;
-        rc = foa_rx_decode_frames_dev(rx, d, (size_t)n_buf, (const foa_frame_desc *)s->d_desc[k].p + i0, s->d_ends[k].p + i0, m, job->dev.p, s->slot,
-                                      (foa_frame_result *)(job->dev.p + o_res));
-        rx->attach_job = nullptr;
-        if (rc) return rc;
-        if (!piped) {
-            HIP_TRY(hipMemcpyAsync(job->pin, job->dev.p, total, hipMemcpyDeviceToHost, rx->stream));
-            HIP_TRY(hipEventRecord(job->done, rx->stream));
-            job->copy_queued = true;
-        }
-        job->busy = true;
-        job->ticket = rx->next_ticket++;
-        fl.ticket = job->ticket;
-        s->alignments += m;
-    }
-    s->flight.push_back(fl);
-    s->cut_prev = cut;
-    s->n_batches++;
-    s->fill = 0;
-    return FOA_OK;
-}
-
-template <typename T>
-int stream_push(foa_stream *s, const T *iq, size_t n)
-{
-    if (!s || (n && !iq)) return fail(FOA_E_INVALID, "NULL argument");
-    if (s->finished) return fail(FOA_E_STATE, "foa_stream: the stream was flushed; create a new one");
-    while (n) {
-        const int k = (int)(s->n_batches % foa::kStreamBufs);
-        const size_t room = (size_t)(s->B - s->fill), take = n < room ? n : room;
-        float *dst = s->pin[k] + 2 * s->fill;
-        if (sizeof(T) == sizeof(float)) memcpy(dst, iq, take * 8);
-        else if (s->pool && take >= 32768) s->pool->run(dst, (const double *)iq, take);
-        else foa::NarrowPool::narrow(dst, (const double *)iq, 0, take);
-        s->fill += (int64_t)take; s->pushed += (int64_t)take;
-        iq += 2 * take; n -= take;
-        if (s->fill == s->B) {
-            // the staging buffer of the NEXT batch must be free again: its last H2D was four batches ago and is long done,
-            // but make that explicit rather than assumed
-            const int rc = stream_submit(s, false);
-            if (rc) return rc;
-            HIP_TRY(hipEventSynchronize(s->in_done[(int)(s->n_batches % foa::kStreamBufs)]));
-        }
-    }
-    return FOA_OK;
+    std::lock_guard<std::mutex> lk(s->gpu.err_m);
+    return fail(rc, "foa_stream: %s", s->gpu.err_text.empty() ? "call sequence error (push after flush?)" : s->gpu.err_text.c_str());
 }
 
 }  // namespace
@@ -275,22 +209,23 @@ int foa_stream_create(foa_rx *rx, size_t batch_samples, int narrow_threads, foa_
     if (batch_samples < 4096 || batch_samples > ((size_t)1 << 28)) return fail(FOA_E_INVALID, "batch_samples must lie in [4096, 2^28]");
     if (narrow_threads < 0 || narrow_threads > 64) return fail(FOA_E_INVALID, "narrow_threads must lie in [0, 64]");
     HIP_TRY(hipSetDevice(rx->device));
+    { int rc0 = drain(rx); if (rc0) return rc0; }
     foa_stream *s = new foa_stream();
-    s->rx = rx;
-    s->B = (int64_t)batch_samples;
-    s->desc_cap = (size_t)((foa::kStreamCarry + s->B) / 300 + 64);
+    StreamGpu &g = s->gpu;
+    g.rx = rx;
+    g.B = (int64_t)batch_samples;
+    g.desc_cap = (size_t)((foa::kStreamCarry + g.B) / 300 + 64);
     int rc = FOA_OK;
     for (int i = 0; i < foa::kStreamBufs && !rc; i++) {
-        if (hipHostMalloc((void **)&s->pin[i], (size_t)s->B * 8, hipHostMallocDefault) != hipSuccess) rc = fail(FOA_E_NOMEM, "hipHostMalloc of a %zu-byte staging buffer failed", (size_t)s->B * 8);
-        if (!rc) rc = s->dev[i].ensure((size_t)(foa::kStreamCarry + s->B) * 2);
-        if (!rc) rc = s->d_desc[i].ensure(s->desc_cap * sizeof(foa_frame_desc));
-        if (!rc) rc = s->d_ends[i].ensure(s->desc_cap);
-        if (!rc && hipEventCreateWithFlags(&s->in_done[i], hipEventDisableTiming) != hipSuccess) rc = fail(FOA_E_HIP, "hipEventCreate failed");
-        if (!rc && hipEventRecord(s->in_done[i], rx->stream) != hipSuccess) rc = fail(FOA_E_HIP, "hipEventRecord failed");
+        if (hipHostMalloc((void **)&g.pin[i], (size_t)g.B * 8, hipHostMallocDefault) != hipSuccess) rc = fail(FOA_E_NOMEM, "hipHostMalloc of a %zu-byte staging buffer failed", (size_t)g.B * 8);
+        if (!rc) rc = g.dev[i].ensure((size_t)(foa::kStreamCarry + g.B) * 2);
+        if (!rc) rc = g.d_desc[i].ensure(g.desc_cap * sizeof(foa_frame_desc));
+        if (!rc) rc = g.d_ends[i].ensure(g.desc_cap);
+        if (!rc && hipEventCreateWithFlags(&g.in_done[i], hipEventDisableTiming) != hipSuccess) rc = fail(FOA_E_HIP, "hipEventCreate failed");
     }
-    if (!rc && hipStreamCreateWithFlags(&s->st_in, hipStreamNonBlocking) != hipSuccess) rc = fail(FOA_E_HIP, "hipStreamCreate failed");
+    if (!rc && hipStreamCreateWithFlags(&g.st_in, hipStreamNonBlocking) != hipSuccess) rc = fail(FOA_E_HIP, "hipStreamCreate failed");
     if (rc) { foa_stream_destroy(s); return rc; }
-    if (narrow_threads > 0) s->pool = new foa::NarrowPool(narrow_threads);
+    s->core = new foa::StreamCore<StreamGpu>(&g, g.B, narrow_threads);
     *out = s;
     return FOA_OK;
 }
@@ -298,65 +233,80 @@ int foa_stream_create(foa_rx *rx, size_t batch_samples, int narrow_threads, foa_
 void foa_stream_destroy(foa_stream *s)
 {
     if (!s) return;
-    (void)hipSetDevice(s->rx->device);
-    (void)foa_rx_sync(s->rx);
+    delete s->core;                                   // joins the helpers and the submitter: from here on this thread owns the handle
+    StreamGpu &g = s->gpu;
+    (void)hipSetDevice(g.rx->device);
+    (void)foa_rx_sync(g.rx);
     // the job slots of batches nobody took are released
-    while (!s->flight.empty()) if (stream_collect_oldest(s, 1) <= 0) break;
-    delete s->pool;
+    while (!g.flight.empty()) { foa::StreamReady r; if (g.collect(g.flight.front().handle, true, &r) <= 0) break; }
     for (int i = 0; i < foa::kStreamBufs; i++) {
-        if (s->pin[i]) (void)hipHostFree(s->pin[i]);
-        s->dev[i].release(); s->d_desc[i].release(); s->d_ends[i].release();
-        if (s->in_done[i]) (void)hipEventDestroy(s->in_done[i]);
+        if (g.pin[i]) (void)hipHostFree(g.pin[i]);
+        g.dev[i].release(); g.d_desc[i].release(); g.d_ends[i].release();
+        if (g.in_done[i]) (void)hipEventDestroy(g.in_done[i]);
     }
-    if (s->st_in) (void)hipStreamDestroy(s->st_in);
+    if (g.st_in) (void)hipStreamDestroy(g.st_in);
     delete s;
 }
 
-int foa_stream_push_f32(foa_stream *s, const float *iq, size_t n_samples) { return stream_push(s, iq, n_samples); }
-int foa_stream_push_f64(foa_stream *s, const double *iq, size_t n_samples) { return stream_push(s, iq, n_samples); }
+int foa_stream_push_f32(foa_stream *s, const float *iq, size_t n_samples)
+{
+    if (!s || (n_samples && !iq)) return fail(FOA_E_INVALID, "NULL argument");
+    const int rc = s->core->push(iq, n_samples, nullptr, nullptr);
+    return rc ? stream_fail(s, rc) : FOA_OK;
+}
+int foa_stream_push_f64(foa_stream *s, const double *iq, size_t n_samples)
+{
+    if (!s || (n_samples && !iq)) return fail(FOA_E_INVALID, "NULL argument");
+    const int rc = s->core->push(iq, n_samples, nullptr, nullptr);
+    return rc ? stream_fail(s, rc) : FOA_OK;
+}
+int foa_stream_push_f64_owned(foa_stream *s, const double *iq, size_t n_samples, void (*release)(void *), void *ctx)
+{
+    if (!s || (n_samples && !iq) || !release) { if (release) release(ctx); return fail(FOA_E_INVALID, "NULL argument"); }
+    const int rc = s->core->push(iq, n_samples, release, ctx);
+    return rc ? stream_fail(s, rc) : FOA_OK;
+}
 
 int foa_stream_flush(foa_stream *s)
 {
     if (!s) return fail(FOA_E_INVALID, "NULL argument");
-    if (s->finished) return FOA_OK;
-    s->finished = true;
-    // (also with an empty staging buffer: the alignments after the last cut are still undecoded)
-    return stream_submit(s, true);
+    const int rc = s->core->flush();
+    return rc ? stream_fail(s, rc) : FOA_OK;
 }
 
 int foa_stream_ready(foa_stream *s, int wait, size_t *n_payloads, size_t *n_bytes)
 {
     if (!s || !n_payloads || !n_bytes) return fail(FOA_E_INVALID, "NULL argument");
     *n_payloads = 0; *n_bytes = 0;
-    if (s->ready.empty()) {
-        HIP_TRY(hipSetDevice(s->rx->device));
-        const int rc = stream_collect_oldest(s, wait);
-        if (rc <= 0) return rc;
+    if (!s->have_ready) {
+        s->ready = foa::StreamReady();
+        const int rc = s->core->take(wait != 0, &s->ready);
+        if (rc < 0) return stream_fail(s, rc);
+        if (rc == 0) return 0;
+        s->have_ready = true;
     }
-    *n_payloads = s->ready.front().len.size();
-    *n_bytes = s->ready.front().bytes.size();
+    *n_payloads = s->ready.len.size();
+    *n_bytes = s->ready.bytes.size();
     return 1;
 }
 
 int foa_stream_take(foa_stream *s, uint8_t *payloads, uint32_t *lengths)
 {
     if (!s) return fail(FOA_E_INVALID, "NULL argument");
-    if (s->ready.empty()) return fail(FOA_E_STATE, "foa_stream_take without a batch reported by foa_stream_ready");
-    const foa_stream::Ready &r = s->ready.front();
+    if (!s->have_ready) return fail(FOA_E_STATE, "foa_stream_take without a batch reported by foa_stream_ready");
+    const foa::StreamReady &r = s->ready;
     if (!r.len.empty() && (!payloads || !lengths)) return fail(FOA_E_INVALID, "NULL argument");
-    if (!r.len.empty()) {
-        if (!r.bytes.empty()) memcpy(payloads, r.bytes.data(), r.bytes.size());
-        memcpy(lengths, r.len.data(), r.len.size() * sizeof(uint32_t));
-    }
-    s->ready.pop_front();
+    if (!r.bytes.empty()) memcpy(payloads, r.bytes.data(), r.bytes.size());
+    if (!r.len.empty()) memcpy(lengths, r.len.data(), r.len.size() * sizeof(uint32_t));
+    s->have_ready = false;
     return FOA_OK;
 }
 
 int foa_stream_stats(const foa_stream *s, uint64_t out[8])
 {
     if (!s || !out) return fail(FOA_E_INVALID, "NULL argument");
-    for (int i = 0; i < 5; i++) out[i] = s->status_count[i];
-    out[5] = s->alignments; out[6] = (uint64_t)s->n_batches; out[7] = (uint64_t)s->pushed;
+    for (int i = 0; i < 5; i++) out[i] = s->gpu.status_count[i].load();
+    out[5] = s->gpu.alignments.load(); out[6] = (uint64_t)s->core->batches_closed(); out[7] = (uint64_t)s->core->pushed();
     return FOA_OK;
 }
 

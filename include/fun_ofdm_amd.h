@@ -214,7 +214,8 @@ int foa_rx_sync_dev(foa_rx *rx, const float *d_iq, size_t n_samples, foa_frame_d
  * more than the longest frame, so a frame is decoded exactly once, by the batch that holds all of it, and the pre-sync
  * sees the same samples around every decision as a single pass over the whole stream would (fun_ofdm_amd/csrc/
  * stream_engine.h).  The payload list equals the reference chain's (tests/test_gpu_stream.py); latency is one batch.
- * One engine per handle at a time; the handle's other entry points must not be used while a stream is open. */
+ * One engine per handle at a time; the handle's other entry points must not be used while a stream is open (the engine's
+ * submitter thread makes the GPU calls; push / flush / ready / take / stats belong to ONE caller thread). */
 typedef struct foa_stream foa_stream;
 /* batch_samples in [4096, 2^28]; narrow_threads: helper threads for the double -> float narrowing of
  * foa_stream_push_f64 (0 = the calling thread alone; used for pushes of >= 32768 samples). */
@@ -224,6 +225,10 @@ void foa_stream_destroy(foa_stream *s);
  * (which may wait for the oldest batch in flight when all buffers are in use). */
 int foa_stream_push_f32(foa_stream *s, const float *iq, size_t n_samples);
 int foa_stream_push_f64(foa_stream *s, const double *iq, size_t n_samples);
+/* The same, handing the buffer over: the call returns at once, the engine's helper threads narrow the samples later and
+ * call release(ctx) (on one of their threads, or on this one) when the buffer is no longer needed.  For callers that own
+ * their buffer anyway -- receiver_chain::process_samples takes its vector by value (src/receiver_chain.h:56). */
+int foa_stream_push_f64_owned(foa_stream *s, const double *iq, size_t n_samples, void (*release)(void *), void *ctx);
 /* End of the stream: submits what is left, the frames after the last batch boundary included.  No pushes afterwards. */
 int foa_stream_flush(foa_stream *s);
 /* 1 if the oldest submitted batch is complete (then *n_payloads / *n_bytes describe its CRC-passing payloads), 0 if it is

@@ -385,7 +385,7 @@ public:
     // Asynchronous mode: everything that can still be decoded, waited for (end of a capture; a radio never ends).
     std::vector<std::vector<unsigned char> > flush()
     {
-        if (device_batch_ > 0) return process_device(std::vector<std::complex<double> >(), true);
+        if (device_batch_ > 0) { std::vector<std::complex<double> > none; return process_device(none, true); }
         if (batch_calls_ > 0) return process_async(std::vector<std::complex<double> >(), true);
         return std::vector<std::vector<unsigned char> >();
     }
@@ -469,11 +469,19 @@ private:
         return out;
     }
     // everything on the device: push, then hand out whatever has finished (final: flush and wait for all of it)
-    std::vector<std::vector<unsigned char> > process_device(const std::vector<std::complex<double> > &samples, bool final)
+    static void release_vector(void *p) { delete static_cast<std::vector<std::complex<double> > *>(p); }
+    std::vector<std::vector<unsigned char> > process_device(std::vector<std::complex<double> > &samples, bool final)
     {
         std::vector<std::vector<unsigned char> > out;
+        if (stream_ && stream_over_) { foa_stream_destroy(stream_); stream_ = nullptr; stream_over_ = false; }     // a new stream after a flush
         if (!stream_) check(foa_stream_create(dev_.get(), device_batch_, narrow_threads_, &stream_), "foa_stream_create");
-        if (!samples.empty()) check(foa_stream_push_f64(stream_, reinterpret_cast<const double *>(samples.data()), samples.size()), "foa_stream_push_f64");
+        if (!samples.empty()) {
+            // process_samples owns its argument (by value, src/receiver_chain.h:56): hand the buffer to the engine instead of
+            // narrowing it here -- its helper threads do that while the caller fetches the next chunk
+            std::vector<std::complex<double> > *own = new std::vector<std::complex<double> >(std::move(samples));
+            check(foa_stream_push_f64_owned(stream_, reinterpret_cast<const double *>(own->data()), own->size(), &receiver_chain::release_vector, own),
+                  "foa_stream_push_f64_owned");
+        }
         if (final) check(foa_stream_flush(stream_), "foa_stream_flush");
         for (;;) {
             size_t n = 0, bytes = 0;
@@ -489,7 +497,7 @@ private:
                 o += take_len_[i];
             }
         }
-        if (final) { foa_stream_destroy(stream_); stream_ = nullptr; }     // a new stream starts with the next call
+        if (final) stream_over_ = true;               // (its page-locked buffers are released by the next call or the destructor)
         return out;
     }
     // drop samples nothing can refer to any more: before the oldest pending alignment, and before what a future
@@ -515,6 +523,7 @@ private:
     long calls_;
     std::deque<job> jobs_;
     foa_stream *stream_;              // device mode
+    bool stream_over_ = false;
     size_t device_batch_;
     int narrow_threads_;
     std::vector<unsigned char> take_bytes_;

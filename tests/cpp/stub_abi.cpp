@@ -97,6 +97,12 @@ int foa_stream_push_f64(foa_stream *s, const double *iq, size_t n)
     for (size_t i = 0; i < 2 * n; i++) s->iq.push_back((float)iq[i]);
     return FOA_OK;
 }
+int foa_stream_push_f64_owned(foa_stream *s, const double *iq, size_t n, void (*release)(void *), void *ctx)
+{
+    const int rc = foa_stream_push_f64(s, iq, n);
+    release(ctx);
+    return rc;
+}
 int foa_stream_flush(foa_stream *s)
 {
     if (s->flushed) return FOA_OK;

@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
-"""Single-stream real-time check of the C++ front end: a capture of back-to-back 54 Mbps frames through
-examples/foa_sim.cpp (file_source -> receiver -> receiver_chain -> callback), synchronous and in asynchronous batches.
-Prints samples per second against the 20 Msample/s of the air."""
+"""Throughput of the drop-in API itself: a capture of back-to-back 54 Mbps frames through
+fun_amd::receiver_chain::process_samples (examples/foa_sim.cpp --preload: the complex<double> chunks are prepared first and only
+the receive loop is timed), in its three modes: synchronous, asynchronous batches over the host pre-sync, and everything on the
+device (foa_stream_*).  Prints one JSON line per run; Msamples/s against the 20 Msample/s of the air.
+usage: tools/bench_stream.py [frames] > gpurun_out/stream.jsonl"""
+import json
 import os
+import re
 import subprocess
 import sys
-import time
 
 import numpy as np
 import torch
@@ -15,7 +18,7 @@ sys.path.insert(0, ROOT)
 import fun_ofdm_amd as foa                      # noqa: E402
 from fun_ofdm_amd import synth                  # noqa: E402
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 60000
 rx = foa.Receiver(0)
 pays = synth.splitmix64_bytes(0xB57, n, 1024)
 frames = rx.tx_build_frames(torch.from_numpy(pays).to("cuda:0"), 10)
@@ -28,10 +31,26 @@ exe = "/tmp/foa_sim"
 libdir = os.path.dirname(foa.library_path())
 subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "examples", "foa_sim.cpp"), "-I", os.path.join(ROOT, "include"), "-L", libdir,
                 "-lfun_ofdm_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lpthread", "-o", exe], check=True)
-air = iq.size / 20e6
-for extra in ([], ["--async", "8"], ["--async", "32"]):
-    t0 = time.perf_counter()
-    r = subprocess.run([exe, cap, "--format", "fc32"] + extra, capture_output=True, text=True)
-    dt = time.perf_counter() - t0
-    print("%-14s %s  | %.2f s for %.2f s of air = %.1f Msamples/s (%.2f x real time; includes process start-up)"
-          % (" ".join(extra) or "synchronous", r.stdout.strip(), dt, air, iq.size / dt / 1e6, air / dt), flush=True)
+short = min(n, 12000)
+runs = [("synchronous", ["--chunk", "4096"], 600), ("async 8", ["--chunk", "4096", "--async", "8"], short), ("async 32", ["--chunk", "4096", "--async", "32"], short)]
+for batch in (1 << 20, 1 << 22, 1 << 24):
+    for chunk, threads in ((4096, 0), (4096, 4), (4096, 8), (4096, 16), (65536, 8), (1 << 20, 16)):
+        if batch != 1 << 22 and (chunk, threads) not in ((4096, 0), (4096, 8)):
+            continue
+        runs.append(("device %dM, calls of %d, %d helpers" % (batch >> 20, chunk, threads),
+                     ["--chunk", str(chunk), "--device-batch", str(batch), "--narrow-threads", str(threads)], n))
+for name, extra, frames_used in runs:
+    src = cap
+    if frames_used < n:                        # the synchronous mode needs a millisecond per call: a shorter capture
+        src = "/tmp/stream_%d.fc32" % frames_used
+        iq[:frames_used * (s + 160)].tofile(src)
+    r = subprocess.run([exe, src, "--format", "fc32", "--preload"] + extra, capture_output=True, text=True)
+    m = re.search(r"([\d.]+) Msamples/s through process_samples \((\d+) samples in ([\d.]+) s, (\d+) calls of (\d+)\)", r.stdout)
+    p = re.search(r"(\d+) packets", r.stdout)
+    if not m:
+        print(json.dumps({"mode": name, "error": (r.stdout + r.stderr)[-400:]}), flush=True)
+        continue
+    rate = float(m.group(1))
+    print(json.dumps({"mode": name, "args": extra, "Msamples_per_s": rate, "x_realtime_20MSps": round(rate / 20.0, 1), "samples": int(m.group(2)),
+                      "seconds": float(m.group(3)), "calls": int(m.group(4)), "chunk": int(m.group(5)), "packets": int(p.group(1)) if p else None,
+                      "frames_sent": frames_used}), flush=True)
