@@ -19,8 +19,8 @@ struct FrameInfo {
     int32_t nsym;        // data symbols to process (0 if nothing to do)
     int32_t sym_off;     // first data symbol's index in the call-wide symbol numbering
     int32_t nsteps;      // trellis steps = nsym * dbps
-    int64_t soft_off;    // byte offset of this frame's depunctured soft bytes
-    int64_t dec_off;     // offset (in 8-byte words) of this frame's decision words
+    int64_t soft_off;    // byte offset of this frame's depunctured soft bytes (= 2 * dec_off: two per trellis step)
+    int64_t dec_off;     // offset (in per-step elements) of this frame's region in the soft-pair, decision and decoded buffers
     int32_t seg_off;     // first chain-back segment's index in the call-wide segment numbering (viterbi_v3.h)
     int32_t reserved_;
 };
@@ -41,10 +41,8 @@ struct DeviceTables {
     uint8_t scramble[128];         // ppdu.cpp:256-264 feedback bit per byte index mod 127
     uint32_t crc_table[256];       // IEEE 802.3 CRC-32, reflected
     double lts_conj_re[64], lts_conj_im[64];   // preamble.h:432 LTS_TIME_DOMAIN_CONJ
-    // look-up forms of two integer formulas, used by the lane-per-symbol front end (frontend_lps.h)
+    // look-up form of the soft demapper, used by the lane-per-symbol and quad-per-symbol front ends
     uint32_t qam_lut[641];         // qam.h:110-125 for pt = -320..320 (constant outside): soft byte i in bits 8i..8i+7
-    uint32_t bm_sum[511];          // viterbi.cpp:242-247: index s0+s1      -> m00 | m11 << 24
-    uint32_t bm_dif[511];          //                      index s0-s1+255  -> m01 << 8 | m10 << 16
     // interleaver.cpp:28-38 + puncturer.cpp:94-118 as one map per rate: demodulated byte c = carrier * bpsc + bit of a
     // symbol -> its position among the symbol's 2 * dbps depunctured soft bytes (frontend_q4.h)
     uint16_t sym_pos[kNumRates][288];

@@ -134,15 +134,12 @@ void foa::build_tables(DeviceTables *t)
         }
         t->qam_lut[p + 320] = word;
     }
-    // (((s0 ^ b0*255) + (s1 ^ b1*255) + 1) >> 1) >> 2 for (b0,b1) = 00, 01, 10, 11 in terms of s0+s1 and s0-s1
-    for (int a = 0; a <= 510; a++) t->bm_sum[a] = (uint32_t)((a + 1) >> 3) | ((uint32_t)((511 - a) >> 3) << 24);
     for (int r = 0; r < kNumRates; r++)
         for (int c = 0; c < t->rates[r].cbps; c++) {
             const int w = c % 48, dd = 48 * (c / 48) + 16 * (w % 3) + w / 3, punct = t->rates[r].punct;     // interleaver.h:66-75 inverse
             static const int k34[4] = { 0, 1, 3, 5 }, k23[3] = { 0, 2, 3 };
             t->sym_pos[r][c] = (uint16_t)(punct == 2 ? 6 * (dd >> 2) + k34[dd & 3] : punct == 1 ? 4 * (dd / 3) + k23[dd % 3] : dd);
         }
-    for (int b = -255; b <= 255; b++) t->bm_dif[b + 255] = ((uint32_t)((b + 256) >> 3) << 8) | ((uint32_t)((256 - b) >> 3) << 16);
 }
 
 // Everything one decode call writes between its header kernel and its finish kernel.  There are two sets so that the
@@ -152,12 +149,12 @@ struct WorkSet {
     DevBuf<double2> hinv;
     DevBuf<int32_t> sym2frame, seg2frame;
     DevBuf<uint16_t> tb_state;
-    DevBuf<uint8_t> soft;
     DevBuf<uint64_t> dec;
-    DevBuf<uint32_t> bm, decoded;
+    DevBuf<uint16_t> sp;          // depunctured soft pairs, one per trellis step (front end -> forward pass, taps)
+    DevBuf<uint32_t> decoded;
     DevBuf<int64_t> totals;
     DevBuf<double2> eq_sig, eq_data;
-    size_t sym_cap = 0, soft_cap = 0, dec_cap = 0;
+    size_t sym_cap = 0, dec_cap = 0;
     hipEvent_t ev[8] = {};       // start, after header, after scan, after symbols, end, after the forward pass, start of the finish,
                                  // start of the forward pass (pipelined path)
     WorkSet *before = nullptr;   // the set of the call queued before this one (pipelined path)
@@ -165,7 +162,7 @@ struct WorkSet {
     bool used = false, have_timing = false, piped = false;
     void release_all()
     {
-        info.release(); hinv.release(); sym2frame.release(); seg2frame.release(); tb_state.release(); soft.release(); dec.release(); bm.release();
+        info.release(); hinv.release(); sym2frame.release(); seg2frame.release(); tb_state.release(); dec.release(); sp.release();
         decoded.release(); totals.release(); eq_sig.release(); eq_data.release();
     }
 };
@@ -194,7 +191,7 @@ struct foa_rx {
     int tb_segment = 960, tb_overlap = 96;   // v3 chain-back: data steps per segment / run-in steps (multiples of 96)
     bool pipeline = true;        // v3: finish of one call overlaps the next call's front end (two work sets, two streams)
     bool record_eq = false;
-    bool record_soft = true;     // keep the depunctured soft bytes (taps, lane-per-state kernel); off = branch metrics only
+    bool record_soft = true;     // (the soft bytes are the front end's output and always there; the option is accepted for compatibility)
     int frontend_kind = -1;      // 1: one lane per symbol (frontend_lps.h), 0: one wave per symbol, 2: four lanes per symbol (frontend_q4.h);
                                  // -1: the default, 2
     WorkSet sets[4];             // three are in use at any time (below); the fourth keeps the call before them readable (timings)
@@ -228,11 +225,10 @@ namespace {
 int workspace(foa_rx *rx, size_t n_samples, size_t n_frames)
 {
     size_t sym_cap = n_samples / 80 + 4;
-    size_t soft_cap = 432 * sym_cap + 256 * (n_frames + 1);
     size_t dec_cap = 216 * sym_cap + 192 * (n_frames + 1);
     int rc;
     if ((rc = rx->w->info.ensure(n_frames + 1)) || (rc = rx->w->hinv.ensure((n_frames + 1) * 64)) || (rc = rx->w->sym2frame.ensure(sym_cap)) ||
-        (rc = rx->w->soft.ensure(soft_cap)) || (rc = rx->w->dec.ensure(dec_cap)) || (rc = rx->w->bm.ensure(dec_cap)) || (rc = rx->w->decoded.ensure(dec_cap)) ||
+        (rc = rx->w->dec.ensure(dec_cap)) || (rc = rx->w->sp.ensure(dec_cap)) || (rc = rx->w->decoded.ensure(dec_cap)) ||
         (rc = rx->w->totals.ensure(8 + 4 * ((n_frames + kScanBlock - 1) / kScanBlock + 1))))
         return rc;
     if (rx->record_eq && ((rc = rx->w->eq_sig.ensure((n_frames + 1) * 48)) || (rc = rx->w->eq_data.ensure(sym_cap * 48)))) return rc;
@@ -240,7 +236,7 @@ int workspace(foa_rx *rx, size_t n_samples, size_t n_frames)
     const size_t seg_cap = dec_cap / 96 + n_frames + 64;
     if ((rc = rx->w->seg2frame.ensure(seg_cap)) || (rc = rx->w->tb_state.ensure(seg_cap))) return rc;
     // capacities handed to the scan are those of the buffers actually allocated
-    rx->w->sym_cap = rx->w->sym2frame.n; rx->w->soft_cap = rx->w->soft.n; rx->w->dec_cap = rx->w->dec.n < rx->w->bm.n ? rx->w->dec.n : rx->w->bm.n;
+    rx->w->sym_cap = rx->w->sym2frame.n; rx->w->dec_cap = rx->w->dec.n < rx->w->sp.n ? rx->w->dec.n : rx->w->sp.n;
     if (rx->record_eq && rx->w->eq_data.n / 48 < rx->w->sym_cap) rx->w->sym_cap = rx->w->eq_data.n / 48;
     return FOA_OK;
 }
@@ -462,23 +458,21 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
     int64_t *blk = rx->w->totals.p + 8;
     hipLaunchKernelGGL(k_scan_sums, dim3(n_sb), dim3(kScanBlock), 0, st, rx->w->info.p, nf, rx->tb_segment, blk);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, blk, n_sb, (int64_t)rx->w->sym_cap, rx->w->totals.p);
-    hipLaunchKernelGGL(k_scan_apply, dim3(n_sb), dim3(kScanBlock), 0, st, rx->w->info.p, nf, (int64_t)rx->w->sym_cap, (int64_t)rx->w->soft_cap,
+    hipLaunchKernelGGL(k_scan_apply, dim3(n_sb), dim3(kScanBlock), 0, st, rx->w->info.p, nf, (int64_t)rx->w->sym_cap,
                        (int64_t)rx->w->dec_cap, rx->tb_segment, (int64_t)rx->w->seg2frame.n, blk, rx->w->sym2frame.p, rx->w->seg2frame.p);
     HIP_TRY(hipEventRecord(rx->w->ev[2], st));
     // upper bound on data symbols in n_samples samples; waves beyond the real total exit at once
     const size_t max_sym = rx->w->sym_cap;
     const int frontend = rx->frontend_kind >= 0 ? rx->frontend_kind : 2;
     if (frontend == 2) {
-        uint8_t *soft_out = (rx->record_soft || rx->viterbi_kind == 0) ? rx->w->soft.p : nullptr;
         hipLaunchKernelGGL(k_data_symbols_q4, dim3((unsigned)((max_sym + 16 * kQ4Waves - 1) / (16 * kQ4Waves))), dim3(64 * kQ4Waves), 0, st, iq,
-                           d_descs, rx->w->info.p, rx->w->sym2frame.p, rx->w->totals.p, rx->w->hinv.p, soft_out, rx->w->bm.p, eq_data);
+                           d_descs, rx->w->info.p, rx->w->sym2frame.p, rx->w->totals.p, rx->w->hinv.p, rx->w->sp.p, eq_data);
     } else if (frontend == 1) {
-        uint8_t *soft_out = (rx->record_soft || rx->viterbi_kind == 0) ? rx->w->soft.p : nullptr;
         hipLaunchKernelGGL(k_data_symbols_lps, dim3((unsigned)((max_sym + 63) / 64)), dim3(64), 0, st, iq, d_descs, rx->w->info.p, rx->w->sym2frame.p,
-                           rx->w->totals.p, rx->w->hinv.p, soft_out, rx->w->bm.p, eq_data);
+                           rx->w->totals.p, rx->w->hinv.p, rx->w->sp.p, eq_data);
     } else {
         hipLaunchKernelGGL(k_data_symbols, dim3((unsigned)((max_sym + kSymWaves - 1) / kSymWaves)), dim3(64 * kSymWaves), 0, st, iq, d_descs,
-                           rx->w->info.p, rx->w->sym2frame.p, rx->w->totals.p, rx->w->hinv.p, rx->w->soft.p, rx->w->bm.p, eq_data);
+                           rx->w->info.p, rx->w->sym2frame.p, rx->w->totals.p, rx->w->hinv.p, rx->w->sp.p, eq_data);
     }
     HIP_TRY(hipEventRecord(rx->w->ev[3], st));
     if (piped) {
@@ -486,18 +480,18 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
         if ((rc = flush_pending(rx, rx->w->ev[3]))) return rc;
         HIP_TRY(hipStreamWaitEvent(st_fwd, rx->w->ev[3], 0));
         HIP_TRY(hipEventRecord(rx->w->ev[7], st_fwd));          // start of the forward pass (this stream idles every other step: free)
-        launch_fwd3(st_fwd, rx->w->info.p, nf, rx->w->bm.p, rx->w->dec.p);
+        launch_fwd3(st_fwd, rx->w->info.p, nf, rx->w->sp.p, rx->w->dec.p);
         HIP_TRY(hipEventRecord(rx->w->ev[5], st_fwd));
         foa_rx::Pending &p = rx->pending;
         p.valid = true; p.w = rx->w; p.nf = nf; p.S = rx->tb_segment; p.L = rx->tb_overlap; p.max_segs = max_segs; p.slot_bytes = slot_bytes;
         p.psdu = d_psdu; p.results = d_results; p.job = rx->attach_job;
     } else {
         if (rx->viterbi_kind == 0)
-            hipLaunchKernelGGL(k_viterbi_v1, dim3(nf), dim3(64), 0, st, rx->w->info.p, nf, rx->w->soft.p, rx->w->dec.p, d_psdu, slot_bytes, d_results);
+            hipLaunchKernelGGL(k_viterbi_v1, dim3(nf), dim3(64), 0, st, rx->w->info.p, nf, rx->w->sp.p, rx->w->dec.p, d_psdu, slot_bytes, d_results);
         else if (rx->viterbi_kind == 1)
-            launch_viterbi_v2(st, rx->w->info.p, nf, rx->w->bm.p, rx->w->dec.p, rx->w->decoded.p, d_psdu, slot_bytes, d_results, rx->w->ev[5]);
+            launch_viterbi_v2(st, rx->w->info.p, nf, rx->w->sp.p, rx->w->dec.p, rx->w->decoded.p, d_psdu, slot_bytes, d_results, rx->w->ev[5]);
         else
-            launch_viterbi_v3(st, rx->w->info.p, nf, rx->w->bm.p, rx->w->dec.p, rx->w->decoded.p, rx->w->seg2frame.p, rx->w->totals.p, rx->w->tb_state.p,
+            launch_viterbi_v3(st, rx->w->info.p, nf, rx->w->sp.p, rx->w->dec.p, rx->w->decoded.p, rx->w->seg2frame.p, rx->w->totals.p, rx->w->tb_state.p,
                               max_segs, rx->tb_segment, rx->tb_overlap, d_psdu, slot_bytes, d_results, rx->w->ev[5]);
         if (rx->viterbi_kind == 0) HIP_TRY(hipEventRecord(rx->w->ev[5], st));
         HIP_TRY(hipEventRecord(rx->w->ev[6], st));                     // (not separable from the forward pass on one stream)
@@ -662,7 +656,6 @@ int foa_rx_get_taps(foa_rx *rx, size_t n_frames, double *hinv, double *eq, size_
     if (!rx) return fail(FOA_E_INVALID, "rx is NULL");
     if (n_frames != rx->last_frames || n_frames == 0) return fail(FOA_E_STATE, "n_frames does not match the last decode call");
     if (eq && !rx->record_eq) return fail(FOA_E_STATE, "set option record_eq=1 before the decode call to get eq");
-    if (soft && !rx->record_soft && rx->viterbi_kind != 0 && rx->frontend_kind != 0) return fail(FOA_E_STATE, "set option record_soft=1 before the decode call to get soft bytes");
     HIP_TRY(hipSetDevice(rx->device));
     { int rc0 = drain(rx); if (rc0) return rc0; }
     std::vector<FrameInfo> info(n_frames);
@@ -686,7 +679,7 @@ int foa_rx_get_taps(foa_rx *rx, size_t n_frames, double *hinv, double *eq, size_
         const size_t sb = nsym ? (size_t)2 * fi.nsteps : 0;
         if (soft && sb) {
             if (so + sb > soft_cap) return fail(FOA_E_INVALID, "soft_cap too small");
-            HIP_TRY(hipMemcpy(soft + so, rx->w->soft.p + fi.soft_off, sb, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(soft + so, rx->w->sp.p + fi.dec_off, sb, hipMemcpyDeviceToHost));
         }
         so += sb;
     }
@@ -856,18 +849,18 @@ int foa_conv_decode(foa_rx *rx, const uint8_t *symbols, uint8_t *data, int data_
                 seg2frame.insert(seg2frame.end(), (size_t)nseg, (int32_t)b);
             }
             const size_t total = n_blocks * (size_t)words + 64;
-            if ((rc = rx->w->info.ensure(n_blocks + 1)) || (rc = rx->w->dec.ensure(total)) || (rc = rx->w->bm.ensure(total)) || (rc = rx->w->decoded.ensure(total)) ||
+            if ((rc = rx->w->info.ensure(n_blocks + 1)) || (rc = rx->w->dec.ensure(total)) || (rc = rx->w->sp.ensure(total)) || (rc = rx->w->decoded.ensure(total)) ||
                 (rc = rx->w->seg2frame.ensure(seg2frame.size() + 64)) || (rc = rx->w->tb_state.ensure(seg2frame.size() + 64)) || (rc = rx->w->totals.ensure(8)))
                 return rc;
             HIP_TRY(hipMemcpyAsync(rx->w->info.p, info.data(), n_blocks * sizeof(FrameInfo), hipMemcpyHostToDevice, st));
             HIP_TRY(hipMemcpyAsync(rx->w->seg2frame.p, seg2frame.data(), seg2frame.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
             const int64_t n_segs = (int64_t)seg2frame.size();
             HIP_TRY(hipMemcpyAsync(rx->w->totals.p + 4, &n_segs, sizeof n_segs, hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(k_conv_bm, dim3((unsigned)((T + 255) / 256), (unsigned)n_blocks), dim3(256), 0, st, d_sym, 2 * nsteps, T, rx->w->info.p, rx->w->bm.p);
+            hipLaunchKernelGGL(k_conv_sp, dim3((unsigned)((T + 255) / 256), (unsigned)n_blocks), dim3(256), 0, st, d_sym, 2 * nsteps, T, rx->w->info.p, rx->w->sp.p);
             if (rx->viterbi_kind == 1)
-                launch_viterbi_v2(st, rx->w->info.p, (int)n_blocks, rx->w->bm.p, rx->w->dec.p, rx->w->decoded.p, nullptr, 0, nullptr, nullptr);
+                launch_viterbi_v2(st, rx->w->info.p, (int)n_blocks, rx->w->sp.p, rx->w->dec.p, rx->w->decoded.p, nullptr, 0, nullptr, nullptr);
             else
-                launch_viterbi_v3(st, rx->w->info.p, (int)n_blocks, rx->w->bm.p, rx->w->dec.p, rx->w->decoded.p, rx->w->seg2frame.p, rx->w->totals.p,
+                launch_viterbi_v3(st, rx->w->info.p, (int)n_blocks, rx->w->sp.p, rx->w->dec.p, rx->w->decoded.p, rx->w->seg2frame.p, rx->w->totals.p,
                                   rx->w->tb_state.p, seg2frame.size(), rx->tb_segment, rx->tb_overlap, nullptr, 0, nullptr, nullptr);
             hipLaunchKernelGGL(k_conv_pack, dim3((unsigned)((nbytes + 255) / 256), (unsigned)n_blocks), dim3(256), 0, st, rx->w->decoded.p, rx->w->info.p,
                                (N + 7) / 8, (int)nbytes, d_out);
@@ -972,7 +965,7 @@ int foa_decode_data_f64(foa_rx *rx, const double *carriers, const uint64_t *carr
     std::vector<FrameInfo> info(n_frames);
     std::vector<int32_t> sym2frame, seg2frame;
     std::vector<int64_t> coff(n_frames + 1);
-    int64_t soft_off = 0, dec_off = 0;
+    int64_t dec_off = 0;
     for (size_t f = 0; f < n_frames; f++) {
         const int rate = results[f].rate, len = results[f].length;
         if (rate < 0 || rate >= kNumRates || len < 0 || len > 4095) return fail(FOA_E_INVALID, "frame %zu: bad rate/length", f);
@@ -980,10 +973,9 @@ int foa_decode_data_f64(foa_rx *rx, const double *carriers, const uint64_t *carr
         if (carrier_off[f + 1] - carrier_off[f] != (uint64_t)nsym * 48) return fail(FOA_E_INVALID, "frame %zu: needs %d carriers", f, nsym * 48);
         FrameInfo &fi = info[f];
         fi.status = FOA_ST_CRC_FAIL; fi.rate = rate; fi.length = len; fi.nsym = nsym; fi.sym_off = (int32_t)sym2frame.size();
-        fi.nsteps = nsym * dbps; fi.soft_off = soft_off; fi.dec_off = dec_off;
+        fi.nsteps = nsym * dbps; fi.soft_off = 2 * dec_off; fi.dec_off = dec_off;
         fi.seg_off = (int32_t)seg2frame.size(); fi.reserved_ = 0;
         seg2frame.insert(seg2frame.end(), (size_t)tb_segments(fi.nsteps, rx->tb_segment), (int32_t)f);
-        soft_off += ((int64_t)2 * fi.nsteps + 255) & ~(int64_t)255;
         dec_off += dec_words(fi.nsteps);
         coff[f] = (int64_t)carrier_off[f];
         sym2frame.insert(sym2frame.end(), (size_t)nsym, (int32_t)f);
@@ -992,8 +984,8 @@ int foa_decode_data_f64(foa_rx *rx, const double *carriers, const uint64_t *carr
     coff[n_frames] = (int64_t)carrier_off[n_frames];
     const size_t n_sym = sym2frame.size(), n_car = (size_t)carrier_off[n_frames];
     int rc;
-    if ((rc = rx->w->info.ensure(n_frames + 1)) || (rc = rx->w->sym2frame.ensure(n_sym + 1)) || (rc = rx->w->soft.ensure((size_t)soft_off + 256)) ||
-        (rc = rx->w->dec.ensure((size_t)dec_off + 64)) || (rc = rx->w->bm.ensure((size_t)dec_off + 64)) || (rc = rx->w->decoded.ensure((size_t)dec_off + 64)) ||
+    if ((rc = rx->w->info.ensure(n_frames + 1)) || (rc = rx->w->sym2frame.ensure(n_sym + 1)) ||
+        (rc = rx->w->dec.ensure((size_t)dec_off + 64)) || (rc = rx->w->sp.ensure((size_t)dec_off + 64)) || (rc = rx->w->decoded.ensure((size_t)dec_off + 64)) ||
         (rc = rx->w->seg2frame.ensure(seg2frame.size() + 64)) || (rc = rx->w->tb_state.ensure(seg2frame.size() + 64)) || (rc = rx->w->totals.ensure(8)))
         return rc;
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -1012,13 +1004,13 @@ int foa_decode_data_f64(foa_rx *rx, const double *carriers, const uint64_t *carr
     HIP_TRY(hipMemcpyAsync(rx->w->totals.p + 4, &n_segs, sizeof n_segs, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(d_psdu, 0, p_b, st));
     hipLaunchKernelGGL(k_stage_demap, dim3((unsigned)((n_sym + kSymWaves - 1) / kSymWaves)), dim3(64 * kSymWaves), 0, st, (const double2 *)b,
-                       (const int64_t *)(b + up(c_b)), rx->w->info.p, rx->w->sym2frame.p, (int)n_sym, rx->w->soft.p, rx->w->bm.p);
+                       (const int64_t *)(b + up(c_b)), rx->w->info.p, rx->w->sym2frame.p, (int)n_sym, rx->w->sp.p);
     if (rx->viterbi_kind == 0)
-        hipLaunchKernelGGL(k_viterbi_v1, dim3((unsigned)n_frames), dim3(64), 0, st, rx->w->info.p, (int)n_frames, rx->w->soft.p, rx->w->dec.p, d_psdu, slot_bytes, d_res);
+        hipLaunchKernelGGL(k_viterbi_v1, dim3((unsigned)n_frames), dim3(64), 0, st, rx->w->info.p, (int)n_frames, rx->w->sp.p, rx->w->dec.p, d_psdu, slot_bytes, d_res);
     else if (rx->viterbi_kind == 1)
-        launch_viterbi_v2(st, rx->w->info.p, (int)n_frames, rx->w->bm.p, rx->w->dec.p, rx->w->decoded.p, d_psdu, slot_bytes, d_res, nullptr);
+        launch_viterbi_v2(st, rx->w->info.p, (int)n_frames, rx->w->sp.p, rx->w->dec.p, rx->w->decoded.p, d_psdu, slot_bytes, d_res, nullptr);
     else
-        launch_viterbi_v3(st, rx->w->info.p, (int)n_frames, rx->w->bm.p, rx->w->dec.p, rx->w->decoded.p, rx->w->seg2frame.p, rx->w->totals.p, rx->w->tb_state.p,
+        launch_viterbi_v3(st, rx->w->info.p, (int)n_frames, rx->w->sp.p, rx->w->dec.p, rx->w->decoded.p, rx->w->seg2frame.p, rx->w->totals.p, rx->w->tb_state.p,
                           seg2frame.size(), rx->tb_segment, rx->tb_overlap, d_psdu, slot_bytes, d_res, nullptr);
     HIP_TRY(hipMemcpyAsync(psdu, d_psdu, p_b, hipMemcpyDeviceToHost, st));
     std::vector<foa_frame_result> out(n_frames);

@@ -296,10 +296,11 @@ __device__ __forceinline__ void decode_signal_bits(const uint8_t *dem, uint64_t 
     }
 }
 
-// One data symbol's 48 derotated carriers -> depunctured soft bytes (+ branch-metric dwords) of its 2*dbps/dbps
-// trellis positions.  Lane with data index di >= 0 holds carrier z.  stage: 448 B of LDS private to the wave.
+// One data symbol's 48 derotated carriers -> the depunctured soft bytes of its dbps trellis steps, two per step (what
+// puncturer::depuncture hands viterbi::conv_decode; the forward pass forms its branch metrics from them, viterbi_v3.h).
+// Lane with data index di >= 0 holds carrier z.  stage: 448 B of LDS private to the wave.
 // modulator.cpp:108-164 / qam.h:110-125, interleaver.cpp:28-38, puncturer.cpp:78-123.
-__device__ __forceinline__ void emit_symbol_soft(cpx z, int di, const RateRow &rr, uint8_t *stage, uint8_t *soft_dst, uint32_t *bm_dst, int lane)
+__device__ __forceinline__ void emit_symbol_soft(cpx z, int di, const RateRow &rr, uint8_t *stage, uint16_t *sp_dst, int lane)
 {
     // erasures first (puncturer.cpp:98,100,114), then scatter this carrier's soft bytes
     const int out_bytes = 2 * rr.dbps;                         // depunctured bytes of this symbol
@@ -319,16 +320,9 @@ __device__ __forceinline__ void emit_symbol_soft(cpx z, int di, const RateRow &r
         }
     }
     wave_lds_sync();
-    uint32_t *dst = (uint32_t *)soft_dst;
+    uint32_t *dst = (uint32_t *)sp_dst;                        // (symbols start on 8-byte boundaries: dbps is a multiple of 4)
     const uint32_t *st32 = (const uint32_t *)stage;
     for (int i = lane; i < out_bytes / 4; i += 64) dst[i] = st32[i];
-    // Branch metrics of this symbol's trellis steps for the packed Viterbi kernel: byte j = 2*b0 + b1 holds
-    // (((s0 ^ b0*255) + (s1 ^ b1*255) + 1) >> 1) >> 2, the value viterbi.cpp:242-247 derives per butterfly
-    // from Branchtab entries (b0, b1).
-    for (int t = lane; t < rr.dbps; t += 64) {
-        const uint32_t s0 = stage[2 * t], s1 = stage[2 * t + 1], n0 = s0 ^ 255u, n1 = s1 ^ 255u;
-        bm_dst[t] = ((s0 + s1 + 1u) >> 3) | (((s0 + n1 + 1u) >> 3) << 8) | (((n0 + s1 + 1u) >> 3) << 16) | (((n0 + n1 + 1u) >> 3) << 24);
-    }
 }
 
 // =================================================================================================
@@ -402,14 +396,14 @@ __host__ __device__ constexpr int tb_segments(int nsteps, int seg_steps) { retur
 // made the one-block version the 50 us tail of a 2 ms call.  One thread per frame throughout.
 constexpr int kScanBlock = 256;
 
-struct ScanQ { int64_t v[4]; };          // data symbols, soft bytes (256-aligned), decision words, chain-back segments
+struct ScanQ { int64_t v[4]; };          // data symbols, (unused), per-step words (soft pairs / decisions / decoded), chain-back segments
 
 __device__ __forceinline__ ScanQ scan_quantities(const FrameInfo *info, int f, int n_frames, int seg_steps)
 {
     ScanQ q = { { 0, 0, 0, 0 } };
     if (f < n_frames) {
         const int nsym = info[f].nsym, nsteps = nsym > 0 ? info[f].nsteps : 0;
-        q.v[0] = nsym; q.v[1] = ((int64_t)2 * nsteps + 255) & ~(int64_t)255; q.v[2] = dec_words(nsteps); q.v[3] = tb_segments(nsteps, seg_steps);
+        q.v[0] = nsym; q.v[1] = 0; q.v[2] = dec_words(nsteps); q.v[3] = tb_segments(nsteps, seg_steps);
     }
     return q;
 }
@@ -488,7 +482,7 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(int64_t *__restrict__ blk,
 // pass 3: offsets into the frame records (frames that do not fit are marked FOA_ST_NO_SPACE), and the symbol -> frame
 // and segment -> frame maps (so that the data-symbol and chain-back kernels find their frame without a search;
 // frames are short: <= 1368 symbols)
-__global__ __launch_bounds__(kScanBlock) void k_scan_apply(FrameInfo *__restrict__ info, int n_frames, int64_t sym_cap, int64_t soft_cap,
+__global__ __launch_bounds__(kScanBlock) void k_scan_apply(FrameInfo *__restrict__ info, int n_frames, int64_t sym_cap,
                                                            int64_t dec_cap, int seg_steps, int64_t seg_cap, const int64_t *__restrict__ blk,
                                                            int32_t *__restrict__ sym2frame, int32_t *__restrict__ seg2frame)
 {
@@ -498,19 +492,19 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_apply(FrameInfo *__restrict
     int64_t tot[4];
     const ScanQ ex = block_exclusive_scan(q, tot, part);
     if (f >= n_frames) return;
-    const int64_t a = ex.v[0] + blk[blockIdx.x], b = ex.v[1] + blk[(size_t)gridDim.x + blockIdx.x],
+    const int64_t a = ex.v[0] + blk[blockIdx.x],
                   c = ex.v[2] + blk[(size_t)2 * gridDim.x + blockIdx.x], d = ex.v[3] + blk[(size_t)3 * gridDim.x + blockIdx.x];
     const int nsym = (int)q.v[0];
     info[f].seg_off = (int32_t)d;
     const int ns = (int)q.v[3];
-    if (nsym > 0 && (a + nsym > sym_cap || b + q.v[1] > soft_cap || c + q.v[2] > dec_cap)) {
+    if (nsym > 0 && (a + nsym > sym_cap || c + q.v[2] > dec_cap)) {
         // keeps its slots in the numbering; they are marked unused (as far as the maps reach)
         info[f].status = FOA_ST_NO_SPACE; info[f].nsteps = -nsym; info[f].nsym = 0;
         for (int k = 0; k < nsym; k++) if (a + k < sym_cap) sym2frame[a + k] = -1;
         for (int k = 0; k < ns; k++) if (d + k < seg_cap) seg2frame[d + k] = -1;
         return;
     }
-    info[f].sym_off = (int32_t)a; info[f].soft_off = b; info[f].dec_off = c;
+    info[f].sym_off = (int32_t)a; info[f].soft_off = 2 * c; info[f].dec_off = c;    // (soft_off: byte offset of the frame's soft pairs)
     for (int k = 0; k < nsym; k++) sym2frame[a + k] = f;
     for (int k = 0; k < ns; k++) if (d + k < seg_cap) seg2frame[d + k] = f;
 }
@@ -523,7 +517,7 @@ constexpr int kSymWaves = 4;
 __global__ __launch_bounds__(64 * kSymWaves) void k_data_symbols(const float2 *__restrict__ iq, const foa_frame_desc *__restrict__ descs,
                                                                  const FrameInfo *__restrict__ info, const int32_t *__restrict__ sym2frame,
                                                                  const int64_t *__restrict__ totals, const double2 *__restrict__ hinv,
-                                                                 uint8_t *__restrict__ soft, uint32_t *__restrict__ bm, double2 *__restrict__ eq_tap)
+                                                                 uint16_t *__restrict__ sp, double2 *__restrict__ eq_tap)
 {
     __shared__ cpx lds_all[kSymWaves][64];
     __shared__ __attribute__((aligned(16))) uint8_t stage_all[kSymWaves][448];
@@ -546,7 +540,7 @@ __global__ __launch_bounds__(64 * kSymWaves) void k_data_symbols(const float2 *_
     const int di = g_tab.data_index[s];
     if (eq_tap && di >= 0) eq_tap[(size_t)w * 48 + di] = make_double2(z.x, z.y);          // data tap: one row per symbol
 
-    emit_symbol_soft(z, di, rr, stage, soft + fi.soft_off + (int64_t)(k - 1) * 2 * rr.dbps, bm + fi.dec_off + (int64_t)(k - 1) * rr.dbps, lane);
+    emit_symbol_soft(z, di, rr, stage, sp + fi.dec_off + (int64_t)(k - 1) * rr.dbps, lane);
 }
 
 }  // namespace foa

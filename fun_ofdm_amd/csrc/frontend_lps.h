@@ -5,7 +5,7 @@
 // puncturer.cpp:78-123), same operation order (so the results are bit-identical to that kernel), but each lane
 // owns a whole symbol: the 64 samples, the radix-4 butterflies and the 48 equalised carriers live in its own
 // registers.  Nothing is exchanged between lanes and nothing is computed 64-fold redundantly (LDS only stages the coalesced
-// loads and stores and holds the demapping / branch-metric tables);
+// loads and stores and holds the demapping table);
 // per symbol this issues roughly 1/10 of the instructions of the wave-per-symbol kernel.  All indices
 // (butterfly wiring, subcarrier order, interleaver and puncturing positions) are compile-time constants of the
 // unrolled code, selected per rate by a wave-uniform switch (lanes of other rates, if any, wait their turn).
@@ -74,13 +74,6 @@ __device__ __forceinline__ void qam_decode_n(double sym, double scale_d, uint32_
     }
 }
 
-// viterbi.cpp:242-247 for the four Branchtab classes at once: byte j = 2*b0 + b1 holds (((s0^b0*255) + (s1^b1*255) + 1) >> 1) >> 2
-__device__ __forceinline__ uint32_t bm_word(uint32_t s0, uint32_t s1)
-{
-    const uint32_t n0 = s0 ^ 255u, n1 = s1 ^ 255u;
-    return ((s0 + s1 + 1u) >> 3) | (((s0 + n1 + 1u) >> 3) << 8) | (((n0 + s1 + 1u) >> 3) << 16) | (((n0 + n1 + 1u) >> 3) << 24);
-}
-
 // qam.h:110-125 through the table: the three soft bytes of one axis in one dword
 __device__ __forceinline__ uint32_t qam_lookup(const uint32_t *qam, double sym, double scale_d)
 {
@@ -91,21 +84,20 @@ __device__ __forceinline__ uint32_t qam_lookup(const uint32_t *qam, double sym, 
 
 // LDS of one wave: staging rows for the coalesced input loads and output stores, and the look-up tables
 struct LpsShared {
-    uint32_t qam[641], bm_sum[511], bm_dif[511];
+    uint32_t qam[641];
     int64_t in_base[64];                 // per lane: first sample index of its symbol
-    int64_t out_base[64];                // per lane: first bm word index of its symbol
+    int64_t out_base[64];                // per lane: index of its symbol's first soft pair
     float4 in[64][9];                    // 16 samples (8 x 16 B) per lane and round, one 16-B pad
-    uint4 out[64][10];                   // up to 36 words (9 x 16 B) per lane and interleaver block, one pad
+    uint2 out[64][10];                   // up to 36 soft pairs (9 x 8 B) per lane and interleaver block, one pad
 };
 
-// Soft bytes of one symbol -> branch-metric words (and, if asked, the depunctured bytes themselves).
+// Soft bytes of one symbol in depunctured order, two per trellis step.
 // zx: the derotated carriers in FFT register order (data carrier di at index subcarrier_lane(data_subcarrier(di))).
 // Works through the symbol in 48-byte interleaver blocks (BPSC of them).  COOP: all 64 lanes run this body together,
-// so each block's words go through LDS and leave as 16-byte pieces, consecutive lanes writing consecutive pieces
-// (a lane-private run of 24-36 words per block would otherwise cost 64 separate 4-byte transactions per store).
+// so each block's pairs go through LDS and leave as 8-byte pieces, consecutive lanes writing consecutive pieces
+// (a lane-private run of 24-36 pairs per block would otherwise cost 64 separate 2-byte transactions per store).
 template <int BPSC, int PUNCT, bool COOP>
-__device__ __forceinline__ void emit_symbol_lps(const cpx (&zx)[64], double scale_d, uint32_t *__restrict__ bm, int64_t my_out,
-                                                uint8_t *__restrict__ soft_dst, LpsShared *sh, int lane)
+__device__ __forceinline__ void emit_symbol_lps(const cpx (&zx)[64], double scale_d, uint16_t *__restrict__ sp, int64_t my_out, LpsShared *sh, int lane)
 {
     constexpr int NB = BPSC == 1 ? 1 : BPSC / 2;
     constexpr int CPB = 48 / BPSC;                                  // carriers per 48-byte block
@@ -126,7 +118,8 @@ __device__ __forceinline__ void emit_symbol_lps(const cpx (&zx)[64], double scal
             }
         }
         // puncturer.cpp:94-102,112-118: step -> (first, second) soft byte, 127 where punctured
-        auto soft_pair = [&](int t, uint32_t &s0, uint32_t &s1) {
+        auto soft_pair = [&](int t) -> uint32_t {
+            uint32_t s0, s1;
             if (PUNCT == 0) { s0 = d[2 * t]; s1 = d[2 * t + 1]; }
             else if (PUNCT == 2) {                                  // 4 in -> {d0,d1,127,d2,127,d3}
                 const int g = t / 3, r = t % 3;
@@ -137,63 +130,51 @@ __device__ __forceinline__ void emit_symbol_lps(const cpx (&zx)[64], double scal
                 s0 = r == 0 ? d[3 * g] : d[3 * g + 1];
                 s1 = r == 0 ? 127u : d[3 * g + 2];
             }
+            return s0 | (s1 << 8);
         };
-        uint32_t wds[STEPS];
+        uint32_t wds[STEPS / 2];                                    // two steps per dword
 #pragma unroll
-        for (int t = 0; t < STEPS; t++) {
-            uint32_t s0, s1;
-            soft_pair(t, s0, s1);
-            wds[t] = sh->bm_sum[s0 + s1] | sh->bm_dif[s0 + 255u - s1];
-        }
-        if (soft_dst) {                                             // diagnostics only: one branch per block, not per step
-#pragma unroll
-            for (int t = 0; t < STEPS; t++) {
-                uint32_t s0, s1;
-                soft_pair(t, s0, s1);
-                *(uint16_t *)(soft_dst + 2 * (q * STEPS + t)) = (uint16_t)(s0 | (s1 << 8));
-            }
-        }
+        for (int t = 0; t < STEPS; t += 2) wds[t / 2] = soft_pair(t) | (soft_pair(t + 1) << 16);
         if constexpr (COOP) {
 #pragma unroll
-            for (int i = 0; i < PIECES; i++) sh->out[lane][i] = make_uint4(wds[4 * i], wds[4 * i + 1], wds[4 * i + 2], wds[4 * i + 3]);
+            for (int i = 0; i < PIECES; i++) sh->out[lane][i] = make_uint2(wds[2 * i], wds[2 * i + 1]);
             wave_lds_sync();
 #pragma unroll
             for (int it = 0; it < PIECES; it++) {
                 const int idx = it * 64 + lane, seg = idx / PIECES, part = idx % PIECES;
-                *(uint4 *)(bm + sh->out_base[seg] + q * STEPS + 4 * part) = sh->out[seg][part];
+                *(uint2 *)(sp + sh->out_base[seg] + q * STEPS + 4 * part) = sh->out[seg][part];
             }
             wave_lds_sync();
         } else {
 #pragma unroll
-            for (int t = 0; t < STEPS; t++) bm[my_out + q * STEPS + t] = wds[t];
+            for (int t = 0; t < STEPS / 2; t++) *(uint32_t *)(sp + my_out + q * STEPS + 2 * t) = wds[t];
         }
     }
 }
 
 template <bool COOP>
-__device__ __forceinline__ void emit_by_rate(int rate, const cpx (&x)[64], double scale_d, uint32_t *bm, int64_t my_out, uint8_t *soft_dst,
-                                             LpsShared *sh, int lane)
+__device__ __forceinline__ void emit_by_rate(int rate, const cpx (&x)[64], double scale_d, uint16_t *sp, int64_t my_out, LpsShared *sh, int lane)
 {
     // one unrolled body per (modulation, puncturing)
     switch (rate) {
-    case 0: emit_symbol_lps<1, 0, COOP>(x, scale_d, bm, my_out, soft_dst, sh, lane); break;
-    case 1: emit_symbol_lps<1, 1, COOP>(x, scale_d, bm, my_out, soft_dst, sh, lane); break;
-    case 2: emit_symbol_lps<1, 2, COOP>(x, scale_d, bm, my_out, soft_dst, sh, lane); break;
-    case 3: emit_symbol_lps<2, 0, COOP>(x, scale_d, bm, my_out, soft_dst, sh, lane); break;
-    case 4: emit_symbol_lps<2, 1, COOP>(x, scale_d, bm, my_out, soft_dst, sh, lane); break;
-    case 5: emit_symbol_lps<2, 2, COOP>(x, scale_d, bm, my_out, soft_dst, sh, lane); break;
-    case 6: emit_symbol_lps<4, 0, COOP>(x, scale_d, bm, my_out, soft_dst, sh, lane); break;
-    case 7: emit_symbol_lps<4, 1, COOP>(x, scale_d, bm, my_out, soft_dst, sh, lane); break;
-    case 8: emit_symbol_lps<4, 2, COOP>(x, scale_d, bm, my_out, soft_dst, sh, lane); break;
-    case 9: emit_symbol_lps<6, 1, COOP>(x, scale_d, bm, my_out, soft_dst, sh, lane); break;
-    default: emit_symbol_lps<6, 2, COOP>(x, scale_d, bm, my_out, soft_dst, sh, lane); break;
+    case 0: emit_symbol_lps<1, 0, COOP>(x, scale_d, sp, my_out, sh, lane); break;
+    case 1: emit_symbol_lps<1, 1, COOP>(x, scale_d, sp, my_out, sh, lane); break;
+    case 2: emit_symbol_lps<1, 2, COOP>(x, scale_d, sp, my_out, sh, lane); break;
+    case 3: emit_symbol_lps<2, 0, COOP>(x, scale_d, sp, my_out, sh, lane); break;
+    case 4: emit_symbol_lps<2, 1, COOP>(x, scale_d, sp, my_out, sh, lane); break;
+    case 5: emit_symbol_lps<2, 2, COOP>(x, scale_d, sp, my_out, sh, lane); break;
+    case 6: emit_symbol_lps<4, 0, COOP>(x, scale_d, sp, my_out, sh, lane); break;
+    case 7: emit_symbol_lps<4, 1, COOP>(x, scale_d, sp, my_out, sh, lane); break;
+    case 8: emit_symbol_lps<4, 2, COOP>(x, scale_d, sp, my_out, sh, lane); break;
+    case 9: emit_symbol_lps<6, 1, COOP>(x, scale_d, sp, my_out, sh, lane); break;
+    default: emit_symbol_lps<6, 2, COOP>(x, scale_d, sp, my_out, sh, lane); break;
     }
 }
 
 __global__ __launch_bounds__(64) void k_data_symbols_lps(const float2 *__restrict__ iq, const foa_frame_desc *__restrict__ descs,
                                                          const FrameInfo *__restrict__ info, const int32_t *__restrict__ sym2frame,
                                                          const int64_t *__restrict__ totals, const double2 *__restrict__ hinv,
-                                                         uint8_t *__restrict__ soft, uint32_t *__restrict__ bm, double2 *__restrict__ eq_tap)
+                                                         uint16_t *__restrict__ sp, double2 *__restrict__ eq_tap)
 {
     __shared__ LpsShared sh;
     const int lane = threadIdx.x;
@@ -202,7 +183,6 @@ __global__ __launch_bounds__(64) void k_data_symbols_lps(const float2 *__restric
     if (w0 >= total) return;
     // tables first, while all 64 lanes are still here (the next wave_lds_sync orders them)
     for (int i = lane; i < 641; i += 64) sh.qam[i] = g_tab.qam_lut[i];
-    for (int i = lane; i < 511; i += 64) { sh.bm_sum[i] = g_tab.bm_sum[i]; sh.bm_dif[i] = g_tab.bm_dif[i]; }
     // lanes past the end (or in unused slots) shadow the wave's first symbol and write nothing
     int f = w < total ? sym2frame[w] : -1;
     const bool valid = f >= 0;
@@ -276,9 +256,8 @@ __global__ __launch_bounds__(64) void k_data_symbols_lps(const float2 *__restric
             eq_tap[(size_t)w * 48 + di] = make_double2(zc.x, zc.y);
         }
     }
-    uint8_t *soft_dst = (soft && valid) ? soft + fi.soft_off + (int64_t)(k - 1) * 2 * rr.dbps : nullptr;
-    if (coop) emit_by_rate<true>(__builtin_amdgcn_readfirstlane(fi.rate), x, rr.scale_d, bm, my_out, soft_dst, &sh, lane);
-    else if (valid) emit_by_rate<false>(fi.rate, x, rr.scale_d, bm, my_out, soft_dst, &sh, lane);
+    if (coop) emit_by_rate<true>(__builtin_amdgcn_readfirstlane(fi.rate), x, rr.scale_d, sp, my_out, &sh, lane);
+    else if (valid) emit_by_rate<false>(fi.rate, x, rr.scale_d, sp, my_out, &sh, lane);
 }
 
 }  // namespace foa

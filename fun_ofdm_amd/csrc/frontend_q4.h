@@ -12,7 +12,7 @@
 //   * equaliser, derotation and soft demapping stay per lane (12 data carriers each on average); the four pilot
 //     terms live in lanes 1 and 2 and are broadcast so that every lane adds them in the reference's order;
 //   * soft bytes are scattered into the symbol's depunctured order in LDS ((carrier, bit) -> position table per
-//     rate), and each lane turns 4 consecutive trellis steps at a time into branch-metric words: 16-byte stores.
+//     rate), and leave in 8-byte stores, four trellis steps per lane and trip.
 // Measured alone (config 2): 0.31 ms against 0.34 ms for the lane-per-symbol kernel, although the fp64 butterflies issue at
 // about 6 clocks per wave instruction and the quad layout spends 1 640 VALU instructions per 16 symbols where
 // lane-per-symbol spends 4 400 per 64: its waves are small (<= 176 VGPRs against 512), so several share a SIMD and hide each
@@ -27,7 +27,7 @@ namespace foa {
 #ifndef FOA_Q4_WAVES
 #define FOA_Q4_WAVES 4
 #endif
-constexpr int kQ4Waves = FOA_Q4_WAVES;       // waves per block: FOUR, one per SIMD (14 KB of tables + 7 KB per wave = 42 KB of LDS).
+constexpr int kQ4Waves = FOA_Q4_WAVES;       // waves per block: FOUR, one per SIMD (10 KB of tables + 7 KB per wave = 38 KB of LDS).
                                              // With five (a block's waves go round the SIMDs, so the fifth doubles up on one) the
                                              // kernel alone took 0.447 ms instead of 0.308 and the pipelined step 1.32 ms instead
                                              // of 1.21 (2, 3, 6 waves per block: 1.23; 8: 1.28).  The register budget does not
@@ -42,7 +42,7 @@ struct Q4Wave {                              // LDS private to one wave
 };
 
 struct Q4Shared {
-    uint32_t qam[641], bm_sum[511], bm_dif[511];
+    uint32_t qam[641];
     double2 tw[64];                          // exp(-2 pi j k / 64)
     uint16_t pos[kNumRates][288];            // demodulated byte (carrier * bpsc + bit) -> depunctured position
     int8_t dindex[64];                       // subcarrier index -> data carrier 0..47, -1 otherwise
@@ -60,11 +60,10 @@ __device__ __forceinline__ void q4_butterfly(cpx a, cpx b, cpx c, cpx d, cpx &y0
 }
 
 // Equalise + derotate this lane's data carriers, demap them, scatter the soft bytes into the symbol's depunctured order and
-// turn them into branch-metric words.  BPSC > 0: bits per carrier known at compile time (rr / rate wave-uniform); 0: generic.
+// store them.  BPSC > 0: bits per carrier known at compile time (rr / rate wave-uniform); 0: generic.
 template <int BPSC>
 __device__ __forceinline__ void q4_emit(Q4Shared &sh, Q4Wave &ws, const cpx (&X)[16], cpx rot, const double2 *__restrict__ h, const RateRow &rr, int rate,
-                                        int qd, int m, bool valid, int64_t w, int64_t my_out, const FrameInfo &fi, int k,
-                                        uint8_t *__restrict__ soft, uint32_t *__restrict__ bm, double2 *__restrict__ eq_tap)
+                                        int qd, int m, bool valid, int64_t w, int64_t my_out, uint16_t *__restrict__ sp, double2 *__restrict__ eq_tap)
 {
     // the symbol's depunctured soft bytes start as erasures (puncturer.cpp:94-102)
     {
@@ -102,27 +101,18 @@ __device__ __forceinline__ void q4_emit(Q4Shared &sh, Q4Wave &ws, const cpx (&X)
         }
     }
     wave_lds_sync();
-    // ---- four trellis steps (8 soft bytes) per lane and trip -> branch-metric words (viterbi.cpp:242-247) ----
-    uint8_t *soft_dst = (soft && valid) ? soft + fi.soft_off + (int64_t)(k - 1) * 2 * rr.dbps : nullptr;
-    const int ngroups = rr.dbps / 4;
-    for (int g4 = m; g4 < ngroups; g4 += 4) {
-        const uint2 sb = *(const uint2 *)&ws.soft[qd][8 * g4];
-        uint32_t wd[4];
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const uint32_t pair = (t < 2 ? sb.x : sb.y) >> (16 * (t & 1));
-            const uint32_t s0 = pair & 255u, s1 = (pair >> 8) & 255u;
-            wd[t] = sh.bm_sum[s0 + s1] | sh.bm_dif[s0 + 255u - s1];
-        }
-        if (valid) *(uint4 *)(bm + my_out + 4 * g4) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
-        if (soft_dst) *(uint2 *)(soft_dst + 8 * g4) = sb;
+    // ---- the symbol's depunctured soft bytes leave as they are, two per trellis step (the forward pass forms the branch
+    // metrics of viterbi.cpp:242-247 from them when it stages a chunk): 8 bytes = four steps per lane and trip ----
+    if (valid) {
+        const int ngroups = rr.dbps / 4;
+        for (int g4 = m; g4 < ngroups; g4 += 4) *(uint2 *)(sp + my_out + 4 * g4) = *(const uint2 *)&ws.soft[qd][8 * g4];
     }
 }
 
 __global__ __launch_bounds__(64 * kQ4Waves)
 void k_data_symbols_q4(const float2 *__restrict__ iq, const foa_frame_desc *__restrict__ descs, const FrameInfo *__restrict__ info,
                        const int32_t *__restrict__ sym2frame, const int64_t *__restrict__ totals, const double2 *__restrict__ hinv,
-                       uint8_t *__restrict__ soft, uint32_t *__restrict__ bm, double2 *__restrict__ eq_tap)
+                       uint16_t *__restrict__ sp, double2 *__restrict__ eq_tap)
 {
     __shared__ Q4Shared sh;
     // In the pipelined path this kernel and the chain-back run one after the other under a neighbouring call's forward pass
@@ -136,7 +126,6 @@ void k_data_symbols_q4(const float2 *__restrict__ iq, const foa_frame_desc *__re
     const int64_t total = min(totals[0], totals[3]);
     if ((int64_t)blockIdx.x * kQ4Waves * 16 >= total) return;       // the grid is sized by an upper bound: surplus blocks leave at once
     for (int i = tid; i < 641; i += 64 * kQ4Waves) sh.qam[i] = g_tab.qam_lut[i];
-    for (int i = tid; i < 511; i += 64 * kQ4Waves) { sh.bm_sum[i] = g_tab.bm_sum[i]; sh.bm_dif[i] = g_tab.bm_dif[i]; }
     static_assert(sizeof(sh.pos) == sizeof(g_tab.sym_pos) && sizeof(sh.pos) % 4 == 0 && offsetof(DeviceTables, sym_pos) % 4 == 0 &&
                   offsetof(Q4Shared, pos) % 4 == 0, "position tables are copied as dwords");
     for (int i = tid; i < (int)(sizeof(sh.pos) / 4); i += 64 * kQ4Waves) ((uint32_t *)sh.pos)[i] = ((const uint32_t *)g_tab.sym_pos)[i];
@@ -227,13 +216,13 @@ void k_data_symbols_q4(const float2 *__restrict__ iq, const foa_frame_desc *__re
     if (__all(rate == rate_u)) {
         const RateRow ru = g_tab.rates[rate_u];
         switch (ru.bpsc) {
-        case 1: q4_emit<1>(sh, ws, X, rot, h, ru, rate_u, qd, m, valid, w, my_out, fi, k, soft, bm, eq_tap); break;
-        case 2: q4_emit<2>(sh, ws, X, rot, h, ru, rate_u, qd, m, valid, w, my_out, fi, k, soft, bm, eq_tap); break;
-        case 4: q4_emit<4>(sh, ws, X, rot, h, ru, rate_u, qd, m, valid, w, my_out, fi, k, soft, bm, eq_tap); break;
-        default: q4_emit<6>(sh, ws, X, rot, h, ru, rate_u, qd, m, valid, w, my_out, fi, k, soft, bm, eq_tap); break;
+        case 1: q4_emit<1>(sh, ws, X, rot, h, ru, rate_u, qd, m, valid, w, my_out, sp, eq_tap); break;
+        case 2: q4_emit<2>(sh, ws, X, rot, h, ru, rate_u, qd, m, valid, w, my_out, sp, eq_tap); break;
+        case 4: q4_emit<4>(sh, ws, X, rot, h, ru, rate_u, qd, m, valid, w, my_out, sp, eq_tap); break;
+        default: q4_emit<6>(sh, ws, X, rot, h, ru, rate_u, qd, m, valid, w, my_out, sp, eq_tap); break;
         }
     } else {
-        q4_emit<0>(sh, ws, X, rot, h, rr, rate, qd, m, valid, w, my_out, fi, k, soft, bm, eq_tap);
+        q4_emit<0>(sh, ws, X, rot, h, rr, rate, qd, m, valid, w, my_out, sp, eq_tap);
     }
 }
 

@@ -85,16 +85,15 @@ __global__ __launch_bounds__(64) void k_stage_header(const double2 *__restrict__
 }
 
 // viterbi::conv_decode through the packed kernels (foa_conv_decode with option "viterbi" = 1 or 2): the soft bytes of
-// block blockIdx.y -> one branch-metric dword per trellis step in the block's region, exactly what the front end hands
-// the forward pass (viterbi.cpp:242-247 per Branchtab class; emit_symbol_soft).
-__global__ __launch_bounds__(256) void k_conv_bm(const uint8_t *__restrict__ symbols, size_t sym_stride, int T, const FrameInfo *__restrict__ info,
-                                                 uint32_t *__restrict__ bm)
+// block blockIdx.y go into the block's region as they are, two per trellis step -- exactly what the front end hands the
+// forward pass.
+__global__ __launch_bounds__(256) void k_conv_sp(const uint8_t *__restrict__ symbols, size_t sym_stride, int T, const FrameInfo *__restrict__ info,
+                                                 uint16_t *__restrict__ sp)
 {
     const int b = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
     if (t >= T) return;
-    const uint8_t *sp = symbols + (size_t)b * sym_stride + 2 * (size_t)t;
-    const uint32_t s0 = sp[0], s1 = sp[1], n0 = s0 ^ 255u, n1 = s1 ^ 255u;
-    bm[info[b].dec_off + t] = ((s0 + s1 + 1u) >> 3) | (((s0 + n1 + 1u) >> 3) << 8) | (((n0 + s1 + 1u) >> 3) << 16) | (((n0 + n1 + 1u) >> 3) << 24);
+    const uint8_t *s = symbols + (size_t)b * sym_stride + 2 * (size_t)t;
+    sp[info[b].dec_off + t] = (uint16_t)(s[0] | (s[1] << 8));
 }
 
 // ... and the decoded bytes (MSB-first, as the chain-back kernels leave them) of every block, packed
@@ -110,7 +109,7 @@ __global__ __launch_bounds__(256) void k_conv_pack(const uint32_t *__restrict__ 
 // front half of ppdu::decode_data (ppdu.cpp:238-244) from derotated carriers: one wave per data symbol
 __global__ __launch_bounds__(64 * kSymWaves) void k_stage_demap(const double2 *__restrict__ carriers, const int64_t *__restrict__ car_off,
                                                                 const FrameInfo *__restrict__ info, const int32_t *__restrict__ sym2frame,
-                                                                int n_sym, uint8_t *__restrict__ soft, uint32_t *__restrict__ bm)
+                                                                int n_sym, uint16_t *__restrict__ sp)
 {
     __shared__ __attribute__((aligned(16))) uint8_t stage_all[kSymWaves][448];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -123,7 +122,7 @@ __global__ __launch_bounds__(64 * kSymWaves) void k_stage_demap(const double2 *_
     cpx z = { 0.0, 0.0 };
     const int di = lane < 48 ? lane : -1;
     if (di >= 0) { const double2 c = carriers[car_off[f] + (size_t)k * 48 + lane]; z = cpx{ c.x, c.y }; }
-    emit_symbol_soft(z, di, rr, stage_all[wave], soft + fi.soft_off + (int64_t)k * 2 * rr.dbps, bm + fi.dec_off + (int64_t)k * rr.dbps, lane);
+    emit_symbol_soft(z, di, rr, stage_all[wave], sp + fi.dec_off + (int64_t)k * rr.dbps, lane);
 }
 
 }  // namespace foa

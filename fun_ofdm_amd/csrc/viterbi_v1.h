@@ -106,7 +106,7 @@ __device__ __forceinline__ void viterbi_forward_wave(const uint16_t *__restrict_
     }
 }
 
-__global__ __launch_bounds__(64) void k_viterbi_v1(const FrameInfo *__restrict__ info, int n_frames, const uint8_t *__restrict__ soft,
+__global__ __launch_bounds__(64) void k_viterbi_v1(const FrameInfo *__restrict__ info, int n_frames, const uint16_t *__restrict__ sp,
                                                    uint64_t *__restrict__ dec, uint8_t *__restrict__ psdu, size_t slot_bytes,
                                                    foa_frame_result *__restrict__ results)
 {
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(64) void k_viterbi_v1(const FrameInfo *__restrict__
     for (int i = lane; i < 256; i += 64) crc_tab[i] = g_tab.crc_table[i];
     const int T = fi.nsteps;
     uint64_t *dp = dec + fi.dec_off;
-    viterbi_forward_wave((const uint16_t *)(soft + fi.soft_off), T, dp, lane);
+    viterbi_forward_wave(sp + fi.dec_off, T, dp, lane);
     __syncthreads();
     int ok = finish_frame_wave(
         fi, [&](int base, int l) -> uint64_t { return base + l < T ? dp[base + l] : 0ull; }, decoded, crc_tab,

@@ -12,8 +12,8 @@
 //     serves both lanes of a pair; only the branch-metric increments differ per lane (constants per phase).
 //   * A VGPR carries the two frames' metrics as u16 halves biased by 0xFF00: `v_pk_add_u16 ... clamp`
 //     saturates at 0xFFFF exactly where `_mm_adds_epu8` saturates at 255; min/compare are bias-invariant.
-//   * Branch metrics arrive precomputed (one dword m00,m01,m10,m11 per step and frame, written by
-//     the front end); a lane selects its butterfly's Branchtab class with one v_perm_b32.
+//   * The front end delivers the two soft bytes of every step; when a chunk is staged, lane = step turns its pair into
+//     the dword (m00,m01,m10,m11) and in the step a lane selects its butterfly's Branchtab class with one v_perm_b32.
 //   * The 64 decision bits of a step are the lane mask of one v_cmp per frame; the mask is parked in lane J of a
 //     VGPR pair (plain v_mov under a one-lane EXEC) and a chunk of 60 steps leaves as one coalesced store.  Bit p of the word of step t says
 //     "slot p's survivor came from the pair's HIGH slot", which is all the chain-back needs:
@@ -81,6 +81,14 @@ __device__ __forceinline__ void dec_put_dyn(DecAcc &a, uint64_t v, int j, int la
 {
     a.lo = lane == j ? (uint32_t)v : a.lo;
     a.hi = lane == j ? (uint32_t)(v >> 32) : a.hi;
+}
+
+// viterbi.cpp:242-247 for the four Branchtab classes of one step: byte 2*b0 + b1 = (((s0 ^ b0*255) + (s1 ^ b1*255) + 1) >> 1) >> 2,
+// from the step's soft pair (s0 | s1 << 8)
+__device__ __forceinline__ uint32_t bm_word_of_pair(uint32_t pair)
+{
+    const uint32_t s0 = pair & 255u, s1 = (pair >> 8) & 255u, n0 = s0 ^ 255u, n1 = s1 ^ 255u;
+    return ((s0 + s1 + 1u) >> 3) | (((s0 + n1 + 1u) >> 3) << 8) | (((n0 + s1 + 1u) >> 3) << 16) | (((n0 + n1 + 1u) >> 3) << 24);
 }
 
 // 6-bit rotate left
@@ -227,7 +235,7 @@ __device__ __forceinline__ uint32_t fwd2_step_dyn(uint32_t M, int j, bool sa, bo
 constexpr int kFwdWaves = FOA_FWD_WAVES;     // waves (frame pairs) per workgroup: whole workgroups spread evenly over a CU's four SIMDs
 
 __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd2(const FrameInfo *__restrict__ info, int n_frames,
-                                                                 const uint32_t *__restrict__ bm, uint64_t *__restrict__ dec)
+                                                                 const uint16_t *__restrict__ sp, uint64_t *__restrict__ dec)
 {
     __shared__ uint2 bml_all[kFwdWaves][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -241,7 +249,7 @@ __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd2(const FrameInfo
     const int TB = (fB < n_frames && ib.nsym > 0) ? ib.nsteps : 0;
     const int T = max(TA, TB), Tboth = min(TA, TB);
     if (T == 0) return;
-    const uint32_t *bmA = bm + ia.dec_off, *bmB = bm + ib.dec_off;
+    const uint16_t *spA = sp + ia.dec_off, *spB = sp + ib.dec_off;
     uint64_t *dA = dec + ia.dec_off, *dB = dec + ib.dec_off;
     const Fwd2Lane c = fwd2_lane_init(lane);
     uint32_t M = lane == 0 ? kBias2 : kBias2 + 0x003F003Fu;               // viterbi.cpp:71-78 (label 0 = slot 0)
@@ -249,7 +257,7 @@ __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd2(const FrameInfo
     for (int t0 = 0; t0 < T; t0 += kChunk) {                              // t0 mod 6 == 0: phase = chunk-relative index mod 6
         const int nn = min(kChunk, T - t0);
         __builtin_amdgcn_wave_barrier();
-        bml[lane] = make_uint2(t0 + lane < TA ? bmA[t0 + lane] : 0u, t0 + lane < TB ? bmB[t0 + lane] : 0u);
+        bml[lane] = make_uint2(t0 + lane < TA ? bm_word_of_pair(spA[t0 + lane]) : 0u, t0 + lane < TB ? bm_word_of_pair(spB[t0 + lane]) : 0u);
         wave_lds_sync();
         DecAcc accA = { 0u, 0u }, accB = { 0u, 0u };
         if (t0 + kChunk <= Tboth) M = fwd2_chunk<true, true>(M, bml, c, accA, accB, lane);
@@ -516,10 +524,10 @@ __global__ __launch_bounds__(64) void k_viterbi_finish2(const FrameInfo *__restr
     finish_crc_psdu(tabs, fwave, fi, live, f, n_frames, decoded, psdu, slot_bytes, results);
 }
 
-inline void launch_viterbi_v2(hipStream_t st, const FrameInfo *info, int nf, const uint32_t *bm, uint64_t *dec, uint32_t *decoded,
+inline void launch_viterbi_v2(hipStream_t st, const FrameInfo *info, int nf, const uint16_t *sp, uint64_t *dec, uint32_t *decoded,
                               uint8_t *psdu, size_t slot_bytes, foa_frame_result *results, hipEvent_t between)
 {
-    hipLaunchKernelGGL(k_viterbi_fwd2, dim3(((nf + 1) / 2 + kFwdWaves - 1) / kFwdWaves), dim3(64 * kFwdWaves), 0, st, info, nf, bm, dec);
+    hipLaunchKernelGGL(k_viterbi_fwd2, dim3(((nf + 1) / 2 + kFwdWaves - 1) / kFwdWaves), dim3(64 * kFwdWaves), 0, st, info, nf, sp, dec);
     if (between) (void)hipEventRecord(between, st);
     hipLaunchKernelGGL(k_viterbi_finish2, dim3((nf + 63) / 64), dim3(64), 0, st, info, nf, dec, decoded, psdu, slot_bytes, results);
 }

@@ -14,7 +14,7 @@
 //     pbar = 63 - p simply copies the bit it reads:   pbar <- (pbar & ~(1<<q)) | (bit << q),  q = 5 - n mod 6.
 //     Steps 0..5 of the trellis carry no data bit (viterbi.cpp:131-142) and are not recorded at all: "data step"
 //     n = t - 6 is the index used from here on; block b holds data steps 16b .. 16b+15.
-//   * Branch-metric increments cost no VALU in the step: when a chunk's metric dwords are staged in LDS, each step
+//   * Branch-metric increments cost no VALU in the step: when a chunk's soft pairs are staged in LDS, each step
 //     gets all eight (Branchtab class, side of the butterfly) variants of the packed increment pair, and a lane
 //     reads the 8 bytes of its variant (v2: one v_perm + two v_xor per step; half the LDS bytes of reading both
 //     frames' dwords and their complements).
@@ -185,7 +185,7 @@ __device__ __forceinline__ uint32_t fwd3_step_dyn(uint32_t M, int j, const uint4
 
 // five resident waves per SIMD (10 000 frames = 4.9 waves per SIMD on 256 CUs): cap the register budget accordingly
 __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd3(const FrameInfo *__restrict__ info, int n_frames,
-                                                                 const uint32_t *__restrict__ bm, uint64_t *__restrict__ dec)
+                                                                 const uint16_t *__restrict__ sp, uint64_t *__restrict__ dec)
 {
     __shared__ uint4 bml_all[kFwdWaves][4 * kChunk3];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -205,25 +205,34 @@ __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd3(const FrameInfo
         return (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)v));
     };
     const int64_t offA = uniform64(ia.dec_off), offB = uniform64(ib.dec_off);     // scalar bases: addresses become base + lane
-    const uint32_t *bmA = bm + offA, *bmB = bm + offB;
+    const uint16_t *spA = sp + offA, *spB = sp + offB;
     uint16_t *dA = (uint16_t *)(dec + offA), *dB = (uint16_t *)(dec + offB);
     const Fwd3Lane c = fwd3_lane_init(lane);
     uint32_t M = lane == 0 ? kBias2 : kBias2 + 0x003F003Fu;               // viterbi.cpp:71-78 (label 0 = slot 0)
     uint32_t acc[3] = { 0u, 0u, 0u };
 
-    // The metric dwords of trellis steps t0 .. t0+47 (lane = step) are fetched one chunk ahead into registers, so a
-    // chunk never waits for HBM; put() turns them into staging entries 0 .. cnt-1.
+    // The soft pairs (s0 | s1 << 8, as the front end left them: 2 bytes per step, half of what metric words would move) of
+    // trellis steps t0 .. t0+47 (lane = step) are fetched one chunk ahead into registers, so a chunk never waits for HBM;
+    // put() turns them into the branch metrics of viterbi.cpp:242-247 for both frames at once --
+    //   (((s0 ^ b0*255) + (s1 ^ b1*255) + 1) >> 1) >> 2  =  (s0+s1+1)>>3, (s0-s1+256)>>3, (s1-s0+256)>>3, (511-s0-s1)>>3
+    // for (b0,b1) = 00, 01, 10, 11, frame A in the low half, frame B in the high half -- and into staging entries 0 .. cnt-1.
+    // (Measured: these ~17 extra VALU and 4 extra LDS instructions per 48 steps cost the kernel 4.7 %; hand-placed
+    // ds_write2_b32 pairs instead of the compiler's stores, or v_perm byte gathers, made it slower still.)
     uint32_t pa = 0, pb = 0;
     auto get = [&](int t0) {
-        pa = (lane < kChunk3 && t0 + lane < TA) ? bmA[t0 + lane] : 0u;
-        pb = (lane < kChunk3 && t0 + lane < TB) ? bmB[t0 + lane] : 0u;
+        pa = (lane < kChunk3 && t0 + lane < TA) ? (uint32_t)spA[t0 + lane] : 0u;
+        pb = (lane < kChunk3 && t0 + lane < TB) ? (uint32_t)spB[t0 + lane] : 0u;
     };
     auto put = [&](int cnt) {
         __builtin_amdgcn_wave_barrier();
         if (lane < cnt) {
+            const uint32_t s0 = (pa & 255u) | ((pb & 255u) << 16), s1 = (pa >> 8) | ((pb >> 8) << 16);     // packed halves (A, B), each <= 255
+            const uint32_t P = s0 + s1, D = s0 - s1 + 0x01000100u;                                              // <= 510, 1 .. 511 per half: no carries
+            const uint32_t m[4] = { ((P + 0x00010001u) >> 3) & 0x003F003Fu, (D >> 3) & 0x003F003Fu, ((0x02000200u - D) >> 3) & 0x003F003Fu,
+                                    ((0x01FF01FFu - P) >> 3) & 0x003F003Fu };
 #pragma unroll
             for (uint32_t cls = 0; cls < 4; cls++) {
-                const uint32_t lo = __builtin_amdgcn_perm(pb, pa, 0x0C000C00u | ((4u + cls) << 16) | cls), hi = lo ^ 0x003F003Fu;
+                const uint32_t lo = m[cls], hi = lo ^ 0x003F003Fu;
                 bml[4 * lane + cls] = make_uint4(lo, hi, hi, lo);
             }
         }
@@ -446,9 +455,9 @@ __global__ __launch_bounds__(64) void k_tb_finish(const FrameInfo *__restrict__ 
     finish_crc_psdu(tabs, fwave, fi, live, f, n_frames, decoded, psdu, slot_bytes, results);
 }
 
-inline void launch_fwd3(hipStream_t st, const FrameInfo *info, int nf, const uint32_t *bm, uint64_t *dec)
+inline void launch_fwd3(hipStream_t st, const FrameInfo *info, int nf, const uint16_t *sp, uint64_t *dec)
 {
-    hipLaunchKernelGGL(k_viterbi_fwd3, dim3(((nf + 1) / 2 + kFwdWaves - 1) / kFwdWaves), dim3(64 * kFwdWaves), 0, st, info, nf, bm, dec);
+    hipLaunchKernelGGL(k_viterbi_fwd3, dim3(((nf + 1) / 2 + kFwdWaves - 1) / kFwdWaves), dim3(64 * kFwdWaves), 0, st, info, nf, sp, dec);
 }
 
 inline void launch_finish3(hipStream_t st, const FrameInfo *info, int nf, const uint64_t *dec, uint32_t *decoded, const int32_t *seg2frame,
@@ -460,11 +469,11 @@ inline void launch_finish3(hipStream_t st, const FrameInfo *info, int nf, const 
     hipLaunchKernelGGL(k_tb_finish, dim3((nf + 63) / 64), dim3(64), 0, st, info, nf, dec, decoded, tb_state, S, psdu, slot_bytes, results);
 }
 
-inline void launch_viterbi_v3(hipStream_t st, const FrameInfo *info, int nf, const uint32_t *bm, uint64_t *dec, uint32_t *decoded,
+inline void launch_viterbi_v3(hipStream_t st, const FrameInfo *info, int nf, const uint16_t *sp, uint64_t *dec, uint32_t *decoded,
                               const int32_t *seg2frame, const int64_t *totals, uint16_t *tb_state, size_t max_segs, int S, int L,
                               uint8_t *psdu, size_t slot_bytes, foa_frame_result *results, hipEvent_t between)
 {
-    launch_fwd3(st, info, nf, bm, dec);
+    launch_fwd3(st, info, nf, sp, dec);
     if (between) (void)hipEventRecord(between, st);
     launch_finish3(st, info, nf, dec, decoded, seg2frame, totals, tb_state, max_segs, S, L, psdu, slot_bytes, results);
 }
