@@ -192,6 +192,8 @@ struct foa_rx {
     bool pipeline = true;        // v3: finish of one call overlaps the next call's front end (two work sets, two streams)
     bool record_eq = false;
     bool record_soft = true;     // (the soft bytes are the front end's output and always there; the option is accepted for compatibility)
+    int fe_hold = 1;             // pipelined path: 1 = header, scan and data symbols of call k+1 wait for the chain-back walk of call k-1;
+                                 // 2 = only the data-symbol kernel does; 0 = nothing is held back (A/B measurement)
     int frontend_kind = -1;      // 1: one lane per symbol (frontend_lps.h), 0: one wave per symbol, 2: four lanes per symbol (frontend_q4.h);
                                  // -1: the default, 2
     WorkSet sets[4];             // three are in use at any time (below); the fourth keeps the call before them readable (timings)
@@ -383,6 +385,11 @@ int foa_rx_set_option(foa_rx *rx, const char *name, int64_t value)
     }
     if (!strcmp(name, "pipeline")) { rx->pipeline = value != 0; return FOA_OK; }
     if (!strcmp(name, "record_eq")) { rx->record_eq = value != 0; return FOA_OK; }
+    if (!strcmp(name, "fe_hold")) {
+        if (value < 0 || value > 2) return fail(FOA_E_INVALID, "fe_hold must be 0, 1 or 2");
+        rx->fe_hold = (int)value;
+        return FOA_OK;
+    }
     if (!strcmp(name, "record_soft")) { rx->record_soft = value != 0; return FOA_OK; }
     if (!strcmp(name, "frontend")) {
         if (value < -1 || value > 2) return fail(FOA_E_INVALID, "frontend must be -1 (by context), 0 (wave per symbol), 1 (lane per symbol) or 2 (quad per symbol)");
@@ -442,8 +449,8 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
     // heavy guests at once slow each other and the forward pass down more than they gain (measured: 1.50 against 1.43 ms per
     // step; letting only the light header and scan run alongside the walk is no better: 1.52).  The stitch/CRC kernel
     // behind the walk is light and latency-bound, so the front end does not wait for that one.
-    if (piped && rx->prev->before && rx->prev->before->used && rx->prev->before->piped && rx->prev->before != rx->w)
-        HIP_TRY(hipStreamWaitEvent(st, rx->prev->before->walk_done, 0));
+    const bool can_hold = piped && rx->prev->before && rx->prev->before->used && rx->prev->before->piped && rx->prev->before != rx->w;
+    if (can_hold && rx->fe_hold == 1) HIP_TRY(hipStreamWaitEvent(st, rx->prev->before->walk_done, 0));
     if (!piped && rx->prev->used && rx->prev != rx->w) HIP_TRY(hipStreamWaitEvent(st, rx->prev->done, 0));
     const int nf = (int)n_frames;
     const float2 *iq = (const float2 *)d_iq;
@@ -463,6 +470,7 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
     HIP_TRY(hipEventRecord(rx->w->ev[2], st));
     // upper bound on data symbols in n_samples samples; waves beyond the real total exit at once
     const size_t max_sym = rx->w->sym_cap;
+    if (can_hold && rx->fe_hold == 2) HIP_TRY(hipStreamWaitEvent(st, rx->prev->before->walk_done, 0));
     const int frontend = rx->frontend_kind >= 0 ? rx->frontend_kind : 2;
     if (frontend == 2) {
         hipLaunchKernelGGL(k_data_symbols_q4, dim3((unsigned)((max_sym + 16 * kQ4Waves - 1) / (16 * kQ4Waves))), dim3(64 * kQ4Waves), 0, st, iq,
