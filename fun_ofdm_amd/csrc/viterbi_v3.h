@@ -223,6 +223,7 @@ __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd3(const FrameInfo
         pa = (lane < kChunk3 && t0 + lane < TA) ? (uint32_t)spA[t0 + lane] : 0u;
         pb = (lane < kChunk3 && t0 + lane < TB) ? (uint32_t)spB[t0 + lane] : 0u;
     };
+    const uint32_t bml_addr = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)bml + 64u * (uint32_t)lane;
     auto put = [&](int cnt) {
         __builtin_amdgcn_wave_barrier();
         if (lane < cnt) {
@@ -230,12 +231,17 @@ __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd3(const FrameInfo
             const uint32_t P = s0 + s1, D = s0 - s1 + 0x01000100u;                                              // <= 510, 1 .. 511 per half: no carries
             const uint32_t m[4] = { ((P + 0x00010001u) >> 3) & 0x003F003Fu, (D >> 3) & 0x003F003Fu, ((0x02000200u - D) >> 3) & 0x003F003Fu,
                                     ((0x01FF01FFu - P) >> 3) & 0x003F003Fu };
+            // (one 16-byte store per class, spelled out: left to itself the compiler breaks these into 4- and 8-byte stores at
+            // a 64-byte lane stride, which the LDS serves sixteen lanes to a bank)
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
             for (uint32_t cls = 0; cls < 4; cls++) {
                 const uint32_t lo = m[cls], hi = lo ^ 0x003F003Fu;
-                bml[4 * lane + cls] = make_uint4(lo, hi, hi, lo);
+                const u32x4 v = { lo, hi, hi, lo };
+                asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(bml_addr), "v"(v), "n"(16 * cls) : "memory");
             }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (the stores above are not the compiler's to wait for)
         wave_lds_sync();
     };
     get(0);

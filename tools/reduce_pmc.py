@@ -66,4 +66,26 @@ if lds:
                "frames_per_gpu": frames,
                "notes": "lds_bank_conflict_frac = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE (extra cycles over all LDS-array cycles); l2_hit_frac = TCC_HIT / (TCC_HIT + TCC_MISS), MI355X_MICROARCH.md L2 section",
                "per_launch": lds}, open(os.path.join(out, tag + "_pmc_lds_l2.json"), "w"), indent=1)
+# effective clock: GRBM_GUI_ACTIVE / launch duration (MI355X_MICROARCH.md "DVFS give-back"); the counter pass serialises kernels
+clk = {}
+for path in glob.glob(os.path.join(out, "pg", "**", "*counter_collection.csv"), recursive=True):
+    with open(path, newline="") as fh:
+        for row in csv.DictReader(fh):
+            low = {k.lower(): v for k, v in row.items()}
+            if low.get("counter_name") != "GRBM_GUI_ACTIVE" or "start_timestamp" not in low:
+                continue
+            name = low["kernel_name"].split("(")[0].split("::")[-1]
+            if not name.startswith("k_"):
+                continue
+            dur = float(low["end_timestamp"]) - float(low["start_timestamp"])
+            a = clk.setdefault(name, [0.0, 0.0, 0])
+            a[0] += float(low["counter_value"]); a[1] += dur; a[2] += 1
+if clk:
+    doc = {"command": "rocprofv3 --pmc GRBM_GUI_ACTIVE (own pass) -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra-legs --no-sync-leg " + " ".join(args),
+           "frames_per_gpu": frames,
+           "notes": "ghz = GRBM_GUI_ACTIVE / (End_Timestamp - Start_Timestamp) of the same dispatches; if the counter is summed over the 8 XCDs the "
+                    "figure is 8 x the clock (ghz_if_summed_over_8_xcd)",
+           "per_kernel": {k: {"launches": v[2], "GRBM_GUI_ACTIVE_per_launch": round(v[0] / v[2], 1), "duration_us_per_launch": round(v[1] / v[2] / 1e3, 2),
+                              "ghz": round(v[0] / v[1], 3), "ghz_if_summed_over_8_xcd": round(v[0] / v[1] / 8, 3)} for k, v in clk.items() if v[1] > 0}}
+    json.dump(doc, open(os.path.join(out, tag + "_pmc_clock.json"), "w"), indent=1)
 print(json.dumps(kern, indent=1))
