@@ -461,16 +461,16 @@ def roofline(args, kms, n_real, ms_per_step, piped):
         ach_gi = nv[0] / t_k / 1e9
         r["valu_issue"] = {"achieved": round(ach_gi, 1), "peak": round(peak_gi, 1), "unit": "G wave-instr/s", "frac": round(ach_gi / peak_gi, 4),
                            "valu_instr_per_launch": int(nv[0]), "source": "SQ_INSTS_VALU, profiles/%s; duration live from HIP events" % nv[1]}
-    # HBM: algorithmic bytes of this kernel = one branch-metric word in, 64 decision bits out per trellis step
-    alg_bytes = steps * (4 + 8)
+    # HBM: algorithmic bytes of this kernel = one soft pair (2 bytes) in, 64 decision bits out per trellis step
+    alg_bytes = steps * (2 + 8)
     tr = _profile_json("_pmc_hbm.json", "kernels", fwd_kernel, args.frames, "hbm_bytes_per_launch")
     r["traffic"] = tr[0] if tr else None
     r["hbm"] = {"achieved": round(alg_bytes / t_k / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(alg_bytes / t_k / 1e9 / HBM_PEAK_GBPS, 5),
                 "algorithmic_bytes_per_launch": int(alg_bytes), "traffic_source": tr[1] if tr else None,
                 "stage_bytes_survey_8d": int(n_real * 39 * (288 + 27)),
-                "note": "12 B per step is what this kernel's interface moves (4-byte metric word in, 8 bytes of decisions out); SURVEY 8d's "
-                        "figure for a fused Viterbi stage is 288 B in + 27 B out per symbol (stage_bytes_survey_8d): decisions and metric "
-                        "words crossing HBM are 8.2 x that"}
+                "note": "10 B per step is what this kernel's interface moves (2 depunctured soft bytes in, 8 bytes of decisions out); SURVEY 8d's "
+                        "figure for a fused Viterbi stage is 288 B in + 27 B out per symbol (stage_bytes_survey_8d): the decisions crossing "
+                        "HBM make it 6.9 x that"}
     if piped:
         # consecutive forward passes run on two streams and overlap at their ends, so a launch lasts longer than a step: the
         # launch duration (what a kernel trace reports, used above) counts the shared time twice
@@ -627,7 +627,17 @@ def main(argv=None):
         sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    out = run(args, rank, world, local_rank)
+    # stdout carries ONE line, the JSON record: whatever libraries print there meanwhile (gloo announces its connections on
+    # stdout) is sent to stderr instead
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        out = run(args, rank, world, local_rank)
+    finally:
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        os.close(real_stdout)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
