@@ -464,7 +464,8 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
     const int n_sb = (nf + kScanBlock - 1) / kScanBlock;
     int64_t *blk = rx->w->totals.p + 8;
     hipLaunchKernelGGL(k_scan_sums, dim3(n_sb), dim3(kScanBlock), 0, st, rx->w->info.p, nf, rx->tb_segment, blk);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, blk, n_sb, (int64_t)rx->w->sym_cap, rx->w->totals.p);
+    if (n_sb <= 4096) hipLaunchKernelGGL(k_scan_blocks_w, dim3(1), dim3(64), 0, st, blk, n_sb, (int64_t)rx->w->sym_cap, rx->w->totals.p);
+    else hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, blk, n_sb, (int64_t)rx->w->sym_cap, rx->w->totals.p);
     hipLaunchKernelGGL(k_scan_apply, dim3(n_sb), dim3(kScanBlock), 0, st, rx->w->info.p, nf, (int64_t)rx->w->sym_cap,
                        (int64_t)rx->w->dec_cap, rx->tb_segment, (int64_t)rx->w->seg2frame.n, blk, rx->w->sym2frame.p, rx->w->seg2frame.p);
     HIP_TRY(hipEventRecord(rx->w->ev[2], st));

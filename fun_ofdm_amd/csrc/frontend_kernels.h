@@ -479,6 +479,27 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(int64_t *__restrict__ blk,
     }
 }
 
+// pass 2 for up to 64 x 64 blocks (a million frames) as ONE wave: under a forward pass a 1024-thread block waits for sixteen
+// free wave slots on one CU (5.8 us alone, 100 us on average and up to 750 us in the pipelined bench), a lone wave for one
+__global__ __launch_bounds__(64) void k_scan_blocks_w(int64_t *__restrict__ blk, int n_blocks, int64_t sym_cap, int64_t *__restrict__ totals)
+{
+    const int lane = threadIdx.x, per = (n_blocks + 63) / 64, lo = lane * per, hi = min(lo + per, n_blocks);
+    if (lane == 0) totals[3] = sym_cap;
+    for (int i = 0; i < 4; i++) {
+        int64_t s = 0;
+        for (int j = lo; j < hi; j++) s += blk[(size_t)i * n_blocks + j];
+        int64_t x = s;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int64_t y = __shfl_up(x, o);
+            if (lane >= o) x += y;
+        }
+        int64_t run = x - s;                                   // exclusive prefix of this lane's run
+        for (int j = lo; j < hi; j++) { const int64_t v = blk[(size_t)i * n_blocks + j]; blk[(size_t)i * n_blocks + j] = run; run += v; }
+        if (lane == 63) totals[i < 3 ? i : 4] = x;
+    }
+}
+
 // pass 3: offsets into the frame records (frames that do not fit are marked FOA_ST_NO_SPACE), and the symbol -> frame
 // and segment -> frame maps (so that the data-symbol and chain-back kernels find their frame without a search;
 // frames are short: <= 1368 symbols)
