@@ -53,6 +53,9 @@ __device__ __forceinline__ uint32_t pk_sub_wrap(uint32_t a, uint32_t b)
 #ifndef FOA_MIN16
 #define FOA_MIN16 1
 #endif
+#ifndef FOA_TEST2
+#define FOA_TEST2 1      // renormalisation test as s_add + s_andn2 + branch (0: the compiler's and/add/and/cmp + branch)
+#endif
 // Smallest metric of one frame of the packed register, wave-uniform.  High half: the unsigned 32-bit minimum of the packed
 // words has the smallest high half in its high half, so the register goes into the reduction as it is and the shift happens
 // on the scalar side.  Low half: v_min_u16 compares low halves only and takes the DPP operand like v_min_u32 does, so no
@@ -96,41 +99,46 @@ __device__ __forceinline__ Fwd3Lane fwd3_lane_init(int lane)
 
 // One trellis step (phase PH) for both frames.  J >= 0: data step J of the chunk (compile time); J == -1: no
 // decision is recorded (trellis steps 0..5); J == -2: data step jdyn (run time).
+// Decision bits: x and y lie in [0xFF00, 0xFFFF], so the 16-bit difference x - y lies in [-255, 255] and its bits
+// 8..15 ALL equal its sign.  An accumulator therefore takes eight steps in bits 8..15 of each half with no shift at
+// all -- v_pk_sub_u16 + v_bfi_b32 under the mask 0x01000100 << (step mod 8) --, and the two accumulators of a 16-step
+// block are merged by one v_perm_b32 when the block is stored (2 + 1/16 instead of 3 VALU instructions per step).
 template <int PH, int J>
-__device__ __forceinline__ uint32_t fwd3_step(uint32_t M, const uint2 w, const Fwd3Lane &c, uint32_t (&acc)[3], int jdyn)
+__device__ __forceinline__ uint32_t fwd3_step(uint32_t M, const uint2 w, const Fwd3Lane &c, uint32_t (&acc)[6], int jdyn)
 {
     const uint32_t inc_lo = w.x, inc_hi = w.y;
     uint32_t lo, hi;
     pair_exchange<5 - PH>(M, lo, hi);
     const uint32_t x = pk_add_sat(lo, inc_lo), y = pk_add_sat(hi, inc_hi);
     // upper predecessor wins ties (viterbi.cpp): survivor = low slot iff x < y iff the 16-bit difference is negative
-    // (both operands lie in [0xFF00, 0xFFFF])
     if constexpr (J >= 0 && !(FOA_ABL & 1)) {
-        // Written as one volatile block: left to itself the compiler sinks these three instructions of all 48 steps
+        // Written as one volatile block: left to itself the compiler sinks these instructions of all 48 steps
         // to the end of the chunk and keeps every step's x and y alive until then (148 VGPRs, 3 waves per SIMD).
-        constexpr int blk = J >> 4, j = J & 15;
-        constexpr uint32_t m = 0x00010001u << j;
+        constexpr uint32_t m = 0x01000100u << (J & 7);
         uint32_t tmp;
-        if constexpr (j == 15)
-            asm volatile("v_pk_sub_u16 %1, %2, %3\n\tv_bfi_b32 %0, %4, %1, %0" : "+v"(acc[blk]), "=&v"(tmp) : "v"(x), "v"(y), "s"(m));
-        else
-            asm volatile("v_pk_sub_u16 %1, %2, %3\n\tv_lshrrev_b32 %1, %5, %1\n\tv_bfi_b32 %0, %4, %1, %0"
-                         : "+v"(acc[blk]), "=&v"(tmp)
-                         : "v"(x), "v"(y), "s"(m), "n"(15 - j));
+        asm volatile("v_pk_sub_u16 %1, %2, %3\n\tv_bfi_b32 %0, %4, %1, %0" : "+v"(acc[J >> 3]), "=&v"(tmp) : "v"(x), "v"(y), "s"(m));
     } else if constexpr (J == -2) {
-        const int blk = jdyn >> 4, j = jdyn & 15;
-        const uint32_t m = 0x00010001u << j;
-        const uint32_t tmp = pk_sub_wrap(x, y) >> (15 - j);
+        const int a = jdyn >> 3;
+        const uint32_t m = 0x01000100u << (jdyn & 7);
+        const uint32_t tmp = pk_sub_wrap(x, y);
 #pragma unroll
-        for (int b = 0; b < 3; b++) acc[b] = blk == b ? ((acc[b] & ~m) | (tmp & m)) : acc[b];
+        for (int b = 0; b < 6; b++) acc[b] = a == b ? ((acc[b] & ~m) | (tmp & m)) : acc[b];
     }
     uint32_t Mn = pk_min(x, y);
     // viterbi.cpp:314-332 per frame: renormalise when the new metric of state 0 (slot 0 = lane 0) exceeds 210.
     // Stored halves are 0xFF00 + metric: adding 45 to the low byte of a half carries into bit 8 iff metric > 210.
     if constexpr (FOA_ABL & 2) return Mn;
     const uint32_t s0 = __builtin_amdgcn_readfirstlane(Mn);
+#if FOA_TEST2
+    // Two scalar instructions in front of the branch: adding 45 to both halves at once carries out of a half iff its
+    // metric exceeds 210 (bit 15 / bit 31 of the sum then reads 0).  A carry out of the low half can push a high half of
+    // exactly 210 over, so the cold path looks at both halves again; the common path only needs "nothing is due".
+    if (__builtin_expect((~(s0 + 0x002D002Du) & 0x80008000u) != 0u, 0)) {
+        const uint32_t over = ((s0 & 0x00FF00FFu) + 0x002D002Du) & 0x01000100u;
+#else
     const uint32_t over = ((s0 & 0x00FF00FFu) + 0x002D002Du) & 0x01000100u;
     if (__builtin_expect(over != 0u, 0)) {      // cold: keeps the common path free of taken branches
+#endif
         // the amount is wave-uniform: subtract the bias on the scalar side so the vector side is one v_sub
         if (over & 0x100u) {
             const uint32_t mn = wave_min_lo16(Mn);
@@ -157,7 +165,7 @@ __device__ __forceinline__ uint2 fwd3_inc(const uint4 *bml, int e, uint32_t ofs)
 
 // six steps (one of each phase) on staging entries E0 .. E0+5
 template <int E0, int J0>
-__device__ __forceinline__ uint32_t fwd3_group(uint32_t M, const uint4 *bml, const Fwd3Lane &c, uint32_t (&acc)[3])
+__device__ __forceinline__ uint32_t fwd3_group(uint32_t M, const uint4 *bml, const Fwd3Lane &c, uint32_t (&acc)[6])
 {
     const uint2 w0 = fwd3_inc(bml, E0 + 0, c.ofs[0]), w1 = fwd3_inc(bml, E0 + 1, c.ofs[1]), w2 = fwd3_inc(bml, E0 + 2, c.ofs[2]),
                 w3 = fwd3_inc(bml, E0 + 3, c.ofs[3]), w4 = fwd3_inc(bml, E0 + 4, c.ofs[4]), w5 = fwd3_inc(bml, E0 + 5, c.ofs[5]);
@@ -171,7 +179,7 @@ __device__ __forceinline__ uint32_t fwd3_group(uint32_t M, const uint4 *bml, con
     return M;
 }
 
-__device__ __forceinline__ uint32_t fwd3_step_dyn(uint32_t M, int j, const uint4 *bml, const Fwd3Lane &c, uint32_t (&acc)[3])
+__device__ __forceinline__ uint32_t fwd3_step_dyn(uint32_t M, int j, const uint4 *bml, const Fwd3Lane &c, uint32_t (&acc)[6])
 {
     switch (j % 6) {
     case 0: return fwd3_step<0, -2>(M, fwd3_inc(bml, j, c.ofs[0]), c, acc, j);
@@ -209,7 +217,7 @@ __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd3(const FrameInfo
     uint16_t *dA = (uint16_t *)(dec + offA), *dB = (uint16_t *)(dec + offB);
     const Fwd3Lane c = fwd3_lane_init(lane);
     uint32_t M = lane == 0 ? kBias2 : kBias2 + 0x003F003Fu;               // viterbi.cpp:71-78 (label 0 = slot 0)
-    uint32_t acc[3] = { 0u, 0u, 0u };
+    uint32_t acc[6] = { 0u, 0u, 0u, 0u, 0u, 0u };
 
     // The soft pairs (s0 | s1 << 8, as the front end left them: 2 bytes per step, half of what metric words would move) of
     // trellis steps t0 .. t0+47 (lane = step) are fetched one chunk ahead into registers, so a chunk never waits for HBM;
@@ -252,7 +260,7 @@ __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd3(const FrameInfo
         const int nn = min(kChunk3, N - n0);
         put(kChunk3);
         get(n0 + kChunk3 + 6);
-        acc[0] = acc[1] = acc[2] = 0xFFFFFFFFu;
+        acc[0] = acc[1] = acc[2] = acc[3] = acc[4] = acc[5] = 0xFFFFFFFFu;
         if (nn == kChunk3) {
             M = fwd3_group<0, 0>(M, bml, c, acc);   M = fwd3_group<6, 6>(M, bml, c, acc);   M = fwd3_group<12, 12>(M, bml, c, acc);
             M = fwd3_group<18, 18>(M, bml, c, acc); M = fwd3_group<24, 24>(M, bml, c, acc); M = fwd3_group<30, 30>(M, bml, c, acc);
@@ -265,13 +273,15 @@ __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd3(const FrameInfo
 #pragma unroll
         for (int blk = 0; blk < 3; blk++) {
             const int b0 = n0 + 16 * blk;
+            // bytes 1 and 3 of the block's two accumulators: (A steps 0-7, A steps 8-15, B steps 0-7, B steps 8-15)
+            const uint32_t word = __builtin_amdgcn_perm(acc[2 * blk + 1], acc[2 * blk], 0x07030501u);
             if (b0 < NAtop) {
                 const int v = NA - b0;
-                dA[(size_t)(b0 >> 4) * 64 + 63 - lane] = (uint16_t)(acc[blk] | (v >= 16 ? 0u : v <= 0 ? 0xFFFFu : 0xFFFFu << v));
+                dA[(size_t)(b0 >> 4) * 64 + 63 - lane] = (uint16_t)(word | (v >= 16 ? 0u : v <= 0 ? 0xFFFFu : 0xFFFFu << v));
             }
             if (b0 < NBtop) {
                 const int v = NB - b0;
-                dB[(size_t)(b0 >> 4) * 64 + 63 - lane] = (uint16_t)((acc[blk] >> 16) | (v >= 16 ? 0u : v <= 0 ? 0xFFFFu : 0xFFFFu << v));
+                dB[(size_t)(b0 >> 4) * 64 + 63 - lane] = (uint16_t)((word >> 16) | (v >= 16 ? 0u : v <= 0 ? 0xFFFFu : 0xFFFFu << v));
             }
         }
     }
