@@ -6,8 +6,9 @@
 // eighteen VALU instructions per step on turning the compare into a lane mask and parking it in a VGPR lane:
 //
 //   * The decision of slot p stays in lane p.  `x - y` as a packed 16-bit subtract has the decision of both
-//     frames in its two sign bits; one shift and one v_bfi_b32 file them as bit j of a packed accumulator
-//     (3 VALU for both frames).  Sixteen steps fill the accumulator: one 16-bit store per lane and frame.
+//     frames in the sign bits of its halves, and since |x - y| <= 255 bits 8..15 of a half all equal that sign: one
+//     v_bfi_b32 files them at bit 8 + (step mod 8) of a packed accumulator (2 VALU for both frames).  Two
+//     accumulators make a 16-step block: one v_perm_b32, then one 16-bit store per lane and frame.
 //     Decision memory is therefore TRANSPOSED relative to v2: u16 [block of 16 steps][slot], same 8 bytes per
 //     step and frame.  Stored bit = 1 means "survivor came from the pair's LOW slot" (the complement of v2's bit),
 //     and slot p's word sits at index 63 - p, so that a chain-back that keeps the complemented slot index
@@ -37,7 +38,8 @@
 namespace foa {
 
 #ifndef FOA_ABL
-#define FOA_ABL 0        // timing experiments only (tools/ablate.sh): 1 no decision ops, 2 no renormalisation
+#define FOA_ABL 0        // timing experiments only (tools/ablate.sh): 1 no decision ops, 2 no renormalisation test, 4 no LDS reads of the
+                         // increments, 8 no lane exchange, 16 no decision stores, 32 test without the renormalisation itself
 #endif
 constexpr int kChunk3 = 48;                  // data steps per forward chunk: 3 decision blocks, 8 phase groups
 constexpr int kTbBlockBytes = 8 * 1024;      // LDS of one 16-step decision block of the wave's 64 lanes: [lane / 8][lane % 8] x 128 B
@@ -52,9 +54,6 @@ __device__ __forceinline__ uint32_t pk_sub_wrap(uint32_t a, uint32_t b)
 
 #ifndef FOA_MIN16
 #define FOA_MIN16 1
-#endif
-#ifndef FOA_TEST2
-#define FOA_TEST2 1      // renormalisation test as s_add + s_andn2 + branch (0: the compiler's and/add/and/cmp + branch)
 #endif
 // Smallest metric of one frame of the packed register, wave-uniform.  High half: the unsigned 32-bit minimum of the packed
 // words has the smallest high half in its high half, so the register goes into the reduction as it is and the shift happens
@@ -97,23 +96,53 @@ __device__ __forceinline__ Fwd3Lane fwd3_lane_init(int lane)
     return c;
 }
 
-// One trellis step (phase PH) for both frames.  J >= 0: data step J of the chunk (compile time); J == -1: no
-// decision is recorded (trellis steps 0..5); J == -2: data step jdyn (run time).
+// Renormalisation of viterbi.cpp:314-332 per frame, given s0 = the packed metrics of state 0 (slot 0 = lane 0): subtract the
+// frame's smallest metric when state 0 exceeds 210.  Stored halves are 0xFF00 + metric: adding 45 to both halves at once
+// carries out of a half iff its metric exceeds 210 (bit 15 / bit 31 of the sum then reads 0).  A carry out of the low half
+// can push a high half of exactly 210 over, so the cold path looks at both halves again; the common path only needs
+// "nothing is due" (two scalar instructions in front of the branch).
+__device__ __forceinline__ bool fwd3_due(uint32_t s0)
+{
+    return (~(s0 + 0x002D002Du) & 0x80008000u) != 0u;
+}
+__device__ __forceinline__ uint32_t fwd3_renorm(uint32_t Mn, uint32_t s0)
+{
+    const uint32_t over = ((s0 & 0x00FF00FFu) + 0x002D002Du) & 0x01000100u;
+    // the amount is wave-uniform: subtract the bias on the scalar side so the vector side is one v_sub
+    if (over & 0x100u) {
+        const uint32_t mn = wave_min_lo16(Mn);
+        uint32_t adj;
+        asm("s_sub_u32 %0, %1, %2" : "=s"(adj) : "s"(mn), "s"(kBias) : "scc");
+        Mn -= adj;
+    }
+    if (over >> 16) {
+        const uint32_t mn = wave_min_hi16(Mn);
+        uint32_t adj;
+        asm("s_sub_u32 %0, %1, %2\n\ts_lshl_b32 %0, %0, 16" : "=s"(adj) : "s"(mn), "s"(kBias) : "scc");
+        Mn -= adj;
+    }
+    return Mn;
+}
+
+// Exchange + add-compare-select of one trellis step (phase PH) for both frames, decision bits filed.  J >= 0: data step J
+// of the chunk (compile time); J == -1: no decision is recorded (trellis steps 0..5); J == -2: data step jdyn (run time).
 // Decision bits: x and y lie in [0xFF00, 0xFFFF], so the 16-bit difference x - y lies in [-255, 255] and its bits
 // 8..15 ALL equal its sign.  An accumulator therefore takes eight steps in bits 8..15 of each half with no shift at
 // all -- v_pk_sub_u16 + v_bfi_b32 under the mask 0x01000100 << (step mod 8) --, and the two accumulators of a 16-step
 // block are merged by one v_perm_b32 when the block is stored (2 + 1/16 instead of 3 VALU instructions per step).
 template <int PH, int J>
-__device__ __forceinline__ uint32_t fwd3_step(uint32_t M, const uint2 w, const Fwd3Lane &c, uint32_t (&acc)[6], int jdyn)
+__device__ __forceinline__ uint32_t fwd3_acs(uint32_t M, const uint2 w, uint32_t (&acc)[6], int jdyn)
 {
     const uint32_t inc_lo = w.x, inc_hi = w.y;
     uint32_t lo, hi;
-    pair_exchange<5 - PH>(M, lo, hi);
+    if constexpr (FOA_ABL & 8) { lo = M; hi = M ^ 0x00010001u; }
+    else pair_exchange<5 - PH>(M, lo, hi);
     const uint32_t x = pk_add_sat(lo, inc_lo), y = pk_add_sat(hi, inc_hi);
     // upper predecessor wins ties (viterbi.cpp): survivor = low slot iff x < y iff the 16-bit difference is negative
     if constexpr (J >= 0 && !(FOA_ABL & 1)) {
         // Written as one volatile block: left to itself the compiler sinks these instructions of all 48 steps
         // to the end of the chunk and keeps every step's x and y alive until then (148 VGPRs, 3 waves per SIMD).
+        // (Filing them one step later instead, into the gaps between that step's exchange, adds and min: no change.)
         constexpr uint32_t m = 0x01000100u << (J & 7);
         uint32_t tmp;
         asm volatile("v_pk_sub_u16 %1, %2, %3\n\tv_bfi_b32 %0, %4, %1, %0" : "+v"(acc[J >> 3]), "=&v"(tmp) : "v"(x), "v"(y), "s"(m));
@@ -124,35 +153,31 @@ __device__ __forceinline__ uint32_t fwd3_step(uint32_t M, const uint2 w, const F
 #pragma unroll
         for (int b = 0; b < 6; b++) acc[b] = a == b ? ((acc[b] & ~m) | (tmp & m)) : acc[b];
     }
-    uint32_t Mn = pk_min(x, y);
-    // viterbi.cpp:314-332 per frame: renormalise when the new metric of state 0 (slot 0 = lane 0) exceeds 210.
-    // Stored halves are 0xFF00 + metric: adding 45 to the low byte of a half carries into bit 8 iff metric > 210.
+    return pk_min(x, y);
+}
+
+// One trellis step: exchange + ACS, then the renormalisation test on its result (v_readfirstlane of state 0, the scalar
+// test, the branch).  (Measured and dropped: doing the next step on the metrics as they are while the scalar unit tests this
+// step's state 0, and repeating that step from the renormalised metrics in the 2 cases in 9 where the test fires.  It takes the
+// readfirstlane -> scalar -> branch chain off a lone wave's critical path, yet a lone wave's 8 424-step frame went from 0.639 to
+// 0.616 ms only -- what a lone wave waits for is the chain of dependent VALU instructions itself, about 14 clocks each -- and
+// at five waves per SIMD the repeated steps cost 11 %.)
+template <int PH, int J>
+__device__ __forceinline__ uint32_t fwd3_step(uint32_t M, const uint2 w, uint32_t (&acc)[6], int jdyn)
+{
+    uint32_t Mn = fwd3_acs<PH, J>(M, w, acc, jdyn);
     if constexpr (FOA_ABL & 2) return Mn;
     const uint32_t s0 = __builtin_amdgcn_readfirstlane(Mn);
-#if FOA_TEST2
-    // Two scalar instructions in front of the branch: adding 45 to both halves at once carries out of a half iff its
-    // metric exceeds 210 (bit 15 / bit 31 of the sum then reads 0).  A carry out of the low half can push a high half of
-    // exactly 210 over, so the cold path looks at both halves again; the common path only needs "nothing is due".
-    if (__builtin_expect((~(s0 + 0x002D002Du) & 0x80008000u) != 0u, 0)) {
-        const uint32_t over = ((s0 & 0x00FF00FFu) + 0x002D002Du) & 0x01000100u;
-#else
-    const uint32_t over = ((s0 & 0x00FF00FFu) + 0x002D002Du) & 0x01000100u;
-    if (__builtin_expect(over != 0u, 0)) {      // cold: keeps the common path free of taken branches
-#endif
-        // the amount is wave-uniform: subtract the bias on the scalar side so the vector side is one v_sub
-        if (over & 0x100u) {
-            const uint32_t mn = wave_min_lo16(Mn);
-            uint32_t adj;
-            asm("s_sub_u32 %0, %1, %2" : "=s"(adj) : "s"(mn), "s"(kBias) : "scc");
-            Mn -= adj;
+    if constexpr (FOA_ABL & 32) { if (__builtin_expect(s0 == 0x12345678u, 0)) Mn = fwd3_renorm(Mn, s0); return Mn; }
+    if constexpr (FOA_ABL & 64) {               // events at a made-up 1 step in 8; 128: the cold path without the reduction; 256: low half only
+        if (__builtin_expect(((s0 >> 1) & 7u) == 0u, 0)) {
+            if constexpr (FOA_ABL & 128) { uint32_t z; asm volatile("s_mov_b32 %0, 0" : "=s"(z)); Mn -= z; }
+            else if constexpr (FOA_ABL & 256) Mn = fwd3_renorm(Mn, 0xFF00FFD3u);
+            else Mn = fwd3_renorm(Mn, (s0 & 16u) ? 0xFF00FFD3u : 0xFFD3FF00u);
         }
-        if (over >> 16) {
-            const uint32_t mn = wave_min_hi16(Mn);
-            uint32_t adj;
-            asm("s_sub_u32 %0, %1, %2\n\ts_lshl_b32 %0, %0, 16" : "=s"(adj) : "s"(mn), "s"(kBias) : "scc");
-            Mn -= adj;
-        }
+        return Mn;
     }
+    if (__builtin_expect(fwd3_due(s0), 0)) Mn = fwd3_renorm(Mn, s0);      // cold: keeps the common path free of taken branches
     return Mn;
 }
 
@@ -160,21 +185,24 @@ __device__ __forceinline__ uint32_t fwd3_step(uint32_t M, const uint2 w, const F
 // halves and hi = lo ^ 0x003F003F (63 - m); the pair's low slot reads (lo, hi) at +0, its high slot (hi, lo) at +8.
 __device__ __forceinline__ uint2 fwd3_inc(const uint4 *bml, int e, uint32_t ofs)
 {
+    if constexpr (FOA_ABL & 4) return make_uint2(ofs + e, ofs ^ e);
     return *(const uint2 *)((const uint8_t *)bml + 64 * e + ofs);
 }
 
 // six steps (one of each phase) on staging entries E0 .. E0+5
+// (Measured and dropped: issuing the LDS reads of group G + 1 before the steps of group G, so that only a chunk's first group
+// waits out an LDS round trip: 10 more VGPRs, no change in time at five waves per SIMD, 1.5 % for a lone wave.)
 template <int E0, int J0>
 __device__ __forceinline__ uint32_t fwd3_group(uint32_t M, const uint4 *bml, const Fwd3Lane &c, uint32_t (&acc)[6])
 {
     const uint2 w0 = fwd3_inc(bml, E0 + 0, c.ofs[0]), w1 = fwd3_inc(bml, E0 + 1, c.ofs[1]), w2 = fwd3_inc(bml, E0 + 2, c.ofs[2]),
                 w3 = fwd3_inc(bml, E0 + 3, c.ofs[3]), w4 = fwd3_inc(bml, E0 + 4, c.ofs[4]), w5 = fwd3_inc(bml, E0 + 5, c.ofs[5]);
-    M = fwd3_step<0, (J0 < 0 ? J0 : J0 + 0)>(M, w0, c, acc, 0);
-    M = fwd3_step<1, (J0 < 0 ? J0 : J0 + 1)>(M, w1, c, acc, 0);
-    M = fwd3_step<2, (J0 < 0 ? J0 : J0 + 2)>(M, w2, c, acc, 0);
-    M = fwd3_step<3, (J0 < 0 ? J0 : J0 + 3)>(M, w3, c, acc, 0);
-    M = fwd3_step<4, (J0 < 0 ? J0 : J0 + 4)>(M, w4, c, acc, 0);
-    M = fwd3_step<5, (J0 < 0 ? J0 : J0 + 5)>(M, w5, c, acc, 0);
+    M = fwd3_step<0, (J0 < 0 ? J0 : J0 + 0)>(M, w0, acc, 0);
+    M = fwd3_step<1, (J0 < 0 ? J0 : J0 + 1)>(M, w1, acc, 0);
+    M = fwd3_step<2, (J0 < 0 ? J0 : J0 + 2)>(M, w2, acc, 0);
+    M = fwd3_step<3, (J0 < 0 ? J0 : J0 + 3)>(M, w3, acc, 0);
+    M = fwd3_step<4, (J0 < 0 ? J0 : J0 + 4)>(M, w4, acc, 0);
+    M = fwd3_step<5, (J0 < 0 ? J0 : J0 + 5)>(M, w5, acc, 0);
     __builtin_amdgcn_sched_barrier(0);          // keep the next groups' LDS reads from being hoisted (registers)
     return M;
 }
@@ -182,12 +210,12 @@ __device__ __forceinline__ uint32_t fwd3_group(uint32_t M, const uint4 *bml, con
 __device__ __forceinline__ uint32_t fwd3_step_dyn(uint32_t M, int j, const uint4 *bml, const Fwd3Lane &c, uint32_t (&acc)[6])
 {
     switch (j % 6) {
-    case 0: return fwd3_step<0, -2>(M, fwd3_inc(bml, j, c.ofs[0]), c, acc, j);
-    case 1: return fwd3_step<1, -2>(M, fwd3_inc(bml, j, c.ofs[1]), c, acc, j);
-    case 2: return fwd3_step<2, -2>(M, fwd3_inc(bml, j, c.ofs[2]), c, acc, j);
-    case 3: return fwd3_step<3, -2>(M, fwd3_inc(bml, j, c.ofs[3]), c, acc, j);
-    case 4: return fwd3_step<4, -2>(M, fwd3_inc(bml, j, c.ofs[4]), c, acc, j);
-    default: return fwd3_step<5, -2>(M, fwd3_inc(bml, j, c.ofs[5]), c, acc, j);
+    case 0: return fwd3_step<0, -2>(M, fwd3_inc(bml, j, c.ofs[0]), acc, j);
+    case 1: return fwd3_step<1, -2>(M, fwd3_inc(bml, j, c.ofs[1]), acc, j);
+    case 2: return fwd3_step<2, -2>(M, fwd3_inc(bml, j, c.ofs[2]), acc, j);
+    case 3: return fwd3_step<3, -2>(M, fwd3_inc(bml, j, c.ofs[3]), acc, j);
+    case 4: return fwd3_step<4, -2>(M, fwd3_inc(bml, j, c.ofs[4]), acc, j);
+    default: return fwd3_step<5, -2>(M, fwd3_inc(bml, j, c.ofs[5]), acc, j);
     }
 }
 
@@ -275,6 +303,7 @@ __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd3(const FrameInfo
             const int b0 = n0 + 16 * blk;
             // bytes 1 and 3 of the block's two accumulators: (A steps 0-7, A steps 8-15, B steps 0-7, B steps 8-15)
             const uint32_t word = __builtin_amdgcn_perm(acc[2 * blk + 1], acc[2 * blk], 0x07030501u);
+            if constexpr (FOA_ABL & 16) { if (word == 0x12345678u) dA[lane] = 1; continue; }
             if (b0 < NAtop) {
                 const int v = NA - b0;
                 dA[(size_t)(b0 >> 4) * 64 + 63 - lane] = (uint16_t)(word | (v >= 16 ? 0u : v <= 0 ? 0xFFFFu : 0xFFFFu << v));

@@ -1,0 +1,8 @@
+#!/bin/bash
+# usage: tools/abargs.sh <rounds> "<bench args A>" "<bench args B>" ...   alternates bench.py over several argument sets on one box
+n=$1; shift
+for i in $(seq $n); do
+  for args in "$@"; do
+    python bench.py --no-cpu-baseline --no-sync-leg --no-extra-legs $args 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); k=d['kernel_ms']; print('[$args]', d['ms_per_step'], 'hdr %.3f scan %.3f sym %.3f fwd %.3f fin %.3f' % (k['header'],k['scan'],k['symbols'],k['viterbi_fwd'],k['viterbi_finish']), d['config']['psdu_bit_exact'])"
+  done
+done
