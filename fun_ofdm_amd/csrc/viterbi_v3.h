@@ -60,7 +60,19 @@ __device__ __forceinline__ uint32_t pk_sub_wrap(uint32_t a, uint32_t b)
 // on the scalar side.  Low half: v_min_u16 compares low halves only and takes the DPP operand like v_min_u32 does, so no
 // mask is needed either.  (s_nop: a DPP operand written by the instruction before needs two wait states; the compiler
 // does not look into an asm block.)
-__device__ __forceinline__ uint32_t wave_min_hi16(uint32_t v) { return wave_min_u32(v) >> 16; }
+__device__ __forceinline__ uint32_t wave_min_hi16_word(uint32_t v)      // the smallest high half, still in the high half of the result
+{
+    uint32_t r;
+    asm("s_nop 1\n\t"
+        "v_min_u32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+        : "=&v"(r) : "v"(v));
+    return __builtin_amdgcn_readlane(r, 63);
+}
 __device__ __forceinline__ uint32_t wave_min_lo16(uint32_t v)
 {
 #if FOA_MIN16
@@ -107,18 +119,17 @@ __device__ __forceinline__ bool fwd3_due(uint32_t s0)
 }
 __device__ __forceinline__ uint32_t fwd3_renorm(uint32_t Mn, uint32_t s0)
 {
-    const uint32_t over = ((s0 & 0x00FF00FFu) + 0x002D002Du) & 0x01000100u;
-    // the amount is wave-uniform: subtract the bias on the scalar side so the vector side is one v_sub
-    if (over & 0x100u) {
-        const uint32_t mn = wave_min_lo16(Mn);
+    // which halves: the low one iff bit 15 of s0 + 0x002D002D reads 0 (nothing carries into it), the high one by comparing it
+    // alone; the amount is wave-uniform, so the bias comes off on the scalar side and the vector side is one v_sub per half
+    // (the scalar subtractions are asm so that they stay scalar: the compiler reassociates Mn - (mn - bias) into two vector ops)
+    if (!((s0 + 0x002D002Du) & 0x8000u)) {
         uint32_t adj;
-        asm("s_sub_u32 %0, %1, %2" : "=s"(adj) : "s"(mn), "s"(kBias) : "scc");
+        asm("s_sub_u32 %0, %1, %2" : "=s"(adj) : "s"(wave_min_lo16(Mn)), "s"(kBias) : "scc");
         Mn -= adj;
     }
-    if (over >> 16) {
-        const uint32_t mn = wave_min_hi16(Mn);
+    if (s0 >= ((kRenormThr + 1u) << 16)) {
         uint32_t adj;
-        asm("s_sub_u32 %0, %1, %2\n\ts_lshl_b32 %0, %0, 16" : "=s"(adj) : "s"(mn), "s"(kBias) : "scc");
+        asm("s_and_b32 %0, %1, 0xffff0000\n\ts_sub_u32 %0, %0, %2" : "=s"(adj) : "s"(wave_min_hi16_word(Mn)), "s"(kBias << 16) : "scc");
         Mn -= adj;
     }
     return Mn;
