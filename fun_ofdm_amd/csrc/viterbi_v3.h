@@ -295,10 +295,36 @@ __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd3(const FrameInfo
     put(6);
     get(6);
     M = fwd3_group<0, -1>(M, bml, c, acc);
+    // The decision words of a chunk leave one chunk LATE (FOA_LATE_ST = 1), right behind the loads that fetch the soft pairs
+    // of the chunk after: vector loads and stores share one counter on gfx950 and complete out of order with respect to each
+    // other, so the wait for those loads is a wait for everything -- and with the stores queued at the end of a chunk it was
+    // a wait for six stores issued a moment ago, at every chunk.  Queued a whole chunk earlier they are long done by then.
+    // Bits of data steps at or beyond a frame's last one, up to the end of the frame's last chunk, are stored
+    // as 1: they hold a chain-back that starts above the frame's end in pbar = 63 (state 0) until it gets there.
+#ifndef FOA_LATE_ST
+#define FOA_LATE_ST 1
+#endif
+    uint32_t word[3] = { 0u, 0u, 0u };                                    // a chunk's three 16-step blocks: (A, B) per lane
+    auto store = [&](int n0) {
+#pragma unroll
+        for (int blk = 0; blk < 3; blk++) {
+            const int b0 = n0 + 16 * blk;
+            if constexpr (FOA_ABL & 16) { if (word[blk] == 0x12345678u) dA[lane] = 1; continue; }
+            if (b0 < NAtop) {
+                const int v = NA - b0;
+                dA[(size_t)(b0 >> 4) * 64 + 63 - lane] = (uint16_t)(word[blk] | (v >= 16 ? 0u : v <= 0 ? 0xFFFFu : 0xFFFFu << v));
+            }
+            if (b0 < NBtop) {
+                const int v = NB - b0;
+                dB[(size_t)(b0 >> 4) * 64 + 63 - lane] = (uint16_t)((word[blk] >> 16) | (v >= 16 ? 0u : v <= 0 ? 0xFFFFu : 0xFFFFu << v));
+            }
+        }
+    };
     for (int n0 = 0; n0 < N; n0 += kChunk3) {                             // n0 mod 6 == 0: phase = chunk-relative index mod 6
         const int nn = min(kChunk3, N - n0);
         put(kChunk3);
         get(n0 + kChunk3 + 6);
+        if (FOA_LATE_ST && n0 > 0) store(n0 - kChunk3);
         acc[0] = acc[1] = acc[2] = acc[3] = acc[4] = acc[5] = 0xFFFFFFFFu;
         if (nn == kChunk3) {
             M = fwd3_group<0, 0>(M, bml, c, acc);   M = fwd3_group<6, 6>(M, bml, c, acc);   M = fwd3_group<12, 12>(M, bml, c, acc);
@@ -307,24 +333,12 @@ __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd3(const FrameInfo
         } else {
             for (int j = 0; j < nn; j++) M = fwd3_step_dyn(M, j, bml, c, acc);
         }
-        // Bits of data steps at or beyond a frame's last one, up to the end of the frame's last chunk, are stored
-        // as 1: they hold a chain-back that starts above the frame's end in pbar = 63 (state 0) until it gets there.
+        // bytes 1 and 3 of a block's two accumulators: (A steps 0-7, A steps 8-15, B steps 0-7, B steps 8-15)
 #pragma unroll
-        for (int blk = 0; blk < 3; blk++) {
-            const int b0 = n0 + 16 * blk;
-            // bytes 1 and 3 of the block's two accumulators: (A steps 0-7, A steps 8-15, B steps 0-7, B steps 8-15)
-            const uint32_t word = __builtin_amdgcn_perm(acc[2 * blk + 1], acc[2 * blk], 0x07030501u);
-            if constexpr (FOA_ABL & 16) { if (word == 0x12345678u) dA[lane] = 1; continue; }
-            if (b0 < NAtop) {
-                const int v = NA - b0;
-                dA[(size_t)(b0 >> 4) * 64 + 63 - lane] = (uint16_t)(word | (v >= 16 ? 0u : v <= 0 ? 0xFFFFu : 0xFFFFu << v));
-            }
-            if (b0 < NBtop) {
-                const int v = NB - b0;
-                dB[(size_t)(b0 >> 4) * 64 + 63 - lane] = (uint16_t)((word >> 16) | (v >= 16 ? 0u : v <= 0 ? 0xFFFFu : 0xFFFFu << v));
-            }
-        }
+        for (int blk = 0; blk < 3; blk++) word[blk] = __builtin_amdgcn_perm(acc[2 * blk + 1], acc[2 * blk], 0x07030501u);
+        if (!FOA_LATE_ST) store(n0);
     }
+    if (FOA_LATE_ST && N > 0) store((N - 1) / kChunk3 * kChunk3);
 }
 
 // ---------------------------------------------------------------------------------------------------------
