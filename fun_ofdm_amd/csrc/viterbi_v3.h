@@ -52,6 +52,9 @@ __device__ __forceinline__ uint32_t pk_sub_wrap(uint32_t a, uint32_t b)
     return __builtin_bit_cast(uint32_t, r);
 }
 
+#ifndef FOA_RN_PRIO
+#define FOA_RN_PRIO 0      // priority of a wave while it renormalises (0: unchanged)
+#endif
 #ifndef FOA_MIN16
 #define FOA_MIN16 1
 #endif
@@ -119,6 +122,9 @@ __device__ __forceinline__ bool fwd3_due(uint32_t s0)
 }
 __device__ __forceinline__ uint32_t fwd3_renorm(uint32_t Mn, uint32_t s0)
 {
+#if FOA_RN_PRIO
+    __builtin_amdgcn_s_setprio(FOA_RN_PRIO);      // the wave's recursion stands still until this is through
+#endif
     // which halves: the low one iff bit 15 of s0 + 0x002D002D reads 0 (nothing carries into it), the high one by comparing it
     // alone; the amount is wave-uniform, so the bias comes off on the scalar side and the vector side is one v_sub per half
     // (the scalar subtractions are asm so that they stay scalar: the compiler reassociates Mn - (mn - bias) into two vector ops)
@@ -132,6 +138,9 @@ __device__ __forceinline__ uint32_t fwd3_renorm(uint32_t Mn, uint32_t s0)
         asm("s_and_b32 %0, %1, 0xffff0000\n\ts_sub_u32 %0, %0, %2" : "=s"(adj) : "s"(wave_min_hi16_word(Mn)), "s"(kBias << 16) : "scc");
         Mn -= adj;
     }
+#if FOA_RN_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     return Mn;
 }
 
