@@ -63,6 +63,10 @@ struct StreamGpu {
     std::mutex err_m;
     std::string err_text;                            // text of the first error raised on the submitter thread
 
+    // where the submitter thread's time goes (ns; printed by foa_stream_destroy when FOA_STREAM_STATS is set)
+    int64_t t_sync = 0, t_desc = 0, t_decode = 0, t_collect = 0, t_collect_wait = 0;
+    static int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
     StreamGpu() { for (auto &c : status_count) c.store(0); alignments.store(0); }
     float *staging(int slot) { return pin[slot]; }
 
@@ -95,8 +99,11 @@ struct StreamGpu {
         hipStream_t st = piped ? rx->stream3 : rx->stream;          // pre-sync and front end run there
         HIP_TRY(hipStreamWaitEvent(st, in_done[k], 0));
         size_t found = 0;
+        int64_t t0 = now_ns();
         int rc = foa_rx_sync_dev(rx, d, (size_t)n_buf, (foa_frame_desc *)d_desc[k].p, d_ends[k].p, desc_cap, &found);
+        t_sync += now_ns() - t0;
         if (rc) return rc;
+        t0 = now_ns();
         // (foa_rx_sync_dev has waited for its stream, hence for the H2D: the staging slot is free again when this returns)
         // which of them are this batch's: STS_END sample in [cut_prev, cut)
         const int64_t cut = final ? pushed + 1 : pushed - L;
@@ -109,6 +116,8 @@ struct StreamGpu {
             while (i1 < found && start + h_desc[i1].rot_start < cut) i1++;
         }
         const size_t m = i1 - i0;
+        t_desc += now_ns() - t0;
+        t0 = now_ns();
         InFlight fl;
         fl.handle = next_handle++; fl.n_frames = m; fl.ticket = 0;
         if (m) {
@@ -149,6 +158,7 @@ struct StreamGpu {
             fl.ticket = job->ticket;
             alignments.fetch_add(m);
         }
+        t_decode += now_ns() - t0;
         flight.push_back(fl);
         *handle = fl.handle;
         cut_prev = cut;
@@ -166,9 +176,10 @@ struct StreamGpu {
             (void)hipSetDevice(rx->device);
             tmp_psdu.resize(f.n_frames * slot_bytes);
             tmp_res.resize(f.n_frames);
+            const int64_t t0 = now_ns();
             const int rc = foa_rx_collect(rx, f.ticket, wait ? 1 : 0, tmp_psdu.data(), tmp_res.data());
             if (rc < 0) { flight.pop_front(); return keep_error(rc); }
-            if (rc == 0) return 0;
+            if (rc == 0) { t_collect_wait += now_ns() - t0; return 0; }
             for (size_t i = 0; i < f.n_frames; i++) {
                 const foa_frame_result &r = tmp_res[i];
                 if (r.status >= 0 && r.status < 5) status_count[r.status].fetch_add(1);
@@ -176,6 +187,7 @@ struct StreamGpu {
                 out->len.push_back((uint32_t)r.length);
                 out->bytes.insert(out->bytes.end(), tmp_psdu.begin() + i * slot_bytes, tmp_psdu.begin() + i * slot_bytes + r.length);
             }
+            t_collect += now_ns() - t0;
         }
         flight.pop_front();
         return 1;
@@ -235,6 +247,9 @@ void foa_stream_destroy(foa_stream *s)
     if (!s) return;
     delete s->core;                                   // joins the helpers and the submitter: from here on this thread owns the handle
     StreamGpu &g = s->gpu;
+    if (getenv("FOA_STREAM_STATS"))
+        fprintf(stderr, "foa_stream: %lld batches; submitter ms: pre-sync (incl. H2D wait) %.1f, descriptors %.1f, decode call %.1f, collect %.1f, polling %.1f\n",
+                (long long)g.n_batches, g.t_sync * 1e-6, g.t_desc * 1e-6, g.t_decode * 1e-6, g.t_collect * 1e-6, g.t_collect_wait * 1e-6);
     (void)hipSetDevice(g.rx->device);
     (void)foa_rx_sync(g.rx);
     // the job slots of batches nobody took are released

@@ -39,14 +39,21 @@ for batch in (1 << 20, 1 << 22, 1 << 24):
             continue
         runs.append(("device %dM, calls of %d, %d helpers" % (batch >> 20, chunk, threads),
                      ["--chunk", str(chunk), "--device-batch", str(batch), "--narrow-threads", str(threads)], n))
+if len(sys.argv) > 2 and sys.argv[2] == "quick":      # two device-mode runs only, with the submitter's time split (FOA_STREAM_STATS)
+    runs = [r for r in runs if r[0] in ("device 4M, calls of 4096, 0 helpers", "device 4M, calls of 4096, 4 helpers", "device 16M, calls of 4096, 8 helpers")]
+    os.environ["FOA_STREAM_STATS"] = "1"
 for name, extra, frames_used in runs:
     src = cap
     if frames_used < n:                        # the synchronous mode needs a millisecond per call: a shorter capture
         src = "/tmp/stream_%d.fc32" % frames_used
         iq[:frames_used * (s + 160)].tofile(src)
-    r = subprocess.run([exe, src, "--format", "fc32", "--preload"] + extra, capture_output=True, text=True)
+    pre = os.environ.get("FOA_SIM_PREFIX", "").split()      # e.g. "taskset -c 0-7": where the chain's threads may run
+    r = subprocess.run(pre + [exe, src, "--format", "fc32", "--preload"] + extra, capture_output=True, text=True)
     m = re.search(r"([\d.]+) Msamples/s through process_samples \((\d+) samples in ([\d.]+) s, (\d+) calls of (\d+)\)", r.stdout)
     p = re.search(r"(\d+) packets", r.stdout)
+    for line in r.stderr.splitlines():
+        if line.startswith("foa_stream:"):
+            print(json.dumps({"mode": name, "stats": line}), flush=True)
     if not m:
         print(json.dumps({"mode": name, "error": (r.stdout + r.stderr)[-400:]}), flush=True)
         continue

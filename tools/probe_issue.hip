@@ -52,28 +52,28 @@ __global__ __launch_bounds__(256) void k(unsigned long long *out, unsigned seed,
             if (V == DS_READ_B64) { unsigned long long v; asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"((threadIdx.x * 8 + i) * 8)); r[i] ^= (unsigned)v; }
             if (V == V_FMA_F64) asm volatile("v_fma_f64 %0, %0, %0, %0" : "+v"(d[i]));
             if (V == MIX_FWD) {
-                // one forward-pass step of viterbi_v3.h as an instruction multiset: 2 DPP moves, 2 clamped adds, sub, shift, bfi, min, readfirstlane
+                // one forward-pass step of viterbi_v3.h as an instruction multiset: 2 DPP moves, 2 clamped adds, sub, bfi, min, readfirstlane
                 unsigned lo, hi, x, y, t, s;
                 asm volatile("v_mov_b32_dpp %0, %2 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
                              "v_mov_b32_dpp %1, %2 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf"
                              : "=&v"(lo), "=&v"(hi) : "v"(r[i]));
                 asm volatile("v_pk_add_u16 %0, %2, %4 clamp\n\tv_pk_add_u16 %1, %3, %4 clamp" : "=&v"(x), "=&v"(y) : "v"(lo), "v"(hi), "v"(seed));
-                asm volatile("v_pk_sub_u16 %0, %1, %2\n\tv_lshrrev_b32 %0, 3, %0" : "=&v"(t) : "v"(x), "v"(y));
-                asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(r[(i + 1) & 7]) : "s"(0x00010001u), "v"(t));
+                asm volatile("v_pk_sub_u16 %0, %1, %2" : "=&v"(t) : "v"(x), "v"(y));
+                asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(r[(i + 1) & 7]) : "s"(0x01000100u), "v"(t));
                 asm volatile("v_pk_min_u16 %0, %1, %2" : "=v"(r[i]) : "v"(x), "v"(y));
                 asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(s) : "v"(r[i]));
                 sacc += s;
             }
             if (V == MIX_FWD_CHAIN) {
-                // the same nine instructions as ONE dependent chain per wave (r[0] -> r[0]), the renormalisation test's scalar
+                // the same eight instructions as ONE dependent chain per wave (r[0] -> r[0]), the renormalisation test's scalar
                 // compare-and-branch included: what a lone frame pair's step looks like to the SIMD
                 unsigned lo, hi, x, y, t, s;
                 asm volatile("v_mov_b32_dpp %0, %2 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
                              "v_mov_b32_dpp %1, %2 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf"
                              : "=&v"(lo), "=&v"(hi) : "v"(r[0]));
                 asm volatile("v_pk_add_u16 %0, %2, %4 clamp\n\tv_pk_add_u16 %1, %3, %4 clamp" : "=&v"(x), "=&v"(y) : "v"(lo), "v"(hi), "v"(seed));
-                asm volatile("v_pk_sub_u16 %0, %1, %2\n\tv_lshrrev_b32 %0, 3, %0" : "=&v"(t) : "v"(x), "v"(y));
-                asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(r[1]) : "s"(0x00010001u), "v"(t));
+                asm volatile("v_pk_sub_u16 %0, %1, %2" : "=&v"(t) : "v"(x), "v"(y));
+                asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(r[1]) : "s"(0x01000100u), "v"(t));
                 asm volatile("v_pk_min_u16 %0, %1, %2" : "=v"(r[0]) : "v"(x), "v"(y));
                 asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(s) : "v"(r[0]));
                 if (__builtin_expect(((s & 0x00FF00FFu) + 0x002D002Du) & 0x01000100u, 0)) r[0] -= 0x00010001u;
@@ -138,7 +138,7 @@ int main()
     run<V_READFIRST>("v_readfirstlane_b32 (+s_add)", d, 1);
     run<DS_READ_B64>("ds_read_b64 (+v_xor)", d, 1);
     run<V_FMA_F64>("v_fma_f64", d, 1);
-    run<MIX_FWD>("forward-step mix (9 VALU)", d, 9);
-    run<MIX_FWD_CHAIN>("forward mix, one chain/wave", d, 9);
+    run<MIX_FWD>("forward-step mix (8 VALU)", d, 8);
+    run<MIX_FWD_CHAIN>("forward mix, one chain/wave", d, 8);
     return 0;
 }

@@ -14,7 +14,7 @@ for line in open(sys.argv[1]):
                                                                        "slowest_over_fastest_wave": float(m.group(6)), "ghz": float(m.group(7))}
     elif line.startswith("gfx"):
         dev = line.strip()
-mix = rows["forward-step mix (9 VALU)"]
+mix = rows.get("forward-step mix (8 VALU)") or rows["forward-step mix (9 VALU)"]
 ghz = sorted(r["W5"]["ghz"] for r in rows.values() if "ds_read" not in str(r) and r["W5"]["ghz"] > 1.5)
 doc = {"device": dev, "source": "tools/probe_issue.hip (fixed window, exactly W waves per SIMD), raw output next to this file",
        # the forward pass runs five waves per SIMD at 10 000 frames
