@@ -1,5 +1,6 @@
-// Latency of the forward pass's renormalisation path on gfx950, one wave alone on its SIMD (s_memtime ticks per iteration,
-// 100 MHz: 1 tick = 24 clocks at 2.4 GHz) and W waves per SIMD (ms for the whole grid).  Variants of "find the smallest
+// Latency of the forward pass's renormalisation path on gfx950: one wave alone on the device (s_memtime ticks per iteration; a
+// tick is about one shader clock here -- the same loop timed over a grid gives 54 clocks at 2.4 GHz for 50.5 ticks) and 1 or 5
+// waves on every SIMD (ms for the whole grid, clocks of SIMD time per iteration).  Variants of "find the smallest
 // 16-bit half over the 64 lanes and subtract it from every lane":
 //   0  the loop alone: packed add + v_readfirstlane + scalar test + branch never taken (the step's frame)
 //   1  six v_min_u16_dpp + v_readlane + s_sub + v_sub, in line (what viterbi_v3.h's cold path runs)
@@ -138,8 +139,8 @@ template <int V> void run(const char *name, unsigned *d, long long *c)
         hipEventRecord(e0); k<V><<<256 * Ws[wi], 256>>>(d, c, 7); hipEventRecord(e1); hipEventSynchronize(e1);
         hipEventElapsedTime(&ms[wi], e0, e1);
     }
-    printf("%-62s %7.2f ticks/iter alone (= %5.0f clk at 2.4 GHz); grid at 1 wave/SIMD %.3f ms, at 5 waves/SIMD %.3f ms (%.0f clk per iteration and SIMD)\n",
-           name, (double)h / N, (double)h / N * 24.0, ms[0], ms[1], ms[1] * 1e-3 * 2.4e9 / N / 5);
+    printf("%-62s %7.2f ticks/iter alone; grid at 1 wave/SIMD %.3f ms (%.0f clk per iteration at 2.4 GHz), at 5 waves/SIMD %.3f ms (%.0f clk per iteration and SIMD)\n",
+           name, (double)h / N, ms[0], ms[0] * 1e-3 * 2.4e9 / N, ms[1], ms[1] * 1e-3 * 2.4e9 / N / 5);
 }
 int main()
 {
