@@ -39,7 +39,8 @@ namespace foa {
 
 #ifndef FOA_ABL
 #define FOA_ABL 0        // timing experiments only (tools/ablate.sh): 1 no decision ops, 2 no renormalisation test, 4 no LDS reads of the
-                         // increments, 8 no lane exchange, 16 no decision stores, 32 test without the renormalisation itself
+                         // increments, 8 no lane exchange, 16 no decision stores, 32 test without the renormalisation itself,
+                         // 64..256 made-up events, 512 four extra taken branches per event, 1024 one extra reduction per event
 #endif
 constexpr int kChunk3 = 48;                  // data steps per forward chunk: 3 decision blocks, 8 phase groups
 constexpr int kTbBlockBytes = 8 * 1024;      // LDS of one 16-step decision block of the wave's 64 lanes: [lane / 8][lane % 8] x 128 B
@@ -125,6 +126,8 @@ __device__ __forceinline__ uint32_t fwd3_renorm(uint32_t Mn, uint32_t s0)
 #if FOA_RN_PRIO
     __builtin_amdgcn_s_setprio(FOA_RN_PRIO);      // the wave's recursion stands still until this is through
 #endif
+    if constexpr (FOA_ABL & 512) asm volatile("s_branch 0\n\ts_branch 0\n\ts_branch 0\n\ts_branch 0");      // what do four more taken branches cost an event?
+    if constexpr (FOA_ABL & 1024) { uint32_t z = wave_min_lo16(Mn ^ s0); asm volatile("" :: "s"(z)); }   // ... and one more reduction?
     // which halves: the low one iff bit 15 of s0 + 0x002D002D reads 0 (nothing carries into it), the high one by comparing it
     // alone; the amount is wave-uniform, so the bias comes off on the scalar side and the vector side is one v_sub per half
     // (the scalar subtractions are asm so that they stay scalar: the compiler reassociates Mn - (mn - bias) into two vector ops)
