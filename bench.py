@@ -611,6 +611,41 @@ def extra_legs(args, rx, dev, iq, descs, ends, real, psdu_dev_path, res_dev_path
                                   "what": "mixed 8 rates back to back, 1024-byte payloads, CFO uniform in +-4 kHz, 25 dB; foa_rx_sync_dev + foa_rx_decode_frames_dev"}
     except Exception as e:
         legs["config5_stream"] = {"error": str(e)}
+
+    # ---- the drop-in call itself: fun_amd::receiver_chain::process_samples in device mode (examples/foa_sim.cpp, its own process and
+    # handle) over a capture of back-to-back 54 Mbps frames handed over as complex<double> chunks of 4096 -- SURVEY 8f #3 ----
+    try:
+        import re
+        import shutil
+        import tempfile
+        n = 60000
+        pays = synth.splitmix64_bytes(0xB57, n, 1024)
+        frames = rx.tx_build_frames(torch.from_numpy(pays).to(dev), RATE)
+        s = frames.shape[1]
+        cap_iq = rx.tx_channel(frames, s + 160, 80, SNR_DB, seed=5).cpu().numpy().reshape(-1).view(np.complex64)      # 8 us between frames
+        del frames
+        tmp = tempfile.mkdtemp(prefix="foa_bench_")
+        try:
+            src, exe = os.path.join(tmp, "stream.fc32"), os.path.join(tmp, "foa_sim")
+            cap_iq.tofile(src)
+            libdir = os.path.dirname(foa.library_path())
+            subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "examples", "foa_sim.cpp"), "-I", os.path.join(ROOT, "include"), "-L", libdir,
+                            "-lfun_ofdm_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lpthread", "-o", exe], check=True, capture_output=True)
+            r = subprocess.run([exe, src, "--format", "fc32", "--preload", "--chunk", "4096", "--device-batch", str(1 << 22), "--narrow-threads", "4"],
+                               capture_output=True, text=True, timeout=300)
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+        mm = re.search(r"([\d.]+) Msamples/s through process_samples \((\d+) samples in ([\d.]+) s, (\d+) calls of (\d+)\)", r.stdout)
+        pk = re.search(r"(\d+) packets", r.stdout)
+        if not mm:
+            raise RuntimeError((r.stdout + r.stderr)[-300:])
+        legs["process_samples_api"] = {"Msamples_per_s": float(mm.group(1)), "x_realtime_20MSps": round(float(mm.group(1)) / 20.0, 1), "samples": int(mm.group(2)),
+                                       "seconds": float(mm.group(3)), "calls": int(mm.group(4)), "chunk": int(mm.group(5)),
+                                       "packets": int(pk.group(1)) if pk else None, "frames_sent": n,
+                                       "what": "fun_amd::receiver_chain::process_samples(std::vector<std::complex<double>>) in device mode: 4 Mi-sample "
+                                               "batches, 4 helper threads, pre-sync and decode on the GPU, payloads through the callback; capture preloaded"}
+    except Exception as e:
+        legs["process_samples_api"] = {"error": str(e)[-300:]}
     return legs
 
 
