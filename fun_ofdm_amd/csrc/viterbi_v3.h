@@ -53,6 +53,9 @@ __device__ __forceinline__ uint32_t pk_sub_wrap(uint32_t a, uint32_t b)
     return __builtin_bit_cast(uint32_t, r);
 }
 
+#ifndef FOA_ADD_FIRST
+#define FOA_ADD_FIRST 1
+#endif
 #ifndef FOA_RN_PRIO
 #define FOA_RN_PRIO 0      // priority of a wave while it renormalises (0: unchanged)
 #endif
@@ -157,10 +160,26 @@ template <int PH, int J>
 __device__ __forceinline__ uint32_t fwd3_acs(uint32_t M, const uint2 w, uint32_t (&acc)[6], int jdyn)
 {
     const uint32_t inc_lo = w.x, inc_hi = w.y;
-    uint32_t lo, hi;
-    if constexpr (FOA_ABL & 8) { lo = M; hi = M ^ 0x00010001u; }
-    else pair_exchange<5 - PH>(M, lo, hi);
-    const uint32_t x = pk_add_sat(lo, inc_lo), y = pk_add_sat(hi, inc_hi);
+    uint32_t x, y;
+#if FOA_ADD_FIRST
+    if constexpr (PH < 2) {
+        // The two phases that exchange with v_permlane32/16_swap add FIRST: every lane adds both of its increments to its OWN
+        // metric -- the pair's low lane forms (x of the low lane, x of the high lane), the high lane (y of the low lane, y of the
+        // high lane): with the staging entry's layout those are the very (first, second) words each lane reads anyway -- and the
+        // swap then hands each lane its x and y.  Saturation is per sum, so the order does not matter; what it saves is the
+        // register copy the swap needs when it runs on the metrics themselves (an atomic exchange of two registers, unlike the
+        // two masked DPP moves of the other phases, which would overwrite each other's source).
+        const uint32_t p = pk_add_sat(M, inc_lo), q = pk_add_sat(M, inc_hi);
+        if constexpr (PH == 0) { auto r = __builtin_amdgcn_permlane32_swap(p, q, false, false); x = r[0]; y = r[1]; }
+        else { auto r = __builtin_amdgcn_permlane16_swap(p, q, false, false); x = r[0]; y = r[1]; }
+    } else
+#endif
+    {
+        uint32_t lo, hi;
+        if constexpr (FOA_ABL & 8) { lo = M; hi = M ^ 0x00010001u; }
+        else pair_exchange<5 - PH>(M, lo, hi);
+        x = pk_add_sat(lo, inc_lo); y = pk_add_sat(hi, inc_hi);
+    }
     // upper predecessor wins ties (viterbi.cpp): survivor = low slot iff x < y iff the 16-bit difference is negative
     if constexpr (J >= 0 && !(FOA_ABL & 1)) {
         // Written as one volatile block: left to itself the compiler sinks these instructions of all 48 steps
