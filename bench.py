@@ -59,6 +59,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the legs that are not `value`: host-pointer entry (H2D + D2H inside), config 3 rate sweep, config 5 stream")
     ap.add_argument("--fe-hold", type=int, default=-1, help="A/B: library option fe_hold (-1: library default)")
+    ap.add_argument("--lanes", type=int, default=-1, help="A/B: library option lanes (-1: library default)")
     ap.add_argument("--legs-frames", type=int, default=1000, help="frames per rate of the config-3 leg")
     return ap.parse_args(argv)
 
@@ -252,6 +253,8 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
     rx.set_option("frontend", args.frontend)
     if args.fe_hold >= 0:
         rx.set_option("fe_hold", args.fe_hold)
+    if args.lanes >= 0:
+        rx.set_option("lanes", args.lanes)
     rx.set_option("pipeline", 0 if args.no_pipeline else 1)
     rx.set_option("record_soft", 0)        # PSDUs are the output; soft bytes are only kept for diagnostics
     rx.reserve(iq.size, m)

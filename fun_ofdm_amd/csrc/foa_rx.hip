@@ -192,6 +192,10 @@ struct foa_rx {
     bool pipeline = true;        // v3: finish of one call overlaps the next call's front end (two work sets, two streams)
     bool record_eq = false;
     bool record_soft = true;     // (the soft bytes are the front end's output and always there; the option is accepted for compatibility)
+    hipEvent_t in_ready = nullptr;     // inputs copied by a host-pointer entry point are on the device (recorded on the copy stream)
+    bool in_wait = false;              // ... and the next decode call's front end has to wait for that
+    bool lanes = true;           // pipelined path: everything on a call's critical loop -- front end, forward pass, chain-back walk -- on ONE stream per
+                                 // call parity (below); false: front end on the third stream, walk + finish on the second (the round-1 arrangement)
     int fe_hold = 1;             // pipelined path: 1 = header, scan and data symbols of call k+1 wait for the chain-back walk of call k-1;
                                  // 2 = only the data-symbol kernel does; 0 = nothing is held back (A/B measurement)
     int frontend_kind = -1;      // 1: one lane per symbol (frontend_lps.h), 0: one wave per symbol, 2: four lanes per symbol (frontend_q4.h);
@@ -203,7 +207,8 @@ struct foa_rx {
     // front end, so that it runs under that call's forward pass (memory-bound next to issue-bound) rather than under its
     // latency-bound front end; foa_rx_sync and everything that needs results queue it at once.
     struct Pending {
-        bool valid = false;
+        bool valid = false, lanes = false;
+        hipStream_t lane = nullptr;  // lanes: the stream of the call's forward pass, where its walk follows
         WorkSet *w = nullptr;
         int nf = 0, S = 0, L = 0;
         size_t max_segs = 0, slot_bytes = 0;
@@ -223,6 +228,26 @@ struct foa_rx {
 };
 
 namespace {
+
+// The stream on which the NEXT decode call's header, scan and data-symbol kernels will run (pre-sync, H2D copies and memsets that
+// feed that call are queued there): pipelined calls take turns on two lanes by the parity of their work set.
+hipStream_t next_front_end_stream(foa_rx *rx)
+{
+    if (!(rx->pipeline && rx->viterbi_kind == 2)) return rx->stream;
+    if (!rx->lanes) return rx->stream3;
+    return (((rx->w - rx->sets) + 1) & 1) ? rx->stream4 : rx->stream;
+}
+
+// Host-pointer entry points copy their inputs (and the pre-sync stage runs) on the third stream when calls are pipelined, off the
+// lanes, so that a copy never sits behind a forward pass; the decode call that follows waits for the event.
+hipStream_t side_stream(foa_rx *rx) { return (rx->pipeline && rx->viterbi_kind == 2) ? rx->stream3 : rx->stream; }
+int inputs_queued(foa_rx *rx, hipStream_t cs)
+{
+    if (cs == rx->stream) return FOA_OK;
+    HIP_TRY(hipEventRecord(rx->in_ready, cs));
+    rx->in_wait = true;
+    return FOA_OK;
+}
 
 int workspace(foa_rx *rx, size_t n_samples, size_t n_frames)
 {
@@ -249,12 +274,21 @@ int flush_pending(foa_rx *rx, hipEvent_t after_front_end)
     foa_rx::Pending &p = rx->pending;
     if (!p.valid) return FOA_OK;
     hipStream_t sb = rx->stream2;
-    HIP_TRY(hipStreamWaitEvent(sb, p.w->ev[5], 0));          // its forward pass (the timing event doubles as the dependency:
+    if (p.lanes) {
+        // the walk follows its forward pass on the call's own lane -- no event between them -- and the next call of that lane
+        // queues its front end behind it; the stitch/CRC kernel, which nothing on the loop waits for, goes to the second stream
+        if (after_front_end) HIP_TRY(hipStreamWaitEvent(p.lane, after_front_end, 0));
+        HIP_TRY(hipEventRecord(p.w->ev[6], p.lane));
+        launch_finish3(p.lane, sb, p.w->info.p, p.nf, p.w->dec.p, p.w->decoded.p, p.w->seg2frame.p, p.w->totals.p, p.w->tb_state.p, p.max_segs, p.S, p.L,
+                       p.psdu, p.slot_bytes, p.results, p.w->walk_done);
+    } else {
+        HIP_TRY(hipStreamWaitEvent(sb, p.w->ev[5], 0));      // its forward pass (the timing event doubles as the dependency:
                                                               // every packet between two forward passes costs their streams microseconds)
-    if (after_front_end) HIP_TRY(hipStreamWaitEvent(sb, after_front_end, 0));
-    HIP_TRY(hipEventRecord(p.w->ev[6], sb));
-    launch_finish3(sb, p.w->info.p, p.nf, p.w->dec.p, p.w->decoded.p, p.w->seg2frame.p, p.w->totals.p, p.w->tb_state.p, p.max_segs, p.S, p.L, p.psdu,
-                   p.slot_bytes, p.results, p.w->walk_done);
+        if (after_front_end) HIP_TRY(hipStreamWaitEvent(sb, after_front_end, 0));
+        HIP_TRY(hipEventRecord(p.w->ev[6], sb));
+        launch_finish3(sb, sb, p.w->info.p, p.nf, p.w->dec.p, p.w->decoded.p, p.w->seg2frame.p, p.w->totals.p, p.w->tb_state.p, p.max_segs, p.S, p.L,
+                       p.psdu, p.slot_bytes, p.results, p.w->walk_done);
+    }
     HIP_TRY(hipEventRecord(p.w->ev[4], sb));
     HIP_TRY(hipEventRecord(p.w->done, sb));
     if (p.job) {
@@ -312,6 +346,7 @@ int foa_rx_create(foa_rx **out, int device)
     HIP_TRY(hipStreamCreateWithFlags(&rx->stream2, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&rx->stream3, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&rx->stream4, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&rx->in_ready, hipEventDisableTiming));
     for (auto &ws : rx->sets) {
         for (auto &e : ws.ev) HIP_TRY(hipEventCreate(&e));
         HIP_TRY(hipEventCreateWithFlags(&ws.done, hipEventDisableTiming));
@@ -335,6 +370,7 @@ void foa_rx_destroy(foa_rx *rx)
         if (ws.done) (void)hipEventDestroy(ws.done);
         if (ws.walk_done) (void)hipEventDestroy(ws.walk_done);
     }
+    if (rx->in_ready) (void)hipEventDestroy(rx->in_ready);
     for (auto &j : rx->jobs) {
         j.dev.release();
         if (j.pin) (void)hipHostFree(j.pin);
@@ -391,6 +427,7 @@ int foa_rx_set_option(foa_rx *rx, const char *name, int64_t value)
         return FOA_OK;
     }
     if (!strcmp(name, "record_soft")) { rx->record_soft = value != 0; return FOA_OK; }
+    if (!strcmp(name, "lanes")) { int rc0 = drain(rx); if (rc0) return rc0; rx->lanes = value != 0; return FOA_OK; }
     if (!strcmp(name, "frontend")) {
         if (value < -1 || value > 2) return fail(FOA_E_INVALID, "frontend must be -1 (by context), 0 (wave per symbol), 1 (lane per symbol) or 2 (quad per symbol)");
         rx->frontend_kind = (int)value;
@@ -444,18 +481,25 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
     // Forward passes of consecutive calls take turns on two streams: nothing orders one behind the other (each has its own
     // work set), so the next one starts the moment its front end is done, into the tail of the one before, instead of
     // ~20 us after it (end-of-kernel release, event packets, dispatch): 1.345 -> 1.316 ms per step at config 2.
-    hipStream_t st = piped ? rx->stream3 : rx->stream, st_fwd = (piped && ((rx->w - rx->sets) & 1)) ? rx->stream4 : rx->stream;
+    // lanes (default): the call's front end runs on the stream of its own forward pass, behind the chain-back walk of the call two
+    // back (queued there when the call before this one was made).  The loop that sets the step -- forward pass k, walk k, header,
+    // scan and data symbols of call k+2, forward pass k+2 -- is then one in-order stream with no event packet in it; with the front
+    // end on the third stream and the walk on the second, every hand-over between them cost 20-26 us, about 90 us per loop.
+    const bool lanes = piped && rx->lanes;
+    hipStream_t st_fwd = (piped && ((rx->w - rx->sets) & 1)) ? rx->stream4 : rx->stream;
+    hipStream_t st = piped ? (lanes ? st_fwd : rx->stream3) : rx->stream;
     // Under one forward pass first the chain-back walk of the call before, then the front end of the call after: the two
     // heavy guests at once slow each other and the forward pass down more than they gain (measured: 1.50 against 1.43 ms per
     // step; letting only the light header and scan run alongside the walk is no better: 1.52).  The stitch/CRC kernel
     // behind the walk is light and latency-bound, so the front end does not wait for that one.
     const bool can_hold = piped && rx->prev->before && rx->prev->before->used && rx->prev->before->piped && rx->prev->before != rx->w;
-    if (can_hold && rx->fe_hold == 1) HIP_TRY(hipStreamWaitEvent(st, rx->prev->before->walk_done, 0));
+    if (can_hold && !lanes && rx->fe_hold == 1) HIP_TRY(hipStreamWaitEvent(st, rx->prev->before->walk_done, 0));
     if (!piped && rx->prev->used && rx->prev != rx->w) HIP_TRY(hipStreamWaitEvent(st, rx->prev->done, 0));
     const int nf = (int)n_frames;
     const float2 *iq = (const float2 *)d_iq;
     double2 *eq_sig = rx->record_eq ? rx->w->eq_sig.p : nullptr, *eq_data = rx->record_eq ? rx->w->eq_data.p : nullptr;
 
+    if (rx->in_wait) { HIP_TRY(hipStreamWaitEvent(st, rx->in_ready, 0)); rx->in_wait = false; }
     HIP_TRY(hipEventRecord(rx->w->ev[0], st));
     hipLaunchKernelGGL(k_header, dim3(nf), dim3(64), 0, st, iq, d_descs, d_ends, (int64_t)n_samples, nf, rx->w->info.p, rx->w->hinv.p, eq_sig);
     HIP_TRY(hipEventRecord(rx->w->ev[1], st));
@@ -471,7 +515,7 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
     HIP_TRY(hipEventRecord(rx->w->ev[2], st));
     // upper bound on data symbols in n_samples samples; waves beyond the real total exit at once
     const size_t max_sym = rx->w->sym_cap;
-    if (can_hold && rx->fe_hold == 2) HIP_TRY(hipStreamWaitEvent(st, rx->prev->before->walk_done, 0));
+    if (can_hold && !lanes && rx->fe_hold == 2) HIP_TRY(hipStreamWaitEvent(st, rx->prev->before->walk_done, 0));
     const int frontend = rx->frontend_kind >= 0 ? rx->frontend_kind : 2;
     if (frontend == 2) {
         hipLaunchKernelGGL(k_data_symbols_q4, dim3((unsigned)((max_sym + 16 * kQ4Waves - 1) / (16 * kQ4Waves))), dim3(64 * kQ4Waves), 0, st, iq,
@@ -487,13 +531,13 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
     if (piped) {
         // the previous call's chain-back + finish goes under this call's forward pass
         if ((rc = flush_pending(rx, rx->w->ev[3]))) return rc;
-        HIP_TRY(hipStreamWaitEvent(st_fwd, rx->w->ev[3], 0));
+        if (!lanes) HIP_TRY(hipStreamWaitEvent(st_fwd, rx->w->ev[3], 0));
         HIP_TRY(hipEventRecord(rx->w->ev[7], st_fwd));          // start of the forward pass (this stream idles every other step: free)
         launch_fwd3(st_fwd, rx->w->info.p, nf, rx->w->sp.p, rx->w->dec.p);
         HIP_TRY(hipEventRecord(rx->w->ev[5], st_fwd));
         foa_rx::Pending &p = rx->pending;
         p.valid = true; p.w = rx->w; p.nf = nf; p.S = rx->tb_segment; p.L = rx->tb_overlap; p.max_segs = max_segs; p.slot_bytes = slot_bytes;
-        p.psdu = d_psdu; p.results = d_results; p.job = rx->attach_job;
+        p.psdu = d_psdu; p.results = d_results; p.job = rx->attach_job; p.lanes = lanes; p.lane = st_fwd;
     } else {
         if (rx->viterbi_kind == 0)
             hipLaunchKernelGGL(k_viterbi_v1, dim3(nf), dim3(64), 0, st, rx->w->info.p, nf, rx->w->sp.p, rx->w->dec.p, d_psdu, slot_bytes, d_results);
@@ -529,11 +573,12 @@ int foa_rx_decode_frames_host(foa_rx *rx, const float *iq, size_t n_samples, con
     int rc = rx->scratch.ensure(total);
     if (rc) return rc;
     uint8_t *b = rx->scratch.p;
-    hipStream_t st = (rx->pipeline && rx->viterbi_kind == 2) ? rx->stream3 : rx->stream;      // the stream the front end will run on
+    hipStream_t st = side_stream(rx);
     HIP_TRY(hipMemcpyAsync(b + o_iq, iq, n_samples * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(b + o_desc, descs, n_frames * sizeof(foa_frame_desc), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(b + o_end, ends, n_frames * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(b + o_psdu, 0, n_frames * slot_bytes, st));
+    if ((rc = inputs_queued(rx, st))) return rc;
     rc = foa_rx_decode_frames_dev(rx, (const float *)(b + o_iq), n_samples, (const foa_frame_desc *)(b + o_desc), (const int64_t *)(b + o_end),
                                   n_frames, b + o_psdu, slot_bytes, (foa_frame_result *)(b + o_res));
     if (rc) return rc;
@@ -572,10 +617,11 @@ int foa_rx_submit_host(foa_rx *rx, const float *iq, size_t n_samples, const foa_
     memcpy(job->pin + o_desc, descs, n_frames * sizeof(foa_frame_desc));
     memcpy(job->pin + o_end, ends, n_frames * 8);
     const bool piped = rx->pipeline && rx->viterbi_kind == 2;
-    hipStream_t st = piped ? rx->stream3 : rx->stream;
+    hipStream_t st = side_stream(rx);
     uint8_t *b = job->dev.p;
     HIP_TRY(hipMemcpyAsync(b, job->pin, o_psdu, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(b + o_psdu, 0, n_frames * slot_bytes, st));
+    if ((rc = inputs_queued(rx, st))) return rc;
     job->total = total; job->o_psdu = o_psdu; job->o_res = o_res; job->n_frames = n_frames; job->slot_bytes = slot_bytes; job->copy_queued = false;
     rx->attach_job = piped ? job : nullptr;
     rc = foa_rx_decode_frames_dev(rx, (const float *)(b + o_iq), n_samples, (const foa_frame_desc *)(b + o_desc), (const int64_t *)(b + o_end), n_frames,
@@ -630,7 +676,7 @@ static int kernel_ms_of(foa_rx *rx, WorkSet *w, float out_ms[6])
     // design (two streams), so this is the launch's own duration, like a kernel trace reports it, not the step's share.
     if (w->piped) HIP_TRY(hipEventElapsedTime(&out_ms[3], w->ev[7], w->ev[5]));
     else HIP_TRY(hipEventElapsedTime(&out_ms[3], w->ev[3], w->ev[5]));
-    // chain-back + descramble + CRC (0 for v1); on the pipelined path from where the second stream starts on it
+    // chain-back + descramble + CRC (0 for v1); on the pipelined path from where the walk is queued behind its forward pass
     if (w->piped) HIP_TRY(hipEventElapsedTime(&out_ms[4], w->ev[6], w->ev[4]));
     else HIP_TRY(hipEventElapsedTime(&out_ms[4], w->ev[5], w->ev[4]));
     HIP_TRY(hipEventElapsedTime(&out_ms[5], w->ev[0], w->ev[4]));      // whole call, first kernel to last (includes the deferral)
@@ -727,10 +773,13 @@ int foa_rx_sync_dev(foa_rx *rx, const float *d_iq, size_t n_samples, foa_frame_d
         (rc = rx->sy_off.ensure((size_t)std::max(n_blocks, (ccap + 255) / 256))) ||
         (rc = rx->sy_x.ensure((size_t)ccap)) || (rc = rx->sy_cand.ensure((size_t)ccap)) || (rc = rx->sy_keep.ensure((size_t)ccap)) || (rc = rx->sy_n.ensure(8)))
         return rc;
-    // With calls pipelined this stage goes where the next call's front end goes: on the third stream, under the forward
-    // pass of the decode call in flight (its own scratch is touched by nothing else; the descriptors it writes are read by
-    // the header and data-symbol kernels of the next decode call, which follow on the same stream).
-    hipStream_t st = (rx->pipeline && rx->viterbi_kind == 2) ? rx->stream3 : rx->stream;      // the predicate of the decode path
+    // With calls pipelined this stage runs on the third stream, under the forward pass of the decode call in flight (its own
+    // scratch is touched by nothing else; the descriptors it writes are read by the header and data-symbol kernels of the next
+    // decode call, which is made after this call has waited for its stream).
+    hipStream_t st = side_stream(rx);
+    // (with the front ends on the lanes nothing else orders this stage behind the decode call before it, whose header and data-symbol
+    // kernels may still be reading the descriptor buffers a caller reuses from round to round)
+    if (st != rx->stream && rx->lanes && rx->w->used && rx->w->piped) HIP_TRY(hipStreamWaitEvent(st, rx->w->ev[3], 0));
     const float2 *iq = (const float2 *)d_iq;
     hipLaunchKernelGGL(k_sync_flags, dim3((unsigned)((n + kFlagSamples - 1) / kFlagSamples)), dim3(256), 0, st, iq, n, rx->sy_flags.p);
     hipLaunchKernelGGL(k_sync_sts_end, dim3(n_blocks), dim3(kSyncBlockWords), 0, st, rx->sy_flags.p, n_words, 0, rx->sy_cnt.p, rx->sy_off.p, rx->sy_x.p, ccap);

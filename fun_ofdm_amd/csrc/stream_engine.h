@@ -96,8 +96,8 @@ struct StreamGpu {
         if (n_new) HIP_TRY(hipMemcpyAsync(d + 2 * C, pin[k], (size_t)n_new * 8, hipMemcpyHostToDevice, st_in));
         HIP_TRY(hipEventRecord(in_done[k], st_in));
         const bool piped = rx->pipeline && rx->viterbi_kind == 2;
-        hipStream_t st = piped ? rx->stream3 : rx->stream;          // pre-sync and front end run there
-        HIP_TRY(hipStreamWaitEvent(st, in_done[k], 0));
+        hipStream_t st = next_front_end_stream(rx);                 // the decode call's front end runs there; the pre-sync on side_stream(rx)
+        HIP_TRY(hipStreamWaitEvent(side_stream(rx), in_done[k], 0));
         size_t found = 0;
         int64_t t0 = now_ns();
         int rc = foa_rx_sync_dev(rx, d, (size_t)n_buf, (foa_frame_desc *)d_desc[k].p, d_ends[k].p, desc_cap, &found);

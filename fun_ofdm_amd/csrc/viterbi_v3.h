@@ -561,13 +561,15 @@ inline void launch_fwd3(hipStream_t st, const FrameInfo *info, int nf, const uin
     hipLaunchKernelGGL(k_viterbi_fwd3, dim3(((nf + 1) / 2 + kFwdWaves - 1) / kFwdWaves), dim3(64 * kFwdWaves), 0, st, info, nf, sp, dec);
 }
 
-inline void launch_finish3(hipStream_t st, const FrameInfo *info, int nf, const uint64_t *dec, uint32_t *decoded, const int32_t *seg2frame,
+// walk on st, stitch + descramble + CRC on st_fin (the same stream, or another one that then waits for walk_done)
+inline void launch_finish3(hipStream_t st, hipStream_t st_fin, const FrameInfo *info, int nf, const uint64_t *dec, uint32_t *decoded, const int32_t *seg2frame,
                            const int64_t *totals, uint16_t *tb_state, size_t max_segs, int S, int L, uint8_t *psdu, size_t slot_bytes,
                            foa_frame_result *results, hipEvent_t walk_done = nullptr)
 {
     hipLaunchKernelGGL(k_tb_walk, dim3((unsigned)((max_segs + 63) / 64)), dim3(64), 0, st, info, seg2frame, totals, dec, decoded, tb_state, S, L);
     if (walk_done) (void)hipEventRecord(walk_done, st);
-    hipLaunchKernelGGL(k_tb_finish, dim3((nf + 63) / 64), dim3(64), 0, st, info, nf, dec, decoded, tb_state, S, psdu, slot_bytes, results);
+    if (st_fin != st) (void)hipStreamWaitEvent(st_fin, walk_done, 0);
+    hipLaunchKernelGGL(k_tb_finish, dim3((nf + 63) / 64), dim3(64), 0, st_fin, info, nf, dec, decoded, tb_state, S, psdu, slot_bytes, results);
 }
 
 inline void launch_viterbi_v3(hipStream_t st, const FrameInfo *info, int nf, const uint16_t *sp, uint64_t *dec, uint32_t *decoded,
@@ -576,7 +578,7 @@ inline void launch_viterbi_v3(hipStream_t st, const FrameInfo *info, int nf, con
 {
     launch_fwd3(st, info, nf, sp, dec);
     if (between) (void)hipEventRecord(between, st);
-    launch_finish3(st, info, nf, dec, decoded, seg2frame, totals, tb_state, max_segs, S, L, psdu, slot_bytes, results);
+    launch_finish3(st, st, info, nf, dec, decoded, seg2frame, totals, tb_state, max_segs, S, L, psdu, slot_bytes, results);
 }
 
 }  // namespace foa

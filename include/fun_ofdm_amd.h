@@ -96,6 +96,9 @@ int foa_rx_reserve(foa_rx *rx, size_t n_samples, size_t n_frames);
  *                 the outputs of a call are final after foa_rx_sync (or, for the call before the most recent one, after
  *                 foa_rx_wait_previous), and the INPUTS of a call must be complete when it is made and stay untouched
  *                 until then.  0 = every call runs start to end on the handle's stream.
+ *   "lanes"       pipelined calls: 1 (default) = a call's front end, forward pass and chain-back walk run on ONE stream per call parity,
+ *                 so that the loop that sets the step has no event packet in it; 0 = front end on a third stream, walk and finish
+ *                 on a second one (A/B)
  *   "frontend"    0 = one wave per data symbol; 1 = one lane per data symbol; 2 = four lanes per data symbol;
  *                 -1 (default) = 2 (fastest alone, and its small waves run under the previous call's forward pass when
  *                 calls are pipelined); all three give bit-identical results
