@@ -594,7 +594,8 @@ def test_device_sync_between_pipelined_decode_calls(rx, po):
             assert np.array_equal(x, y)
 
 
-def test_pipelined_calls_keep_their_results_apart(rx, po):
+@pytest.mark.parametrize("lanes", [1, 0], ids=["lanes", "three-streams"])
+def test_pipelined_calls_keep_their_results_apart(rx, po, lanes):
     """Back-to-back decode calls without a sync in between (the finish of call k runs on a second stream under the
     forward pass of call k+1, on alternating work sets): every call must produce exactly what it produces alone."""
     import torch
@@ -611,6 +612,7 @@ def test_pipelined_calls_keep_their_results_apart(rx, po):
     rx.set_option("pipeline", 0)
     alone = [rx.decode_frames_host(iq, d, e) for iq, d, e in cases]
     rx.set_option("pipeline", 1)
+    rx.set_option("lanes", lanes)                          # both stream arrangements of the pipelined path (fun_ofdm_amd.h)
     bufs = []
     for iq, d, e in cases:
         t_iq = torch.from_numpy(iq.view(np.float32).reshape(-1, 2)).to(dev)
@@ -629,6 +631,18 @@ def test_pipelined_calls_keep_their_results_apart(rx, po):
         assert np.array_equal(b[3].cpu().numpy(), psdu)
     ms = rx.kernel_ms()
     assert ms["viterbi_finish"] > 0 and rx.kernel_ms(previous=True)["viterbi_fwd"] > 0
+    # a host-pointer call and a pre-sync + decode round in the same arrangement (their copies and the pre-sync run off the lanes)
+    iq, d, e = cases[-1]
+    psdu, res = rx.decode_frames_host(iq, d, e)
+    assert np.array_equal(res.view(np.int32), alone[-1][1].view(np.int32)) and np.array_equal(psdu, alone[-1][0])
+    t_iq, t_d, t_e, t_p, t_r = bufs[-1]
+    for _ in range(3):
+        n = rx.sync_dev(t_iq, t_d, t_e)
+        assert n == d.size
+        rx.decode_frames_dev(t_iq, t_d[:n * 48], t_e[:n], t_p[:n], t_r[:n])
+    rx.sync()
+    assert np.array_equal(t_r.cpu().numpy(), alone[-1][1].view(np.int32).reshape(-1, 4)) and np.array_equal(t_p.cpu().numpy(), alone[-1][0])
+    rx.set_option("lanes", 1)
 
 
 @pytest.mark.parametrize("seed", [101, 102, 103])
