@@ -85,7 +85,10 @@ void foa_rx_destroy(foa_rx *rx);
  * alignments, so that later decode calls allocate nothing. */
 int foa_rx_reserve(foa_rx *rx, size_t n_samples, size_t n_frames);
 
-/* Options (results are identical for every setting; they exist for A/B measurement and diagnostics):
+/* Options (results are identical for every setting; they exist for A/B measurement and diagnostics).  The production path is the
+ * default of every option.  "viterbi" 0 / 1 and "frontend" 0 / 1 select earlier, 2-10 x slower implementations of the same stages that
+ * are kept only as independent cross-checks for the parity suite (three Viterbi kernels and three front ends must agree bit for bit with
+ * each other and with the oracle); nothing else uses them.
  *   "viterbi"     0 = one wave per frame, lane per state (viterbi_v1.h); 1 = two frames per wave, serial chain-back
  *                 (viterbi_v2.h); 2 = two frames per wave, chain-back in parallel segments (viterbi_v3.h, default)
  *   "tb_segment"  viterbi 2: data steps per chain-back segment, a multiple of 96 in [96, 3072] (default 960)
