@@ -474,6 +474,22 @@ def roofline(args, kms, n_real, ms_per_step, piped):
                 "note": "10 B per step is what this kernel's interface moves (2 depunctured soft bytes in, 8 bytes of decisions out); SURVEY 8d's "
                         "figure for a fused Viterbi stage is 288 B in + 27 B out per symbol (stage_bytes_survey_8d): the decisions crossing "
                         "HBM make it 6.9 x that"}
+    # what BASELINE.json's north_star asks rocprof to show, from the counter passes of the same workload (profiles/): HBM rate of the
+    # FFT / demap stage against the HBM peak, L2 and LDS behaviour of the Viterbi ACS
+    fe = _profile_json("_pmc_hbm.json", "kernels", "k_data_symbols_q4", args.frames, "hbm_bytes_per_launch")
+    l2 = _profile_json("_pmc_lds_l2.json", "per_launch", fwd_kernel, args.frames, "l2_hit_frac")
+    bc = _profile_json("_pmc_lds_l2.json", "per_launch", fwd_kernel, args.frames, "lds_bank_conflict_frac")
+    stages = {}
+    if fe and kms.get("symbols"):
+        gbps = fe[0] / (kms["symbols"] * 1e-3) / 1e9
+        stages["fft_equalise_demap"] = {"kernel": "k_data_symbols_q4", "hbm_bytes_per_launch": int(fe[0]), "ms": round(kms["symbols"], 4),
+                                        "hbm_GBps": round(gbps, 1), "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBPS, 4), "source": fe[1],
+                                        "note": "duration live (HIP events, under the forward pass it shares the machine with when calls are pipelined)"}
+    if l2 or bc:
+        stages["viterbi_acs"] = {"kernel": fwd_kernel, "l2_hit_frac": l2[0] if l2 else None, "lds_bank_conflict_frac": bc[0] if bc else None,
+                                 "source": (l2 or bc)[1]}
+    if stages:
+        r["stages"] = stages
     if piped:
         # consecutive forward passes run on two streams and overlap at their ends, so a launch lasts longer than a step: the
         # launch duration (what a kernel trace reports, used above) counts the shared time twice
