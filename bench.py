@@ -25,6 +25,11 @@ import time
 
 import numpy as np
 
+# The library keeps up to six HIP streams busy (four lanes of pipelined calls, the finish stream, the copy / pre-sync stream); the
+# runtime's default of four hardware queues per process makes streams share queues, i.e. run one after the other.  Must be set
+# before the runtime starts (before torch is imported).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -59,6 +64,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the legs that are not `value`: host-pointer entry (H2D + D2H inside), config 3 rate sweep, config 5 stream")
     ap.add_argument("--fe-hold", type=int, default=-1, help="A/B: library option fe_hold (-1: library default)")
+    ap.add_argument("--depth", type=int, default=-1, help="A/B: library option depth (-1: library default = by grid size)")
     ap.add_argument("--lanes", type=int, default=-1, help="A/B: library option lanes (-1: library default)")
     ap.add_argument("--legs-frames", type=int, default=1000, help="frames per rate of the config-3 leg")
     return ap.parse_args(argv)
@@ -255,6 +261,8 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
         rx.set_option("fe_hold", args.fe_hold)
     if args.lanes >= 0:
         rx.set_option("lanes", args.lanes)
+    if args.depth >= 0:
+        rx.set_option("depth", args.depth)
     rx.set_option("pipeline", 0 if args.no_pipeline else 1)
     rx.set_option("record_soft", 0)        # PSDUs are the output; soft bytes are only kept for diagnostics
     rx.reserve(iq.size, m)
@@ -509,7 +517,7 @@ def extra_legs(args, rx, dev, iq, descs, ends, real, psdu_dev_path, res_dev_path
     STD = (0, 2, 3, 5, 6, 8, 9, 10)
 
     def timed(fn, reps):
-        for _ in range(4):                               # once per rotating work set of the library: each sizes its buffers on first use
+        for _ in range(8):                               # at least once per rotating work set of the library: each sizes its buffers on first use
             fn()
         rx.sync(); torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -181,12 +181,18 @@ struct HostJob {
 };
 constexpr int kMaxJobs = 8;
 
+constexpr int kSets = 6;
+
 struct foa_rx {
     int device = 0;
     hipStream_t stream = nullptr;      // front end + forward pass (and everything else)
     hipStream_t stream2 = nullptr;     // chain-back + finish of the pipelined path
     hipStream_t stream3 = nullptr;     // header + scan + front end of the pipelined path
-    hipStream_t stream4 = nullptr;     // forward passes of every other pipelined call (the rest are on `stream`)
+    hipStream_t stream4 = nullptr;     // the second lane of pipelined calls (the first is `stream`)
+    hipStream_t stream5 = nullptr, stream6 = nullptr;      // third and fourth lane, used for small grids (option "depth")
+    int depth = 0;                     // lanes: how many calls' loops are in flight; 0 = by grid size (2, or 4 below kDeepBelow frames)
+    int depth_saved = -1;              // (the stream engine pins 2 while a stream is open and restores this)
+    unsigned n_calls = 0;              // pipelined decode calls made so far (a call's lane is n_calls mod depth)
     int viterbi_kind = 2;        // 0: lane per state (viterbi_v1.h), 1: packed, serial chain-back (v2), 2: packed, segment chain-back (v3)
     int tb_segment = 960, tb_overlap = 96;   // v3 chain-back: data steps per segment / run-in steps (multiples of 96)
     bool pipeline = true;        // v3: finish of one call overlaps the next call's front end (two work sets, two streams)
@@ -200,7 +206,7 @@ struct foa_rx {
                                  // 2 = only the data-symbol kernel does; 0 = nothing is held back (A/B measurement)
     int frontend_kind = -1;      // 1: one lane per symbol (frontend_lps.h), 0: one wave per symbol, 2: four lanes per symbol (frontend_q4.h);
                                  // -1: the default, 2
-    WorkSet sets[4];             // three are in use at any time (below); the fourth keeps the call before them readable (timings)
+    WorkSet sets[kSets];         // up to depth + 1 are in use at any time (below); one more keeps the call before them readable (timings)
     WorkSet *w = &sets[0];       // the set of the most recent decode call
     WorkSet *prev = nullptr;     // the set of the call before it (kernel times of a call that is certainly complete)
     // Pipelined path: the chain-back + finish of a call is queued (on stream2) only when the NEXT call has queued its
@@ -229,14 +235,14 @@ struct foa_rx {
 
 namespace {
 
-// The stream on which the NEXT decode call's header, scan and data-symbol kernels will run (pre-sync, H2D copies and memsets that
-// feed that call are queued there): pipelined calls take turns on two lanes by the parity of their work set.
-hipStream_t next_front_end_stream(foa_rx *rx)
-{
-    if (!(rx->pipeline && rx->viterbi_kind == 2)) return rx->stream;
-    if (!rx->lanes) return rx->stream3;
-    return (((rx->w - rx->sets) + 1) & 1) ? rx->stream4 : rx->stream;
-}
+// A machine that a call fills (config 2: five forward-pass waves per SIMD) is best served by two calls' loops in flight; a call of a few
+// thousand frames leaves most SIMDs one wave or none, its forward pass lasts as long as ONE wave needs for its frames' trellis steps
+// whatever the batch, and more loops in flight are what raises the throughput then (1 000 frames x 4 092 bytes at 54 Mbps: 1.69 ms per
+// batch with two, the (forward pass + walk + front end) / depth rule with more).  Needs as many hardware queues as streams in use:
+// GPU_MAX_HW_QUEUES >= 6 (the runtime's default of 4 makes two lanes share a queue, i.e. run one after the other).
+constexpr int kDeepBelow = 2049;                 // frames: up to one forward-pass wave per SIMD (measured: 1 000-frame batches gain 20-30 % with four
+                                                 // loops in flight, a 4 000-frame stream of mixed rates loses 5 %, 10 000 frames lose 9 %)
+hipStream_t lane_stream(foa_rx *rx, int lane) { return lane == 0 ? rx->stream : lane == 1 ? rx->stream4 : lane == 2 ? rx->stream5 : rx->stream6; }
 
 // Host-pointer entry points copy their inputs (and the pre-sync stage runs) on the third stream when calls are pipelined, off the
 // lanes, so that a copy never sits behind a forward pass; the decode call that follows waits for the event.
@@ -311,6 +317,8 @@ int drain(foa_rx *rx)
     HIP_TRY(hipStreamSynchronize(rx->stream2));
     HIP_TRY(hipStreamSynchronize(rx->stream3));
     HIP_TRY(hipStreamSynchronize(rx->stream4));
+    HIP_TRY(hipStreamSynchronize(rx->stream5));
+    HIP_TRY(hipStreamSynchronize(rx->stream6));
     return FOA_OK;
 }
 
@@ -346,6 +354,8 @@ int foa_rx_create(foa_rx **out, int device)
     HIP_TRY(hipStreamCreateWithFlags(&rx->stream2, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&rx->stream3, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&rx->stream4, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&rx->stream5, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&rx->stream6, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&rx->in_ready, hipEventDisableTiming));
     for (auto &ws : rx->sets) {
         for (auto &e : ws.ev) HIP_TRY(hipEventCreate(&e));
@@ -382,6 +392,8 @@ void foa_rx_destroy(foa_rx *rx)
     if (rx->stream2) (void)hipStreamDestroy(rx->stream2);
     if (rx->stream3) (void)hipStreamDestroy(rx->stream3);
     if (rx->stream4) (void)hipStreamDestroy(rx->stream4);
+    if (rx->stream5) (void)hipStreamDestroy(rx->stream5);
+    if (rx->stream6) (void)hipStreamDestroy(rx->stream6);
     delete rx;
 }
 
@@ -427,6 +439,11 @@ int foa_rx_set_option(foa_rx *rx, const char *name, int64_t value)
         return FOA_OK;
     }
     if (!strcmp(name, "record_soft")) { rx->record_soft = value != 0; return FOA_OK; }
+    if (!strcmp(name, "depth")) {
+        if (value != 0 && (value < 2 || value > 4)) return fail(FOA_E_INVALID, "depth must be 0 (by grid size), 2, 3 or 4");
+        rx->depth = (int)value;
+        return FOA_OK;
+    }
     if (!strcmp(name, "lanes")) { int rc0 = drain(rx); if (rc0) return rc0; rx->lanes = value != 0; return FOA_OK; }
     if (!strcmp(name, "frontend")) {
         if (value < -1 || value > 2) return fail(FOA_E_INVALID, "frontend must be -1 (by context), 0 (wave per symbol), 1 (lane per symbol) or 2 (quad per symbol)");
@@ -447,7 +464,7 @@ int foa_rx_sync(foa_rx *rx)
 int foa_rx_wait_age(foa_rx *rx, int age)
 {
     if (!rx) return fail(FOA_E_INVALID, "rx is NULL");
-    if (age < 0 || age > 2) return fail(FOA_E_INVALID, "age must be 0, 1 or 2");
+    if (age < 0 || age > 4) return fail(FOA_E_INVALID, "age must lie in 0 .. 4");
     WorkSet *w = rx->w;
     if (age == 1 && !(rx->pipeline && rx->viterbi_kind == 2)) w = rx->prev;      // calls in line: the same set again
     else for (int i = 0; i < age && w; i++) w = w->before;
@@ -472,7 +489,7 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
     const bool piped = rx->pipeline && rx->viterbi_kind == 2;
     if (!piped) { int rc0 = flush_pending(rx, nullptr); if (rc0) return rc0; }
     rx->prev = rx->w;
-    if (piped) rx->w = &rx->sets[(int)((rx->w - rx->sets) + 1) % 4];     // in use: front end k+1 | forward pass k | finish k-1
+    if (piped) rx->w = &rx->sets[(int)((rx->w - rx->sets) + 1) % kSets];     // in use: front end k+1 | forward pass k | finish k-1
     if (rx->w->used) HIP_TRY(hipEventSynchronize(rx->w->done));      // the call that last used this set is complete
     int rc = workspace(rx, n_samples, n_frames);
     if (rc) return rc;
@@ -486,7 +503,8 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
     // scan and data symbols of call k+2, forward pass k+2 -- is then one in-order stream with no event packet in it; with the front
     // end on the third stream and the walk on the second, every hand-over between them cost 20-26 us, about 90 us per loop.
     const bool lanes = piped && rx->lanes;
-    hipStream_t st_fwd = (piped && ((rx->w - rx->sets) & 1)) ? rx->stream4 : rx->stream;
+    const int depth = !lanes ? 2 : rx->depth > 0 ? rx->depth : (n_frames < (size_t)kDeepBelow ? 4 : 2);
+    hipStream_t st_fwd = piped ? lane_stream(rx, (int)(rx->n_calls++ % (unsigned)depth)) : rx->stream;
     hipStream_t st = piped ? (lanes ? st_fwd : rx->stream3) : rx->stream;
     // Under one forward pass first the chain-back walk of the call before, then the front end of the call after: the two
     // heavy guests at once slow each other and the forward pass down more than they gain (measured: 1.50 against 1.43 ms per
@@ -698,7 +716,7 @@ int foa_rx_prev_kernel_ms(foa_rx *rx, float out_ms[6])
 int foa_rx_kernel_ms_age(foa_rx *rx, int age, float out_ms[6])
 {
     if (!rx || !out_ms) return fail(FOA_E_INVALID, "NULL argument");
-    if (age < 0 || age > 2) return fail(FOA_E_INVALID, "age must be 0, 1 or 2");
+    if (age < 0 || age > 4) return fail(FOA_E_INVALID, "age must lie in 0 .. 4");
     WorkSet *w = rx->w;
     for (int i = 0; i < age && w; i++) w = w->before;                // the pipelined calls link their work sets
     if (age > 0 && (!w || w == rx->w)) return fail(FOA_E_STATE, "no decode call of that age (calls must be pipelined)");

@@ -26,7 +26,7 @@ RATES = (0, 2, 3, 5, 6, 8, 9, 10)
 
 
 def timed(fn, reps=5):
-    for _ in range(4):                       # once per rotating work set of the library: each sizes its buffers on first use
+    for _ in range(8):                       # at least once per rotating work set of the library: each sizes its buffers on first use
         fn()
     rx.sync(); torch.cuda.synchronize()
     t0 = time.perf_counter()
