@@ -5,6 +5,7 @@
 #include <complex>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -341,6 +342,9 @@ int foa_rx_create(foa_rx **out, int device)
 {
     if (!out) return fail(FOA_E_INVALID, "out is NULL");
     *out = nullptr;
+    // six streams want six hardware queues (lane_stream above); the runtime reads this when it starts, so it only takes effect in a
+    // process whose first HIP call is this one -- others set it themselves
+    (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(FOA_E_NO_DEVICE, "no HIP device (this library has no CPU path)");
     if (device < 0 || device >= n) return fail(FOA_E_INVALID, "device %d out of range (0..%d)", device, n - 1);
