@@ -143,8 +143,8 @@ void foa::build_tables(DeviceTables *t)
         }
 }
 
-// Everything one decode call writes between its header kernel and its finish kernel.  There are two sets so that the
-// chain-back of call k (HBM-bound, on the second stream) can run under the front end and forward pass of call k+1.
+// Everything one decode call writes between its header kernel and its finish kernel.  Several sets rotate (kSets) so that the
+// chain-back of call k can run under the forward pass of call k+1 while call k+2's front end is already filling the next one.
 struct WorkSet {
     DevBuf<FrameInfo> info;
     DevBuf<double2> hinv;
@@ -186,9 +186,10 @@ constexpr int kSets = 6;
 
 struct foa_rx {
     int device = 0;
-    hipStream_t stream = nullptr;      // front end + forward pass (and everything else)
-    hipStream_t stream2 = nullptr;     // chain-back + finish of the pipelined path
-    hipStream_t stream3 = nullptr;     // header + scan + front end of the pipelined path
+    hipStream_t stream = nullptr;      // everything when calls run in line; the first lane of pipelined calls
+    hipStream_t stream2 = nullptr;     // pipelined path: the stitch / CRC kernel behind a walk (lanes), or walk + finish (lanes off)
+    hipStream_t stream3 = nullptr;     // pipelined path: copies of the host-pointer entry points and the pre-sync stage (lanes), or header + scan +
+                                       // data symbols (lanes off)
     hipStream_t stream4 = nullptr;     // the second lane of pipelined calls (the first is `stream`)
     hipStream_t stream5 = nullptr, stream6 = nullptr;      // third and fourth lane, used for small grids (option "depth")
     int depth = 0;                     // lanes: how many calls' loops are in flight; 0 = by grid size (2, or 4 below kDeepBelow frames)
@@ -497,11 +498,9 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
     if (rx->w->used) HIP_TRY(hipEventSynchronize(rx->w->done));      // the call that last used this set is complete
     int rc = workspace(rx, n_samples, n_frames);
     if (rc) return rc;
-    // st: header, scan, front end.  Pipelined, that is the third stream, so that they can run under the forward pass of
-    // the call before (still busy on its own stream) wherever registers and LDS allow.
-    // Forward passes of consecutive calls take turns on two streams: nothing orders one behind the other (each has its own
-    // work set), so the next one starts the moment its front end is done, into the tail of the one before, instead of
-    // ~20 us after it (end-of-kernel release, event packets, dispatch): 1.345 -> 1.316 ms per step at config 2.
+    // st: header, scan, data symbols; st_fwd: the forward pass.  Forward passes of consecutive calls take turns on two (or four)
+    // streams: nothing orders one behind the other (each has its own work set), so the next one starts the moment its front end is
+    // done, into the tail of the one before.
     // lanes (default): the call's front end runs on the stream of its own forward pass, behind the chain-back walk of the call two
     // back (queued there when the call before this one was made).  The loop that sets the step -- forward pass k, walk k, header,
     // scan and data symbols of call k+2, forward pass k+2 -- is then one in-order stream with no event packet in it; with the front
