@@ -558,7 +558,7 @@ def extra_legs(args, rx, dev, iq, descs, ends, real, psdu_dev_path, res_dev_path
             m = rx.sync_dev(d_iq, d_desc, d_end)
             d_psdu = torch.zeros((m, length), dtype=torch.uint8, device=dev)
             d_res = torch.zeros((m, 4), dtype=torch.int32, device=dev)
-            dt = timed(lambda: rx.decode_frames_dev(d_iq, d_desc[:m * 48], d_end[:m], d_psdu, d_res), 5)
+            dt = timed(lambda: rx.decode_frames_dev(d_iq, d_desc[:m * 48], d_end[:m], d_psdu, d_res), 24)   # (steady state: four loops in flight fill and drain)
             r = d_res.cpu().numpy()
             d = d_desc.cpu().numpy()[:m * 48].view(foa.frame_desc_dtype)
             on = np.nonzero((d["lts1_pos"] - 360) % pitch == 0)[0]

@@ -239,10 +239,10 @@ namespace {
 
 // A machine that a call fills (config 2: five forward-pass waves per SIMD) is best served by two calls' loops in flight; a call of a few
 // thousand frames leaves most SIMDs one wave or none, its forward pass lasts as long as ONE wave needs for its frames' trellis steps
-// whatever the batch, and more loops in flight are what raises the throughput then (1 000 frames x 4 092 bytes at 54 Mbps: 1.69 ms per
-// batch with two, the (forward pass + walk + front end) / depth rule with more).  Needs as many hardware queues as streams in use:
+// whatever the batch, and more loops in flight are what raises the throughput then (1 000 frames x 4 092 bytes at 54 Mbps: 1.43 ms per
+// batch with two, 0.94 with four).  Needs as many hardware queues as streams in use:
 // GPU_MAX_HW_QUEUES >= 6 (the runtime's default of 4 makes two lanes share a queue, i.e. run one after the other).
-constexpr int kDeepBelow = 2049;                 // frames: up to one forward-pass wave per SIMD (measured: 1 000-frame batches gain 20-30 % with four
+constexpr int kDeepBelow = 2049;                 // frames: up to one forward-pass wave per SIMD (measured: 1 000-frame batches gain 40-50 % with four
                                                  // loops in flight, a 4 000-frame stream of mixed rates loses 5 %, 10 000 frames lose 9 %)
 hipStream_t lane_stream(foa_rx *rx, int lane) { return lane == 0 ? rx->stream : lane == 1 ? rx->stream4 : lane == 2 ? rx->stream5 : rx->stream6; }
 

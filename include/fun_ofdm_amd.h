@@ -103,7 +103,7 @@ int foa_rx_reserve(foa_rx *rx, size_t n_samples, size_t n_frames);
  *                 so that the loop that sets the step has no event packet in it; 0 = front end on a third stream, walk and finish
  *                 on a second one (A/B)
  *   "depth"       lanes: how many calls' loops are in flight -- 0 (default) = by grid size: 2, or 4 for calls of up to 2048 frames, whose
- *                 forward pass leaves most SIMDs a single wave (1 000-frame batches decode 20-30 % faster); 2, 3, 4 = fixed (A/B).  More
+ *                 forward pass leaves most SIMDs a single wave (1 000-frame batches decode 40-50 % faster in steady state); 2, 3, 4 = fixed (A/B).  More
  *                 than two lanes need more hardware queues than the runtime's default of four: GPU_MAX_HW_QUEUES=8 in the environment
  *                 before the HIP runtime starts (bench.py sets it)
  *   "frontend"    0 = one wave per data symbol; 1 = one lane per data symbol; 2 = four lanes per data symbol;
