@@ -622,13 +622,19 @@ def test_pipelined_calls_keep_their_results_apart(rx, po, lanes):
         t_r = torch.zeros((d.size, 4), dtype=torch.int32, device=dev)
         bufs.append((t_iq, t_d, t_e, t_p, t_r))
     torch.cuda.synchronize()
-    for rep in range(3):                                   # 15 calls in flight order, no sync between them
+    for depth in ((0, 2, 3, 4) if lanes else (0,)):       # loops in flight: by grid size (these small batches: four), or fixed
+        rx.set_option("depth", depth)
         for b in bufs:
-            rx.decode_frames_dev(*b)
-    rx.sync()
-    for (psdu, res), b in zip(alone, bufs):
-        assert np.array_equal(b[4].cpu().numpy(), res.view(np.int32).reshape(-1, 4))
-        assert np.array_equal(b[3].cpu().numpy(), psdu)
+            b[3].zero_(); b[4].zero_()
+        torch.cuda.synchronize()
+        for rep in range(3):                               # 15 calls in flight order, no sync between them
+            for b in bufs:
+                rx.decode_frames_dev(*b)
+        rx.sync()
+        for (psdu, res), b in zip(alone, bufs):
+            assert np.array_equal(b[4].cpu().numpy(), res.view(np.int32).reshape(-1, 4)), depth
+            assert np.array_equal(b[3].cpu().numpy(), psdu), depth
+    rx.set_option("depth", 0)
     ms = rx.kernel_ms()
     assert ms["viterbi_finish"] > 0 and rx.kernel_ms(previous=True)["viterbi_fwd"] > 0
     # a host-pointer call and a pre-sync + decode round in the same arrangement (their copies and the pre-sync run off the lanes)
