@@ -341,11 +341,11 @@ __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd3(const FrameInfo
         for (int blk = 0; blk < 3; blk++) {
             const int b0 = n0 + 16 * blk;
             if constexpr (FOA_ABL & 16) { if (word[blk] == 0x12345678u) dA[lane] = 1; continue; }
-            if (b0 < NAtop) {
+            if (__builtin_expect(b0 < NAtop, 1)) {         // (said so that the stores stay in line: as unlikely blocks each cost two taken branches)
                 const int v = NA - b0;
                 dA[(size_t)(b0 >> 4) * 64 + 63 - lane] = (uint16_t)(word[blk] | (v >= 16 ? 0u : v <= 0 ? 0xFFFFu : 0xFFFFu << v));
             }
-            if (b0 < NBtop) {
+            if (__builtin_expect(b0 < NBtop, 1)) {
                 const int v = NB - b0;
                 dB[(size_t)(b0 >> 4) * 64 + 63 - lane] = (uint16_t)((word[blk] >> 16) | (v >= 16 ? 0u : v <= 0 ? 0xFFFFu : 0xFFFFu << v));
             }
