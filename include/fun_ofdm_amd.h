@@ -95,7 +95,7 @@ int foa_rx_reserve(foa_rx *rx, size_t n_samples, size_t n_frames);
  *   "tb_overlap"  viterbi 2: run-in steps above a segment, a multiple of 96 in [0, 3072] (default 96); any value gives
  *                 the same result as the serial chain-back, small values cost re-walks
  *   "pipeline"    viterbi 2: consecutive decode calls form a three-stage pipeline (front end | forward pass | chain-back
- *                 and finish) over four streams and rotating work sets (default 1).  Results and their order are unchanged;
+ *                 and finish) over several streams and rotating work sets (default 1).  Results and their order are unchanged;
  *                 the outputs of a call are final after foa_rx_sync (or, for the call before the most recent one, after
  *                 foa_rx_wait_previous), and the INPUTS of a call must be complete when it is made and stay untouched
  *                 until then.  0 = every call runs start to end on the handle's stream.
