@@ -28,7 +28,7 @@ def _free_port():
 class StubReceiver:
     """What bench.run() needs of fun_ofdm_amd.Receiver.  decode_frames_dev() only QUEUES a call; its outputs are written
     when the real library guarantees them: at wait_age(age) for the calls `age` back and older, at sync(), or when the call
-    four back has to be complete because its work set is taken again (four rotating sets)."""
+    six back has to be complete because its work set is taken again (six rotating sets)."""
     pays = None        # set per rank: uint8[n_frames, 1024], payload of local frame i
     pitch, first = 4096, 176 + 184
 
@@ -61,7 +61,7 @@ class StubReceiver:
         psdu.fill_(0xEE)                                   # in flight: whoever reads this set now reads garbage
         self.queue.append((descs, psdu, results))
         self.calls += 1
-        while len(self.queue) > 3:
+        while len(self.queue) > 5:
             self._complete(self.queue.pop(0))
 
     def wait_age(self, age):
@@ -98,8 +98,13 @@ def _worker(rank, world, port, frames, steps, q):
     dist.destroy_process_group()
 
 
-def test_bench_host_logic_two_ranks_over_gloo():
-    world, frames, steps = 2, 24, 5
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 8], ids=["two-ranks", "eight-ranks"])
+def test_bench_host_logic_two_ranks_over_gloo(world):
+    """(world 8 = the rank count of BASELINE config 4; the name is kept from the two-rank version)"""
+    frames, steps = 24, 5
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -111,11 +116,11 @@ def test_bench_host_logic_two_ranks_over_gloo():
         p.join(timeout=120)
         assert p.exitcode == 0
     json.dumps(out)                                        # the record is one JSON-serialisable object
-    assert out["n_gpus"] == 2 and out["steps"] == steps and out["scaling"] == "weak" and out["vs_baseline"] is None
+    assert out["n_gpus"] == world and out["steps"] == steps and out["scaling"] == "weak" and out["vs_baseline"] is None
     cfg = out["config"]
     assert cfg["psdu_bit_exact"] is True                   # incl. the gathered slots of both ranks, in global frame order
     assert cfg["frames_ok"] == world * frames and cfg["frames_per_gpu"] == frames
-    assert "rank i mod 2" in cfg["sharding"] and "gloo" in cfg["sharding"]
+    assert ("rank i mod %d" % world) in cfg["sharding"] and "gloo" in cfg["sharding"]
     # value counts the frames of ALL ranks (whole-job throughput)
     assert abs(out["value"] - world * frames * 3520 / (out["ms_per_step"] * 1e-3) / 1e6) / out["value"] < 1e-3
 
