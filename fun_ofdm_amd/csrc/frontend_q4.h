@@ -91,11 +91,16 @@ __device__ __forceinline__ void q4_emit(Q4Shared &sh, Q4Wave &ws, const cpx (&X)
             const cpx zc = cmul(cmul(cpx{ hh.x, hh.y }, X[4 * a + j]), rot);
             if (eq_tap && valid) eq_tap[(size_t)w * 48 + di] = make_double2(zc.x, zc.y);
             const uint32_t li = qam_lookup(sh.qam, zc.x, rr.scale_d), lq = bpsc > 1 ? qam_lookup(sh.qam, zc.y, rr.scale_d) : 0u;
+            // the carrier's positions first, all of them, then its bytes: read and written one by one, every byte waited out an LDS
+            // round trip of its own (72 per lane and symbol at 64-QAM)
+            uint32_t at[6];
+#pragma unroll
+            for (int b = 0; b < 6; b++) at[b] = b < bpsc ? pos[di * bpsc + b] : 0u;
 #pragma unroll
             for (int b = 0; b < 6; b++) {
                 if (b < bpsc) {
                     const uint32_t byte = b < nb ? (li >> (8 * b)) & 255u : (lq >> (8 * (b - nb))) & 255u;
-                    ws.soft[qd][pos[di * bpsc + b]] = (uint8_t)byte;             // interleaver.cpp:33-36, puncturer.cpp:112-118
+                    ws.soft[qd][at[b]] = (uint8_t)byte;                          // interleaver.cpp:33-36, puncturer.cpp:112-118
                 }
             }
         }
