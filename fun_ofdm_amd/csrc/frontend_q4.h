@@ -74,6 +74,11 @@ __device__ __forceinline__ void q4_emit(Q4Shared &sh, Q4Wave &ws, const cpx (&X)
     wave_lds_sync();
     const int bpsc = BPSC > 0 ? BPSC : rr.bpsc, nb = bpsc == 1 ? 1 : bpsc / 2;
     const uint16_t *pos = sh.pos[rate];
+    // data-carrier index of this lane's sixteen bins, four dwords read at once (bins 16 j + 4 m + a, a = 0..3, are four consecutive
+    // bytes of the table): one LDS round trip instead of sixteen
+    uint32_t dj[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) dj[j] = *(const uint32_t *)&sh.dindex[(16 * j + 4 * m + 32) & 63];
 #pragma unroll
     for (int a = 0; a < 4; a++) {
         __builtin_amdgcn_sched_barrier(0);
@@ -84,8 +89,7 @@ __device__ __forceinline__ void q4_emit(Q4Shared &sh, Q4Wave &ws, const cpx (&X)
         for (int j = 0; j < 4; j++) hh4[j] = h[(16 * j + 4 * m + a + 32) & 63];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const int s_idx = (16 * j + 4 * m + a + 32) & 63;
-            const int di = sh.dindex[s_idx];
+            const int di = (int)(int8_t)(dj[j] >> (8 * a));
             if (di < 0) continue;
             const double2 hh = hh4[j];
             const cpx zc = cmul(cmul(cpx{ hh.x, hh.y }, X[4 * a + j]), rot);
