@@ -51,6 +51,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node (default: WORLD_SIZE, else 1)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reps", type=int, default=3, help="timed regions of --steps steps each inside the one run; value = the median region")
     ap.add_argument("--frames", type=int, default=10000, help="frames per GPU (BASELINE config 2: 10000)")
     ap.add_argument("--viterbi", type=int, default=2, help="0: lane per state, 1: packed + serial chain-back, 2: packed + segment chain-back")
     ap.add_argument("--tb-segment", type=int, default=0, help="viterbi 2: data steps per chain-back segment (0: library default)")
@@ -323,40 +324,73 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
     for _ in range(args.warmup):
         step()
     d_psdu, d_res = finish_steps()
-    dev_sync()
-    if world > 1:
-        dist.barrier()
     piped = bool(args.viterbi == 2 and not args.no_pipeline)
-    kern = {k: 0.0 for k in ("header", "scan", "symbols", "viterbi_fwd", "viterbi_finish", "total")}
-    kern_n = 0
-    n_gathers[0] = 0
-    t_start = time.perf_counter()
-    for i in range(args.steps):
-        step()
-        # per-kernel HIP-event times of the step two back: complete for sure, so the host is not held up (the next call's
-        # front end must be queued while this step's forward pass is still running).  Calls in line (--no-pipeline, other
-        # kernels) keep one event set per call, and reading it would stall the loop at every step: they are read after it.
-        if piped and args.steps <= 50 and i > 1:
-            for k, v in rx.kernel_ms(age=2).items():
+
+    def timed_region():
+        """EXACTLY args.steps steps between barrier + synchronize on both sides; returns (seconds, max over ranks; per-kernel
+        HIP-event ms summed over the steps read; how many were read; the last step's outputs)."""
+        dev_sync()
+        if world > 1:
+            dist.barrier()
+        kern = {k: 0.0 for k in ("header", "scan", "symbols", "viterbi_fwd", "viterbi_finish", "total")}
+        kern_n = 0
+        n_gathers[0] = 0
+        t_start = time.perf_counter()
+        for i in range(args.steps):
+            step()
+            # per-kernel HIP-event times of the step two back: complete for sure, so the host is not held up (the next call's
+            # front end must be queued while this step's forward pass is still running).  Calls in line (--no-pipeline, other
+            # kernels) keep one event set per call, and reading it would stall the loop at every step: they are read after it.
+            if piped and args.steps <= 50 and i > 1:
+                for k, v in rx.kernel_ms(age=2).items():
+                    kern[k] += v
+                kern_n += 1
+        d_psdu, d_res = finish_steps()
+        dev_sync()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t_start
+        if args.steps <= 50:                                 # ... and of the last step(s), after the clock has stopped
+            if piped and args.steps > 1:
+                for k, v in rx.kernel_ms(previous=True).items():
+                    kern[k] += v
+                kern_n += 1
+            for k, v in rx.kernel_ms().items():
                 kern[k] += v
             kern_n += 1
-    d_psdu, d_res = finish_steps()
-    dev_sync()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t_start
-    if args.steps <= 50:                                 # ... and of the last step(s), after the clock has stopped
-        if piped and args.steps > 1:
-            for k, v in rx.kernel_ms(previous=True).items():
-                kern[k] += v
-            kern_n += 1
-        for k, v in rx.kernel_ms().items():
-            kern[k] += v
-        kern_n += 1
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, kern, kern_n, d_psdu, d_res, n_gathers[0]
+
+    # The timed region is repeated (--reps) inside the one run and `value` is the MEDIAN region: a single 20-step region is
+    # ~25 ms, and one unlucky arrangement of the overlapping kernels would be the whole measurement (VERDICT round 2).
+    regions = [timed_region() for _ in range(max(1, args.reps))]
+    order = sorted(range(len(regions)), key=lambda j: regions[j][0])
+    med = order[len(order) // 2] if len(order) % 2 else order[len(order) // 2 - 1]      # (even count: the lower middle, a region that was really run)
+    elapsed, kern, kern_n, _, _, _ = regions[med]
+    d_psdu, d_res = regions[-1][3], regions[-1][4]
+    gathers_ok = all(r[5] == args.steps for r in regions)
+    rep_ms = [r[0] / args.steps * 1e3 for r in regions]
+    rep_fwd = [r[1]["viterbi_fwd"] / r[2] if r[2] else None for r in regions]
+
+    # ---- self-check (not `value`): every kernel with the machine to itself, calls in line on one stream, on THIS box in THIS run.
+    # forward_ms_live / forward_ms_alone tells a good arrangement of the overlapping calls (about 1.2-1.3: the forward pass shares the
+    # SIMDs with its guests) from a bad one (VERDICT round 2 measured 2.9 on the driver's box).
+    alone = None
+    if piped and not on_cpu and args.steps <= 50:
+        rx.sync()
+        rx.set_option("pipeline", 0)
+        acc = {}
+        for j in range(4):
+            rx.decode_frames_dev(d_iq, d_desc, d_ends, out_psdu[0], out_res[0])
+            rx.sync()
+            if j:
+                for k, v in rx.kernel_ms().items():
+                    acc[k] = acc.get(k, 0.0) + v / 3.0
+        rx.set_option("pipeline", 1)
+        alone = acc
 
     # ---- extra leg (not `value`): the same pass preceded by frame_detector + timing_sync on the device ----
     with_sync = None
@@ -403,7 +437,7 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
             all_pays = synth.splitmix64_bytes(SEED_BASE, n_global, PAYLOAD)
             nz = g.any(axis=1)                           # frames whose CRC failed leave their slot zeroed
             exact = exact and bool(np.array_equal(g[nz], all_pays[nz])) and int(nz.sum()) == ok_frames
-            exact = exact and n_gathers[0] == args.steps     # one gather per timed step, all inside the timed region
+            exact = exact and gathers_ok                     # one gather per timed step, all inside the timed region (every region)
 
     out = None
     if rank == 0:
@@ -428,6 +462,18 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
         }
         if with_sync:
             out["config"]["incl_device_pre_sync"] = with_sync
+        srt = sorted(rep_ms)
+        out["repeats"] = {"regions": len(rep_ms), "steps_per_region": args.steps, "value_is": "median region",
+                          "ms_per_step": [round(v, 4) for v in rep_ms], "min": round(srt[0], 4), "median": round(ms_per_step, 4), "max": round(srt[-1], 4),
+                          "spread_frac": round((srt[-1] - srt[0]) / ms_per_step, 4),
+                          "forward_ms_live": [round(v, 4) if v is not None else None for v in rep_fwd]}
+        if alone:
+            out["kernel_ms_alone"] = {k: round(v, 4) for k, v in alone.items()}
+            if kern_n and alone.get("viterbi_fwd"):
+                live = kern["viterbi_fwd"] / kern_n
+                out["repeats"]["forward_ms_alone"] = round(alone["viterbi_fwd"], 4)
+                out["repeats"]["forward_live_over_alone"] = round(live / alone["viterbi_fwd"], 3)
+                out["repeats"]["step_over_sum_alone"] = round(ms_per_step / alone["total"], 3)
         if args.steps <= 50 and kern_n and not on_cpu:
             kms = {k: v / kern_n for k, v in kern.items()}
             out["roofline"] = roofline(args, kms, real.size, ms_per_step, piped)
