@@ -68,6 +68,9 @@ def parse_args(argv=None):
     ap.add_argument("--depth", type=int, default=-1, help="A/B: library option depth (-1: library default = by grid size)")
     ap.add_argument("--lanes", type=int, default=-1, help="A/B: library option lanes (-1: library default)")
     ap.add_argument("--legs-frames", type=int, default=1000, help="frames per rate of the config-3 leg")
+    ap.add_argument("--timing-age", type=int, default=4, help="pipelined steps: the per-kernel HIP-event times read inside the timed loop are those of the "
+                    "call this many calls back (2..4): the further back, the more calls the host may run ahead of the GPU")
+    ap.add_argument("--host-jitter-us", type=int, default=0, help="A/B: sleep this long on the host after every fifth step (how much host delay the pipeline absorbs)")
     return ap.parse_args(argv)
 
 
@@ -119,38 +122,57 @@ def make_workload(frame_ids, noise_seed):
     return iq, pays
 
 
-def cpu_baseline(iq, descs, ends, pays, budget_s=15.0):
-    """The oracle (a port of the reference's per-frame path: fft_symbols..frame_decoder on one
-    alignment) timed on this host's cores on a bounded sample of the same workload."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(iq, descs, ends, pays, budget_s=18.0):
+    """The oracle (a port of the reference's per-frame path: fft_symbols..frame_decoder on one alignment) timed on this
+    host's cores on a bounded sample of the same workload.  SURVEY 8d protocol: >= 3 repetitions, the median is the
+    figure; CPU model and thread count stated."""
     from oracle import pyoracle as po
     cores = os.cpu_count() or 1
-    # size the sample from a quick probe so that the leg stays near budget_s
+    # size the sample from a quick probe so that the three repetitions together stay near budget_s
     t0 = time.perf_counter()
     po.decode_batch_f32(iq, descs[:cores], ends[:cores], slot_bytes=PAYLOAD, threads=cores)
     probe = time.perf_counter() - t0
-    n = int(min(descs.size, max(cores, cores * budget_s / max(probe, 1e-3))))
+    n = int(min(descs.size, max(cores, cores * (budget_s / 3.0) / max(probe, 1e-3))))
     n_samp = int(ends[n - 1])
-    t0 = time.perf_counter()
-    psdu, res = po.decode_batch_f32(iq[:n_samp], descs[:n], ends[:n], slot_bytes=PAYLOAD, threads=cores)
-    dt = time.perf_counter() - t0
+    runs = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        psdu, res = po.decode_batch_f32(iq[:n_samp], descs[:n], ends[:n], slot_bytes=PAYLOAD, threads=cores)
+        runs.append(time.perf_counter() - t0)
+    dt = sorted(runs)[1]
     real = np.nonzero((descs["lts1_pos"][:n] - (LEAD + 184)) % PITCH == 0)[0]
     in_frame = real.size * FRAME_SAMPLES
-    out = dict(value=in_frame / dt / 1e6, unit="Msamples/s", cores=cores, kind="port",
-               sample="%d of the workload's alignments (%d frames, %d samples fed), oracle fo_decode_batch_f32 on %d threads, %.1f s"
+    out = dict(value=in_frame / dt / 1e6, unit="Msamples/s", cores=cores, threads=cores, cpu_model=cpu_model(), kind="port",
+               protocol="median of 3 repetitions", runs_s=[round(v, 3) for v in runs],
+               sample="%d of the workload's alignments (%d frames, %d samples fed), oracle fo_decode_batch_f32 on %d threads, %.2f s per repetition"
                       % (n, real.size, n_samp, cores, dt),
                note="a port: the reference itself needs FFTW3 and Boost, which this image does not have (oracle/Makefile builds "
                     "the ten reference translation units that need neither and the port is pinned against them)")
     # the reference's own structure for comparison (SURVEY 8d): process_samples() over six block threads + the caller,
-    # 4096-sample chunks, pre-sync included -- one chain, on a few hundred frames
+    # 4096-sample chunks, pre-sync included -- one chain, >= 2000 frames, median of 3
     try:
-        nf = min(len(pays), 400)
-        chain = po.ReceiverChain(threaded=True)
-        t0 = time.perf_counter()
-        got = chain.run_stream(iq[:nf * PITCH], chunk=4096)
-        dt_c = time.perf_counter() - t0
-        out["reference_structure"] = {"value": round(nf * FRAME_SAMPLES / dt_c / 1e6, 2), "unit": "Msamples/s", "threads": 7,
+        nf = min(len(pays), 2000)
+        rs, got = [], []
+        for _ in range(3):
+            chain = po.ReceiverChain(threaded=True)
+            t0 = time.perf_counter()
+            got = chain.run_stream(iq[:nf * PITCH], chunk=4096)
+            rs.append(time.perf_counter() - t0)
+        dt_c = sorted(rs)[1]
+        out["reference_structure"] = {"value": round(nf * FRAME_SAMPLES / dt_c / 1e6, 2), "unit": "Msamples/s", "threads": 7, "protocol": "median of 3 repetitions",
+                                      "runs_s": [round(v, 3) for v in rs],
                                       "sample": "%d frames through the oracle's receiver_chain (frame_detector .. frame_decoder as "
-                                                "six block threads, 4096-sample calls), %d payloads out, %.1f s" % (nf, len(got), dt_c)}
+                                                "six block threads, 4096-sample calls), %d payloads out, %.2f s per repetition" % (nf, len(got), dt_c)}
     except Exception as e:                                # the headline baseline above does not depend on this leg
         out["reference_structure"] = {"error": str(e)}
     return out, psdu, res, n
@@ -168,17 +190,6 @@ def _profile_json(suffix, key, kernel, frames, field):
                 v = d[key][kernel].get(field)
                 if v is not None:
                     best = (v, name)
-    return best
-
-
-def valu_clocks_per_instr():
-    """Clocks of SIMD time one wave64 VALU instruction of the forward pass's mix costs, measured by tools/probe_issue.hip on
-    this part (profiles/*_probe_issue.json).  The issue roof follows from it: 1024 SIMDs x f / clocks."""
-    pdir = os.path.join(ROOT, "profiles")
-    best = None
-    for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
-        if name.endswith("_probe_issue.json"):
-            best = (json.load(open(os.path.join(pdir, name))), name)
     return best
 
 
@@ -217,13 +228,22 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
         if not on_cpu:
             torch.cuda.synchronize()
 
-    if world > 1 and not dist.is_initialized():
+    # FOA_BENCH_FORCE_DIST=1: take the N > 1 host path (process group, three rotating output sets, wait_age(2), read_done
+    # events, one dist.gather per step) with however many ranks there are -- at world 1 on a one-GPU box this runs the very
+    # RCCL calls the 8-GPU job makes, with one rank
+    multi = world > 1 or os.environ.get("FOA_BENCH_FORCE_DIST") == "1"
+    if multi and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        if rank == 0:
+            log("[bench] process group up: %s saw %d rank%s" % ("RCCL" if backend == "nccl" else backend, dist.get_world_size(), "" if dist.get_world_size() == 1 else "s"))
     cdev = dev if backend == "nccl" else torch.device("cpu")       # where collective tensors live
 
     t0 = time.perf_counter()
@@ -272,7 +292,7 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
     d_ends = torch.from_numpy(ends).to(dev)
     # three output sets in rotation: with several ranks the PSDUs of step k-2 are gathered while step k is being queued and
     # step k-1's chain-back has yet to run, so consecutive steps must not share their output buffers
-    n_out = 3 if world > 1 else 1
+    n_out = 3 if multi else 1
     out_psdu = [torch.zeros((m, PAYLOAD), dtype=torch.uint8, device=dev) for _ in range(n_out)]
     out_res = [torch.zeros((m, 4), dtype=torch.int32, device=dev) for _ in range(n_out)]
     d_real = torch.from_numpy(real).to(dev)
@@ -288,7 +308,7 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
         local.index_copy_(0, d_which, buf.index_select(0, d_real))
         read_done[i] = _CpuEvent() if on_cpu else torch.cuda.Event()
         read_done[i].record()
-        gathered[0] = shard.gather_psdus(local.to(cdev), n_global, rank, world)
+        gathered[0] = shard.gather_psdus(local.to(cdev), n_global, rank, world, force_collective=multi)
         n_gathers[0] += 1
 
     issued = [0]          # steps queued since the last finish_steps()
@@ -307,14 +327,14 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
             read_done[k % n_out] = None
         rx.decode_frames_dev(d_iq, d_desc, d_ends, out_psdu[k % n_out], out_res[k % n_out])
         issued[0] = k + 1
-        if world > 1 and k - done[0] >= 2:
+        if multi and k - done[0] >= 2:
             rx.wait_age(2)
             gather_now(done[0] % n_out)
             done[0] += 1
 
     def finish_steps():
         rx.sync()
-        while world > 1 and done[0] < issued[0]:         # the last two steps' PSDUs
+        while multi and done[0] < issued[0]:             # the last two steps' PSDUs
             gather_now(done[0] % n_out)
             done[0] += 1
         last = (issued[0] - 1) % n_out if issued[0] else 0
@@ -330,35 +350,38 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
         """EXACTLY args.steps steps between barrier + synchronize on both sides; returns (seconds, max over ranks; per-kernel
         HIP-event ms summed over the steps read; how many were read; the last step's outputs)."""
         dev_sync()
-        if world > 1:
+        if multi:
             dist.barrier()
         kern = {k: 0.0 for k in ("header", "scan", "symbols", "viterbi_fwd", "viterbi_finish", "total")}
         kern_n = 0
         n_gathers[0] = 0
+        age = min(4, max(2, args.timing_age))
         t_start = time.perf_counter()
         for i in range(args.steps):
             step()
             # per-kernel HIP-event times of the step two back: complete for sure, so the host is not held up (the next call's
             # front end must be queued while this step's forward pass is still running).  Calls in line (--no-pipeline, other
             # kernels) keep one event set per call, and reading it would stall the loop at every step: they are read after it.
-            if piped and args.steps <= 50 and i > 1:
-                for k, v in rx.kernel_ms(age=2).items():
+            if piped and args.steps <= 50 and i >= age:
+                for k, v in rx.kernel_ms(age=age).items():
                     kern[k] += v
                 kern_n += 1
+            if args.host_jitter_us and i % 5 == 4:
+                time.sleep(args.host_jitter_us * 1e-6)
         d_psdu, d_res = finish_steps()
         dev_sync()
-        if world > 1:
+        if multi:
             dist.barrier()
         elapsed = time.perf_counter() - t_start
         if args.steps <= 50:                                 # ... and of the last step(s), after the clock has stopped
-            if piped and args.steps > 1:
-                for k, v in rx.kernel_ms(previous=True).items():
+            for back in range(min(age, args.steps) - 1, 0, -1) if piped else ():
+                for k, v in rx.kernel_ms(age=back).items():
                     kern[k] += v
                 kern_n += 1
             for k, v in rx.kernel_ms().items():
                 kern[k] += v
             kern_n += 1
-        if world > 1:
+        if multi:
             t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -391,6 +414,9 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
                     acc[k] = acc.get(k, 0.0) + v / 3.0
         rx.set_option("pipeline", 1)
         alone = acc
+    probe = None
+    if not on_cpu and hasattr(rx, "probe_issue"):
+        probe = rx.probe_issue()
 
     # ---- extra leg (not `value`): the same pass preceded by frame_detector + timing_sync on the device ----
     with_sync = None
@@ -423,7 +449,7 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
     # its CRC at 25 dB; the CPU receiver fails the same ones -- checked against the oracle below)
     # (the reference's detector may also miss a frame: such a frame is reported, not counted as exact or inexact)
     exact = bool(np.array_equal(psdu[real][okm], pays[which][okm])) and np.unique(which).size == real.size
-    if world > 1:
+    if multi:
         flag = torch.tensor([1 if exact else 0], dtype=torch.int32, device=cdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         exact = bool(flag.item())
@@ -458,10 +484,12 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
                        "steps_pipelined": piped,
                        "sharding": ("global frame i on rank i mod %d, one %s gather of PSDU slots to rank 0 per step%s"
                                     % (world, "RCCL" if backend == "nccl" else backend,
-                                       "" if backend == "nccl" else " (ranks share %d device(s); host-memory gather)" % max(n_dev, 1))) if world > 1 else "single GPU"},
+                                       "" if backend == "nccl" else " (ranks share %d device(s); host-memory gather)" % max(n_dev, 1))) if multi else "single GPU"},
         }
         if with_sync:
             out["config"]["incl_device_pre_sync"] = with_sync
+        if multi:
+            out["config"]["collective"] = {"backend": backend, "ranks": dist.get_world_size(), "gathers_per_region": regions[-1][5]}
         srt = sorted(rep_ms)
         out["repeats"] = {"regions": len(rep_ms), "steps_per_region": args.steps, "value_is": "median region",
                           "ms_per_step": [round(v, 4) for v in rep_ms], "min": round(srt[0], 4), "median": round(ms_per_step, 4), "max": round(srt[-1], 4),
@@ -476,7 +504,7 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
                 out["repeats"]["step_over_sum_alone"] = round(ms_per_step / alone["total"], 3)
         if args.steps <= 50 and kern_n and not on_cpu:
             kms = {k: v / kern_n for k, v in kern.items()}
-            out["roofline"] = roofline(args, kms, real.size, ms_per_step, piped)
+            out["roofline"] = roofline(args, kms, real.size, ms_per_step, piped, probe)
             out["kernel_ms"] = {k: round(v, 4) for k, v in kms.items()}
     if rank == 0 and not args.no_extra_legs and world == 1 and not on_cpu:
         out["legs"] = extra_legs(args, rx, dev, iq, descs, ends, real, psdu, res)
@@ -493,62 +521,73 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
     return out
 
 
-def roofline(args, kms, n_real, ms_per_step, piped):
+def roofline(args, kms, n_real, ms_per_step, piped, probe):
     """The dominant kernel is the Viterbi forward pass and what binds it is VALU issue, not HBM:
-    `bound`/`achieved`/`peak`/`frac` describe that roof; the HBM figures the contract also asks for are the `hbm` object."""
+    `bound`/`achieved`/`peak`/`frac` describe that roof; the HBM figures the contract also asks for are the `hbm` object.
+
+    Counted ops: 288 per trellis step and frame.  They execute as PACKED u16 instructions, two frames per lane, so
+    one lane slot of v_pk_add_u16 / v_pk_min_u16 / v_pk_sub_u16 performs TWO counted ops and the peak for them is
+    N_SIMD x f x 64 lanes x 2 / (clocks per packed wave64 instruction) -- with the guide's figures (SIMD-32: 32 plain lane-ops
+    per clock and SIMD, 2.4 GHz; a packed instruction takes twice the clocks and does twice the ops) 1024 x 32 x 2.4e9 = 78.6 T/s.
+    Consecutive forward passes overlap (two streams), so a launch lasts longer than a step: the PRIMARY figure divides by the
+    step time (what the machine sustains); the per-launch figure the contract defines is given next to it."""
     fwd_kernel = {0: "k_viterbi_v1", 1: "k_viterbi_fwd2", 2: "k_viterbi_fwd3"}[args.viterbi]
     t_k = kms["viterbi_fwd"] * 1e-3                      # average launch duration, live from HIP events on the kernel's own stream
+    t_step = ms_per_step * 1e-3 if piped else t_k        # calls in line: one launch at a time, the launch IS the kernel's share of the step
     steps = n_real * 39 * 216                            # trellis steps per launch (frames found x 39 symbols x 216)
-    alg_ops = steps * ALG_LANE_OPS_PER_STEP              # SURVEY 8d: (256 + 32) lane-ops per step
-    probe = valu_clocks_per_instr()
-    clk = probe[0]["forward_mix_clk_per_wave_instr"] if probe else 4.0
-    f_ghz = probe[0]["shader_clock_ghz"] if probe else 2.4
-    # one wave64 VALU instruction = 64 lane-ops and holds its SIMD for `clk` clocks
-    peak_lane = N_SIMD * f_ghz * 1e9 * 64.0 / clk        # lane-ops/s the part can issue with this instruction mix
-    ach_lane = alg_ops / t_k
-    r = {"bound": "valu", "kernel": fwd_kernel, "achieved": round(ach_lane / 1e12, 3), "peak": round(peak_lane / 1e12, 3), "unit": "T lane-ops/s",
-         "frac": round(ach_lane / peak_lane, 4),
-         "definition": "algorithmic integer lane-ops (SURVEY 8d: 64 states x (2 saturating adds + min + compare) + 32 branch metrics = 288 per "
-                       "trellis step) x %d steps per launch / average launch duration; peak = 1024 SIMDs x %.2f GHz x 64 lanes / %.2f clocks per "
-                       "wave64 instruction of this kernel's mix (%s)" % (steps, f_ghz, clk, probe[1] if probe else "no probe file: 4 assumed"),
-         "algorithmic_ops_per_launch": int(alg_ops), "avg_kernel_ms": round(kms["viterbi_fwd"], 4)}
+    alg_ops = steps * ALG_LANE_OPS_PER_STEP              # SURVEY 8d: (256 + 32) ops per step
+    peak = N_SIMD * 32 * 2.4e9                           # MI355X_MICROARCH.md: 4 SIMD-32 per CU, 256 CUs, 2.4 GHz
+    r = {"bound": "valu", "kernel": fwd_kernel, "achieved": round(alg_ops / t_step / 1e12, 3), "peak": round(peak / 1e12, 2), "unit": "T ops/s",
+         "frac": round(alg_ops / t_step / peak, 4),
+         "definition": "algorithmic integer ops (SURVEY 8d: 64 states x (2 saturating adds + min + compare) + 32 branch metrics = 288 per trellis "
+                       "step and frame) x %d steps per launch / %s; peak = 1024 SIMD-32 x 32 lane-ops per clock x 2.4 GHz (MI355X_MICROARCH.md; "
+                       "a packed-u16 instruction does two of the counted ops per lane in twice the clocks: the same peak)"
+                       % (steps, "ms_per_step (one launch per step; consecutive launches overlap on two streams)" if piped else "average launch duration"),
+         "algorithmic_ops_per_launch": int(alg_ops), "avg_kernel_ms": round(kms["viterbi_fwd"], 4),
+         "per_launch": {"achieved": round(alg_ops / t_k / 1e12, 3), "frac": round(alg_ops / t_k / peak, 4),
+                        "what": "the same ops / the launch's own duration (HIP events on its stream); below the step-rate figure when launches overlap"}}
+    if probe:
+        live_peak = probe["pk_u16"]["wave_instr_per_s"] * 64 * 2
+        r["peak_measured_live"] = {"value": round(live_peak / 1e12, 2), "unit": "T ops/s", "frac": round(alg_ops / t_step / live_peak, 4),
+                                   "clk_per_packed_wave_instr": round(probe["pk_u16"]["clk_per_wave_instr"], 3), "ghz": round(probe["pk_u16"]["ghz"], 3),
+                                   "clk_per_plain_vop2_wave_instr": round(probe["vop2_u32"]["clk_per_wave_instr"], 3),
+                                   "source": "foa_rx_probe_issue in THIS run on THIS device: 8 waves per SIMD issuing v_pk_add_u16 clamp for a fixed window"}
+    # Deterministic per-launch counts of this workload (same seeded input, same kernels => the same instruction and byte counts on any
+    # box), taken by rocprofv3 --pmc passes (tools/profile_round.sh) and kept under profiles/: NOT measured in this run.
     nv = _profile_json("_pmc_sq.json", "per_launch", fwd_kernel, args.frames, "SQ_INSTS_VALU")
-    if nv:
-        peak_gi = N_SIMD * f_ghz / clk
-        ach_gi = nv[0] / t_k / 1e9
-        r["valu_issue"] = {"achieved": round(ach_gi, 1), "peak": round(peak_gi, 1), "unit": "G wave-instr/s", "frac": round(ach_gi / peak_gi, 4),
-                           "valu_instr_per_launch": int(nv[0]), "source": "SQ_INSTS_VALU, profiles/%s; duration live from HIP events" % nv[1]}
-    # HBM: algorithmic bytes of this kernel = one soft pair (2 bytes) in, 64 decision bits out per trellis step
-    alg_bytes = steps * (2 + 8)
     tr = _profile_json("_pmc_hbm.json", "kernels", fwd_kernel, args.frames, "hbm_bytes_per_launch")
-    r["traffic"] = tr[0] if tr else None
-    r["hbm"] = {"achieved": round(alg_bytes / t_k / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(alg_bytes / t_k / 1e9 / HBM_PEAK_GBPS, 5),
-                "algorithmic_bytes_per_launch": int(alg_bytes), "traffic_source": tr[1] if tr else None,
-                "stage_bytes_survey_8d": int(n_real * 39 * (288 + 27)),
-                "note": "10 B per step is what this kernel's interface moves (2 depunctured soft bytes in, 8 bytes of decisions out); SURVEY 8d's "
-                        "figure for a fused Viterbi stage is 288 B in + 27 B out per symbol (stage_bytes_survey_8d): the decisions crossing "
-                        "HBM make it 6.9 x that"}
-    # what BASELINE.json's north_star asks rocprof to show, from the counter passes of the same workload (profiles/): HBM rate of the
-    # FFT / demap stage against the HBM peak, L2 and LDS behaviour of the Viterbi ACS
     fe = _profile_json("_pmc_hbm.json", "kernels", "k_data_symbols_q4", args.frames, "hbm_bytes_per_launch")
     l2 = _profile_json("_pmc_lds_l2.json", "per_launch", fwd_kernel, args.frames, "l2_hit_frac")
     bc = _profile_json("_pmc_lds_l2.json", "per_launch", fwd_kernel, args.frames, "lds_bank_conflict_frac")
-    stages = {}
+    r["counters_from_profiles"] = {
+        "what": "per-launch counter values of this same seeded workload from separate rocprofv3 --pmc runs (another lease); durations and "
+                "rates in this record are live, these counts are not",
+        "valu_instr_per_launch": {"value": int(nv[0]), "file": nv[1]} if nv else None,
+        "hbm_bytes_per_launch": {"value": int(tr[0]), "file": tr[1]} if tr else None,
+        "l2_hit_frac": {"value": l2[0], "file": l2[1]} if l2 else None,
+        "lds_bank_conflict_frac": {"value": bc[0], "file": bc[1]} if bc else None}
+    if nv and probe:
+        ach = nv[0] / t_step
+        r["valu_issue"] = {"achieved": round(ach / 1e9, 1), "peak": round(probe["pk_u16"]["wave_instr_per_s"] / 1e9, 1), "unit": "G wave-instr/s",
+                           "frac": round(ach / probe["pk_u16"]["wave_instr_per_s"], 4),
+                           "what": "VALU wave-instructions of the forward pass (count from profiles/, above) / %s against the live-probed issue rate of "
+                                   "packed instructions" % ("ms_per_step" if piped else "launch duration")}
+    # HBM: algorithmic bytes of this kernel = one soft pair (2 bytes) in, 64 decision bits out per trellis step
+    alg_bytes = steps * (2 + 8)
+    r["traffic"] = int(tr[0]) if tr else None
+    r["traffic_source"] = tr[1] if tr else None
+    r["hbm"] = {"achieved": round(alg_bytes / t_k / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(alg_bytes / t_k / 1e9 / HBM_PEAK_GBPS, 5),
+                "algorithmic_bytes_per_launch": int(alg_bytes), "stage_bytes_survey_8d": int(n_real * 39 * (288 + 27)),
+                "note": "10 B per step is what this kernel's interface moves (2 depunctured soft bytes in, 8 bytes of decisions out), over the launch's "
+                        "own duration; SURVEY 8d's figure for a fused Viterbi stage is 288 B in + 27 B out per symbol (stage_bytes_survey_8d): the "
+                        "decisions crossing HBM make it 6.9 x that"}
+    # what BASELINE.json's north_star asks rocprof to show: HBM rate of the FFT / demap stage against the HBM peak (bytes from profiles/,
+    # duration live), L2 and LDS behaviour of the Viterbi ACS (counters_from_profiles)
     if fe and kms.get("symbols"):
         gbps = fe[0] / (kms["symbols"] * 1e-3) / 1e9
-        stages["fft_equalise_demap"] = {"kernel": "k_data_symbols_q4", "hbm_bytes_per_launch": int(fe[0]), "ms": round(kms["symbols"], 4),
-                                        "hbm_GBps": round(gbps, 1), "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBPS, 4), "source": fe[1],
-                                        "note": "duration live (HIP events, under the forward pass it shares the machine with when calls are pipelined)"}
-    if l2 or bc:
-        stages["viterbi_acs"] = {"kernel": fwd_kernel, "l2_hit_frac": l2[0] if l2 else None, "lds_bank_conflict_frac": bc[0] if bc else None,
-                                 "source": (l2 or bc)[1]}
-    if stages:
-        r["stages"] = stages
-    if piped:
-        # consecutive forward passes run on two streams and overlap at their ends, so a launch lasts longer than a step: the
-        # launch duration (what a kernel trace reports, used above) counts the shared time twice
-        r["launches_overlap"] = {"ms_per_step": round(ms_per_step, 4), "frac_at_step_rate": round(alg_ops / (ms_per_step * 1e-3) / peak_lane, 4),
-                                 "evidence": "profiles/*_kernel_trace_excerpt.csv: forward passes alternate on two queues and overlap"}
+        r["stages"] = {"fft_equalise_demap": {"kernel": "k_data_symbols_q4", "hbm_bytes_per_launch": int(fe[0]), "bytes_file": fe[1], "ms": round(kms["symbols"], 4),
+                                              "hbm_GBps": round(gbps, 1), "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBPS, 4),
+                                              "note": "duration live (HIP events; under the forward pass it shares the machine with when calls are pipelined)"}}
     return r
 
 
@@ -610,16 +649,25 @@ def extra_legs(args, rx, dev, iq, descs, ends, real, psdu_dev_path, res_dev_path
             on = np.nonzero((d["lts1_pos"] - 360) % pitch == 0)[0]
             ok = on[r[on, 0] == 0]
             exact = bool(np.array_equal(d_psdu.cpu().numpy()[ok], pays[(d["lts1_pos"][ok] - 360) // pitch]))
-            k = min(m, 16)                               # CPU oracle on the first alignments: same status and PSDUs
+            # CPU oracle, same status and PSDUs: on ALL alignments of the 9 Mbps leg (the one rate whose long frames fail their CRC now
+            # and then at 25 dB: parity = the same failures), on the first 256 (or all, if fewer) of the others; the same call, timed,
+            # is the per-rate CPU figure (decode only, all host threads, one repetition)
+            k = m if rate == 2 else min(m, max(256, 16))
             e = d_end[:k].cpu().numpy()
             h_iq = d_iq[:int(e[-1])].cpu().numpy().reshape(-1).view(np.complex64)
-            opsdu, ores = po.decode_batch_f32(h_iq, d[:k], e, slot_bytes=length, threads=min(16, os.cpu_count() or 1))
+            thr = os.cpu_count() or 1
+            t0 = time.perf_counter()
+            opsdu, ores = po.decode_batch_f32(h_iq, d[:k], e, slot_bytes=length, threads=thr)
+            dt_cpu = time.perf_counter() - t0
             same = bool(np.array_equal(ores.view(np.int32).reshape(-1, 4), r[:k]))
             okk = r[:k, 0] == 0
             same = same and bool(np.array_equal(opsdu[okk], d_psdu[:k].cpu().numpy()[okk]))
+            on_k = int(np.count_nonzero((d["lts1_pos"][:k] - 360) % pitch == 0))
             rows.append({"rate_enum": rate, "mbps": foa.RATE_MBPS[rate], "frame_samples": int(s), "frames_found": int(on.size), "crc_ok": int(ok.size),
-                         "psdu_bit_exact": exact, "gpu_equals_cpu_on_%d" % k: same, "ms": round(dt * 1e3, 3),
-                         "Msamples_per_s": round(on.size * s / dt / 1e6, 1)})
+                         "psdu_bit_exact": exact, "gpu_equals_cpu_on_all" if k == m else "gpu_equals_cpu_on_%d" % k: same, "cpu_checked_alignments": int(k),
+                         "cpu_crc_fail": int(np.count_nonzero(ores["status"] == foa.ST_CRC_FAIL)), "gpu_crc_fail_same_sample": int(np.count_nonzero(r[:k, 0] == foa.ST_CRC_FAIL)),
+                         "ms": round(dt * 1e3, 3), "Msamples_per_s": round(on.size * s / dt / 1e6, 1),
+                         "cpu_Msamples_per_s": round(on_k * s / dt_cpu / 1e6, 1), "cpu_threads": thr})
             del d_iq, d_psdu, d_res, d_desc, d_end
         legs["config3_rate_sweep"] = {"frames_per_rate": n, "payload_bytes": length, "snr_db": 25.0, "counted_samples": "in-frame", "rates": rows}
     except Exception as e:
@@ -670,16 +718,18 @@ def extra_legs(args, rx, dev, iq, descs, ends, real, psdu_dev_path, res_dev_path
         okl = [(a, start_of[int(p)]) for a, p in enumerate(d["lts1_pos"]) if int(p) in start_of and r[a, 0] == 0]
         hp = d_psdu[:m].cpu().numpy()
         exact = all(np.array_equal(hp[a], lookup[i]) for a, i in okl)
-        k = min(m, 64)
+        k = m                                            # CPU oracle on ALL alignments of the stream: same sync decisions, status and PSDUs
         e = d_end[:k].cpu().numpy()
         h_iq = stream[:int(e[-1])].cpu().numpy().reshape(-1).view(np.complex64)
         hd = po.find_alignments_f32(h_iq)
         hd = hd[:k] if hd.size >= k else hd
         same = hd.size == k and bool(np.array_equal(hd["lts1_pos"], d["lts1_pos"][:k]))
-        opsdu, ores = po.decode_batch_f32(h_iq, d[:k], e, slot_bytes=length, threads=min(16, os.cpu_count() or 1))
+        opsdu, ores = po.decode_batch_f32(h_iq, d[:k], e, slot_bytes=length, threads=os.cpu_count() or 1)
         same = same and bool(np.array_equal(ores.view(np.int32).reshape(-1, 4), r[:k]))
+        okk = r[:k, 0] == 0
+        same = same and bool(np.array_equal(opsdu[okk], hp[:k][okk]))
         legs["config5_stream"] = {"frames": n, "stream_samples": int(total), "alignments": int(m), "frames_ok": len(okl), "psdu_bit_exact": bool(exact),
-                                  "gpu_equals_cpu_on_first_%d" % k: same, "ms_sync_plus_decode": round(dt * 1e3, 3),
+                                  "gpu_equals_cpu_on_all": same, "cpu_checked_alignments": int(k), "ms_sync_plus_decode": round(dt * 1e3, 3),
                                   "Msamples_per_s": round(total / dt / 1e6, 1), "counted_samples": "whole stream",
                                   "what": "mixed 8 rates back to back, 1024-byte payloads, CFO uniform in +-4 kHz, 25 dB; foa_rx_sync_dev + foa_rx_decode_frames_dev"}
     except Exception as e:
@@ -704,10 +754,35 @@ def extra_legs(args, rx, dev, iq, descs, ends, real, psdu_dev_path, res_dev_path
             libdir = os.path.dirname(foa.library_path())
             subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "examples", "foa_sim.cpp"), "-I", os.path.join(ROOT, "include"), "-L", libdir,
                             "-lfun_ofdm_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lpthread", "-o", exe], check=True, capture_output=True)
-            r = subprocess.run([exe, src, "--format", "fc32", "--preload", "--chunk", "4096", "--device-batch", str(1 << 22), "--narrow-threads", "4"],
-                               capture_output=True, text=True, timeout=300)
+            cmd = [exe, src, "--format", "fc32", "--preload", "--chunk", "4096", "--device-batch", str(1 << 22), "--narrow-threads", "4"]
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)                 # the timed run: payloads counted, not written
+            recs = os.path.join(tmp, "psdus.rec")
+            r2 = subprocess.run(cmd + ["--out", recs], capture_output=True, text=True, timeout=300)   # the checked run: every payload written as a record
+            raw = np.fromfile(recs, np.uint8) if (r2.returncode == 0 and os.path.exists(recs)) else np.zeros(0, np.uint8)
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
+        # checker: the ORDERED payload list process_samples() returned must equal the batch path's on the same capture
+        # -- device pre-sync + one decode call over all of it, CRC-passing frames in stream order (receiver_chain.cpp:106-126: payloads of
+        # CRC-passing frames, in stream order)
+        api_list, pos = [], 0
+        while pos + 4 <= raw.size:
+            ln = int(raw[pos]) | int(raw[pos + 1]) << 8 | int(raw[pos + 2]) << 16 | int(raw[pos + 3]) << 24
+            api_list.append(raw[pos + 4:pos + 4 + ln])
+            pos += 4 + ln
+        d_cap = torch.from_numpy(cap_iq.view(np.float32).reshape(-1, 2)).to(dev)
+        capn = n + 8192
+        b_desc = torch.zeros(capn * 48, dtype=torch.uint8, device=dev)
+        b_end = torch.zeros(capn, dtype=torch.int64, device=dev)
+        bm = rx.sync_dev(d_cap, b_desc, b_end)
+        b_psdu = torch.zeros((bm, 1024), dtype=torch.uint8, device=dev)
+        b_res = torch.zeros((bm, 4), dtype=torch.int32, device=dev)
+        rx.decode_frames_dev(d_cap, b_desc[:bm * 48], b_end[:bm], b_psdu, b_res)
+        rx.sync(); torch.cuda.synchronize()
+        br = b_res.cpu().numpy()
+        bp = b_psdu.cpu().numpy()
+        batch_list = [bp[a, :br[a, 2]] for a in np.nonzero(br[:, 0] == 0)[0]]
+        same_list = len(api_list) == len(batch_list) and all(np.array_equal(x, y) for x, y in zip(api_list, batch_list))
+        del d_cap, b_desc, b_end, b_psdu, b_res
         mm = re.search(r"([\d.]+) Msamples/s through process_samples \((\d+) samples in ([\d.]+) s, (\d+) calls of (\d+)\)", r.stdout)
         pk = re.search(r"(\d+) packets", r.stdout)
         if not mm:
@@ -715,6 +790,7 @@ def extra_legs(args, rx, dev, iq, descs, ends, real, psdu_dev_path, res_dev_path
         legs["process_samples_api"] = {"Msamples_per_s": float(mm.group(1)), "x_realtime_20MSps": round(float(mm.group(1)) / 20.0, 1), "samples": int(mm.group(2)),
                                        "seconds": float(mm.group(3)), "calls": int(mm.group(4)), "chunk": int(mm.group(5)),
                                        "packets": int(pk.group(1)) if pk else None, "frames_sent": n,
+                                       "same_list_as_batch_path": bool(same_list), "batch_path_payloads": len(batch_list),
                                        "what": "fun_amd::receiver_chain::process_samples(std::vector<std::complex<double>>) in device mode: 4 Mi-sample "
                                                "batches, 4 helper threads, pre-sync and decode on the GPU, payloads through the callback; capture preloaded"}
     except Exception as e:
@@ -748,9 +824,10 @@ def main(argv=None):
         os.close(real_stdout)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or os.environ.get("FOA_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
-        dist.destroy_process_group()
+        if dist.is_initialized():
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

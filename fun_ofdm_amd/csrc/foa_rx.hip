@@ -19,6 +19,7 @@
 #include "sync_host.h"
 #include "sync_kernels.h"
 #include "tx_kernels.h"
+#include "probe_kernels.h"
 
 using namespace foa;
 
@@ -724,6 +725,45 @@ int foa_rx_kernel_ms_age(foa_rx *rx, int age, float out_ms[6])
     for (int i = 0; i < age && w; i++) w = w->before;                // the pipelined calls link their work sets
     if (age > 0 && (!w || w == rx->w)) return fail(FOA_E_STATE, "no decode call of that age (calls must be pipelined)");
     return kernel_ms_of(rx, w, out_ms);
+}
+
+int foa_rx_probe_issue(foa_rx *rx, double out[6])
+{
+    if (!rx || !out) return fail(FOA_E_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(rx->device));
+    { int rc0 = drain(rx); if (rc0) return rc0; }
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, rx->device));
+    const int n_simd = prop.multiProcessorCount * 4, W = 8, nw = n_simd * W, window_k = 600;      // ~0.26 ms per launch
+    DevBuf<unsigned long long> buf;
+    int rc = buf.ensure((size_t)3 * nw);
+    if (rc) return rc;
+    std::vector<unsigned long long> h((size_t)3 * nw);
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    for (int kind = 0; kind < 2; kind++) {
+        float ms = 0;
+        for (int it = 0; it < 3; it++) {                       // the first launches bring the clock to where a busy chip holds it
+            HIP_TRY(hipEventRecord(e0, rx->stream));
+            if (kind == 0) hipLaunchKernelGGL(k_probe_issue<0>, dim3(nw / 4), dim3(256), 0, rx->stream, buf.p, 7u, window_k);
+            else hipLaunchKernelGGL(k_probe_issue<1>, dim3(nw / 4), dim3(256), 0, rx->stream, buf.p, 7u, window_k);
+            HIP_TRY(hipEventRecord(e1, rx->stream));
+            HIP_TRY(hipStreamSynchronize(rx->stream));
+            HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        }
+        HIP_TRY(hipMemcpy(h.data(), buf.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        double ticks = 0, instr = 0;
+        for (int i = 0; i < nw; i++) { ticks += (double)h[3 * i]; instr += (double)h[3 * i + 1] * 64.0; }
+        const double window = ticks / nw;                      // shader clocks every wave was issuing for
+        out[3 * kind + 0] = window / (instr / n_simd);         // SIMD clocks per wave64 instruction
+        out[3 * kind + 1] = window / (ms * 1e6);               // GHz sustained during the launch
+        out[3 * kind + 2] = instr / (ms * 1e-3);               // wave-instructions per second, whole chip
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    buf.release();
+    return FOA_OK;
 }
 
 int foa_rx_get_taps(foa_rx *rx, size_t n_frames, double *hinv, double *eq, size_t eq_cap, uint64_t *eq_off, uint8_t *soft, size_t soft_cap,

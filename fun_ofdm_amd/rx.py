@@ -140,6 +140,13 @@ class Receiver:
         """Block until the decode call `age` calls back is complete (see foa_rx_wait_age)."""
         check(lib().foa_rx_wait_age(self._h, int(age)))
 
+    def probe_issue(self):
+        """Live issue-rate probe (foa_rx_probe_issue): {"pk_u16": {clk_per_wave_instr, ghz, wave_instr_per_s}, "vop2_u32": {...}}."""
+        out = (C.c_double * 6)()
+        check(lib().foa_rx_probe_issue(self._h, out))
+        keys = ("clk_per_wave_instr", "ghz", "wave_instr_per_s")
+        return {"pk_u16": dict(zip(keys, out[0:3])), "vop2_u32": dict(zip(keys, out[3:6]))}
+
     def kernel_ms(self, previous=False, age=None):
         """HIP-event durations of the last decode (previous=True: of the one before it; age=2: of the one before that,
         which is certainly complete in a pipelined sequence of calls) in ms: header, scan, symbols, viterbi_fwd,

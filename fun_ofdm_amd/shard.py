@@ -12,10 +12,12 @@ def local_frame_ids(n_global, rank, world):
     return torch.arange(rank, max(n_global, rank), world)
 
 
-def gather_psdus(psdu_local, n_global, rank, world, group=None):
+def gather_psdus(psdu_local, n_global, rank, world, group=None, force_collective=False):
     """psdu_local: uint8[m_local, slot] for this rank's frames in local order (global ids rank, rank+G, ...).
-    Returns on rank 0 a uint8[n_global, slot] tensor in GLOBAL frame order, None elsewhere.  One gather."""
-    if world == 1:
+    Returns on rank 0 a uint8[n_global, slot] tensor in GLOBAL frame order, None elsewhere.  One gather.
+    force_collective: make the dist.gather call at world 1 too (a one-GPU box then exercises the very RCCL call the
+    8-GPU job makes; needs an initialised process group)."""
+    if world == 1 and not force_collective:
         return psdu_local
     slot = psdu_local.shape[1]
     m_max = (n_global + world - 1) // world

@@ -168,6 +168,12 @@ int foa_rx_prev_kernel_ms(foa_rx *rx, float out_ms[6]);
  * forward pass that is on the GPU now). */
 int foa_rx_kernel_ms_age(foa_rx *rx, int age, float out_ms[6]);
 
+/* Issue-rate probe of the device the handle lives on (measurement aid for bench.py's roofline; nothing in the receive path
+ * uses it): out[0..2] = SIMD clocks per wave64 `v_pk_add_u16 ... clamp`, shader clock (GHz) sustained meanwhile, wave-instructions
+ * per second over the whole chip; out[3..5] the same for the plain 32-bit VOP2 `v_add_u32`.  Eight waves per SIMD issue from
+ * independent chains for a fixed window of shader clocks (csrc/probe_kernels.h).  Synchronises; about a millisecond. */
+int foa_rx_probe_issue(foa_rx *rx, double out[6]);
+
 /* Intermediates of the most recent decode call, copied to HOST memory (parity tests).
  *   hinv    64 complex doubles (re,im) per frame: channel_est's m_chan_est (channel_est.cpp:53-58)
  *   eq      per frame (1 + num_symbols) * 48 complex doubles: phase_tracker output incl. SIGNAL

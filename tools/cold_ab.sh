@@ -6,7 +6,7 @@
 tag=$1
 out=gpurun_out/cold_$tag; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-{ date; nproc; grep -m1 'model name' /proc/cpuinfo; } > $out/box.txt 2>&1
+{ date; hostname; nproc; grep -m1 'model name' /proc/cpuinfo; rocm-smi --showuniqueid --showperflevel --showmaxpower --showcomputepartition --showmemorypartition --showpids; } > $out/box.txt 2>&1
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/driver_cmd_1.json 2> $out/driver_cmd_1.err
 rocm-smi --showclocks --showpower --showtemp >> $out/box.txt 2>&1
 Q="--steps 20 --warmup 5 --no-cpu-baseline --no-extra-legs --no-sync-leg"
