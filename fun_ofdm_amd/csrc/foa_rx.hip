@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -234,6 +235,7 @@ struct foa_rx {
     DevBuf<int64_t> sy_x;
     DevBuf<SyncCand> sy_cand;
     size_t last_frames = 0;
+    int64_t ns_wait_set = 0;     // host time spent waiting for a work set to come free (the GPU is more than kSets - 1 calls behind)
 };
 
 namespace {
@@ -260,6 +262,9 @@ int inputs_queued(foa_rx *rx, hipStream_t cs)
 
 int workspace(foa_rx *rx, size_t n_samples, size_t n_frames)
 {
+    // (room for an eighth more frames than asked for, in steps of 1024: a stream's batches differ by a few frames, and a buffer that
+    // grows by one element costs a hipFree, which waits for the whole device)
+    n_frames = ((n_frames + (n_frames >> 3) + 1024) & ~(size_t)1023);
     size_t sym_cap = n_samples / 80 + 4;
     size_t dec_cap = 216 * sym_cap + 192 * (n_frames + 1);
     int rc;
@@ -496,7 +501,11 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
     if (!piped) { int rc0 = flush_pending(rx, nullptr); if (rc0) return rc0; }
     rx->prev = rx->w;
     if (piped) rx->w = &rx->sets[(int)((rx->w - rx->sets) + 1) % kSets];     // in use: front end k+1 | forward pass k | finish k-1
-    if (rx->w->used) HIP_TRY(hipEventSynchronize(rx->w->done));      // the call that last used this set is complete
+    if (rx->w->used) {                                                 // the call that last used this set is complete
+        const auto t0 = std::chrono::steady_clock::now();
+        HIP_TRY(hipEventSynchronize(rx->w->done));
+        rx->ns_wait_set += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    }
     int rc = workspace(rx, n_samples, n_frames);
     if (rc) return rc;
     // st: header, scan, data symbols; st_fwd: the forward pass.  Forward passes of consecutive calls take turns on two (or four)
@@ -661,9 +670,12 @@ int foa_rx_submit_host(foa_rx *rx, const float *iq, size_t n_samples, const foa_
     return FOA_OK;
 }
 
-int foa_rx_collect(foa_rx *rx, uint64_t ticket, int wait, uint8_t *psdu, foa_frame_result *results)
+}  // extern "C"
+
+// The job behind a ticket once its outputs are in its page-locked mirror: 1 = *out is complete (the caller reads job->pin and then
+// clears job->busy), 0 = not yet (wait == false), < 0 = error.  Shared by foa_rx_collect and the stream engine.
+static int job_ready(foa_rx *rx, uint64_t ticket, bool wait, HostJob **out)
 {
-    if (!rx || !psdu || !results) return fail(FOA_E_INVALID, "NULL argument");
     HostJob *job = nullptr;
     for (auto &j : rx->jobs) if (j.busy && j.ticket == ticket) { job = &j; break; }
     if (!job) return fail(FOA_E_INVALID, "unknown ticket");
@@ -681,6 +693,18 @@ int foa_rx_collect(foa_rx *rx, uint64_t ticket, int wait, uint8_t *psdu, foa_fra
         if (e == hipErrorNotReady) return 0;
         if (e != hipSuccess) return fail(FOA_E_HIP, "hipEventQuery: %s", hipGetErrorString(e));
     }
+    *out = job;
+    return 1;
+}
+
+extern "C" {
+
+int foa_rx_collect(foa_rx *rx, uint64_t ticket, int wait, uint8_t *psdu, foa_frame_result *results)
+{
+    if (!rx || !psdu || !results) return fail(FOA_E_INVALID, "NULL argument");
+    HostJob *job = nullptr;
+    const int rc = job_ready(rx, ticket, wait != 0, &job);
+    if (rc <= 0) return rc;
     memcpy(psdu, job->pin + job->o_psdu, job->n_frames * job->slot_bytes);
     memcpy(results, job->pin + job->o_res, job->n_frames * sizeof(foa_frame_result));
     job->busy = false;
@@ -819,13 +843,13 @@ int foa_rx_get_decisions(foa_rx *rx, size_t frame, uint64_t *out, size_t cap, si
     return FOA_OK;
 }
 
-int foa_rx_sync_dev(foa_rx *rx, const float *d_iq, size_t n_samples, foa_frame_desc *d_descs, int64_t *d_ends, size_t cap, size_t *n_found)
+}  // extern "C"
+
+// The launching half of foa_rx_sync_dev: every kernel of the pre-sync stage queued on the side stream, nothing waited for.  The counts
+// stay on the device in rx->sy_n ([0] STS_END candidates, [3] alignments found); *ccap_out = the candidate capacity they are checked
+// against.  (The stream engine queues this for batch k+1 while batch k decodes and reads the counts later.)
+static int sync_dev_issue(foa_rx *rx, const float *d_iq, size_t n_samples, foa_frame_desc *d_descs, int64_t *d_ends, size_t cap, int32_t *ccap_out)
 {
-    if (!rx || !d_iq || !d_descs || !d_ends || !n_found) return fail(FOA_E_INVALID, "NULL argument");
-    *n_found = 0;
-    if (n_samples == 0 || cap == 0) return FOA_OK;
-    if (n_samples > 0x7FFFFFFFull * 16) return fail(FOA_E_INVALID, "stream too long for one call");
-    HIP_TRY(hipSetDevice(rx->device));
     const int64_t n = (int64_t)n_samples, n_words = (n + 31) / 32;
     const int n_blocks = (int)((n_words + kSyncBlockWords - 1) / kSyncBlockWords);
     const int32_t ccap = (int32_t)std::min<size_t>(n_samples / 64 + 64, 0x7FFFFFF0u);
@@ -854,6 +878,22 @@ int foa_rx_sync_dev(foa_rx *rx, const float *d_iq, size_t n_samples, foa_frame_d
     hipLaunchKernelGGL(k_sync_scan, dim3(1), dim3(1024), 0, st, rx->sy_cnt.p, kb, rx->sy_off.p, rx->sy_n.p + 3);
     hipLaunchKernelGGL(k_sync_emit, dim3(kb), dim3(256), 0, st, rx->sy_cand.p, rx->sy_keep.p, rx->sy_n.p, ccap, rx->sy_off.p, rx->sy_n.p + 3, n, d_descs, d_ends,
                        (int32_t)std::min<size_t>(cap, 0x7FFFFFF0u));
+    *ccap_out = ccap;
+    return FOA_OK;
+}
+
+extern "C" {
+
+int foa_rx_sync_dev(foa_rx *rx, const float *d_iq, size_t n_samples, foa_frame_desc *d_descs, int64_t *d_ends, size_t cap, size_t *n_found)
+{
+    if (!rx || !d_iq || !d_descs || !d_ends || !n_found) return fail(FOA_E_INVALID, "NULL argument");
+    *n_found = 0;
+    if (n_samples == 0 || cap == 0) return FOA_OK;
+    if (n_samples > 0x7FFFFFFFull * 16) return fail(FOA_E_INVALID, "stream too long for one call");
+    HIP_TRY(hipSetDevice(rx->device));
+    int32_t ccap = 0;
+    { int rc = sync_dev_issue(rx, d_iq, n_samples, d_descs, d_ends, cap, &ccap); if (rc) return rc; }
+    hipStream_t st = side_stream(rx);
     int32_t cnt[4] = { 0, 0, 0, 0 };         // [0] STS_END candidates, [3] alignments found
     HIP_TRY(hipMemcpyAsync(cnt, rx->sy_n.p, sizeof cnt, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

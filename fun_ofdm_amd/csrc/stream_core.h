@@ -26,7 +26,11 @@
 #if defined(__linux__)
 #include <pthread.h>
 #include <sched.h>
+#include <stdio.h>
 #include <stdlib.h>
+#endif
+#if defined(__x86_64__)
+#include <immintrin.h>
 #endif
 
 namespace foa {
@@ -35,12 +39,19 @@ struct StreamReady { std::vector<uint8_t> bytes; std::vector<uint32_t> len; };
 
 // What the core needs from the GPU side (stream_engine.h) or from a test double.
 //   float *staging(int slot)                         page-locked buffer of `batch` float2
-//   int submit(int slot, int64_t n_new, bool final, uint64_t *handle)      queue the batch (may block on the GPU); 0 = ok
+//   int stage(int slot, int64_t n_new, bool final)    queue the upload of the batch's samples and whatever else can run before the batch
+//                                                     is submitted (never blocks); 0 = ok
+//   bool uploaded(int slot)                           all of that is through
+//   int submit(int slot, int64_t n_new, bool final, uint64_t *handle)      queue the batch's kernels (may block on the GPU); 0 = ok;
+//                                                     the staging slot is free again when it returns
 //   int collect(uint64_t handle, bool wait, StreamReady *out)             1 = done (payloads in *out), 0 = not yet, < 0 error
+// A batch is STAGED the moment its last sample is narrowed and SUBMITTED once its upload is through, so the upload of batch
+// k+1 runs under the kernels of batch k instead of in front of its own (the submitter used to wait out 0.6 ms of PCIe per 4 Mi
+// samples inside every submit: a third of its time).
 template <typename Backend>
 class StreamCore {
 public:
-    static constexpr int kSlots = 4;
+    static constexpr int kSlots = 6;
     typedef void (*release_fn)(void *);
 
     StreamCore(Backend *be, int64_t batch, int narrow_threads) : be_(be), B_(batch), ring_(kRing)
@@ -58,8 +69,13 @@ public:
         for (auto &t : helpers_) t.join();
         if (submitter_.joinable()) submitter_.join();
         // buffers nobody narrowed (the stream was torn down early) are still released
+        publish();
         Task t;
         while (try_pop(t)) drop_owner(t.owner);
+        if (stats_on_)
+            fprintf(stderr, "foa_stream: caller ms in push %.1f (%lld pushes, of which waiting for a staging slot %.1f; %lld tasks narrowed by the caller); "
+                            "%d helpers: %lld tasks, %.1f ms busy in total\n", st_push_ns_ * 1e-6, (long long)st_pushes_, st_wait_slot_ns_ * 1e-6,
+                    (long long)st_inline_, (int)helpers_.size(), (long long)st_helper_tasks_.load(), st_helper_ns_.load() * 1e-6);
     }
     StreamCore(const StreamCore &) = delete;
     StreamCore &operator=(const StreamCore &) = delete;
@@ -69,8 +85,17 @@ public:
     template <typename T>
     int push(const T *iq, size_t n, release_fn release, void *ctx)
     {
+        const int64_t st0 = stats_on_ ? now_ns() : 0;
+        const int rc = push_impl(iq, n, release, ctx);
+        if (stats_on_) { st_push_ns_ += now_ns() - st0; st_pushes_++; }
+        return rc;
+    }
+    static int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    template <typename T>
+    int push_impl(const T *iq, size_t n, release_fn release, void *ctx)
+    {
         if (finished_) { if (release) release(ctx); return -5; }
-        if (int e = error()) { if (release) release(ctx); return e; }
+        if (int e = error_flag_.load(std::memory_order_acquire)) { if (release) release(ctx); return e; }
         Owner *own = nullptr;
         if (release) { own = new Owner; own->refs.store(1, std::memory_order_relaxed); own->release = release; own->ctx = ctx; }
         const bool defer = own != nullptr && !helpers_.empty();
@@ -83,7 +108,7 @@ public:
             t.src = iq; t.is_double = sizeof(T) == sizeof(double); t.dst = be_->staging(slot) + 2 * fill_; t.n = take; t.slot = slot; t.owner = own; t.landed = nullptr;
             if (defer) {
                 own->refs.fetch_add(1, std::memory_order_relaxed);
-                if (!try_push(t)) run_task(t, true);           // the queue is full: the helpers are behind, narrow this one here
+                if (!try_push(t)) { st_inline_++; run_task(t, true); }           // the queue is full: the helpers are behind, narrow this one here
             } else if (!helpers_.empty() && take >= 65536) {
                 split_and_wait(t);
             } else {
@@ -93,6 +118,7 @@ public:
             iq += 2 * take; n -= take;
             if (fill_ == B_) close_batch(false);
         }
+        if (rc) publish();                                     // (an error path must not sit on queued buffers)
         drop_owner(own);                                       // the caller's own reference
         return rc;
     }
@@ -100,6 +126,7 @@ public:
     int flush()
     {
         if (finished_) return 0;
+        publish();
         if (fill_ == 0) { if (int rc = wait_for_slot()) return rc; }
         finished_ = true;
         close_batch(true);                                     // also when empty: the frames after the last cut are still undecoded
@@ -109,9 +136,11 @@ public:
     // 1: *out = the payloads of the oldest finished batch; 0: nothing finished (wait: and nothing outstanding); < 0: error
     int take(bool wait, StreamReady *out)
     {
+        // (the common call -- "anything finished?" after every push -- answers from one atomic, without the lock)
+        if (!wait && ready_n_.load(std::memory_order_acquire) == 0) return error_flag_.load(std::memory_order_acquire);
         std::unique_lock<std::mutex> lk(m_);
         for (;;) {
-            if (!ready_.empty()) { *out = std::move(ready_.front()); ready_.pop_front(); return 1; }
+            if (!ready_.empty()) { *out = std::move(ready_.front()); ready_.pop_front(); ready_n_.fetch_sub(1, std::memory_order_acq_rel); return 1; }
             if (error_) return error_;
             if (!wait || closed_ == collected_) return 0;      // every closed batch has been collected (open samples need a flush)
             cv_ready_.wait(lk);
@@ -127,6 +156,9 @@ private:
     // both sockets (EPYC 9575F, 220 M samples: 2.1 against 1.2-1.6 Gsample/s with four helpers).  So the engine's threads are
     // confined to the block of eight consecutive CPUs the creating thread runs on (one core complex where CPUs are numbered
     // core by core), within the process's own affinity mask.  FOA_STREAM_AFFINITY=0 leaves them to the scheduler.
+    // (Measured in round 3 and dropped: one core complex PER helper on the caller's NUMA node, from sysfs -- a task then takes a
+    // helper 7.2 us instead of 4.0, the buffers it releases belong to an allocator arena another complex owns, and the rate
+    // falls from 2.2 to 1.7 Gsample/s; four helpers on one complex already move 100 GB/s.)
     void keep_threads_near_caller()
     {
 #if defined(__linux__)
@@ -159,12 +191,28 @@ private:
     {
         for (size_t i = 0; i < n2; i++) dst[i] = (float)src[i];        // (vcvtpd2ps on four doubles at a time)
     }
+    // Sixteen doubles -> one 64-byte line of floats (vcvtpd2ps rounds to nearest even like the scalar conversion), stored
+    // NON-TEMPORALLY: the staging buffer is written once and then read by the GPU's DMA engine, so a cached store would first
+    // fetch every line it is about to overwrite (8 of the 32 bytes per sample this loop moves) and evict the caller's samples.
+    __attribute__((target("avx512f,avx512dq"))) static void narrow_avx512(float *dst, const double *src, size_t n2)
+    {
+        size_t i = 0;
+        while (i < n2 && ((uintptr_t)(dst + i) & 63)) { dst[i] = (float)src[i]; i++; }
+        for (; i + 16 <= n2; i += 16) {
+            const __m256 lo = _mm512_cvtpd_ps(_mm512_loadu_pd(src + i)), hi = _mm512_cvtpd_ps(_mm512_loadu_pd(src + i + 8));
+            _mm512_stream_ps(dst + i, _mm512_insertf32x8(_mm512_castps256_ps512(lo), hi, 1));
+        }
+        for (; i < n2; i++) dst[i] = (float)src[i];
+        _mm_sfence();                                                  // the counter that publishes these samples is bumped next
+    }
 #endif
     static void narrow(const Task &t)
     {
         if (!t.is_double) { memcpy(t.dst, t.src, t.n * 8); return; }
         const double *s = (const double *)t.src;
 #if defined(__x86_64__)
+        static const bool avx512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq") && !getenv("FOA_STREAM_NO_AVX512");
+        if (avx512) { narrow_avx512(t.dst, s, 2 * t.n); return; }
         static const bool avx2 = __builtin_cpu_supports("avx2");
         if (avx2) { narrow_avx2(t.dst, s, 2 * t.n); return; }
 #endif
@@ -192,6 +240,7 @@ private:
             if (o == 0 || !try_push(p)) run_task(p, false);
         }
         // help, then wait: every piece of this push must have landed before the caller's buffer is given back
+        publish();
         Task q;
         while (landed.load(std::memory_order_acquire) < (int64_t)t.n) {
             if (try_pop(q)) run_task(q, true);
@@ -201,14 +250,24 @@ private:
     // Task queue: a bounded ring with a sequence number per cell (D. Vyukov's MPMC queue, used with one producer -- the
     // caller -- and many consumers).  No lock and no system call on the producer's path: at 4096-sample pushes the caller
     // has about two microseconds per call.
+    // The sequence number that makes a cell visible is stored for kPublish cells at a time: idle helpers all poll the cell at the head
+    // of the queue, i.e. the very line the caller writes next, and with the helpers on other core complexes every such store first
+    // has to pull the line back from them -- at 4096-sample pushes that was most of the caller's two microseconds.  Whatever is
+    // written but not yet published goes out when a batch closes, on flush() and on every error path; samples of an OPEN batch may
+    // therefore sit unnarrowed (and owned buffers unreleased) until the next few pushes -- nothing waits for an open batch.
+    static constexpr uint64_t kPublish = 16;
     bool try_push(const Task &t)
     {
         Cell &c = ring_[tail_ & (kRing - 1)];
-        if (c.seq.load(std::memory_order_acquire) != tail_) return false;             // full
+        if (c.seq.load(std::memory_order_acquire) != tail_) { publish(); return false; }             // full
         c.task = t;
-        c.seq.store(tail_ + 1, std::memory_order_release);
         tail_++;
+        if (tail_ - pub_ >= kPublish) publish();
         return true;
+    }
+    void publish()
+    {
+        for (; pub_ < tail_; pub_++) ring_[pub_ & (kRing - 1)].seq.store(pub_ + 1, std::memory_order_release);
     }
     bool try_pop(Task &t)
     {
@@ -235,12 +294,18 @@ private:
         int idle = 0;
         Task t;
         for (;;) {
-            if (try_pop(t)) { run_task(t, true); idle = 0; continue; }
+            if (try_pop(t)) {
+                const int64_t h0 = stats_on_ ? now_ns() : 0;
+                run_task(t, true);
+                if (stats_on_) { st_helper_ns_.fetch_add(now_ns() - h0, std::memory_order_relaxed); st_helper_tasks_.fetch_add(1, std::memory_order_relaxed); }
+                idle = 0;
+                continue;
+            }
             if (stop_.load(std::memory_order_acquire)) return;
-            if (++idle < 20000) { cpu_relax(); continue; }                             // poll for roughly 100 us, then doze
+            if (++idle < 2500) { for (int k = 0; k < 8; k++) cpu_relax(); continue; }  // poll (sparsely: every poll shares the line the caller writes next) for roughly 100 us, then doze
             std::unique_lock<std::mutex> lk(m_);
             if (!stop_.load()) cv_work_.wait_until(lk, std::chrono::system_clock::now() + std::chrono::microseconds(500));
-            idle = 19000;
+            idle = 2300;
         }
     }
     static void cpu_relax()
@@ -254,8 +319,11 @@ private:
     // the staging slot of the batch about to be filled is free once the batch kSlots before it has been submitted
     int wait_for_slot()
     {
+        publish();
+        const int64_t w0 = stats_on_ ? now_ns() : 0;
         std::unique_lock<std::mutex> lk(m_);
         cv_room_.wait(lk, [this] { return stop_.load() || error_ || batch_ - submitted_ < kSlots; });
+        if (stats_on_) st_wait_slot_ns_ += now_ns() - w0;
         if (error_) return error_;
         done_[batch_ % kSlots].store(0, std::memory_order_relaxed);
         need_[batch_ % kSlots].store(-1, std::memory_order_release);
@@ -263,6 +331,7 @@ private:
     }
     void close_batch(bool final)
     {
+        publish();
         {
             std::lock_guard<std::mutex> lk(m_);
             need_[batch_ % kSlots].store(fill_, std::memory_order_release);
@@ -273,9 +342,12 @@ private:
         batch_++;
         fill_ = 0;
     }
+    struct Staged { int slot; int64_t n_new; bool final; };
     void submitter_loop()
     {
         std::deque<uint64_t> flight;
+        std::deque<Staged> staged;
+        int64_t staged_n = 0;                                        // batches staged so far (this thread only)
         for (;;) {
             int slot = -1;
             int64_t n_new = 0;
@@ -284,30 +356,56 @@ private:
                 std::unique_lock<std::mutex> lk(m_);
                 for (;;) {
                     if (stop_.load()) return;
-                    if (submitted_ < closed_) {
-                        const int s = (int)(submitted_ % kSlots);
+                    if (staged_n < closed_) {
+                        const int s = (int)(staged_n % kSlots);
                         const int64_t need = need_[s].load(std::memory_order_acquire);
                         if (done_[s].load(std::memory_order_acquire) >= need) { slot = s; n_new = need; final = final_[s]; break; }
                     }
-                    // (timed: a helper's nudge can fall between the test above and the wait)
-                    cv_sub_.wait_until(lk, std::chrono::system_clock::now() + std::chrono::microseconds(200));   // (system clock: pthread_cond_timedwait, which ThreadSanitizer knows)
-                    if (!flight.empty()) break;                      // nothing to submit yet: see whether a batch in flight has finished
+                    // (timed: a helper's nudge can fall between the test above and the wait; shorter while an upload or a batch is in flight)
+                    const bool busy = !staged.empty() || !flight.empty();
+                    cv_sub_.wait_until(lk, std::chrono::system_clock::now() + std::chrono::microseconds(busy ? 40 : 200));   // (system clock: pthread_cond_timedwait, which ThreadSanitizer knows)
+                    if (busy) break;                                 // nothing to stage yet: see whether an upload or a batch in flight has finished
                 }
             }
             int rc = 0;
             if (slot >= 0) {
-                // at most kSlots - 1 batches in flight: the one about to go out takes the last device buffer
-                while (!rc && (int)flight.size() >= kSlots - 1) rc = collect_one(flight, true) < 0 ? -1 : 0;
-                uint64_t h = 0;
-                if (!rc) rc = be_->submit(slot, n_new, final, &h);
-                if (!rc) flight.push_back(h);
-                { std::lock_guard<std::mutex> lk(m_); if (rc && !error_) error_ = rc < 0 ? rc : -3; submitted_++; }
-                cv_room_.notify_all();
-                cv_ready_.notify_all();
+                // a device buffer is written again kSlots batches later: at most kSlots - 1 batches staged or in flight, the one
+                // about to be staged included
+                while (!rc && (int)(staged.size() + flight.size()) >= kSlots - 1) {
+                    if (flight.empty()) rc = submit_front(staged, flight);
+                    else rc = collect_one(flight, true) < 0 ? -1 : 0;
+                }
+                if (!rc) rc = be_->stage(slot, n_new, final);
+                staged_n++;
+                if (!rc) staged.push_back(Staged{ slot, n_new, final });
+                else fail_batch(rc);
             }
-            // hand finished batches over as they complete (polling: a batch that becomes ready to submit must not wait for the GPU)
+            // the oldest staged batch goes out once its samples are on the device
+            while (!staged.empty() && be_->uploaded(staged.front().slot)) (void)submit_front(staged, flight);
+            // hand finished batches over as they complete (polling: a batch that becomes ready to stage must not wait for the GPU)
             while (!flight.empty() && collect_one(flight, false) > 0) {}
         }
+    }
+    // a batch that could not be staged or submitted still counts as submitted (the caller waits for its staging slot) and as
+    // collected (take() waits for every closed batch)
+    void fail_batch(int rc)
+    {
+        { std::lock_guard<std::mutex> lk(m_); if (!error_) { error_ = rc < 0 ? rc : -3; error_flag_.store(error_, std::memory_order_release); } submitted_++; collected_++; }
+        cv_room_.notify_all();
+        cv_ready_.notify_all();
+    }
+    int submit_front(std::deque<Staged> &staged, std::deque<uint64_t> &flight)
+    {
+        const Staged s = staged.front();
+        staged.pop_front();
+        uint64_t h = 0;
+        const int rc = be_->submit(s.slot, s.n_new, s.final, &h);
+        if (rc) { fail_batch(rc); return rc; }
+        flight.push_back(h);
+        { std::lock_guard<std::mutex> lk(m_); submitted_++; }
+        cv_room_.notify_all();
+        cv_ready_.notify_all();
+        return 0;
     }
     int collect_one(std::deque<uint64_t> &flight, bool wait)
     {
@@ -315,9 +413,10 @@ private:
         const int rc = be_->collect(flight.front(), wait, &r);
         if (rc == 0) return 0;
         std::lock_guard<std::mutex> lk(m_);
-        if (rc < 0) { if (!error_) error_ = rc; flight.pop_front(); collected_++; cv_ready_.notify_all(); return rc; }
+        if (rc < 0) { if (!error_) { error_ = rc; error_flag_.store(rc, std::memory_order_release); } flight.pop_front(); collected_++; cv_ready_.notify_all(); return rc; }
         flight.pop_front();
         ready_.push_back(std::move(r));
+        ready_n_.fetch_add(1, std::memory_order_acq_rel);
         collected_++;
         cv_ready_.notify_all();
         return 1;
@@ -332,7 +431,7 @@ private:
     std::mutex m_;
     std::condition_variable cv_work_, cv_sub_, cv_ready_, cv_room_;
     std::vector<Cell> ring_;
-    uint64_t tail_ = 0;                              // producer (caller) only
+    uint64_t tail_ = 0, pub_ = 0;                    // producer (caller) only: cells written / cells made visible
     std::atomic<uint64_t> head_{ 0 };
     std::deque<StreamReady> ready_;
     std::atomic<int64_t> done_[kSlots] = {};
@@ -340,6 +439,15 @@ private:
     bool final_[kSlots] = {};
     int64_t closed_ = 0, submitted_ = 0, collected_ = 0;
     int error_ = 0;
+    std::atomic<int> error_flag_{ 0 };               // = error_, readable without the lock
+public:
+    // where the time goes (FOA_STREAM_STATS; ns / counts): caller inside push(), helpers narrowing, tasks the caller narrowed itself
+    // because the queue was full, time the caller waited for a staging slot
+    const bool stats_on_ = getenv("FOA_STREAM_STATS") != nullptr;
+    int64_t st_push_ns_ = 0, st_wait_slot_ns_ = 0, st_inline_ = 0, st_pushes_ = 0;
+    std::atomic<int64_t> st_helper_ns_{ 0 }, st_helper_tasks_{ 0 };
+private:
+    std::atomic<int> ready_n_{ 0 };                  // = ready_.size(), readable without the lock
     std::atomic<bool> stop_{ false };
     std::vector<std::thread> helpers_;
     std::thread submitter_;

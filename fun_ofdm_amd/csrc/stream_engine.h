@@ -33,7 +33,7 @@ namespace foa {
 
 constexpr int64_t kStreamLongest = 110592;          // >= 320 + 80 * 1369 (4095 bytes at 6 Mbps) + 32 + timing_sync's 160-sample look-ahead
 constexpr int64_t kStreamCarry = kStreamLongest + 2048;
-constexpr int kStreamBufs = 4;                      // device sample buffers / pinned staging buffers in rotation
+constexpr int kStreamBufs = 6;                      // device sample buffers / pinned staging buffers in rotation (= StreamCore::kSlots)
 
 }  // namespace foa
 
@@ -51,20 +51,23 @@ struct StreamGpu {
     size_t desc_cap = 0;
     int64_t submitted_samples = 0;                   // samples in the batches submitted so far
     int64_t n_batches = 0;
-    int64_t cut_prev = 0;                            // STS_END positions below this have been dealt with
-    double prev_c = 1.0, prev_s = 0.0;               // phasor of the last alignment decoded (timing_sync's m_phase_acc)
+    int64_t n_staged = 0;                            // batches whose upload has been queued
+    int64_t cut_prev = 0;                            // STS_END positions below this have been dealt with (batches staged so far)
+    int64_t staged_samples = 0;                      // samples in the batches staged so far
+    DevBuf<double> d_prev;                           // phasor of the last alignment decoded (timing_sync's m_phase_acc), kept on the device
+    DevBuf<int32_t> sel_dev;                         // the same on the device, copied out behind the selection kernel
+    int32_t *sel = nullptr;                          // page-locked: per buffer { STS_END candidates, alignments found, first of the batch, count }
+    hipEvent_t sel_done[foa::kStreamBufs] = {};      // pre-sync + selection of the buffer's batch are through and `sel` is written
+    int32_t ccap[foa::kStreamBufs] = {};
     struct InFlight { uint64_t handle, ticket; size_t n_frames; };
     std::deque<InFlight> flight;
     uint64_t next_handle = 1;
-    std::vector<uint8_t> tmp_psdu;
-    std::vector<foa_frame_result> tmp_res;
-    std::vector<foa_frame_desc> h_desc;
     std::atomic<uint64_t> status_count[5], alignments;
     std::mutex err_m;
     std::string err_text;                            // text of the first error raised on the submitter thread
 
     // where the submitter thread's time goes (ns; printed by foa_stream_destroy when FOA_STREAM_STATS is set)
-    int64_t t_sync = 0, t_desc = 0, t_decode = 0, t_collect = 0, t_collect_wait = 0;
+    int64_t t_sync = 0, t_desc = 0, t_decode = 0, t_collect = 0, t_collect_wait = 0, t_prep = 0;
     static int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
     StreamGpu() { for (auto &c : status_count) c.store(0); alignments.store(0); }
@@ -77,7 +80,46 @@ struct StreamGpu {
         return rc;
     }
 
-    // queue batch `n_batches`: n_new samples wait in staging slot `slot`
+    // queue the upload of the next batch: n_new samples wait in staging slot k.  Device buffer k = the last C samples before the
+    // batch (out of buffer k-1, whose own upload is ahead of this copy on the same stream) + the batch.  Never blocks.
+    int stage(int k, int64_t n_new, bool final)
+    {
+        const int rc = stage_impl(k, n_new, final);
+        return rc ? keep_error(rc) : 0;
+    }
+    int stage_impl(int k, int64_t n_new, bool final)
+    {
+        const int64_t C = foa::kStreamCarry;
+        const int kp = (k + foa::kStreamBufs - 1) % foa::kStreamBufs;
+        HIP_TRY(hipSetDevice(rx->device));
+        float *d = dev[k].p;
+        if (n_staged == 0) HIP_TRY(hipMemsetAsync(d, 0, (size_t)C * 8, st_in));                     // silence before the stream
+        else HIP_TRY(hipMemcpyAsync(d, dev[kp].p + 2 * B, (size_t)C * 8, hipMemcpyDeviceToDevice, st_in));   // (every batch but the last is full)
+        if (n_new) HIP_TRY(hipMemcpyAsync(d + 2 * C, pin[k], (size_t)n_new * 8, hipMemcpyHostToDevice, st_in));
+        HIP_TRY(hipEventRecord(in_done[k], st_in));
+        // ... and right behind it, on the side stream, the pre-sync over the whole buffer and the selection of this batch's alignments:
+        // by the time the batch is submitted the host has nothing to wait for but four integers
+        hipStream_t st = side_stream(rx);
+        HIP_TRY(hipStreamWaitEvent(st, in_done[k], 0));
+        const int64_t L = foa::kStreamLongest, n_buf = C + n_new, pushed = staged_samples + n_new;
+        const int64_t start = pushed - n_new - C;                    // stream index of the buffer's first sample
+        const int64_t cut = final ? pushed + 1 : pushed - L;        // this batch decodes the alignments whose STS_END sample lies in [cut_prev, cut)
+        int rc = sync_dev_issue(rx, d, (size_t)n_buf, (foa_frame_desc *)d_desc[k].p, d_ends[k].p, desc_cap, &ccap[k]);
+        if (rc) return rc;
+        hipLaunchKernelGGL(foa::k_stream_select, dim3(1), dim3(64), 0, st, (foa_frame_desc *)d_desc[k].p, rx->sy_n.p, (int32_t)desc_cap, cut_prev - start, cut - start,
+                           d_prev.p, sel_dev.p + 4 * k);
+        HIP_TRY(hipMemcpyAsync(sel + 4 * k, sel_dev.p + 4 * k, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(sel_done[k], st));
+        HIP_TRY(hipGetLastError());
+        cut_prev = cut;
+        staged_samples = pushed;
+        n_staged++;
+        return FOA_OK;
+    }
+    // (the core asks this before it submits: the batch's samples are on the device AND its alignments are known)
+    bool uploaded(int k) { return hipEventQuery(sel_done[k]) != hipErrorNotReady; }
+
+    // queue the kernels of batch `n_batches`, whose samples stage() put into device buffer k
     int submit(int slot, int64_t n_new, bool final, uint64_t *handle)
     {
         const int rc = submit_impl(slot, n_new, final, handle);
@@ -85,66 +127,44 @@ struct StreamGpu {
     }
     int submit_impl(int k, int64_t n_new, bool final, uint64_t *handle)
     {
-        const int64_t C = foa::kStreamCarry, L = foa::kStreamLongest;
-        const int kp = (k + foa::kStreamBufs - 1) % foa::kStreamBufs;
+        const int64_t C = foa::kStreamCarry;
         const int64_t n_buf = C + n_new, pushed = submitted_samples + n_new;
-        const int64_t start = pushed - n_new - C;                    // stream index of the buffer's first sample
         HIP_TRY(hipSetDevice(rx->device));
         float *d = dev[k].p;
-        if (n_batches == 0) HIP_TRY(hipMemsetAsync(d, 0, (size_t)C * 8, st_in));                    // silence before the stream
-        else HIP_TRY(hipMemcpyAsync(d, dev[kp].p + 2 * B, (size_t)C * 8, hipMemcpyDeviceToDevice, st_in));   // (every batch but the last is full)
-        if (n_new) HIP_TRY(hipMemcpyAsync(d + 2 * C, pin[k], (size_t)n_new * 8, hipMemcpyHostToDevice, st_in));
-        HIP_TRY(hipEventRecord(in_done[k], st_in));
         const bool piped = rx->pipeline && rx->viterbi_kind == 2;
-        hipStream_t st = side_stream(rx);                           // the pre-sync runs there, and what the decode call's front end has to wait for
-        HIP_TRY(hipStreamWaitEvent(st, in_done[k], 0));
-        size_t found = 0;
         int64_t t0 = now_ns();
-        int rc = foa_rx_sync_dev(rx, d, (size_t)n_buf, (foa_frame_desc *)d_desc[k].p, d_ends[k].p, desc_cap, &found);
+        HIP_TRY(hipEventSynchronize(sel_done[k]));                   // (through already when the core asked uploaded(); the staging slot is free again)
         t_sync += now_ns() - t0;
-        if (rc) return rc;
-        t0 = now_ns();
-        // (foa_rx_sync_dev has waited for its stream, hence for the H2D: the staging slot is free again when this returns)
-        // which of them are this batch's: STS_END sample in [cut_prev, cut)
-        const int64_t cut = final ? pushed + 1 : pushed - L;
-        size_t i0 = 0, i1 = 0;
-        if (found) {
-            h_desc.resize(found);
-            HIP_TRY(hipMemcpy(h_desc.data(), d_desc[k].p, found * sizeof(foa_frame_desc), hipMemcpyDeviceToHost));
-            while (i0 < found && start + h_desc[i0].rot_start < cut_prev) i0++;
-            i1 = i0;
-            while (i1 < found && start + h_desc[i1].rot_start < cut) i1++;
-        }
-        const size_t m = i1 - i0;
-        t_desc += now_ns() - t0;
+        const int32_t *q = sel + 4 * k;
+        if (q[0] > ccap[k]) return fail(FOA_E_NOMEM, "too many STS_END candidates (%d)", q[0]);
+        if ((size_t)q[1] > desc_cap) return fail(FOA_E_INVALID, "internal: %d alignments in one batch buffer", q[1]);
+        const size_t i0 = (size_t)q[2], m = (size_t)q[3];
+        int rc;
         t0 = now_ns();
         InFlight fl;
         fl.handle = next_handle++; fl.n_frames = m; fl.ticket = 0;
         if (m) {
-            // timing_sync's phasor before the first alignment of the batch: the one the last decoded alignment set
-            foa_frame_desc &first = h_desc[i0];
-            first.c_prev = prev_c; first.s_prev = prev_s;
-            HIP_TRY(hipMemcpyAsync(d_desc[k].p + i0 * sizeof(foa_frame_desc), &first, sizeof first, hipMemcpyHostToDevice, st));
-            prev_c = h_desc[i1 - 1].c; prev_s = h_desc[i1 - 1].s;
             // outputs go through a job slot of the asynchronous host entry (page-locked mirror, D2H behind the finish kernel)
             HostJob *job = nullptr;
             for (auto &j : rx->jobs) if (!j.busy) { job = &j; break; }
             if (!job) return fail(FOA_E_STATE, "internal: no free job slot");
             auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
             const size_t o_res = up(m * slot_bytes), total = o_res + up(m * sizeof(foa_frame_result));
-            if ((rc = job->dev.ensure(total))) return rc;
+            // (twice what this batch needs: the number of frames differs a little from batch to batch, and growing a buffer means a
+            // hipFree, which waits for the whole device -- with exact sizes that was 0.4-0.9 ms of the submitter's time per batch)
+            const size_t roomy = (2 * total + ((size_t)1 << 20)) & ~(((size_t)1 << 20) - 1);
+            if (job->dev.n < total && (rc = job->dev.ensure(roomy))) return rc;
             if (job->pin_cap < total) {
                 if (job->pin) (void)hipHostFree(job->pin);
                 job->pin = nullptr; job->pin_cap = 0;
-                const size_t want = total + total / 2;
-                HIP_TRY(hipHostMalloc((void **)&job->pin, want, hipHostMallocDefault));
-                job->pin_cap = want;
+                HIP_TRY(hipHostMalloc((void **)&job->pin, roomy, hipHostMallocDefault));
+                job->pin_cap = roomy;
             }
             if (!job->done) HIP_TRY(hipEventCreateWithFlags(&job->done, hipEventDisableTiming));
-            HIP_TRY(hipMemsetAsync(job->dev.p, 0, m * slot_bytes, st));
+            // (the slots are not cleared: collect() reads the payload of a frame only where the result says it passed)
             job->total = total; job->o_psdu = 0; job->o_res = o_res; job->n_frames = m; job->slot_bytes = slot_bytes; job->copy_queued = false;
             rx->attach_job = piped ? job : nullptr;
-            if ((rc = inputs_queued(rx, st))) return rc;            // (the patched descriptor and the cleared slots)
+            t_prep += now_ns() - t0;
             rc = foa_rx_decode_frames_dev(rx, d, (size_t)n_buf, (const foa_frame_desc *)d_desc[k].p + i0, d_ends[k].p + i0, m, job->dev.p, slot_bytes,
                                           (foa_frame_result *)(job->dev.p + o_res));
             rx->attach_job = nullptr;
@@ -162,7 +182,6 @@ struct StreamGpu {
         t_decode += now_ns() - t0;
         flight.push_back(fl);
         *handle = fl.handle;
-        cut_prev = cut;
         submitted_samples = pushed;
         n_batches++;
         return FOA_OK;
@@ -175,25 +194,33 @@ struct StreamGpu {
         const InFlight f = flight.front();
         if (f.n_frames) {
             (void)hipSetDevice(rx->device);
-            tmp_psdu.resize(f.n_frames * slot_bytes);
-            tmp_res.resize(f.n_frames);
             const int64_t t0 = now_ns();
-            const int rc = foa_rx_collect(rx, f.ticket, wait ? 1 : 0, tmp_psdu.data(), tmp_res.data());
+            HostJob *job = nullptr;
+            const int rc = job_ready(rx, f.ticket, wait, &job);
             if (rc < 0) { flight.pop_front(); return keep_error(rc); }
             if (rc == 0) { t_collect_wait += now_ns() - t0; return 0; }
+            // straight out of the job's page-locked mirror: only the payload bytes of the frames that passed move again
+            const foa_frame_result *res = (const foa_frame_result *)(job->pin + job->o_res);
+            const uint8_t *ps = job->pin + job->o_psdu;
+            size_t bytes = 0;
+            for (size_t i = 0; i < f.n_frames; i++) if (res[i].status == FOA_ST_OK) bytes += (size_t)res[i].length;
+            out->bytes.reserve(out->bytes.size() + bytes);
             for (size_t i = 0; i < f.n_frames; i++) {
-                const foa_frame_result &r = tmp_res[i];
-                if (r.status >= 0 && r.status < 5) status_count[r.status].fetch_add(1);
+                const foa_frame_result &r = res[i];
+                if (r.status >= 0 && r.status < 5) status_count[r.status].fetch_add(1, std::memory_order_relaxed);
                 if (r.status != FOA_ST_OK) continue;
                 out->len.push_back((uint32_t)r.length);
-                out->bytes.insert(out->bytes.end(), tmp_psdu.begin() + i * slot_bytes, tmp_psdu.begin() + i * slot_bytes + r.length);
+                out->bytes.insert(out->bytes.end(), ps + i * job->slot_bytes, ps + i * job->slot_bytes + r.length);
             }
+            job->busy = false;
             t_collect += now_ns() - t0;
         }
         flight.pop_front();
         return 1;
     }
 };
+
+static_assert(foa::kStreamBufs == foa::StreamCore<StreamGpu>::kSlots, "one device buffer and one staging buffer per slot of the core");
 
 struct foa_stream {
     StreamGpu gpu;
@@ -235,8 +262,16 @@ int foa_stream_create(foa_rx *rx, size_t batch_samples, int narrow_threads, foa_
         if (!rc) rc = g.d_desc[i].ensure(g.desc_cap * sizeof(foa_frame_desc));
         if (!rc) rc = g.d_ends[i].ensure(g.desc_cap);
         if (!rc && hipEventCreateWithFlags(&g.in_done[i], hipEventDisableTiming) != hipSuccess) rc = fail(FOA_E_HIP, "hipEventCreate failed");
+        if (!rc && hipEventCreateWithFlags(&g.sel_done[i], hipEventDisableTiming) != hipSuccess) rc = fail(FOA_E_HIP, "hipEventCreate failed");
     }
     if (!rc && hipStreamCreateWithFlags(&g.st_in, hipStreamNonBlocking) != hipSuccess) rc = fail(FOA_E_HIP, "hipStreamCreate failed");
+    if (!rc && hipHostMalloc((void **)&g.sel, (size_t)foa::kStreamBufs * 4 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) rc = fail(FOA_E_NOMEM, "hipHostMalloc failed");
+    if (!rc) rc = g.sel_dev.ensure((size_t)foa::kStreamBufs * 4);
+    if (!rc) rc = g.d_prev.ensure(2);
+    if (!rc) {
+        const double one[2] = { 1.0, 0.0 };                         // timing_sync's m_phase_acc before the first frame: 0
+        if (hipMemcpy(g.d_prev.p, one, sizeof one, hipMemcpyHostToDevice) != hipSuccess) rc = fail(FOA_E_HIP, "hipMemcpy failed");
+    }
     if (rc) { foa_stream_destroy(s); return rc; }
     // the engine's batches are small grids, but its decode calls alternate with a pre-sync the host waits for: two loops in flight
     // serve it better than four (2.2 against 2.0 Gsample/s through process_samples)
@@ -252,8 +287,8 @@ void foa_stream_destroy(foa_stream *s)
     delete s->core;                                   // joins the helpers and the submitter: from here on this thread owns the handle
     StreamGpu &g = s->gpu;
     if (getenv("FOA_STREAM_STATS"))
-        fprintf(stderr, "foa_stream: %lld batches; submitter ms: pre-sync (incl. H2D wait) %.1f, descriptors %.1f, decode call %.1f, collect %.1f, polling %.1f\n",
-                (long long)g.n_batches, g.t_sync * 1e-6, g.t_desc * 1e-6, g.t_decode * 1e-6, g.t_collect * 1e-6, g.t_collect_wait * 1e-6);
+        fprintf(stderr, "foa_stream: %lld batches; submitter ms: waiting for upload + pre-sync %.1f, decode call %.1f (of which output slots %.1f, waiting for a work set %.1f), collect %.1f, polling %.1f\n",
+                (long long)g.n_batches, g.t_sync * 1e-6, g.t_decode * 1e-6, g.t_prep * 1e-6, g.rx->ns_wait_set * 1e-6, g.t_collect * 1e-6, g.t_collect_wait * 1e-6);
     (void)hipSetDevice(g.rx->device);
     (void)foa_rx_sync(g.rx);
     if (g.rx->depth_saved >= 0) { g.rx->depth = g.rx->depth_saved; g.rx->depth_saved = -1; }
@@ -263,8 +298,11 @@ void foa_stream_destroy(foa_stream *s)
         if (g.pin[i]) (void)hipHostFree(g.pin[i]);
         g.dev[i].release(); g.d_desc[i].release(); g.d_ends[i].release();
         if (g.in_done[i]) (void)hipEventDestroy(g.in_done[i]);
+        if (g.sel_done[i]) (void)hipEventDestroy(g.sel_done[i]);
     }
     if (g.st_in) (void)hipStreamDestroy(g.st_in);
+    if (g.sel) (void)hipHostFree(g.sel);
+    g.sel_dev.release(); g.d_prev.release();
     delete s;
 }
 

@@ -14,19 +14,31 @@ static int failures = 0;
 
 struct FakeGpu {
     int64_t B;
-    std::vector<float> stage[4];
+    static constexpr int kBufs = foa::StreamCore<FakeGpu>::kSlots;
+    std::vector<float> stage_buf[kBufs];
+    std::vector<float> dev[kBufs];                 // what stage() uploaded, per slot
+    int upload_polls[kBufs] = {};
     std::vector<float> received;                   // the stream as the "device" saw it
     struct Fl { uint64_t h; int64_t n; int polls; };
     std::deque<Fl> flight;
     uint64_t next = 1;
     int fail_at = -1, submits = 0;
-    explicit FakeGpu(int64_t b) : B(b) { for (auto &s : stage) s.assign(2 * b, -1.0f); }
-    float *staging(int slot) { return stage[slot].data(); }
+    explicit FakeGpu(int64_t b) : B(b) { for (auto &s : stage_buf) s.assign(2 * b, -1.0f); }
+    float *staging(int slot) { return stage_buf[slot].data(); }
+    int stage(int slot, int64_t n_new, bool)
+    {
+        dev[slot].assign(stage_buf[slot].begin(), stage_buf[slot].begin() + 2 * n_new);
+        std::fill(stage_buf[slot].begin(), stage_buf[slot].end(), -1.0f);   // a sample that arrives late would be lost
+        upload_polls[slot] = 0;
+        return 0;
+    }
+    bool uploaded(int slot) { return ++upload_polls[slot] > 2; }            // "still copying" a couple of times
     int submit(int slot, int64_t n_new, bool final, uint64_t *handle)
     {
         if (submits++ == fail_at) return -3;
-        received.insert(received.end(), stage[slot].begin(), stage[slot].begin() + 2 * n_new);
-        std::fill(stage[slot].begin(), stage[slot].end(), -1.0f);           // a sample that arrives late would be lost
+        if ((int64_t)dev[slot].size() != 2 * n_new) return -2;              // submitted without (or with another batch's) upload
+        received.insert(received.end(), dev[slot].begin(), dev[slot].end());
+        dev[slot].clear();
         if (!final && n_new != B) return -1;
         flight.push_back(Fl{ next, n_new, 0 });
         *handle = next++;
