@@ -70,6 +70,7 @@ def parse_args(argv=None):
     ap.add_argument("--legs-frames", type=int, default=1000, help="frames per rate of the config-3 leg")
     ap.add_argument("--timing-age", type=int, default=4, help="pipelined steps: the per-kernel HIP-event times read inside the timed loop are those of the "
                     "call this many calls back (2..4): the further back, the more calls the host may run ahead of the GPU")
+    ap.add_argument("--no-self-check", action="store_true", help="skip the alone-speed leg and the issue probe (profiling: keeps their launches out of the kernel averages)")
     ap.add_argument("--host-jitter-us", type=int, default=0, help="A/B: sleep this long on the host after every fifth step (how much host delay the pipeline absorbs)")
     return ap.parse_args(argv)
 
@@ -402,7 +403,7 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
     # forward_ms_live / forward_ms_alone tells a good arrangement of the overlapping calls (about 1.2-1.3: the forward pass shares the
     # SIMDs with its guests) from a bad one (VERDICT round 2 measured 2.9 on the driver's box).
     alone = None
-    if piped and not on_cpu and args.steps <= 50:
+    if piped and not on_cpu and args.steps <= 50 and not args.no_self_check:
         rx.sync()
         rx.set_option("pipeline", 0)
         acc = {}
@@ -415,7 +416,7 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
         rx.set_option("pipeline", 1)
         alone = acc
     probe = None
-    if not on_cpu and hasattr(rx, "probe_issue"):
+    if not on_cpu and hasattr(rx, "probe_issue") and not args.no_self_check:
         probe = rx.probe_issue()
 
     # ---- extra leg (not `value`): the same pass preceded by frame_detector + timing_sync on the device ----

@@ -186,6 +186,9 @@ constexpr int kMaxJobs = 8;
 
 constexpr int kSets = 6;
 
+struct foa_stream;
+void foa_stream_shutdown(foa_stream *s);
+
 struct foa_rx {
     int device = 0;
     hipStream_t stream = nullptr;      // everything when calls run in line; the first lane of pipelined calls
@@ -235,6 +238,7 @@ struct foa_rx {
     DevBuf<int64_t> sy_x;
     DevBuf<SyncCand> sy_cand;
     size_t last_frames = 0;
+    struct foa_stream *open_stream = nullptr;      // the stream engine that owns this handle right now (stream_engine.h), if any
     int64_t ns_wait_set = 0;     // host time spent waiting for a work set to come free (the GPU is more than kSets - 1 calls behind)
 };
 
@@ -383,6 +387,7 @@ int foa_rx_create(foa_rx **out, int device)
 void foa_rx_destroy(foa_rx *rx)
 {
     if (!rx) return;
+    if (rx->open_stream) foa_stream_shutdown(rx->open_stream);       // (joins the engine's threads: they use the handle; the owner still frees the shell)
     (void)hipSetDevice(rx->device);
     (void)drain(rx);
     for (auto &ws : rx->sets) {

@@ -248,6 +248,8 @@ int foa_stream_create(foa_rx *rx, size_t batch_samples, int narrow_threads, foa_
     *out = nullptr;
     if (batch_samples < 4096 || batch_samples > ((size_t)1 << 28)) return fail(FOA_E_INVALID, "batch_samples must lie in [4096, 2^28]");
     if (narrow_threads < 0 || narrow_threads > 64) return fail(FOA_E_INVALID, "narrow_threads must lie in [0, 64]");
+    // one stream per handle: its submitter thread owns the handle's streams, work sets and job slots until the stream is destroyed
+    if (rx->open_stream) return fail(FOA_E_STATE, "a stream is already open on this handle: destroy it first (one engine per handle)");
     HIP_TRY(hipSetDevice(rx->device));
     { int rc0 = drain(rx); if (rc0) return rc0; }
     foa_stream *s = new foa_stream();
@@ -277,49 +279,87 @@ int foa_stream_create(foa_rx *rx, size_t batch_samples, int narrow_threads, foa_
     // serve it better than four (2.2 against 2.0 Gsample/s through process_samples)
     rx->depth_saved = rx->depth; rx->depth = 2;
     s->core = new foa::StreamCore<StreamGpu>(&g, g.B, narrow_threads);
+    rx->open_stream = s;
     *out = s;
     return FOA_OK;
 }
 
-void foa_stream_destroy(foa_stream *s)
+}  // extern "C"
+
+// Stops the engine and gives everything it holds on the device back; the handle is the caller's again.  Idempotent: foa_rx_destroy
+// calls it for a stream that is still open (its threads use the handle), and the owner's later foa_stream_destroy then only frees
+// the shell -- every other foa_stream_* call on such a stream fails with FOA_E_STATE.
+void foa_stream_shutdown(foa_stream *s)
 {
-    if (!s) return;
+    if (!s || !s->core) return;
     delete s->core;                                   // joins the helpers and the submitter: from here on this thread owns the handle
+    s->core = nullptr;
     StreamGpu &g = s->gpu;
     if (getenv("FOA_STREAM_STATS"))
         fprintf(stderr, "foa_stream: %lld batches; submitter ms: waiting for upload + pre-sync %.1f, decode call %.1f (of which output slots %.1f, waiting for a work set %.1f), collect %.1f, polling %.1f\n",
                 (long long)g.n_batches, g.t_sync * 1e-6, g.t_decode * 1e-6, g.t_prep * 1e-6, g.rx->ns_wait_set * 1e-6, g.t_collect * 1e-6, g.t_collect_wait * 1e-6);
     (void)hipSetDevice(g.rx->device);
+    if (g.rx->open_stream == s) g.rx->open_stream = nullptr;
     (void)foa_rx_sync(g.rx);
     if (g.rx->depth_saved >= 0) { g.rx->depth = g.rx->depth_saved; g.rx->depth_saved = -1; }
     // the job slots of batches nobody took are released
     while (!g.flight.empty()) { foa::StreamReady r; if (g.collect(g.flight.front().handle, true, &r) <= 0) break; }
     for (int i = 0; i < foa::kStreamBufs; i++) {
         if (g.pin[i]) (void)hipHostFree(g.pin[i]);
+        g.pin[i] = nullptr;
         g.dev[i].release(); g.d_desc[i].release(); g.d_ends[i].release();
         if (g.in_done[i]) (void)hipEventDestroy(g.in_done[i]);
         if (g.sel_done[i]) (void)hipEventDestroy(g.sel_done[i]);
+        g.in_done[i] = g.sel_done[i] = nullptr;
     }
     if (g.st_in) (void)hipStreamDestroy(g.st_in);
+    g.st_in = nullptr;
     if (g.sel) (void)hipHostFree(g.sel);
+    g.sel = nullptr;
     g.sel_dev.release(); g.d_prev.release();
+}
+
+extern "C" {
+
+void foa_stream_destroy(foa_stream *s)
+{
+    if (!s) return;
+    if (s->core) foa_stream_shutdown(s);
+    else if (s->gpu.rx == nullptr || s->gpu.st_in) {
+        // (creation failed half-way: no engine yet, but buffers may exist)
+        StreamGpu &g = s->gpu;
+        for (int i = 0; i < foa::kStreamBufs; i++) {
+            if (g.pin[i]) (void)hipHostFree(g.pin[i]);
+            g.dev[i].release(); g.d_desc[i].release(); g.d_ends[i].release();
+            if (g.in_done[i]) (void)hipEventDestroy(g.in_done[i]);
+            if (g.sel_done[i]) (void)hipEventDestroy(g.sel_done[i]);
+        }
+        if (g.st_in) (void)hipStreamDestroy(g.st_in);
+        if (g.sel) (void)hipHostFree(g.sel);
+        g.sel_dev.release(); g.d_prev.release();
+    }
     delete s;
 }
 
+#define FOA_STREAM_LIVE(s) do { if ((s) && !(s)->core) return fail(FOA_E_STATE, "the stream was shut down (its handle was destroyed)"); } while (0)
+
 int foa_stream_push_f32(foa_stream *s, const float *iq, size_t n_samples)
 {
+    FOA_STREAM_LIVE(s);
     if (!s || (n_samples && !iq)) return fail(FOA_E_INVALID, "NULL argument");
     const int rc = s->core->push(iq, n_samples, nullptr, nullptr);
     return rc ? stream_fail(s, rc) : FOA_OK;
 }
 int foa_stream_push_f64(foa_stream *s, const double *iq, size_t n_samples)
 {
+    FOA_STREAM_LIVE(s);
     if (!s || (n_samples && !iq)) return fail(FOA_E_INVALID, "NULL argument");
     const int rc = s->core->push(iq, n_samples, nullptr, nullptr);
     return rc ? stream_fail(s, rc) : FOA_OK;
 }
 int foa_stream_push_f64_owned(foa_stream *s, const double *iq, size_t n_samples, void (*release)(void *), void *ctx)
 {
+    if (s && !s->core) { if (release) release(ctx); return fail(FOA_E_STATE, "the stream was shut down (its handle was destroyed)"); }
     if (!s || (n_samples && !iq) || !release) { if (release) release(ctx); return fail(FOA_E_INVALID, "NULL argument"); }
     const int rc = s->core->push(iq, n_samples, release, ctx);
     return rc ? stream_fail(s, rc) : FOA_OK;
@@ -327,6 +367,7 @@ int foa_stream_push_f64_owned(foa_stream *s, const double *iq, size_t n_samples,
 
 int foa_stream_flush(foa_stream *s)
 {
+    FOA_STREAM_LIVE(s);
     if (!s) return fail(FOA_E_INVALID, "NULL argument");
     const int rc = s->core->flush();
     return rc ? stream_fail(s, rc) : FOA_OK;
@@ -334,6 +375,7 @@ int foa_stream_flush(foa_stream *s)
 
 int foa_stream_ready(foa_stream *s, int wait, size_t *n_payloads, size_t *n_bytes)
 {
+    FOA_STREAM_LIVE(s);
     if (!s || !n_payloads || !n_bytes) return fail(FOA_E_INVALID, "NULL argument");
     *n_payloads = 0; *n_bytes = 0;
     if (!s->have_ready) {
@@ -362,6 +404,7 @@ int foa_stream_take(foa_stream *s, uint8_t *payloads, uint32_t *lengths)
 
 int foa_stream_stats(const foa_stream *s, uint64_t out[8])
 {
+    FOA_STREAM_LIVE(s);
     if (!s || !out) return fail(FOA_E_INVALID, "NULL argument");
     for (int i = 0; i < 5; i++) out[i] = s->gpu.status_count[i].load();
     out[5] = s->gpu.alignments.load(); out[6] = (uint64_t)s->core->batches_closed(); out[7] = (uint64_t)s->core->pushed();

@@ -42,6 +42,10 @@ namespace foa {
                          // increments, 8 no lane exchange, 16 no decision stores, 32 test without the renormalisation itself,
                          // 64..256 made-up events, 512 four extra taken branches per event, 1024 one extra reduction per event
 #endif
+#ifndef FOA_EXP
+#define FOA_EXP 0        // timing experiments only (tools/exp_chainback.sh; results are wrong by design): 1 the chain-back walk is not launched, 2 / 4 one / two
+                         // extra VALU instructions in every forward step -- the bounds on what a chain-back fused into the forward pass could gain and must cost
+#endif
 constexpr int kChunk3 = 48;                  // data steps per forward chunk: 3 decision blocks, 8 phase groups
 constexpr int kTbBlockBytes = 8 * 1024;      // LDS of one 16-step decision block of the wave's 64 lanes: [lane / 8][lane % 8] x 128 B
 constexpr int kTbRing = 3;                   // blocks resident per wave: one being walked, two streaming in
@@ -208,6 +212,8 @@ template <int PH, int J>
 __device__ __forceinline__ uint32_t fwd3_step(uint32_t M, const uint2 w, uint32_t (&acc)[6], int jdyn)
 {
     uint32_t Mn = fwd3_acs<PH, J>(M, w, acc, jdyn);
+    if constexpr (FOA_EXP & 2) asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(acc[5]) : "s"(0u), "v"(Mn));          // (mask 0: acc[5] unchanged)
+    if constexpr (FOA_EXP & 4) asm volatile("v_bfi_b32 %0, %1, %2, %0\n\tv_bfi_b32 %0, %1, %2, %0" : "+v"(acc[5]) : "s"(0u), "v"(Mn));
     if constexpr (FOA_ABL & 2) return Mn;
     const uint32_t s0 = __builtin_amdgcn_readfirstlane(Mn);
     if constexpr (FOA_ABL & 32) { if (__builtin_expect(s0 == 0x12345678u, 0)) Mn = fwd3_renorm(Mn, s0); return Mn; }
@@ -566,6 +572,7 @@ inline void launch_finish3(hipStream_t st, hipStream_t st_fin, const FrameInfo *
                            const int64_t *totals, uint16_t *tb_state, size_t max_segs, int S, int L, uint8_t *psdu, size_t slot_bytes,
                            foa_frame_result *results, hipEvent_t walk_done = nullptr)
 {
+    if constexpr (!(FOA_EXP & 1))
     hipLaunchKernelGGL(k_tb_walk, dim3((unsigned)((max_segs + 63) / 64)), dim3(64), 0, st, info, seg2frame, totals, dec, decoded, tb_state, S, L);
     if (walk_done) (void)hipEventRecord(walk_done, st);
     if (st_fin != st) (void)hipStreamWaitEvent(st_fin, walk_done, 0);

@@ -149,3 +149,26 @@ def test_process_samples_device_mode_through_the_cpp_chain(tmp_path, po, mixed):
             recs.append(raw[o + 4:o + 4 + n])
             o += 4 + n
         assert recs == want, (fmt, extra, len(recs), len(want))
+
+
+def test_one_stream_per_handle_and_handle_destroyed_first(po):
+    """a second foa_stream_create on a handle whose stream is open is refused (FOA_E_STATE) instead of corrupting the
+    first one's state; destroying the HANDLE while its stream is open stops the engine (its threads use the handle), after which every
+    call on the stream fails cleanly and destroying the stream only frees the shell."""
+    import fun_ofdm_amd as foa
+    from fun_ofdm_amd._lib import FoaError
+    rng = np.random.default_rng(5)
+    s, pays = _stream(po, rng, [(10, 300), (0, 120), (8, 500)])
+    r = foa.Receiver(0)
+    st = foa.Stream(r, 8192, 2)
+    with pytest.raises(FoaError):
+        foa.Stream(r, 8192, 0)
+    got = st.push(s) + st.flush()
+    assert got == pays
+    st.close()
+    st2 = foa.Stream(r, 16384, 1)                   # ... and the handle takes a new stream once the first is gone
+    got = st2.push(s[:4000])
+    r.close()                                          # the handle goes first
+    with pytest.raises(FoaError):
+        st2.push(s[4000:])
+    st2.close()

@@ -23,7 +23,7 @@ t0 = rows[lo][0]
 sel = [r for r in rows[max(0, lo - 4):hi + 1]]
 keep = [r for r in sel if "scan_sums" not in r[2] and "scan_apply" not in r[2]]        # the three scan launches show as k_scan_blocks
 with open(dst, "w") as out:
-    out.write("# rocprofv3 --kernel-trace of `python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-sync-leg --no-extra-legs`; times in us relative to the first row's forward pass\n")
+    out.write("# rocprofv3 --kernel-trace of `python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-sync-leg --no-extra-legs --no-self-check`; times in us relative to the first row's forward pass\n")
     out.write("kernel,queue,start_us,end_us,duration_us\n")
     for s, e, n, q in keep[:58]:
         out.write("%s,%s,%.1f,%.1f,%.1f\n" % (n, q, (s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3))
