@@ -291,9 +291,13 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
     d_iq = torch.from_numpy(iq.view(np.float32).reshape(-1, 2)).to(dev)
     d_desc = torch.from_numpy(descs.view(np.uint8).copy()).to(dev)
     d_ends = torch.from_numpy(ends).to(dev)
-    # three output sets in rotation: with several ranks the PSDUs of step k-2 are gathered while step k is being queued and
-    # step k-1's chain-back has yet to run, so consecutive steps must not share their output buffers
-    n_out = 3 if multi else 1
+    # Output sets in rotation: with several ranks the PSDUs of step k - LAG are gathered while step k is being queued, so the steps in
+    # between must not share their output buffers.  LAG = 4 (the library keeps the results of the last four calls addressable,
+    # foa_rx_wait_age): a step that old is complete, so the gather never holds the host up and the host stays calls ahead of the GPU
+    # (with LAG = 2, round 2, the forced-collective run on one GPU was 19 % slower than the plain one: every step waited for the step two
+    # back and queued its successor late)
+    LAG = 4
+    n_out = LAG + 2 if multi else 1
     out_psdu = [torch.zeros((m, PAYLOAD), dtype=torch.uint8, device=dev) for _ in range(n_out)]
     out_res = [torch.zeros((m, 4), dtype=torch.int32, device=dev) for _ in range(n_out)]
     d_real = torch.from_numpy(real).to(dev)
@@ -328,14 +332,14 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
             read_done[k % n_out] = None
         rx.decode_frames_dev(d_iq, d_desc, d_ends, out_psdu[k % n_out], out_res[k % n_out])
         issued[0] = k + 1
-        if multi and k - done[0] >= 2:
-            rx.wait_age(2)
+        if multi and k - done[0] >= LAG:
+            rx.wait_age(LAG)
             gather_now(done[0] % n_out)
             done[0] += 1
 
     def finish_steps():
         rx.sync()
-        while multi and done[0] < issued[0]:             # the last two steps' PSDUs
+        while multi and done[0] < issued[0]:             # the last LAG steps' PSDUs
             gather_now(done[0] % n_out)
             done[0] += 1
         last = (issued[0] - 1) % n_out if issued[0] else 0

@@ -14,7 +14,8 @@
 
 #define REP 1500        // window = REP x 1000 shader clocks (~0.65 ms)
 
-enum { V_ADD, V_FMA, V_PK_ADD_CLAMP, V_PK_MIN, V_PK_SUB, V_DPP_QUAD, V_DPP_ROW, V_PERMLANE32, V_PERMLANE16, V_BFI, V_LSHR, V_READFIRST, DS_READ_B64, V_FMA_F64, MIX_FWD, MIX_FWD_CHAIN };
+enum { V_ADD, V_FMA, V_PK_ADD_CLAMP, V_PK_MIN, V_PK_SUB, V_DPP_QUAD, V_DPP_ROW, V_PERMLANE32, V_PERMLANE16, V_BFI, V_LSHR, V_READFIRST, DS_READ_B64, V_FMA_F64, MIX_FWD, MIX_FWD_CHAIN,
+       V_MIN_U16, V_MIN_U32, V_CNDMASK, V_AND, V_SUB_U32, V_MOV, V_PERM, V_ADD_U16, V_MIN_U16_DPP, DS_SWIZZLE, DS_SWIZZLE_MIN, V_READLANE, V_AND_OR, V_CNDMASK_E64, V_ADD_U32_DPP, DS_BPERMUTE };
 
 template <int V>
 __global__ __launch_bounds__(256) void k(unsigned long long *out, unsigned seed, int rep)
@@ -51,6 +52,22 @@ __global__ __launch_bounds__(256) void k(unsigned long long *out, unsigned seed,
             if (V == V_READFIRST) { unsigned s; asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(s) : "v"(r[i])); sacc += s; }
             if (V == DS_READ_B64) { unsigned long long v; asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"((threadIdx.x * 8 + i) * 8)); r[i] ^= (unsigned)v; }
             if (V == V_FMA_F64) asm volatile("v_fma_f64 %0, %0, %0, %0" : "+v"(d[i]));
+            if (V == V_MIN_U16) asm volatile("v_min_u16 %0, %0, %1" : "+v"(r[i]) : "v"(r[(i + 1) & 7]));
+            if (V == V_MIN_U32) asm volatile("v_min_u32 %0, %0, %1" : "+v"(r[i]) : "v"(r[(i + 1) & 7]));
+            if (V == V_CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r[i]) : "v"(r[(i + 1) & 7]) : "vcc");
+            if (V == V_CNDMASK_E64) asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(r[i]) : "v"(r[(i + 1) & 7]), "s"(0x00ff00ff00ff00ffull));
+            if (V == V_AND) asm volatile("v_and_b32 %0, %1, %0" : "+v"(r[i]) : "v"(r[(i + 1) & 7]));
+            if (V == V_SUB_U32) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(r[i]) : "v"(seed));
+            if (V == V_MOV) asm volatile("v_mov_b32 %0, %1" : "=v"(r[i]) : "v"(r[(i + 1) & 7]));
+            if (V == V_PERM) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(r[i]) : "v"(r[(i + 1) & 7]), "s"(0x07030501u));
+            if (V == V_ADD_U16) asm volatile("v_add_u16 %0, %0, %1" : "+v"(r[i]) : "v"(seed));
+            if (V == V_MIN_U16_DPP) asm volatile("v_min_u16_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(r[i]));
+            if (V == DS_SWIZZLE) { asm volatile("ds_swizzle_b32 %0, %0 offset:0x101f\n\ts_waitcnt lgkmcnt(0)" : "+v"(r[i])); }
+            if (V == DS_SWIZZLE_MIN) { unsigned t; asm volatile("ds_swizzle_b32 %1, %0 offset:0x101f\n\ts_waitcnt lgkmcnt(0)\n\tv_min_u16 %0, %0, %1" : "+v"(r[i]), "=&v"(t)); }
+            if (V == V_READLANE) { unsigned s; asm volatile("v_readlane_b32 %0, %1, 63" : "=s"(s) : "v"(r[i])); sacc += s; }
+            if (V == V_AND_OR) asm volatile("v_and_or_b32 %0, %1, %2, %0" : "+v"(r[i]) : "v"(r[(i + 1) & 7]), "s"(0x01000100u));
+            if (V == V_ADD_U32_DPP) asm volatile("v_add_u32_dpp %0, %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(r[i]) : "v"(seed));
+            if (V == DS_BPERMUTE) { asm volatile("ds_bpermute_b32 %0, %1, %0\n\ts_waitcnt lgkmcnt(0)" : "+v"(r[i]) : "v"((threadIdx.x ^ 32) * 4)); }
             if (V == MIX_FWD) {
                 // one forward-pass step of viterbi_v3.h as an instruction multiset: 2 DPP moves, 2 clamped adds, sub, bfi, min, readfirstlane
                 unsigned lo, hi, x, y, t, s;
@@ -138,6 +155,22 @@ int main()
     run<V_READFIRST>("v_readfirstlane_b32 (+s_add)", d, 1);
     run<DS_READ_B64>("ds_read_b64 (+v_xor)", d, 1);
     run<V_FMA_F64>("v_fma_f64", d, 1);
+    run<V_MIN_U16>("v_min_u16", d, 1);
+    run<V_MIN_U32>("v_min_u32", d, 1);
+    run<V_CNDMASK>("v_cndmask_b32 (vcc)", d, 1);
+    run<V_CNDMASK_E64>("v_cndmask_b32 (sgpr pair)", d, 1);
+    run<V_AND>("v_and_b32", d, 1);
+    run<V_SUB_U32>("v_sub_u32", d, 1);
+    run<V_MOV>("v_mov_b32", d, 1);
+    run<V_PERM>("v_perm_b32", d, 1);
+    run<V_ADD_U16>("v_add_u16", d, 1);
+    run<V_AND_OR>("v_and_or_b32", d, 1);
+    run<V_MIN_U16_DPP>("v_min_u16_dpp", d, 1);
+    run<V_ADD_U32_DPP>("v_add_u32_dpp", d, 1);
+    run<V_READLANE>("v_readlane_b32 (+s_add)", d, 1);
+    run<DS_SWIZZLE>("ds_swizzle_b32 (+wait)", d, 1);
+    run<DS_SWIZZLE_MIN>("ds_swizzle_b32 + wait + v_min_u16", d, 1);
+    run<DS_BPERMUTE>("ds_bpermute_b32 (+wait)", d, 1);
     run<MIX_FWD>("forward-step mix (8 VALU)", d, 8);
     run<MIX_FWD_CHAIN>("forward mix, one chain/wave", d, 8);
     return 0;
