@@ -11,20 +11,26 @@ class FoaError(RuntimeError):
     pass
 
 
-def library_path():
+def library_path(xcheck=False):
+    """The product library, or (xcheck) the build that also holds the kernels kept only as cross-checks for the parity suite
+    (csrc/foa_common.h, FOA_XCHECK): tests load that one; nothing in the product path does."""
+    if xcheck:
+        return os.path.join(CSRC, "libfun_ofdm_amd_xcheck.so")
     # FOA_LIB: alternative build of the same library (kernel A/B experiments)
     return os.environ.get("FOA_LIB") or os.path.join(CSRC, "libfun_ofdm_amd.so")
 
 
 def build(force=False):
     """Compile the gfx950 library in-tree with hipcc (cross-compiles without a GPU)."""
-    if force and os.path.exists(library_path()):
-        os.remove(library_path())
+    for path in (library_path(), library_path(True)):
+        if force and os.path.exists(path):
+            os.remove(path)
     subprocess.run(["make", "-s", "-C", CSRC], check=True)
     return library_path()
 
 
 _lib = None
+_lib_x = None
 
 _SIGS = {
     "foa_version": (C.c_int, []),
@@ -78,12 +84,12 @@ _SIGS = {
 EXPORTS = tuple(_SIGS)
 
 
-def lib():
+def lib(xcheck=False):
     """The loaded library.  There is deliberately no fallback: a missing or unloadable HIP library
     is an error."""
-    global _lib
-    if _lib is None:
-        path = library_path()
+    global _lib, _lib_x
+    if (_lib_x if xcheck else _lib) is None:
+        path = library_path(xcheck)
         if not os.path.exists(path):
             raise FoaError("%s not found: build it with fun_ofdm_amd.build() / `make -C fun_ofdm_amd/csrc` "
                            "(this package has no CPU implementation)" % path)
@@ -98,10 +104,13 @@ def lib():
         for name, (res, args) in _SIGS.items():
             f = getattr(L, name)
             f.restype, f.argtypes = res, args
-        _lib = L
-    return _lib
+        if xcheck:
+            _lib_x = L
+        else:
+            _lib = L
+    return _lib_x if xcheck else _lib
 
 
-def check(rc):
+def check(rc, L=None):
     if rc != 0:
-        raise FoaError("fun_ofdm_amd error %d: %s" % (rc, lib().foa_last_error().decode()))
+        raise FoaError("fun_ofdm_amd error %d: %s" % (rc, (L or lib()).foa_last_error().decode()))

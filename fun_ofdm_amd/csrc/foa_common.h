@@ -1,6 +1,13 @@
 // foa_common.h -- shared declarations of the gfx950 receive path (device + host side).
 #pragma once
 
+// FOA_XCHECK = 1 builds libfun_ofdm_amd_xcheck.so: the product plus the kernels kept ONLY as independent cross-checks for the parity
+// suite (viterbi_v1.h, the v2 forward / chain-back kernels, the wave-per-symbol and lane-per-symbol front ends).  The shipped
+// library (FOA_XCHECK = 0) does not contain them.
+#ifndef FOA_XCHECK
+#define FOA_XCHECK 0
+#endif
+
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

@@ -434,6 +434,7 @@ int foa_rx_set_option(foa_rx *rx, const char *name, int64_t value)
     if (!rx || !name) return fail(FOA_E_INVALID, "NULL argument");
     if (!strcmp(name, "viterbi")) {
         if (value < 0 || value > 2) return fail(FOA_E_INVALID, "viterbi must be 0 (lane per state), 1 (packed, serial chain-back) or 2 (packed, segment chain-back)");
+        if (!FOA_XCHECK && value != 2) return fail(FOA_E_INVALID, "viterbi %d is a cross-check kernel: it is only in libfun_ofdm_amd_xcheck.so (make xcheck)", (int)value);
         rx->viterbi_kind = (int)value;
         return FOA_OK;
     }
@@ -463,6 +464,7 @@ int foa_rx_set_option(foa_rx *rx, const char *name, int64_t value)
     if (!strcmp(name, "lanes")) { int rc0 = drain(rx); if (rc0) return rc0; rx->lanes = value != 0; return FOA_OK; }
     if (!strcmp(name, "frontend")) {
         if (value < -1 || value > 2) return fail(FOA_E_INVALID, "frontend must be -1 (by context), 0 (wave per symbol), 1 (lane per symbol) or 2 (quad per symbol)");
+        if (!FOA_XCHECK && (value == 0 || value == 1)) return fail(FOA_E_INVALID, "frontend %d is a cross-check kernel: it is only in libfun_ofdm_amd_xcheck.so (make xcheck)", (int)value);
         rx->frontend_kind = (int)value;
         return FOA_OK;
     }
@@ -553,15 +555,19 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
     const size_t max_sym = rx->w->sym_cap;
     if (can_hold && !lanes && rx->fe_hold == 2) HIP_TRY(hipStreamWaitEvent(st, rx->prev->before->walk_done, 0));
     const int frontend = rx->frontend_kind >= 0 ? rx->frontend_kind : 2;
-    if (frontend == 2) {
-        hipLaunchKernelGGL(k_data_symbols_q4, dim3((unsigned)((max_sym + 16 * kQ4Waves - 1) / (16 * kQ4Waves))), dim3(64 * kQ4Waves), 0, st, iq,
-                           d_descs, rx->w->info.p, rx->w->sym2frame.p, rx->w->totals.p, rx->w->hinv.p, rx->w->sp.p, eq_data);
-    } else if (frontend == 1) {
+#if FOA_XCHECK
+    if (frontend == 1) {
         hipLaunchKernelGGL(k_data_symbols_lps, dim3((unsigned)((max_sym + 63) / 64)), dim3(64), 0, st, iq, d_descs, rx->w->info.p, rx->w->sym2frame.p,
                            rx->w->totals.p, rx->w->hinv.p, rx->w->sp.p, eq_data);
-    } else {
+    } else if (frontend == 0) {
         hipLaunchKernelGGL(k_data_symbols, dim3((unsigned)((max_sym + kSymWaves - 1) / kSymWaves)), dim3(64 * kSymWaves), 0, st, iq, d_descs,
                            rx->w->info.p, rx->w->sym2frame.p, rx->w->totals.p, rx->w->hinv.p, rx->w->sp.p, eq_data);
+    } else
+#endif
+    {
+        (void)frontend;
+        hipLaunchKernelGGL(k_data_symbols_q4, dim3((unsigned)((max_sym + 16 * kQ4Waves - 1) / (16 * kQ4Waves))), dim3(64 * kQ4Waves), 0, st, iq,
+                           d_descs, rx->w->info.p, rx->w->sym2frame.p, rx->w->totals.p, rx->w->hinv.p, rx->w->sp.p, eq_data);
     }
     HIP_TRY(hipEventRecord(rx->w->ev[3], st));
     if (piped) {
@@ -575,11 +581,13 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
         p.valid = true; p.w = rx->w; p.nf = nf; p.S = rx->tb_segment; p.L = rx->tb_overlap; p.max_segs = max_segs; p.slot_bytes = slot_bytes;
         p.psdu = d_psdu; p.results = d_results; p.job = rx->attach_job; p.lanes = lanes; p.lane = st_fwd;
     } else {
+#if FOA_XCHECK
         if (rx->viterbi_kind == 0)
             hipLaunchKernelGGL(k_viterbi_v1, dim3(nf), dim3(64), 0, st, rx->w->info.p, nf, rx->w->sp.p, rx->w->dec.p, d_psdu, slot_bytes, d_results);
         else if (rx->viterbi_kind == 1)
             launch_viterbi_v2(st, rx->w->info.p, nf, rx->w->sp.p, rx->w->dec.p, rx->w->decoded.p, d_psdu, slot_bytes, d_results, rx->w->ev[5]);
         else
+#endif
             launch_viterbi_v3(st, rx->w->info.p, nf, rx->w->sp.p, rx->w->dec.p, rx->w->decoded.p, rx->w->seg2frame.p, rx->w->totals.p, rx->w->tb_state.p,
                               max_segs, rx->tb_segment, rx->tb_overlap, d_psdu, slot_bytes, d_results, rx->w->ev[5]);
         if (rx->viterbi_kind == 0) HIP_TRY(hipEventRecord(rx->w->ev[5], st));
@@ -990,11 +998,14 @@ int foa_conv_decode(foa_rx *rx, const uint8_t *symbols, uint8_t *data, int data_
     uint8_t *d_sym = rx->scratch.p, *d_out = rx->scratch.p + up(sym_bytes);
     hipStream_t st = rx->stream;
     HIP_TRY(hipMemcpyAsync(d_sym, symbols, sym_bytes, hipMemcpyHostToDevice, st));
+#if FOA_XCHECK
     if (rx->viterbi_kind == 0) {
         const size_t stride = (nsteps + 63) & ~(size_t)63;
         if ((rc = rx->w->dec.ensure(n_blocks * stride))) return rc;
         hipLaunchKernelGGL(k_conv_decode, dim3((unsigned)n_blocks), dim3(64), 0, st, d_sym, d_out, data_bits, (int)n_blocks, rx->w->dec.p, (int)stride);
-    } else {
+    } else
+#endif
+    {
         // The kernels of the batch path (option "viterbi" = 1: k_viterbi_fwd2 + k_viterbi_finish2; 2: k_viterbi_fwd3 + k_tb_walk +
         // k_tb_finish), fed the way the front end feeds them: one frame record and one region of branch-metric words per block.
         // viterbi.cpp:209 drops an odd last step: its decision word stays zero (viterbi.cpp:193-194), so the chain-back reads
@@ -1021,9 +1032,11 @@ int foa_conv_decode(foa_rx *rx, const uint8_t *symbols, uint8_t *data, int data_
             const int64_t n_segs = (int64_t)seg2frame.size();
             HIP_TRY(hipMemcpyAsync(rx->w->totals.p + 4, &n_segs, sizeof n_segs, hipMemcpyHostToDevice, st));
             hipLaunchKernelGGL(k_conv_sp, dim3((unsigned)((T + 255) / 256), (unsigned)n_blocks), dim3(256), 0, st, d_sym, 2 * nsteps, T, rx->w->info.p, rx->w->sp.p);
+#if FOA_XCHECK
             if (rx->viterbi_kind == 1)
                 launch_viterbi_v2(st, rx->w->info.p, (int)n_blocks, rx->w->sp.p, rx->w->dec.p, rx->w->decoded.p, nullptr, 0, nullptr, nullptr);
             else
+#endif
                 launch_viterbi_v3(st, rx->w->info.p, (int)n_blocks, rx->w->sp.p, rx->w->dec.p, rx->w->decoded.p, rx->w->seg2frame.p, rx->w->totals.p,
                                   rx->w->tb_state.p, seg2frame.size(), rx->tb_segment, rx->tb_overlap, nullptr, 0, nullptr, nullptr);
             hipLaunchKernelGGL(k_conv_pack, dim3((unsigned)((nbytes + 255) / 256), (unsigned)n_blocks), dim3(256), 0, st, rx->w->decoded.p, rx->w->info.p,
@@ -1169,11 +1182,13 @@ int foa_decode_data_f64(foa_rx *rx, const double *carriers, const uint64_t *carr
     HIP_TRY(hipMemsetAsync(d_psdu, 0, p_b, st));
     hipLaunchKernelGGL(k_stage_demap, dim3((unsigned)((n_sym + kSymWaves - 1) / kSymWaves)), dim3(64 * kSymWaves), 0, st, (const double2 *)b,
                        (const int64_t *)(b + up(c_b)), rx->w->info.p, rx->w->sym2frame.p, (int)n_sym, rx->w->sp.p);
+#if FOA_XCHECK
     if (rx->viterbi_kind == 0)
         hipLaunchKernelGGL(k_viterbi_v1, dim3((unsigned)n_frames), dim3(64), 0, st, rx->w->info.p, (int)n_frames, rx->w->sp.p, rx->w->dec.p, d_psdu, slot_bytes, d_res);
     else if (rx->viterbi_kind == 1)
         launch_viterbi_v2(st, rx->w->info.p, (int)n_frames, rx->w->sp.p, rx->w->dec.p, rx->w->decoded.p, d_psdu, slot_bytes, d_res, nullptr);
     else
+#endif
         launch_viterbi_v3(st, rx->w->info.p, (int)n_frames, rx->w->sp.p, rx->w->dec.p, rx->w->decoded.p, rx->w->seg2frame.p, rx->w->totals.p, rx->w->tb_state.p,
                           seg2frame.size(), rx->tb_segment, rx->tb_overlap, d_psdu, slot_bytes, d_res, nullptr);
     HIP_TRY(hipMemcpyAsync(psdu, d_psdu, p_b, hipMemcpyDeviceToHost, st));

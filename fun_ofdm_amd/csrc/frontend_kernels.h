@@ -534,6 +534,7 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_apply(FrameInfo *__restrict
 // K3: data symbols.  One wave per symbol, 4 waves per block.
 // =================================================================================================
 constexpr int kSymWaves = 4;
+#if FOA_XCHECK      // cross-check build only: the wave-per-symbol front end
 
 __global__ __launch_bounds__(64 * kSymWaves) void k_data_symbols(const float2 *__restrict__ iq, const foa_frame_desc *__restrict__ descs,
                                                                  const FrameInfo *__restrict__ info, const int32_t *__restrict__ sym2frame,
@@ -563,5 +564,7 @@ __global__ __launch_bounds__(64 * kSymWaves) void k_data_symbols(const float2 *_
 
     emit_symbol_soft(z, di, rr, stage, sp + fi.dec_off + (int64_t)(k - 1) * rr.dbps, lane);
 }
+
+#endif  // FOA_XCHECK
 
 }  // namespace foa

@@ -171,6 +171,7 @@ __device__ __forceinline__ void emit_by_rate(int rate, const cpx (&x)[64], doubl
     }
 }
 
+#if FOA_XCHECK      // cross-check build only: the lane-per-symbol front end (its per-symbol arithmetic above is what the quad kernel runs)
 __global__ __launch_bounds__(64) void k_data_symbols_lps(const float2 *__restrict__ iq, const foa_frame_desc *__restrict__ descs,
                                                          const FrameInfo *__restrict__ info, const int32_t *__restrict__ sym2frame,
                                                          const int64_t *__restrict__ totals, const double2 *__restrict__ hinv,
@@ -259,5 +260,7 @@ __global__ __launch_bounds__(64) void k_data_symbols_lps(const float2 *__restric
     if (coop) emit_by_rate<true>(__builtin_amdgcn_readfirstlane(fi.rate), x, rr.scale_d, sp, my_out, &sh, lane);
     else if (valid) emit_by_rate<false>(fi.rate, x, rr.scale_d, sp, my_out, &sh, lane);
 }
+
+#endif  // FOA_XCHECK
 
 }  // namespace foa

@@ -19,6 +19,16 @@ namespace foa {
 
 constexpr int kMaxDecodedBytes = 4128;   // num_data_bytes <= 4104 for length <= 4095 at any rate
 
+__device__ __forceinline__ void write_result(foa_frame_result *res, const FrameInfo &fi, int status)
+{
+    foa_frame_result r;
+    r.status = status; r.rate = fi.rate; r.length = fi.length;
+    r.num_symbols = fi.nsym > 0 ? fi.nsym : (fi.nsteps < 0 ? -fi.nsteps : 0);
+    *res = r;
+}
+
+#if FOA_XCHECK      // cross-check build only (foa_common.h): the lane-per-state kernels
+
 // Chain-back + descramble + CRC + payload copy, shared by v1 and v2.  `dec_at(n6)` must return the
 // reference-layout decision word of trellis step n6.  Runs on one wave; `decoded` is LDS.
 template <typename DecAt>
@@ -63,14 +73,6 @@ __device__ __forceinline__ int finish_frame_wave(const FrameInfo &fi, DecAt dec_
     if (ok)                                                // ppdu.cpp:283-285
         for (int x = lane; x < len; x += 64) psdu_slot[x] = decoded[2 + x];
     return ok;
-}
-
-__device__ __forceinline__ void write_result(foa_frame_result *res, const FrameInfo &fi, int status)
-{
-    foa_frame_result r;
-    r.status = status; r.rate = fi.rate; r.length = fi.length;
-    r.num_symbols = fi.nsym > 0 ? fi.nsym : (fi.nsteps < 0 ? -fi.nsteps : 0);
-    *res = r;
 }
 
 
@@ -163,5 +165,7 @@ __global__ __launch_bounds__(64) void k_conv_decode(const uint8_t *__restrict__ 
     __syncthreads();
     for (int x = lane; x < nbytes; x += 64) data[(size_t)b * nbytes + x] = decoded[x];
 }
+
+#endif  // FOA_XCHECK
 
 }  // namespace foa

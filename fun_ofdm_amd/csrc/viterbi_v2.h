@@ -50,6 +50,14 @@ __device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b)
     return __builtin_bit_cast(uint32_t, r);
 }
 
+// 6-bit rotate left
+__host__ __device__ constexpr int rotl6(int v, int r)
+{
+    r %= 6;
+    return ((v << r) | (v >> (6 - r))) & 63;
+}
+
+#if FOA_XCHECK      // cross-check build only: decision words of the v2 forward pass
 // Decision words are collected in VGPRs, lane J holding the word of the chunk's step J, and leave as one
 // coalesced 8-byte-per-lane store per chunk.  (Scalar stores would cost no VALU slot at all, but gfx950's
 // scalar data cache retires only about one s_store per 10 clocks per CU -- measured, tools/probe_sstore.hip.)
@@ -91,12 +99,7 @@ __device__ __forceinline__ uint32_t bm_word_of_pair(uint32_t pair)
     return ((s0 + s1 + 1u) >> 3) | (((s0 + n1 + 1u) >> 3) << 8) | (((n0 + s1 + 1u) >> 3) << 16) | (((n0 + n1 + 1u) >> 3) << 24);
 }
 
-// 6-bit rotate left
-__host__ __device__ constexpr int rotl6(int v, int r)
-{
-    r %= 6;
-    return ((v << r) | (v >> (6 - r))) & 63;
-}
+#endif  // FOA_XCHECK
 
 // After this every lane has lo = metric of its pair's low slot, hi = metric of the high slot (pair = lanes that
 // differ in bit Q).
@@ -124,6 +127,7 @@ __device__ __forceinline__ void pair_exchange(uint32_t M, uint32_t &lo, uint32_t
     }
 }
 
+#if FOA_XCHECK      // cross-check build only: the v2 forward pass
 // per-lane constants of the six phases
 struct Fwd2Lane {
     uint32_t sel[6];      // v_perm selector {0, B.byte[cls], 0, A.byte[cls]} of this lane's butterfly class
@@ -229,11 +233,14 @@ __device__ __forceinline__ uint32_t fwd2_step_dyn(uint32_t M, int j, bool sa, bo
 #undef FOA_DYN
 }
 
+#endif  // FOA_XCHECK
+
 #ifndef FOA_FWD_WAVES
 #define FOA_FWD_WAVES 4
 #endif
 constexpr int kFwdWaves = FOA_FWD_WAVES;     // waves (frame pairs) per workgroup: whole workgroups spread evenly over a CU's four SIMDs
 
+#if FOA_XCHECK      // cross-check build only
 __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd2(const FrameInfo *__restrict__ info, int n_frames,
                                                                  const uint16_t *__restrict__ sp, uint64_t *__restrict__ dec)
 {
@@ -274,6 +281,8 @@ __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd2(const FrameInfo
     if (TB > 0)
         for (int i = TB + lane; i < dec_words(TB); i += 64) dB[i] = 0;
 }
+
+#endif  // FOA_XCHECK
 
 // descramble + CRC-32 + payload copy of one frame per lane; shared by k_viterbi_finish2 and k_tb_finish
 struct FinishTables { uint32_t crc[1024]; uint32_t scr[128]; };
@@ -422,6 +431,7 @@ __device__ __forceinline__ void finish_crc_psdu(const FinishTables &t, FinishWav
     }
 }
 
+#if FOA_XCHECK      // cross-check build only: serial chain-back, one lane per frame
 constexpr int kTbChunk = 48;      // chain-back steps per LDS-DMA chunk (multiple of 6 and 8; two chunks = 48 loads in flight)
 
 // Chain-back (viterbi.cpp:108-146) in slot space, descrambler and CRC-32 (ppdu.cpp:256-293), one LANE per frame:
@@ -531,5 +541,7 @@ inline void launch_viterbi_v2(hipStream_t st, const FrameInfo *info, int nf, con
     if (between) (void)hipEventRecord(between, st);
     hipLaunchKernelGGL(k_viterbi_finish2, dim3((nf + 63) / 64), dim3(64), 0, st, info, nf, dec, decoded, psdu, slot_bytes, results);
 }
+
+#endif  // FOA_XCHECK
 
 }  // namespace foa

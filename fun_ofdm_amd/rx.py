@@ -26,26 +26,32 @@ def _vp(a):
 class Receiver:
     """One receiver handle = one HIP stream on one device."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, xcheck=False):
+        """xcheck: bind to libfun_ofdm_amd_xcheck.so, the build that also contains the cross-check kernels (options "viterbi" 0 / 1,
+        "frontend" 0 / 1) -- for the parity suite only."""
+        self._lib = lib(xcheck)
         self._h = C.c_void_p()
-        check(lib().foa_rx_create(C.byref(self._h), int(device)))
+        self._check(self._lib.foa_rx_create(C.byref(self._h), int(device)))
         self.device = int(device)
+
+    def _check(self, rc):
+        check(rc, self._lib)
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().foa_rx_destroy(self._h)
+            self._lib.foa_rx_destroy(self._h)
             self._h = None
 
     __del__ = close
 
     def set_option(self, name, value):
-        check(lib().foa_rx_set_option(self._h, name.encode(), int(value)))
+        self._check(self._lib.foa_rx_set_option(self._h, name.encode(), int(value)))
 
     def reserve(self, n_samples, n_frames):
-        check(lib().foa_rx_reserve(self._h, int(n_samples), int(n_frames)))
+        self._check(self._lib.foa_rx_reserve(self._h, int(n_samples), int(n_frames)))
 
     def sync(self):
-        check(lib().foa_rx_sync(self._h))
+        self._check(self._lib.foa_rx_sync(self._h))
 
     # ---- batch decode, host buffers -------------------------------------------------------------
     def decode_frames_host(self, iq, descs, ends, slot_bytes=4096, psdu_out=None):
@@ -58,7 +64,7 @@ class Receiver:
         psdu = np.zeros((m, slot_bytes), np.uint8) if psdu_out is None else psdu_out
         assert psdu.shape == (m, slot_bytes) and psdu.dtype == np.uint8 and psdu.flags.c_contiguous
         res = np.zeros(m, frame_result_dtype)
-        check(lib().foa_rx_decode_frames_host(self._h, _vp(iq), iq.size, _vp(descs), _vp(ends), m, _vp(psdu), slot_bytes, _vp(res)))
+        self._check(self._lib.foa_rx_decode_frames_host(self._h, _vp(iq), iq.size, _vp(descs), _vp(ends), m, _vp(psdu), slot_bytes, _vp(res)))
         return psdu, res
 
     def submit_host(self, iq, descs, ends, slot_bytes=4096):
@@ -67,7 +73,7 @@ class Receiver:
         descs = np.ascontiguousarray(descs, frame_desc_dtype)
         ends = np.ascontiguousarray(ends, np.int64)
         t = C.c_uint64(0)
-        check(lib().foa_rx_submit_host(self._h, _vp(iq), iq.size, _vp(descs), _vp(ends), descs.size, slot_bytes, C.byref(t)))
+        self._check(self._lib.foa_rx_submit_host(self._h, _vp(iq), iq.size, _vp(descs), _vp(ends), descs.size, slot_bytes, C.byref(t)))
         return (int(t.value), descs.size, slot_bytes)
 
     def collect(self, ticket, wait=True):
@@ -75,9 +81,9 @@ class Receiver:
         t, m, slot_bytes = ticket
         psdu = np.zeros((m, slot_bytes), np.uint8)
         res = np.zeros(m, frame_result_dtype)
-        rc = lib().foa_rx_collect(self._h, t, 1 if wait else 0, _vp(psdu), _vp(res))
+        rc = self._lib.foa_rx_collect(self._h, t, 1 if wait else 0, _vp(psdu), _vp(res))
         if rc < 0:
-            check(rc)
+            self._check(rc)
         return (psdu, res) if rc == 1 else None
 
     # ---- batch decode, device buffers (torch tensors on this device) ------------------------------
@@ -91,7 +97,7 @@ class Receiver:
         m = ends.numel()
         assert descs.numel() * descs.element_size() == m * frame_desc_dtype.itemsize
         assert psdu.shape[0] == m and results.numel() == 4 * m
-        check(lib().foa_rx_decode_frames_dev(self._h, iq.data_ptr(), n, descs.data_ptr(), ends.data_ptr(), m, psdu.data_ptr(),
+        self._check(self._lib.foa_rx_decode_frames_dev(self._h, iq.data_ptr(), n, descs.data_ptr(), ends.data_ptr(), m, psdu.data_ptr(),
                                              psdu.shape[1], results.data_ptr()))
 
     def sync_dev(self, iq, descs, ends):
@@ -101,12 +107,12 @@ class Receiver:
         cap = ends.numel()
         assert descs.numel() * descs.element_size() >= cap * frame_desc_dtype.itemsize
         got = C.c_size_t(0)
-        check(lib().foa_rx_sync_dev(self._h, iq.data_ptr(), n, descs.data_ptr(), ends.data_ptr(), cap, C.byref(got)))
+        self._check(self._lib.foa_rx_sync_dev(self._h, iq.data_ptr(), n, descs.data_ptr(), ends.data_ptr(), cap, C.byref(got)))
         return int(got.value)
 
     def tx_frame_samples(self, length, rate):
         n = C.c_size_t(0)
-        check(lib().foa_tx_build_frames_dev(self._h, None, 0, int(length), int(rate), 0, None, C.byref(n)))
+        self._check(self._lib.foa_tx_build_frames_dev(self._h, None, 0, int(length), int(rate), 0, None, C.byref(n)))
         return int(n.value)
 
     def tx_build_frames(self, payloads, rate):
@@ -118,7 +124,7 @@ class Receiver:
         out = torch.empty((n, s, 2), dtype=torch.float64, device=payloads.device)
         got = C.c_size_t(0)
         torch.cuda.current_stream(payloads.device).synchronize()
-        check(lib().foa_tx_build_frames_dev(self._h, payloads.data_ptr(), payloads.stride(0), int(length), int(rate), n, out.data_ptr(), C.byref(got)))
+        self._check(self._lib.foa_tx_build_frames_dev(self._h, payloads.data_ptr(), payloads.stride(0), int(length), int(rate), n, out.data_ptr(), C.byref(got)))
         self.sync()
         return out
 
@@ -128,22 +134,22 @@ class Receiver:
         n, s, _ = frames.shape
         iq = torch.empty((n * pitch, 2), dtype=torch.float32, device=frames.device)
         torch.cuda.current_stream(frames.device).synchronize()
-        check(lib().foa_tx_channel_dev(self._h, frames.data_ptr(), n, s, int(pitch), int(lead), float(snr_db), float(cfo_hz), int(seed), iq.data_ptr()))
+        self._check(self._lib.foa_tx_channel_dev(self._h, frames.data_ptr(), n, s, int(pitch), int(lead), float(snr_db), float(cfo_hz), int(seed), iq.data_ptr()))
         self.sync()
         return iq
 
     def wait_previous(self):
         """Block until the decode call before the most recent one is complete (see foa_rx_wait_previous)."""
-        check(lib().foa_rx_wait_previous(self._h))
+        self._check(self._lib.foa_rx_wait_previous(self._h))
 
     def wait_age(self, age):
         """Block until the decode call `age` calls back is complete (see foa_rx_wait_age)."""
-        check(lib().foa_rx_wait_age(self._h, int(age)))
+        self._check(self._lib.foa_rx_wait_age(self._h, int(age)))
 
     def probe_issue(self):
         """Live issue-rate probe (foa_rx_probe_issue): {"pk_u16": {clk_per_wave_instr, ghz, wave_instr_per_s}, "vop2_u32": {...}}."""
         out = (C.c_double * 6)()
-        check(lib().foa_rx_probe_issue(self._h, out))
+        self._check(self._lib.foa_rx_probe_issue(self._h, out))
         keys = ("clk_per_wave_instr", "ghz", "wave_instr_per_s")
         return {"pk_u16": dict(zip(keys, out[0:3])), "vop2_u32": dict(zip(keys, out[3:6]))}
 
@@ -153,9 +159,9 @@ class Receiver:
         viterbi_finish, total."""
         out = (C.c_float * 6)()
         if age is not None:
-            check(lib().foa_rx_kernel_ms_age(self._h, int(age), out))
+            self._check(self._lib.foa_rx_kernel_ms_age(self._h, int(age), out))
         else:
-            check((lib().foa_rx_prev_kernel_ms if previous else lib().foa_rx_last_kernel_ms)(self._h, out))
+            self._check((self._lib.foa_rx_prev_kernel_ms if previous else self._lib.foa_rx_last_kernel_ms)(self._h, out))
         return dict(zip(("header", "scan", "symbols", "viterbi_fwd", "viterbi_finish", "total"), (float(x) for x in out)))
 
     def taps(self, n_frames, eq=False, soft=True, cap_symbols=None):
@@ -166,7 +172,7 @@ class Receiver:
         eq_off = np.zeros(n_frames + 1, np.uint64)
         soft_buf = np.zeros(cap_symbols * 432, np.uint8) if soft else None
         soft_off = np.zeros(n_frames + 1, np.uint64)
-        check(lib().foa_rx_get_taps(self._h, n_frames, _vp(hinv), _vp(eq_buf) if eq else None, eq_buf.size if eq else 0, _vp(eq_off),
+        self._check(self._lib.foa_rx_get_taps(self._h, n_frames, _vp(hinv), _vp(eq_buf) if eq else None, eq_buf.size if eq else 0, _vp(eq_off),
                                     _vp(soft_buf) if soft else None, soft_buf.size if soft else 0, _vp(soft_off)))
         return dict(hinv=hinv, eq=eq_buf, eq_off=eq_off.astype(np.int64), soft=soft_buf, soft_off=soft_off.astype(np.int64))
 
@@ -174,14 +180,14 @@ class Receiver:
         """Raw decision words of one frame of the last decode call (layout: see foa_rx_get_decisions)."""
         out = np.zeros(cap, np.uint64)
         n = C.c_size_t(0)
-        check(lib().foa_rx_get_decisions(self._h, int(frame), _vp(out), cap, C.byref(n)))
+        self._check(self._lib.foa_rx_get_decisions(self._h, int(frame), _vp(out), cap, C.byref(n)))
         return out[:n.value]
 
     # ---- stage-level entry points ------------------------------------------------------------------
     def fft_forward(self, vectors):
         """fft::forward on [n,64] complex128 (src/fft.cpp:50-59)."""
         v = np.array(vectors, np.complex128).reshape(-1, 64)
-        check(lib().foa_fft_forward_f64(self._h, _vp(v), v.shape[0]))
+        self._check(self._lib.foa_fft_forward_f64(self._h, _vp(v), v.shape[0]))
         return v
 
     def conv_decode(self, symbols, data_bits, n_blocks=1):
@@ -189,7 +195,7 @@ class Receiver:
         s = np.ascontiguousarray(symbols, np.uint8)
         assert s.size >= n_blocks * 2 * (data_bits + 6)
         out = np.zeros((n_blocks, (data_bits + 7) // 8), np.uint8)
-        check(lib().foa_conv_decode(self._h, _vp(s), _vp(out), int(data_bits), int(n_blocks)))
+        self._check(self._lib.foa_conv_decode(self._h, _vp(s), _vp(out), int(data_bits), int(n_blocks)))
         return out
 
 
@@ -198,12 +204,16 @@ class Stream:
 
     def __init__(self, receiver, batch_samples, narrow_threads=0):
         self._rx = receiver
+        self._lib = receiver._lib
         self._h = C.c_void_p()
-        check(lib().foa_stream_create(receiver._h, int(batch_samples), int(narrow_threads), C.byref(self._h)))
+        self._check(self._lib.foa_stream_create(receiver._h, int(batch_samples), int(narrow_threads), C.byref(self._h)))
+
+    def _check(self, rc):
+        check(rc, self._lib)
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().foa_stream_destroy(self._h)
+            self._lib.foa_stream_destroy(self._h)
             self._h = None
 
     __del__ = close
@@ -211,14 +221,14 @@ class Stream:
     def push(self, iq):
         iq = np.ascontiguousarray(iq)
         if iq.dtype == np.complex64:
-            check(lib().foa_stream_push_f32(self._h, _vp(iq), iq.size))
+            self._check(self._lib.foa_stream_push_f32(self._h, _vp(iq), iq.size))
         else:
             iq = iq.astype(np.complex128, copy=False)
-            check(lib().foa_stream_push_f64(self._h, _vp(iq), iq.size))
+            self._check(self._lib.foa_stream_push_f64(self._h, _vp(iq), iq.size))
         return self.take()
 
     def flush(self):
-        check(lib().foa_stream_flush(self._h))
+        self._check(self._lib.foa_stream_flush(self._h))
         return self.take(wait=True)
 
     def take(self, wait=False):
@@ -226,14 +236,14 @@ class Stream:
         out = []
         while True:
             n, nb = C.c_size_t(0), C.c_size_t(0)
-            rc = lib().foa_stream_ready(self._h, 1 if wait else 0, C.byref(n), C.byref(nb))
+            rc = self._lib.foa_stream_ready(self._h, 1 if wait else 0, C.byref(n), C.byref(nb))
             if rc < 0:
-                check(rc)
+                self._check(rc)
             if rc == 0:
                 return out
             buf = np.zeros(max(nb.value, 1), np.uint8)
             lens = np.zeros(max(n.value, 1), np.uint32)
-            check(lib().foa_stream_take(self._h, _vp(buf), _vp(lens)))
+            self._check(self._lib.foa_stream_take(self._h, _vp(buf), _vp(lens)))
             o = 0
             for k in range(n.value):
                 out.append(buf[o:o + int(lens[k])].tobytes())
@@ -241,7 +251,7 @@ class Stream:
 
     def stats(self):
         a = np.zeros(8, np.uint64)
-        check(lib().foa_stream_stats(self._h, _vp(a)))
+        self._check(self._lib.foa_stream_stats(self._h, _vp(a)))
         return dict(ok=int(a[0]), header_fail=int(a[1]), crc_fail=int(a[2]), truncated=int(a[3]), no_space=int(a[4]), alignments=int(a[5]),
                     batches=int(a[6]), samples=int(a[7]))
 

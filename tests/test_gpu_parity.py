@@ -7,12 +7,60 @@ pytestmark = pytest.mark.gpu
 REL_TOL = 1e-4     # north_star: FFT / equaliser intermediates within 1e-4 relative (max-norm per symbol)
 
 
+class _RxPair:
+    """The product library's receiver, and -- for the options that select a kernel the product does not ship ("viterbi" 0 / 1,
+    "frontend" 0 / 1: independent implementations kept as cross-checks, csrc/foa_common.h FOA_XCHECK) -- a receiver of the
+    cross-check build.  Every other call goes to whichever the options last selected, every option to both."""
+
+    def __init__(self):
+        import fun_ofdm_amd as foa
+        self._prod, self._x = foa.Receiver(0), foa.Receiver(0, xcheck=True)
+        self._v, self._f = 2, -1
+
+    def _cur(self):
+        return self._x if (self._v != 2 or self._f in (0, 1)) else self._prod
+
+    def set_option(self, name, value):
+        if name == "viterbi":
+            self._v = int(value)
+        if name == "frontend":
+            self._f = int(value)
+        if name in ("viterbi", "frontend"):
+            self._x.set_option(name, value)
+            if self._cur() is self._prod:
+                self._prod.set_option(name, value)
+            return
+        self._prod.set_option(name, value)
+        self._x.set_option(name, value)
+
+    def __getattr__(self, name):
+        return getattr(self._cur(), name)
+
+    def close(self):
+        self._prod.close()
+        self._x.close()
+
+
 @pytest.fixture(scope="module")
 def rx():
-    import fun_ofdm_amd as foa
-    r = foa.Receiver(0)
+    r = _RxPair()
     yield r
     r.close()
+
+
+def test_product_library_does_not_carry_the_cross_check_kernels():
+    """The shipped library holds ONE Viterbi path and ONE front end; asking it for a cross-check kernel is an error, not a fallback."""
+    import fun_ofdm_amd as foa
+    r = foa.Receiver(0)
+    try:
+        for name, value in (("viterbi", 0), ("viterbi", 1), ("frontend", 0), ("frontend", 1)):
+            with pytest.raises(foa.FoaError):
+                r.set_option(name, value)
+        r.set_option("viterbi", 2)
+        r.set_option("frontend", 2)
+        r.set_option("frontend", -1)
+    finally:
+        r.close()
 
 
 # Viterbi kernel variants: 0 = lane per state; 1 = packed, serial chain-back; 2 = packed, segment chain-back with

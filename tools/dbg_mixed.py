@@ -5,7 +5,7 @@ import fun_ofdm_amd as foa
 from oracle import pyoracle as po
 sys.path.insert(0, 'tests')
 from test_gpu_parity import _make_stream, _ends
-rx = foa.Receiver(0); rx.set_option("viterbi", 1)
+rx = foa.Receiver(0, xcheck=True); rx.set_option("viterbi", 1)
 rng = np.random.default_rng(23)
 specs = [(r, int(rng.integers(1, 400))) for r in range(11)] * 2 + [(10, 1024), (0, 37), (2, 1500), (9, 4095), (8, 1)]
 iq, pays = _make_stream(po, rng, specs, snr_db=19.0, cfo_hz=3000.0)
