@@ -86,11 +86,14 @@ void foa_rx_destroy(foa_rx *rx);
 int foa_rx_reserve(foa_rx *rx, size_t n_samples, size_t n_frames);
 
 /* Options (results are identical for every setting; they exist for A/B measurement and diagnostics).  The production path is the
- * default of every option.  "viterbi" 0 / 1 and "frontend" 0 / 1 select earlier, 2-10 x slower implementations of the same stages that
- * are kept only as independent cross-checks for the parity suite (three Viterbi kernels and three front ends must agree bit for bit with
- * each other and with the oracle); nothing else uses them.
- *   "viterbi"     0 = one wave per frame, lane per state (viterbi_v1.h); 1 = two frames per wave, serial chain-back
- *                 (viterbi_v2.h); 2 = two frames per wave, chain-back in parallel segments (viterbi_v3.h, default)
+ * default of every option.  libfun_ofdm_amd.so holds ONE Viterbi path ("viterbi" 2) and ONE front end ("frontend" 2): the other values
+ * select earlier, 2-10 x slower implementations of the same stages that are kept only as independent cross-checks for the parity suite
+ * (three Viterbi kernels and three front ends must agree bit for bit with each other and with the oracle).  They are compiled into the
+ * test-only build libfun_ofdm_amd_xcheck.so (make -C fun_ofdm_amd/csrc xcheck, -DFOA_XCHECK=1); the shipped library answers them with
+ * FOA_E_INVALID.
+ *   "viterbi"     2 = two frames per wave, chain-back in parallel segments (viterbi_v3.h; the default and the only shipped value);
+ *                 cross-check build: 0 = one wave per frame, lane per state (viterbi_v1.h); 1 = two frames per wave, serial chain-back
+ *                 (viterbi_v2.h)
  *   "tb_segment"  viterbi 2: data steps per chain-back segment, a multiple of 96 in [96, 3072] (default 960)
  *   "tb_overlap"  viterbi 2: run-in steps above a segment, a multiple of 96 in [0, 3072] (default 96); any value gives
  *                 the same result as the serial chain-back, small values cost re-walks
@@ -106,9 +109,9 @@ int foa_rx_reserve(foa_rx *rx, size_t n_samples, size_t n_frames);
  *                 forward pass leaves most SIMDs a single wave (1 000-frame batches decode 40-50 % faster in steady state); 2, 3, 4 = fixed (A/B).  More
  *                 than two lanes need more hardware queues than the runtime's default of four: GPU_MAX_HW_QUEUES=8 in the environment
  *                 before the HIP runtime starts (bench.py sets it)
- *   "frontend"    0 = one wave per data symbol; 1 = one lane per data symbol; 2 = four lanes per data symbol;
- *                 -1 (default) = 2 (fastest alone, and its small waves run under the previous call's forward pass when
- *                 calls are pipelined); all three give bit-identical results
+ *   "frontend"    2 = four lanes per data symbol (frontend_q4.h), -1 (default) = 2: fastest alone, and its small waves run under the
+ *                 previous call's forward pass when calls are pipelined; cross-check build: 0 = one wave per data symbol,
+ *                 1 = one lane per data symbol; all three give bit-identical results
  *   "record_soft" keep the depunctured soft bytes for foa_rx_get_taps (default 1; 0 saves their HBM writes)
  *   "record_eq"   keep the equalised carriers for foa_rx_get_taps (default 0) */
 int foa_rx_set_option(foa_rx *rx, const char *name, int64_t value);
@@ -238,7 +241,11 @@ typedef struct foa_stream foa_stream;
  * foa_stream_push_f64_owned).  The engine's threads are confined to the block of eight consecutive CPUs the creating thread runs
  * on (the cores that share its last-level cache on the hosts measured; several times faster than threads spread over two
  * sockets); the environment variable FOA_STREAM_AFFINITY=0 leaves them to the scheduler.  Measured on a 2 x EPYC 9575F host:
- * 4 Mi-sample batches with four helpers carry 2.2 Gsample/s of complex<double> through process_samples (profiles/). */
+ * 4 Mi-sample batches with four helpers carry 3.1-3.3 Gsample/s of complex<double> through process_samples (profiles/).
+ * One stream per handle: a second create while one is open fails with FOA_E_STATE (the engine's submitter thread owns the handle's
+ * streams and work sets); destroying the HANDLE first stops the engine -- every later call on the stream then fails with FOA_E_STATE
+ * and foa_stream_destroy only frees it.  Samples pushed with foa_stream_push_f64_owned into a batch that is still open may stay
+ * un-narrowed (and their buffers unreleased) until a few more pushes, a flush or the destroy: nothing waits for an open batch. */
 int foa_stream_create(foa_rx *rx, size_t batch_samples, int narrow_threads, foa_stream **out);
 void foa_stream_destroy(foa_stream *s);
 /* The next n_samples of the stream (interleaved re,im).  Returns when they are copied; submits a batch whenever one is full
