@@ -759,7 +759,7 @@ def extra_legs(args, rx, dev, iq, descs, ends, real, psdu_dev_path, res_dev_path
             libdir = os.path.dirname(foa.library_path())
             subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "examples", "foa_sim.cpp"), "-I", os.path.join(ROOT, "include"), "-L", libdir,
                             "-lfun_ofdm_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lpthread", "-o", exe], check=True, capture_output=True)
-            cmd = [exe, src, "--format", "fc32", "--preload", "--chunk", "4096", "--device-batch", str(1 << 22), "--narrow-threads", "4"]
+            cmd = [exe, src, "--format", "fc32", "--preload", "--chunk", "4096", "--device-batch", str(1 << 22), "--narrow-threads", "8"]
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)                 # the timed run: payloads counted, not written
             recs = os.path.join(tmp, "psdus.rec")
             r2 = subprocess.run(cmd + ["--out", recs], capture_output=True, text=True, timeout=300)   # the checked run: every payload written as a record
@@ -797,7 +797,7 @@ def extra_legs(args, rx, dev, iq, descs, ends, real, psdu_dev_path, res_dev_path
                                        "packets": int(pk.group(1)) if pk else None, "frames_sent": n,
                                        "same_list_as_batch_path": bool(same_list), "batch_path_payloads": len(batch_list),
                                        "what": "fun_amd::receiver_chain::process_samples(std::vector<std::complex<double>>) in device mode: 4 Mi-sample "
-                                               "batches, 4 helper threads, pre-sync and decode on the GPU, payloads through the callback; capture preloaded"}
+                                               "batches, 8 helper threads (two core complexes), pre-sync and decode on the GPU, payloads through the callback; capture preloaded"}
     except Exception as e:
         legs["process_samples_api"] = {"error": str(e)[-300:]}
     return legs

@@ -72,6 +72,7 @@ public:
         publish();
         Task t;
         while (try_pop(t)) drop_owner(t.owner);
+        release_parked();
         if (stats_on_)
             fprintf(stderr, "foa_stream: caller ms in push %.1f (%lld pushes, of which waiting for a staging slot %.1f; %lld tasks narrowed by the caller); "
                             "%d helpers: %lld tasks, %.1f ms busy in total\n", st_push_ns_ * 1e-6, (long long)st_pushes_, st_wait_slot_ns_ * 1e-6,
@@ -86,6 +87,7 @@ public:
     int push(const T *iq, size_t n, release_fn release, void *ctx)
     {
         const int64_t st0 = stats_on_ ? now_ns() : 0;
+        release_parked();
         const int rc = push_impl(iq, n, release, ctx);
         if (stats_on_) { st_push_ns_ += now_ns() - st0; st_pushes_++; }
         return rc;
@@ -125,6 +127,7 @@ public:
 
     int flush()
     {
+        release_parked();
         if (finished_) return 0;
         publish();
         if (fill_ == 0) { if (int rc = wait_for_slot()) return rc; }
@@ -136,6 +139,7 @@ public:
     // 1: *out = the payloads of the oldest finished batch; 0: nothing finished (wait: and nothing outstanding); < 0: error
     int take(bool wait, StreamReady *out)
     {
+        release_parked();
         // (the common call -- "anything finished?" after every push -- answers from one atomic, without the lock)
         if (!wait && ready_n_.load(std::memory_order_acquire) == 0) return error_flag_.load(std::memory_order_acquire);
         std::unique_lock<std::mutex> lk(m_);
@@ -169,22 +173,49 @@ private:
         if (cpu < 0 || sched_getaffinity(0, sizeof have, &have) != 0) return;
         CPU_ZERO(&want);
         int n = 0;
-        for (int c = cpu & ~7; c < (cpu & ~7) + 8; c++)
+        const int b0 = cpu & ~7;
+        for (int c = b0; c < b0 + 8; c++)
             if (c < CPU_SETSIZE && CPU_ISSET(c, &have)) { CPU_SET(c, &want); n++; }
         if (n < 2) return;
-        for (auto &t : helpers_) (void)pthread_setaffinity_np(t.native_handle(), sizeof want, &want);
+        // more than four helpers: every second one on the neighbouring block of eight (the same socket: blocks of 64 CPUs), so that two
+        // core complexes' links to memory carry the samples; FOA_STREAM_AFFINITY=1 keeps everything on the caller's block
+        cpu_set_t want2;
+        CPU_ZERO(&want2);
+        int n2 = 0;
+        const int b1 = ((b0 + 8) / 64 == b0 / 64) ? b0 + 8 : b0 - 8;
+        const bool two = helpers_.size() > 4 && !(e && e[0] == '1') && b1 >= 0;
+        if (two)
+            for (int c = b1; c < b1 + 8; c++)
+                if (c < CPU_SETSIZE && CPU_ISSET(c, &have)) { CPU_SET(c, &want2); n2++; }
+        for (size_t i = 0; i < helpers_.size(); i++) {
+            const cpu_set_t &w = (two && n2 >= 2 && (i & 1)) ? want2 : want;
+            (void)pthread_setaffinity_np(helpers_[i].native_handle(), sizeof w, &w);
+        }
         (void)pthread_setaffinity_np(submitter_.native_handle(), sizeof want, &want);
 #endif
     }
-    struct Owner { std::atomic<int> refs; release_fn release; void *ctx; };
+    struct Owner { std::atomic<int> refs; release_fn release; void *ctx; Owner *next; };
     struct Task { const void *src; bool is_double; float *dst; size_t n; int slot; Owner *owner; std::atomic<int64_t> *landed; };
     struct Cell { std::atomic<uint64_t> seq; Task task; };
     static constexpr size_t kRing = 1 << 14;
 
     int64_t closed_load() const { return closed_; }
-    static void drop_owner(Owner *o)
+    // A buffer is given back by the thread that handed it over wherever possible: a helper that drops the last reference only parks the
+    // owner on a list the caller empties at its next push / flush / take (the buffers are the caller's allocator's: released from another
+    // core complex every free takes that arena's lock across the fabric -- with helpers on two complexes that was most of a task's time).
+    static void release_now(Owner *o) { o->release(o->ctx); delete o; }
+    void drop_owner(Owner *o, bool on_caller = true)
     {
-        if (o && o->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) { o->release(o->ctx); delete o; }
+        if (!o || o->refs.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
+        if (on_caller) { release_now(o); return; }
+        Owner *h = parked_.load(std::memory_order_relaxed);
+        do { o->next = h; } while (!parked_.compare_exchange_weak(h, o, std::memory_order_release, std::memory_order_relaxed));
+    }
+    void release_parked()
+    {
+        if (parked_.load(std::memory_order_relaxed) == nullptr) return;
+        Owner *o = parked_.exchange(nullptr, std::memory_order_acquire);
+        while (o) { Owner *n = o->next; release_now(o); o = n; }
     }
 #if defined(__x86_64__)
     __attribute__((target("avx2"))) static void narrow_avx2(float *dst, const double *src, size_t n2)
@@ -218,10 +249,10 @@ private:
 #endif
         for (size_t i = 0; i < 2 * t.n; i++) t.dst[i] = (float)s[i];
     }
-    void run_task(const Task &t, bool from_queue)
+    void run_task(const Task &t, bool from_queue, bool on_caller = true)
     {
         narrow(t);
-        if (from_queue) drop_owner(t.owner);
+        if (from_queue) drop_owner(t.owner, on_caller);
         std::atomic<int64_t> *landed = t.landed;               // (t may be a copy of a queue entry: the counter outlives it)
         const int64_t now = done_[t.slot].fetch_add((int64_t)t.n, std::memory_order_acq_rel) + (int64_t)t.n;
         if (landed) landed->fetch_add((int64_t)t.n, std::memory_order_release);
@@ -296,7 +327,7 @@ private:
         for (;;) {
             if (try_pop(t)) {
                 const int64_t h0 = stats_on_ ? now_ns() : 0;
-                run_task(t, true);
+                run_task(t, true, false);
                 if (stats_on_) { st_helper_ns_.fetch_add(now_ns() - h0, std::memory_order_relaxed); st_helper_tasks_.fetch_add(1, std::memory_order_relaxed); }
                 idle = 0;
                 continue;
@@ -448,6 +479,7 @@ public:
     std::atomic<int64_t> st_helper_ns_{ 0 }, st_helper_tasks_{ 0 };
 private:
     std::atomic<int> ready_n_{ 0 };                  // = ready_.size(), readable without the lock
+    std::atomic<Owner *> parked_{ nullptr };         // owners whose last reference a helper dropped: released by the caller
     std::atomic<bool> stop_{ false };
     std::vector<std::thread> helpers_;
     std::thread submitter_;

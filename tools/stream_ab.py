@@ -31,8 +31,10 @@ subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "examples", "foa_
 print(json.dumps({"lscpu": subprocess.run("lscpu | grep -E 'Model name|Socket|Core|Thread|NUMA|L3'", shell=True, capture_output=True, text=True).stdout}), flush=True)
 runs = []
 for batch in (1 << 22, 1 << 23):
-    for helpers in (3, 4, 6):
-        for env in ({}, {"FOA_STREAM_DEPTH": "0"}):
+    for helpers in (4, 6, 8, 12):
+        for env in ({}, {"FOA_STREAM_AFFINITY": "1"}):
+            if helpers == 4 and env:
+                continue
             runs.append((batch, helpers, env))
 for batch, helpers, env in runs:
     best = None
