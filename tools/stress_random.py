@@ -4,7 +4,7 @@ import numpy as np
 import fun_ofdm_amd as foa
 from oracle import pyoracle as po
 import test_gpu_parity as T
-rx = foa.Receiver(0)
+rx = T._RxPair()          # product + cross-check receivers, as the test fixture
 bad = 0
 lo = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 hi = int(sys.argv[2]) if len(sys.argv) > 2 else 260
