@@ -654,10 +654,10 @@ def extra_legs(args, rx, dev, iq, descs, ends, real, psdu_dev_path, res_dev_path
             on = np.nonzero((d["lts1_pos"] - 360) % pitch == 0)[0]
             ok = on[r[on, 0] == 0]
             exact = bool(np.array_equal(d_psdu.cpu().numpy()[ok], pays[(d["lts1_pos"][ok] - 360) // pitch]))
-            # CPU oracle, same status and PSDUs: on ALL alignments of the 9 Mbps leg (the one rate whose long frames fail their CRC now
-            # and then at 25 dB: parity = the same failures), on the first 256 (or all, if fewer) of the others; the same call, timed,
-            # is the per-rate CPU figure (decode only, all host threads, one repetition)
-            k = m if rate == 2 else min(m, max(256, 16))
+            # CPU oracle, same status and PSDUs, on ALL alignments of every rate (the 9 Mbps leg is the one whose long frames fail their
+            # CRC now and then at 25 dB: parity = the same failures); the same call, timed, is the per-rate CPU figure (decode only, all
+            # host threads, one repetition)
+            k = m
             e = d_end[:k].cpu().numpy()
             h_iq = d_iq[:int(e[-1])].cpu().numpy().reshape(-1).view(np.complex64)
             thr = os.cpu_count() or 1
