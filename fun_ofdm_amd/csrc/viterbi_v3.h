@@ -160,8 +160,12 @@ __device__ __forceinline__ uint32_t fwd3_renorm(uint32_t Mn, uint32_t s0)
 // 8..15 ALL equal its sign.  An accumulator therefore takes eight steps in bits 8..15 of each half with no shift at
 // all -- v_pk_sub_u16 + v_bfi_b32 under the mask 0x01000100 << (step mod 8) --, and the two accumulators of a 16-step
 // block are merged by one v_perm_b32 when the block is stored (2 + 1/16 instead of 3 VALU instructions per step).
+#ifndef FOA_FILE_LATE
+#define FOA_FILE_LATE 1   // 1: the two decision instructions are issued BEHIND the v_readfirstlane of the renormalisation test, in the shadow of its
+                          // way to the scalar unit, instead of in front of it (they do not depend on it; a wave issues in order)
+#endif
 template <int PH, int J>
-__device__ __forceinline__ uint32_t fwd3_acs(uint32_t M, const uint2 w, uint32_t (&acc)[6], int jdyn)
+__device__ __forceinline__ uint32_t fwd3_acs(uint32_t M, const uint2 w, uint32_t (&acc)[6], int jdyn, uint32_t &xo, uint32_t &yo)
 {
     const uint32_t inc_lo = w.x, inc_hi = w.y;
     uint32_t x, y;
@@ -184,8 +188,11 @@ __device__ __forceinline__ uint32_t fwd3_acs(uint32_t M, const uint2 w, uint32_t
         else pair_exchange<5 - PH>(M, lo, hi);
         x = pk_add_sat(lo, inc_lo); y = pk_add_sat(hi, inc_hi);
     }
+    xo = x; yo = y;
     // upper predecessor wins ties (viterbi.cpp): survivor = low slot iff x < y iff the 16-bit difference is negative
-    if constexpr (J >= 0 && !(FOA_ABL & 1)) {
+    if constexpr (FOA_FILE_LATE && J >= 0) {
+        // (filed by fwd3_step, behind the test's v_readfirstlane)
+    } else if constexpr (J >= 0 && !(FOA_ABL & 1)) {
         // Written as one volatile block: left to itself the compiler sinks these instructions of all 48 steps
         // to the end of the chunk and keeps every step's x and y alive until then (148 VGPRs, 3 waves per SIMD).
         // (Filing them one step later instead, into the gaps between that step's exchange, adds and min: no change.)
@@ -211,7 +218,24 @@ __device__ __forceinline__ uint32_t fwd3_acs(uint32_t M, const uint2 w, uint32_t
 template <int PH, int J>
 __device__ __forceinline__ uint32_t fwd3_step(uint32_t M, const uint2 w, uint32_t (&acc)[6], int jdyn)
 {
-    uint32_t Mn = fwd3_acs<PH, J>(M, w, acc, jdyn);
+    uint32_t x, y;
+    uint32_t Mn = fwd3_acs<PH, J>(M, w, acc, jdyn, x, y);
+    if constexpr (FOA_FILE_LATE && J >= 0 && !(FOA_ABL & 1) && !(FOA_ABL & 2)) {
+        const uint32_t s0 = __builtin_amdgcn_readfirstlane(Mn);
+        constexpr uint32_t m = 0x01000100u << (J & 7);
+        uint32_t tmp;
+        // (s0 is named as an input only to keep the block behind the v_readfirstlane)
+        asm volatile("v_pk_sub_u16 %1, %2, %3\n\tv_bfi_b32 %0, %4, %1, %0" : "+v"(acc[J >> 3]), "=&v"(tmp) : "v"(x), "v"(y), "s"(m), "s"(s0));
+        if constexpr (FOA_EXP & 2) asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(acc[5]) : "s"(0u), "v"(Mn));
+        if constexpr (FOA_EXP & 4) asm volatile("v_bfi_b32 %0, %1, %2, %0\n\tv_bfi_b32 %0, %1, %2, %0" : "+v"(acc[5]) : "s"(0u), "v"(Mn));
+        if (__builtin_expect(fwd3_due(s0), 0)) Mn = fwd3_renorm(Mn, s0);
+        return Mn;
+    }
+    if constexpr (FOA_FILE_LATE && J >= 0 && !(FOA_ABL & 1)) {           // (ablation build without the test: file in line)
+        constexpr uint32_t m = 0x01000100u << (J & 7);
+        uint32_t tmp;
+        asm volatile("v_pk_sub_u16 %1, %2, %3\n\tv_bfi_b32 %0, %4, %1, %0" : "+v"(acc[J >> 3]), "=&v"(tmp) : "v"(x), "v"(y), "s"(m));
+    }
     if constexpr (FOA_EXP & 2) asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(acc[5]) : "s"(0u), "v"(Mn));          // (mask 0: acc[5] unchanged)
     if constexpr (FOA_EXP & 4) asm volatile("v_bfi_b32 %0, %1, %2, %0\n\tv_bfi_b32 %0, %1, %2, %0" : "+v"(acc[5]) : "s"(0u), "v"(Mn));
     if constexpr (FOA_ABL & 2) return Mn;
