@@ -160,6 +160,12 @@ __device__ __forceinline__ uint32_t fwd3_renorm(uint32_t Mn, uint32_t s0)
 // 8..15 ALL equal its sign.  An accumulator therefore takes eight steps in bits 8..15 of each half with no shift at
 // all -- v_pk_sub_u16 + v_bfi_b32 under the mask 0x01000100 << (step mod 8) --, and the two accumulators of a 16-step
 // block are merged by one v_perm_b32 when the block is stored (2 + 1/16 instead of 3 VALU instructions per step).
+#ifndef FOA_ACC2
+#define FOA_ACC2 1       // 1: two decision accumulators, a 16-step block's word is formed (and its store queued) as soon as the block is complete;
+                         // 0: six accumulators, a chunk's three words formed at its end (the round-2 arrangement, kept for A/B)
+#endif
+constexpr int fwd3_acc_index(int j) { return FOA_ACC2 ? (j >> 3) & 1 : j >> 3; }
+
 #ifndef FOA_FILE_LATE
 #define FOA_FILE_LATE 1   // 1: the two decision instructions are issued BEHIND the v_readfirstlane of the renormalisation test, in the shadow of its
                           // way to the scalar unit, instead of in front of it (they do not depend on it; a wave issues in order)
@@ -198,13 +204,13 @@ __device__ __forceinline__ uint32_t fwd3_acs(uint32_t M, const uint2 w, uint32_t
         // (Filing them one step later instead, into the gaps between that step's exchange, adds and min: no change.)
         constexpr uint32_t m = 0x01000100u << (J & 7);
         uint32_t tmp;
-        asm volatile("v_pk_sub_u16 %1, %2, %3\n\tv_bfi_b32 %0, %4, %1, %0" : "+v"(acc[J >> 3]), "=&v"(tmp) : "v"(x), "v"(y), "s"(m));
+        asm volatile("v_pk_sub_u16 %1, %2, %3\n\tv_bfi_b32 %0, %4, %1, %0" : "+v"(acc[fwd3_acc_index(J)]), "=&v"(tmp) : "v"(x), "v"(y), "s"(m));
     } else if constexpr (J == -2) {
-        const int a = jdyn >> 3;
+        const int a = fwd3_acc_index(jdyn);
         const uint32_t m = 0x01000100u << (jdyn & 7);
         const uint32_t tmp = pk_sub_wrap(x, y);
 #pragma unroll
-        for (int b = 0; b < 6; b++) acc[b] = a == b ? ((acc[b] & ~m) | (tmp & m)) : acc[b];
+        for (int b = 0; b < (FOA_ACC2 ? 2 : 6); b++) acc[b] = a == b ? ((acc[b] & ~m) | (tmp & m)) : acc[b];
     }
     return pk_min(x, y);
 }
@@ -225,7 +231,7 @@ __device__ __forceinline__ uint32_t fwd3_step(uint32_t M, const uint2 w, uint32_
         constexpr uint32_t m = 0x01000100u << (J & 7);
         uint32_t tmp;
         // (s0 is named as an input only to keep the block behind the v_readfirstlane)
-        asm volatile("v_pk_sub_u16 %1, %2, %3\n\tv_bfi_b32 %0, %4, %1, %0" : "+v"(acc[J >> 3]), "=&v"(tmp) : "v"(x), "v"(y), "s"(m), "s"(s0));
+        asm volatile("v_pk_sub_u16 %1, %2, %3\n\tv_bfi_b32 %0, %4, %1, %0" : "+v"(acc[fwd3_acc_index(J)]), "=&v"(tmp) : "v"(x), "v"(y), "s"(m), "s"(s0));
         if constexpr (FOA_EXP & 2) asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(acc[5]) : "s"(0u), "v"(Mn));
         if constexpr (FOA_EXP & 4) asm volatile("v_bfi_b32 %0, %1, %2, %0\n\tv_bfi_b32 %0, %1, %2, %0" : "+v"(acc[5]) : "s"(0u), "v"(Mn));
         if (__builtin_expect(fwd3_due(s0), 0)) Mn = fwd3_renorm(Mn, s0);
@@ -234,7 +240,7 @@ __device__ __forceinline__ uint32_t fwd3_step(uint32_t M, const uint2 w, uint32_
     if constexpr (FOA_FILE_LATE && J >= 0 && !(FOA_ABL & 1)) {           // (ablation build without the test: file in line)
         constexpr uint32_t m = 0x01000100u << (J & 7);
         uint32_t tmp;
-        asm volatile("v_pk_sub_u16 %1, %2, %3\n\tv_bfi_b32 %0, %4, %1, %0" : "+v"(acc[J >> 3]), "=&v"(tmp) : "v"(x), "v"(y), "s"(m));
+        asm volatile("v_pk_sub_u16 %1, %2, %3\n\tv_bfi_b32 %0, %4, %1, %0" : "+v"(acc[fwd3_acc_index(J)]), "=&v"(tmp) : "v"(x), "v"(y), "s"(m));
     }
     if constexpr (FOA_EXP & 2) asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(acc[5]) : "s"(0u), "v"(Mn));          // (mask 0: acc[5] unchanged)
     if constexpr (FOA_EXP & 4) asm volatile("v_bfi_b32 %0, %1, %2, %0\n\tv_bfi_b32 %0, %1, %2, %0" : "+v"(acc[5]) : "s"(0u), "v"(Mn));
@@ -264,17 +270,26 @@ __device__ __forceinline__ uint2 fwd3_inc(const uint4 *bml, int e, uint32_t ofs)
 // six steps (one of each phase) on staging entries E0 .. E0+5
 // (Measured and dropped: issuing the LDS reads of group G + 1 before the steps of group G, so that only a chunk's first group
 // waits out an LDS round trip: 10 more VGPRs, no change in time at five waves per SIMD, 1.5 % for a lone wave.)
-template <int E0, int J0>
-__device__ __forceinline__ uint32_t fwd3_group(uint32_t M, const uint4 *bml, const Fwd3Lane &c, uint32_t (&acc)[6])
+struct Fwd3NoFlush { __device__ __forceinline__ void operator()(int) const {} };
+
+// flush(blk): called right behind the step that completes the 16-step block blk of the chunk (FOA_ACC2)
+template <int E0, int J0, typename Flush = Fwd3NoFlush>
+__device__ __forceinline__ uint32_t fwd3_group(uint32_t M, const uint4 *bml, const Fwd3Lane &c, uint32_t (&acc)[6], const Flush &flush = Flush())
 {
     const uint2 w0 = fwd3_inc(bml, E0 + 0, c.ofs[0]), w1 = fwd3_inc(bml, E0 + 1, c.ofs[1]), w2 = fwd3_inc(bml, E0 + 2, c.ofs[2]),
                 w3 = fwd3_inc(bml, E0 + 3, c.ofs[3]), w4 = fwd3_inc(bml, E0 + 4, c.ofs[4]), w5 = fwd3_inc(bml, E0 + 5, c.ofs[5]);
     M = fwd3_step<0, (J0 < 0 ? J0 : J0 + 0)>(M, w0, acc, 0);
+    if constexpr (FOA_ACC2 && J0 >= 0 && ((J0 + 0) & 15) == 15) flush((J0 + 0) >> 4);
     M = fwd3_step<1, (J0 < 0 ? J0 : J0 + 1)>(M, w1, acc, 0);
+    if constexpr (FOA_ACC2 && J0 >= 0 && ((J0 + 1) & 15) == 15) flush((J0 + 1) >> 4);
     M = fwd3_step<2, (J0 < 0 ? J0 : J0 + 2)>(M, w2, acc, 0);
+    if constexpr (FOA_ACC2 && J0 >= 0 && ((J0 + 2) & 15) == 15) flush((J0 + 2) >> 4);
     M = fwd3_step<3, (J0 < 0 ? J0 : J0 + 3)>(M, w3, acc, 0);
+    if constexpr (FOA_ACC2 && J0 >= 0 && ((J0 + 3) & 15) == 15) flush((J0 + 3) >> 4);
     M = fwd3_step<4, (J0 < 0 ? J0 : J0 + 4)>(M, w4, acc, 0);
+    if constexpr (FOA_ACC2 && J0 >= 0 && ((J0 + 4) & 15) == 15) flush((J0 + 4) >> 4);
     M = fwd3_step<5, (J0 < 0 ? J0 : J0 + 5)>(M, w5, acc, 0);
+    if constexpr (FOA_ACC2 && J0 >= 0 && ((J0 + 5) & 15) == 15) flush((J0 + 5) >> 4);
     __builtin_amdgcn_sched_barrier(0);          // keep the next groups' LDS reads from being hoisted (registers)
     return M;
 }
@@ -337,16 +352,17 @@ __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd3(const FrameInfo
         if (lane < cnt) {
             const uint32_t s0 = (pa & 255u) | ((pb & 255u) << 16), s1 = (pa >> 8) | ((pb >> 8) << 16);     // packed halves (A, B), each <= 255
             const uint32_t P = s0 + s1, D = s0 - s1 + 0x01000100u;                                              // <= 510, 1 .. 511 per half: no carries
-            const uint32_t m[4] = { ((P + 0x00010001u) >> 3) & 0x003F003Fu, (D >> 3) & 0x003F003Fu, ((0x02000200u - D) >> 3) & 0x003F003Fu,
-                                    ((0x01FF01FFu - P) >> 3) & 0x003F003Fu };
             // (one 16-byte store per class, spelled out: left to itself the compiler breaks these into 4- and 8-byte stores at
-            // a 64-byte lane stride, which the LDS serves sixteen lanes to a bank)
+            // a 64-byte lane stride, which the LDS serves sixteen lanes to a bank; one class at a time, fenced, so that the four
+            // vectors share their registers: this block, not the steps, was the kernel's register peak)
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
             for (uint32_t cls = 0; cls < 4; cls++) {
-                const uint32_t lo = m[cls], hi = lo ^ 0x003F003Fu;
+                const uint32_t t = cls == 0 ? P + 0x00010001u : cls == 1 ? D : cls == 2 ? 0x02000200u - D : 0x01FF01FFu - P;
+                const uint32_t lo = (t >> 3) & 0x003F003Fu, hi = lo ^ 0x003F003Fu;
                 const u32x4 v = { lo, hi, hi, lo };
                 asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(bml_addr), "v"(v), "n"(16 * cls) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (the stores above are not the compiler's to wait for)
@@ -365,6 +381,51 @@ __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd3(const FrameInfo
 #ifndef FOA_LATE_ST
 #define FOA_LATE_ST 1
 #endif
+#if FOA_ACC2
+    // A 16-step block's word -- bytes 1 and 3 of its two accumulators: (A steps 0-7, A steps 8-15, B steps 0-7, B steps 8-15) -- is formed
+    // the moment the block is complete.  The first two blocks of a chunk are stored at once (thirty-two and sixteen steps before the
+    // next wait for loads: old enough), the third one chunk LATE, behind the next chunk's loads, as all three were in round 2.  Three
+    // live registers instead of nine; the accumulators need no initialisation either (eight steps overwrite all the bits the word takes,
+    // and bits at or beyond a frame's last step are forced to 1 by the store).
+    auto store_block = [&](int b0, uint32_t w) {
+        if constexpr (FOA_ABL & 16) { if (w == 0x12345678u) dA[lane] = 1; return; }
+        if (__builtin_expect(b0 < NAtop, 1)) {             // (said so that the stores stay in line: as unlikely blocks each cost two taken branches)
+            const int v = NA - b0;
+            dA[(size_t)(b0 >> 4) * 64 + 63 - lane] = (uint16_t)(w | (v >= 16 ? 0u : v <= 0 ? 0xFFFFu : 0xFFFFu << v));
+        }
+        if (__builtin_expect(b0 < NBtop, 1)) {
+            const int v = NB - b0;
+            dB[(size_t)(b0 >> 4) * 64 + 63 - lane] = (uint16_t)((w >> 16) | (v >= 16 ? 0u : v <= 0 ? 0xFFFFu : 0xFFFFu << v));
+        }
+    };
+    uint32_t late = 0u;
+    int n_chunk = 0;                                                      // (the flush hook reads the chunk's first step through this)
+    auto flush = [&](int blk) {
+        const uint32_t w = __builtin_amdgcn_perm(acc[1], acc[0], 0x07030501u);
+        if (blk < 2) store_block(n_chunk + 16 * blk, w);
+        else late = w;
+    };
+    for (int n0 = 0; n0 < N; n0 += kChunk3) {                             // n0 mod 6 == 0: phase = chunk-relative index mod 6
+        const int nn = min(kChunk3, N - n0);
+        put(kChunk3);
+        get(n0 + kChunk3 + 6);
+        if (n0 > 0) store_block(n0 - 16, late);
+        n_chunk = n0;
+        if (nn == kChunk3) {
+            M = fwd3_group<0, 0>(M, bml, c, acc, flush);   M = fwd3_group<6, 6>(M, bml, c, acc, flush);   M = fwd3_group<12, 12>(M, bml, c, acc, flush);
+            M = fwd3_group<18, 18>(M, bml, c, acc, flush); M = fwd3_group<24, 24>(M, bml, c, acc, flush); M = fwd3_group<30, 30>(M, bml, c, acc, flush);
+            M = fwd3_group<36, 36>(M, bml, c, acc, flush); M = fwd3_group<42, 42>(M, bml, c, acc, flush);
+        } else {
+            // the last, partial chunk: blocks the steps do not reach are still stored (all ones: the store's mask)
+            for (int j = 0; j < nn; j++) {
+                M = fwd3_step_dyn(M, j, bml, c, acc);
+                if ((j & 15) == 15) flush(j >> 4);
+            }
+            for (int blk = nn >> 4; blk < 3; blk++) flush(blk);
+        }
+    }
+    if (N > 0) store_block((N - 1) / kChunk3 * kChunk3 + 32, late);
+#else
     uint32_t word[3] = { 0u, 0u, 0u };                                    // a chunk's three 16-step blocks: (A, B) per lane
     auto store = [&](int n0) {
 #pragma unroll
@@ -400,6 +461,7 @@ __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd3(const FrameInfo
         if (!FOA_LATE_ST) store(n0);
     }
     if (FOA_LATE_ST && N > 0) store((N - 1) / kChunk3 * kChunk3);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------
