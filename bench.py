@@ -760,7 +760,17 @@ def extra_legs(args, rx, dev, iq, descs, ends, real, psdu_dev_path, res_dev_path
             subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "examples", "foa_sim.cpp"), "-I", os.path.join(ROOT, "include"), "-L", libdir,
                             "-lfun_ofdm_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lpthread", "-o", exe], check=True, capture_output=True)
             cmd = [exe, src, "--format", "fc32", "--preload", "--chunk", "4096", "--device-batch", str(1 << 22), "--narrow-threads", "8"]
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)                 # the timed run: payloads counted, not written
+            # the timed runs (payloads counted, not written): three, the median is the figure -- the host is shared and where the
+            # chain's threads land decides a run
+            runs_ps = []
+            for _ in range(3):
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+                mm0 = re.search(r"([\d.]+) Msamples/s through process_samples", r.stdout)
+                if not mm0:
+                    raise RuntimeError((r.stdout + r.stderr)[-300:])
+                runs_ps.append((float(mm0.group(1)), r))
+            runs_ps.sort(key=lambda t: t[0])
+            r = runs_ps[1][1]
             recs = os.path.join(tmp, "psdus.rec")
             r2 = subprocess.run(cmd + ["--out", recs], capture_output=True, text=True, timeout=300)   # the checked run: every payload written as a record
             raw = np.fromfile(recs, np.uint8) if (r2.returncode == 0 and os.path.exists(recs)) else np.zeros(0, np.uint8)
@@ -794,7 +804,7 @@ def extra_legs(args, rx, dev, iq, descs, ends, real, psdu_dev_path, res_dev_path
             raise RuntimeError((r.stdout + r.stderr)[-300:])
         legs["process_samples_api"] = {"Msamples_per_s": float(mm.group(1)), "x_realtime_20MSps": round(float(mm.group(1)) / 20.0, 1), "samples": int(mm.group(2)),
                                        "seconds": float(mm.group(3)), "calls": int(mm.group(4)), "chunk": int(mm.group(5)),
-                                       "packets": int(pk.group(1)) if pk else None, "frames_sent": n,
+                                       "packets": int(pk.group(1)) if pk else None, "frames_sent": n, "runs_Msamples_per_s": [t[0] for t in runs_ps], "protocol": "median of 3 runs",
                                        "same_list_as_batch_path": bool(same_list), "batch_path_payloads": len(batch_list),
                                        "what": "fun_amd::receiver_chain::process_samples(std::vector<std::complex<double>>) in device mode: 4 Mi-sample "
                                                "batches, 8 helper threads (two core complexes), pre-sync and decode on the GPU, payloads through the callback; capture preloaded"}
