@@ -268,6 +268,35 @@ def test_mixed_rate_stream_vs_oracle(rx, po, kind):
     assert n_ok >= 10 and n_fail >= 1, (n_ok, n_fail)      # the case really has both outcomes
 
 
+def test_frame_pairs_of_extreme_length_mismatch(rx, po):
+    """The forward pass packs frames 2i and 2i+1 into one wave.  Shortest against longest in one wave, in both orders, next to an
+    odd frame out and a header failure: the short frame's blocks beyond its end (stored as ones), the long frame's last partial
+    chunk and the late store of each chunk's third block are all in play.  Status, fields, PSDUs and every soft byte vs the oracle."""
+    rx.set_option("record_soft", 1)
+    _set_viterbi(rx, VITERBI_KINDS[2])
+    rng = np.random.default_rng(97)
+    specs = [(10, 1), (0, 4095), (0, 4095), (10, 0), (2, 3000), (10, 2), (9, 47), (0, 1300), (5, 4095), (8, 7), (3, 100)]
+    iq, pays = _make_stream(po, rng, specs, snr_db=24.0, gap=(120, 300))
+    descs = po.find_alignments_f32(iq)
+    assert descs.size == len(specs)
+    ends = _ends(descs, iq.size)
+    # a garbage SIGNAL in the middle: frame 5 loses its header, its pair partner must not notice
+    bad = int(descs["lts1_pos"][5]) + 144
+    iq2 = iq.copy()
+    iq2[bad:bad + 64] = (rng.normal(size=64) + 1j * rng.normal(size=64)).astype(np.complex64) * 0.05
+    for stream in (iq, iq2):
+        psdu, res = rx.decode_frames_host(stream, descs, ends)
+        t = rx.taps(descs.size)
+        opsdu, ores = po.decode_batch_f32(stream, descs, ends, threads=4)
+        for f in range(descs.size):
+            assert tuple(res[f]) == tuple(ores[f]), (f, res[f], ores[f])
+            assert np.array_equal(psdu[f], opsdu[f]), f
+            if res[f]["rate"] >= 0 and res[f]["status"] in (0, 2):
+                _, _, taps = po.decode_alignment_f32(stream, descs[f], end=ends[f], taps=True)
+                assert np.array_equal(t["soft"][t["soft_off"][f]:t["soft_off"][f + 1]], taps["soft"]), f
+    assert (res["status"] == 0).sum() >= len(specs) - 2
+
+
 @pytest.mark.parametrize("frontend", [0, 1, 2], ids=["wave-per-symbol", "lane-per-symbol", "quad-per-symbol"])
 def test_frontends_vs_oracle(rx, po, frontend):
     """Each front-end kernel on a mixed-rate stream with CFO: status, PSDUs, every soft byte and the equalised
