@@ -202,15 +202,25 @@ struct StreamGpu {
             // straight out of the job's page-locked mirror: only the payload bytes of the frames that passed move again
             const foa_frame_result *res = (const foa_frame_result *)(job->pin + job->o_res);
             const uint8_t *ps = job->pin + job->o_psdu;
-            size_t bytes = 0;
-            for (size_t i = 0; i < f.n_frames; i++) if (res[i].status == FOA_ST_OK) bytes += (size_t)res[i].length;
-            out->bytes.reserve(out->bytes.size() + bytes);
+            size_t bytes = 0, n_ok = 0;
+            uint64_t by_status[5] = { 0, 0, 0, 0, 0 };
+            for (size_t i = 0; i < f.n_frames; i++) {
+                const int st = res[i].status;
+                if (st >= 0 && st < 5) by_status[st]++;
+                if (st == FOA_ST_OK) { bytes += (size_t)res[i].length; n_ok++; }
+            }
+            for (int k = 0; k < 5; k++) if (by_status[k]) status_count[k].fetch_add(by_status[k], std::memory_order_relaxed);
+            const size_t at = out->bytes.size(), at_len = out->len.size();
+            out->bytes.resize(at + bytes);
+            out->len.resize(at_len + n_ok);
+            uint8_t *dst = out->bytes.data() + at;
+            uint32_t *dl = out->len.data() + at_len;
             for (size_t i = 0; i < f.n_frames; i++) {
                 const foa_frame_result &r = res[i];
-                if (r.status >= 0 && r.status < 5) status_count[r.status].fetch_add(1, std::memory_order_relaxed);
                 if (r.status != FOA_ST_OK) continue;
-                out->len.push_back((uint32_t)r.length);
-                out->bytes.insert(out->bytes.end(), ps + i * job->slot_bytes, ps + i * job->slot_bytes + r.length);
+                *dl++ = (uint32_t)r.length;
+                memcpy(dst, ps + i * job->slot_bytes, (size_t)r.length);
+                dst += r.length;
             }
             job->busy = false;
             t_collect += now_ns() - t0;
@@ -273,6 +283,27 @@ int foa_stream_create(foa_rx *rx, size_t batch_samples, int narrow_threads, foa_
     if (!rc) {
         const double one[2] = { 1.0, 0.0 };                         // timing_sync's m_phase_acc before the first frame: 0
         if (hipMemcpy(g.d_prev.p, one, sizeof one, hipMemcpyHostToDevice) != hipSuccess) rc = fail(FOA_E_HIP, "hipMemcpy failed");
+    }
+    if (rc) { foa_stream_destroy(s); return rc; }
+    // Everything a batch will need is allocated HERE, not by the first batches that need it: a first-use hipMalloc (and every growth, whose
+    // hipFree waits for the device) inside the stream cost a 53-batch capture a fifth of its time.  Work sets for a buffer's worth of
+    // samples and as many frames as its shortest-plausible spacing gives, job slots for twice a 54 Mbps-dense batch (both grow if a stream
+    // turns out denser).
+    if (!rc) rc = foa_rx_reserve(rx, (size_t)(foa::kStreamCarry + g.B), (size_t)((foa::kStreamCarry + g.B) / 1200 + 64));
+    for (auto &j : rx->jobs) {
+        if (rc) break;
+        auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        const size_t m = (size_t)(g.B / 3600 + 64), total = up(m * g.slot_bytes) + up(m * sizeof(foa_frame_result));
+        const size_t roomy = (2 * total + ((size_t)1 << 20)) & ~(((size_t)1 << 20) - 1);
+        if (j.busy) continue;
+        if (j.dev.n < roomy) rc = j.dev.ensure(roomy);
+        if (!rc && j.pin_cap < roomy) {
+            if (j.pin) (void)hipHostFree(j.pin);
+            j.pin = nullptr; j.pin_cap = 0;
+            if (hipHostMalloc((void **)&j.pin, roomy, hipHostMallocDefault) != hipSuccess) rc = fail(FOA_E_NOMEM, "hipHostMalloc of a %zu-byte result mirror failed", roomy);
+            else j.pin_cap = roomy;
+        }
+        if (!rc && !j.done && hipEventCreateWithFlags(&j.done, hipEventDisableTiming) != hipSuccess) rc = fail(FOA_E_HIP, "hipEventCreate failed");
     }
     if (rc) { foa_stream_destroy(s); return rc; }
     // the engine's batches are small grids, but its decode calls alternate with a pre-sync the host waits for: two loops in flight
