@@ -443,6 +443,35 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
         same_sync = n_found == m and bool(torch.equal(s_psdu, d_psdu)) and bool(torch.equal(s_res, d_res))
         with_sync = {"Msamples_per_s": round(args.frames * FRAME_SAMPLES / dt_s / 1e6, 1), "ms_per_step": round(dt_s * 1e3, 4),
                      "alignments": int(n_found), "same_results_as_host_sync": same_sync}
+        if hasattr(rx, "sync_dev_begin"):
+            # the same work with the pre-sync of batch k+1 queued before the decode call of batch k (foa_rx_sync_dev_begin / _end,
+            # two descriptor sets): N pre-syncs and N decode calls inside the timed region, the host never waits on what it just queued
+            t_desc = torch.zeros_like(s_desc)
+            t_ends = torch.zeros_like(s_ends)
+            sets = [(s_desc, s_ends), (t_desc, t_ends)]
+            s_psdu.zero_(); s_res.zero_()
+            n_p = 20
+            founds = []
+            for timed_pass in (False, True):
+                rx.sync(); torch.cuda.synchronize()
+                t_s = time.perf_counter()
+                rx.sync_dev_begin(d_iq, *sets[0])
+                for k in range(n_p):
+                    nf = rx.sync_dev_end()
+                    if k + 1 < n_p:
+                        rx.sync_dev_begin(d_iq, *sets[(k + 1) % 2])
+                    dsc, en = sets[k % 2]
+                    rx.decode_frames_dev(d_iq, dsc[:nf * 48], en[:nf], s_psdu[:nf], s_res[:nf])
+                    founds.append(nf)
+                rx.sync()
+                torch.cuda.synchronize()
+                dt_p = (time.perf_counter() - t_s) / n_p
+            same_p = all(f == m for f in founds) and bool(torch.equal(s_psdu, d_psdu)) and bool(torch.equal(s_res, d_res)) \
+                and bool(torch.equal(s_desc, t_desc)) and bool(torch.equal(s_ends, t_ends))
+            with_sync["pipelined"] = {"Msamples_per_s": round(args.frames * FRAME_SAMPLES / dt_p / 1e6, 1), "ms_per_step": round(dt_p * 1e3, 4),
+                                      "steps": n_p, "same_results_as_host_sync": same_p,
+                                      "how": "per step: foa_rx_sync_dev_end(k), foa_rx_sync_dev_begin(k+1), foa_rx_decode_frames_dev(k)"}
+            del t_desc, t_ends
         del s_desc, s_ends, s_psdu, s_res
 
     # ---- correctness of what was timed: every frame decodes to its payload, bit-exact ----
@@ -733,10 +762,37 @@ def extra_legs(args, rx, dev, iq, descs, ends, real, psdu_dev_path, res_dev_path
         same = same and bool(np.array_equal(ores.view(np.int32).reshape(-1, 4), r[:k]))
         okk = r[:k, 0] == 0
         same = same and bool(np.array_equal(opsdu[okk], hp[:k][okk]))
+        piped5 = None
+        if hasattr(rx, "sync_dev_begin"):
+            # the same with the pre-sync of pass k+1 queued before the decode call of pass k (two descriptor sets); checked: both sets
+            # end up identical to the blocking call's, and the results of the last pass are the ones compared below
+            e_desc, e_end = torch.zeros_like(d_desc), torch.zeros_like(d_end)
+            sets5 = [(d_desc, d_end), (e_desc, e_end)]
+            ref_desc, ref_end = d_desc.clone(), d_end.clone()
+            for n_p in (8, 6):
+                rx.sync(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                rx.sync_dev_begin(stream, *sets5[0])
+                for kk in range(n_p):
+                    nf = rx.sync_dev_end()
+                    if kk + 1 < n_p:
+                        rx.sync_dev_begin(stream, *sets5[(kk + 1) % 2])
+                    dsc, en = sets5[kk % 2]
+                    rx.decode_frames_dev(stream, dsc[:nf * 48], en[:nf], d_psdu[:nf], d_res[:nf])
+                rx.sync(); torch.cuda.synchronize()
+                dtp = (time.perf_counter() - t0) / n_p
+            piped5 = {"ms_sync_plus_decode": round(dtp * 1e3, 3), "Msamples_per_s": round(total / dtp / 1e6, 1), "passes": n_p,
+                      "same_descriptors_as_blocking_call": nf == m and bool(torch.equal(e_desc[:m * 48], ref_desc[:m * 48])) and bool(torch.equal(e_end[:m], ref_end[:m]))
+                      and bool(torch.equal(d_desc[:m * 48], ref_desc[:m * 48])),
+                      "same_results_as_blocking_call": bool(np.array_equal(d_res[:m].cpu().numpy(), r)) and bool(np.array_equal(d_psdu[:m].cpu().numpy(), hp)),
+                      "how": "foa_rx_sync_dev_end(k), foa_rx_sync_dev_begin(k+1), foa_rx_decode_frames_dev(k)"}
+            del e_desc, e_end, ref_desc, ref_end
         legs["config5_stream"] = {"frames": n, "stream_samples": int(total), "alignments": int(m), "frames_ok": len(okl), "psdu_bit_exact": bool(exact),
                                   "gpu_equals_cpu_on_all": same, "cpu_checked_alignments": int(k), "ms_sync_plus_decode": round(dt * 1e3, 3),
                                   "Msamples_per_s": round(total / dt / 1e6, 1), "counted_samples": "whole stream",
                                   "what": "mixed 8 rates back to back, 1024-byte payloads, CFO uniform in +-4 kHz, 25 dB; foa_rx_sync_dev + foa_rx_decode_frames_dev"}
+        if piped5:
+            legs["config5_stream"]["pipelined"] = piped5
     except Exception as e:
         legs["config5_stream"] = {"error": str(e)}
 

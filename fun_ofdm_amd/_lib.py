@@ -58,6 +58,8 @@ _SIGS = {
     "foa_tx_channel_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_double, C.c_double,
                                      C.c_uint64, C.c_void_p]),
     "foa_rx_sync_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "foa_rx_sync_dev_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "foa_rx_sync_dev_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
     "foa_stream_create": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),
     "foa_stream_destroy": (None, [C.c_void_p]),
     "foa_stream_push_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),

@@ -238,6 +238,11 @@ struct foa_rx {
     DevBuf<int64_t> sy_x;
     DevBuf<SyncCand> sy_cand;
     size_t last_frames = 0;
+    int32_t *sy_pin = nullptr;       // page-locked { STS_END candidates, -, -, alignments found } of the pre-sync begun last (foa_rx_sync_dev_begin)
+    hipEvent_t sy_done = nullptr;
+    bool sy_open = false;
+    int32_t sy_ccap = 0;
+    size_t sy_cap = 0;
     struct foa_stream *open_stream = nullptr;      // the stream engine that owns this handle right now (stream_engine.h), if any
     int64_t ns_wait_set = 0;     // host time spent waiting for a work set to come free (the GPU is more than kSets - 1 calls behind)
 };
@@ -397,6 +402,8 @@ void foa_rx_destroy(foa_rx *rx)
         if (ws.walk_done) (void)hipEventDestroy(ws.walk_done);
     }
     if (rx->in_ready) (void)hipEventDestroy(rx->in_ready);
+    if (rx->sy_done) (void)hipEventDestroy(rx->sy_done);
+    if (rx->sy_pin) (void)hipHostFree(rx->sy_pin);
     for (auto &j : rx->jobs) {
         j.dev.release();
         if (j.pin) (void)hipHostFree(j.pin);
@@ -901,24 +908,48 @@ static int sync_dev_issue(foa_rx *rx, const float *d_iq, size_t n_samples, foa_f
 
 extern "C" {
 
-int foa_rx_sync_dev(foa_rx *rx, const float *d_iq, size_t n_samples, foa_frame_desc *d_descs, int64_t *d_ends, size_t cap, size_t *n_found)
+int foa_rx_sync_dev_begin(foa_rx *rx, const float *d_iq, size_t n_samples, foa_frame_desc *d_descs, int64_t *d_ends, size_t cap)
 {
-    if (!rx || !d_iq || !d_descs || !d_ends || !n_found) return fail(FOA_E_INVALID, "NULL argument");
-    *n_found = 0;
-    if (n_samples == 0 || cap == 0) return FOA_OK;
+    if (!rx || !d_iq || !d_descs || !d_ends) return fail(FOA_E_INVALID, "NULL argument");
+    if (rx->sy_open) return fail(FOA_E_STATE, "a pre-sync is already in flight on this handle: foa_rx_sync_dev_end first");
     if (n_samples > 0x7FFFFFFFull * 16) return fail(FOA_E_INVALID, "stream too long for one call");
     HIP_TRY(hipSetDevice(rx->device));
-    int32_t ccap = 0;
-    { int rc = sync_dev_issue(rx, d_iq, n_samples, d_descs, d_ends, cap, &ccap); if (rc) return rc; }
+    if (!rx->sy_pin) HIP_TRY(hipHostMalloc((void **)&rx->sy_pin, 4 * sizeof(int32_t), hipHostMallocDefault));
+    if (!rx->sy_done) HIP_TRY(hipEventCreateWithFlags(&rx->sy_done, hipEventDisableTiming));
+    rx->sy_pin[0] = rx->sy_pin[1] = rx->sy_pin[2] = rx->sy_pin[3] = 0;
+    rx->sy_cap = cap; rx->sy_ccap = 0;
+    rx->sy_open = true;
+    if (n_samples == 0 || cap == 0) { rx->sy_cap = 0; return FOA_OK; }          // (nothing queued; _end reports 0)
+    { int rc = sync_dev_issue(rx, d_iq, n_samples, d_descs, d_ends, cap, &rx->sy_ccap); if (rc) { rx->sy_open = false; return rc; } }
     hipStream_t st = side_stream(rx);
-    int32_t cnt[4] = { 0, 0, 0, 0 };         // [0] STS_END candidates, [3] alignments found
-    HIP_TRY(hipMemcpyAsync(cnt, rx->sy_n.p, sizeof cnt, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpyAsync(rx->sy_pin, rx->sy_n.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(rx->sy_done, st));
     HIP_TRY(hipGetLastError());
-    if (cnt[0] > ccap) return fail(FOA_E_NOMEM, "too many STS_END candidates (%d)", cnt[0]);
-    if ((size_t)cnt[3] > cap) return fail(FOA_E_INVALID, "cap too small: %d alignments found", cnt[3]);
-    *n_found = (size_t)cnt[3];
     return FOA_OK;
+}
+
+int foa_rx_sync_dev_end(foa_rx *rx, size_t *n_found)
+{
+    if (!rx || !n_found) return fail(FOA_E_INVALID, "NULL argument");
+    *n_found = 0;
+    if (!rx->sy_open) return fail(FOA_E_STATE, "no pre-sync in flight (foa_rx_sync_dev_begin first)");
+    rx->sy_open = false;
+    if (rx->sy_cap == 0) return FOA_OK;
+    HIP_TRY(hipSetDevice(rx->device));
+    HIP_TRY(hipEventSynchronize(rx->sy_done));
+    if (rx->sy_pin[0] > rx->sy_ccap) return fail(FOA_E_NOMEM, "too many STS_END candidates (%d)", rx->sy_pin[0]);
+    if ((size_t)rx->sy_pin[3] > rx->sy_cap) return fail(FOA_E_INVALID, "cap too small: %d alignments found", rx->sy_pin[3]);
+    *n_found = (size_t)rx->sy_pin[3];
+    return FOA_OK;
+}
+
+int foa_rx_sync_dev(foa_rx *rx, const float *d_iq, size_t n_samples, foa_frame_desc *d_descs, int64_t *d_ends, size_t cap, size_t *n_found)
+{
+    if (!n_found) return fail(FOA_E_INVALID, "NULL argument");
+    *n_found = 0;
+    int rc = foa_rx_sync_dev_begin(rx, d_iq, n_samples, d_descs, d_ends, cap);
+    if (rc) return rc;
+    return foa_rx_sync_dev_end(rx, n_found);
 }
 
 void foa_stream_destroy(struct foa_stream *s);

@@ -110,6 +110,18 @@ class Receiver:
         self._check(self._lib.foa_rx_sync_dev(self._h, iq.data_ptr(), n, descs.data_ptr(), ends.data_ptr(), cap, C.byref(got)))
         return int(got.value)
 
+    def sync_dev_begin(self, iq, descs, ends):
+        """Queue the device pre-sync (foa_rx_sync_dev_begin); sync_dev_end() waits for it and returns the count."""
+        n = iq.numel() if iq.is_complex() else iq.numel() // 2
+        cap = ends.numel()
+        assert descs.numel() * descs.element_size() >= cap * frame_desc_dtype.itemsize
+        self._check(self._lib.foa_rx_sync_dev_begin(self._h, iq.data_ptr(), n, descs.data_ptr(), ends.data_ptr(), cap))
+
+    def sync_dev_end(self):
+        got = C.c_size_t(0)
+        self._check(self._lib.foa_rx_sync_dev_end(self._h, C.byref(got)))
+        return int(got.value)
+
     def tx_frame_samples(self, length, rate):
         n = C.c_size_t(0)
         self._check(self._lib.foa_tx_build_frames_dev(self._h, None, 0, int(length), int(rate), 0, None, C.byref(n)))

@@ -221,6 +221,13 @@ int64_t foa_sync_settled(const foa_sync *s);
  * FOA_E_INVALID if more than cap alignments are found, FOA_E_NOMEM if the stream holds more STS_END candidates than
  * one per 64 samples. */
 int foa_rx_sync_dev(foa_rx *rx, const float *d_iq, size_t n_samples, foa_frame_desc *d_descs, int64_t *d_ends, size_t cap, size_t *n_found);
+/* The same in two halves, for a caller that pipelines pre-sync and decode over consecutive batches: _begin queues the kernels
+ * (nothing is waited for; one pre-sync in flight per handle), _end waits for them and returns the count.  Between the two the caller
+ * may queue decode calls -- e.g. _end(k), _begin(k+1), foa_rx_decode_frames_dev(k) per step: the host then never waits for a
+ * pre-sync it has only just queued, and the pre-sync of batch k+1 runs under the forward pass of batch k.  The descriptor and end
+ * buffers of a batch must stay untouched from its _begin to the completion of the decode call that reads them. */
+int foa_rx_sync_dev_begin(foa_rx *rx, const float *d_iq, size_t n_samples, foa_frame_desc *d_descs, int64_t *d_ends, size_t cap);
+int foa_rx_sync_dev_end(foa_rx *rx, size_t *n_found);
 
 /* ---- process_samples() entirely on the device (SURVEY 8f #1 + #3): a stream engine over the calls above ------------
  *

@@ -609,6 +609,66 @@ def test_device_sync_at_the_detection_threshold(rx, po):
     assert np.array_equal(po.find_alignments_f32(s)["lts1_pos"], want["lts1_pos"])
 
 
+def test_device_sync_in_two_halves_pipelined_with_decode(rx, po):
+    """foa_rx_sync_dev_begin / _end: (a) the same descriptors, ends and count as the blocking call; (b) used the way it is meant --
+    _end(k), _begin(k+1), decode(k) over a series of DIFFERENT streams with two descriptor sets -- every batch's PSDUs equal the
+    oracle's from the host-made descriptors; (c) the state errors: a second _begin, an _end without _begin, and the degenerate
+    empty stream."""
+    import torch
+    import fun_ofdm_amd as foa
+    from fun_ofdm_amd import synth
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(31337)
+    streams = []
+    for b in range(7):
+        parts = [np.zeros(int(rng.integers(50, 400)), complex)]
+        for i in range(24 + 3 * b):
+            pay = synth.splitmix64_bytes(70000 + 100 * b + i, 1, 30 + 41 * ((i + b) % 9))[0]
+            f = synth.build_frames(pay[None, :], (0, 2, 3, 5, 6, 8, 9, 10)[(i + b) % 8])[0] * np.exp(1j * rng.uniform(0, 6.28))
+            f = f * np.exp(2j * np.pi * rng.uniform(-3000, 3000) * np.arange(f.size) / 20e6)
+            parts += [f, np.zeros(int(rng.integers(0, 300)), complex)]
+        s = np.concatenate(parts)
+        s = (s + (rng.normal(size=s.size) + 1j * rng.normal(size=s.size)) * np.sqrt(0.0124 / 2 / 10 ** 2.5)).astype(np.complex64)
+        streams.append(s)
+    t_iq = [torch.from_numpy(s.view(np.float32).reshape(-1, 2)).to(dev) for s in streams]
+    cap = max(s.size for s in streams) // 300 + 16
+    sets = [(torch.zeros(cap * 48, dtype=torch.uint8, device=dev), torch.zeros(cap, dtype=torch.int64, device=dev)) for _ in range(2)]
+    # (a) against the blocking call
+    b_desc, b_ends = torch.zeros_like(sets[0][0]), torch.zeros_like(sets[0][1])
+    nb = rx.sync_dev(t_iq[0], b_desc, b_ends)
+    rx.sync_dev_begin(t_iq[0], *sets[0])
+    with pytest.raises(foa.FoaError):
+        rx.sync_dev_begin(t_iq[0], *sets[1])               # one in flight per handle
+    assert rx.sync_dev_end() == nb and nb >= 20
+    assert torch.equal(sets[0][0][:nb * 48], b_desc[:nb * 48]) and torch.equal(sets[0][1][:nb], b_ends[:nb])
+    with pytest.raises(foa.FoaError):
+        rx.sync_dev_end()                                  # nothing in flight
+    # (b) pipelined over different streams
+    outs = [(torch.zeros((cap, 512), dtype=torch.uint8, device=dev), torch.zeros((cap, 4), dtype=torch.int32, device=dev)) for _ in streams]
+    ns = []
+    rx.sync_dev_begin(t_iq[0], *sets[0])
+    for k in range(len(streams)):
+        n = rx.sync_dev_end()
+        if k + 1 < len(streams):
+            rx.sync_dev_begin(t_iq[k + 1], *sets[(k + 1) % 2])
+        d, e = sets[k % 2]
+        rx.decode_frames_dev(t_iq[k], d[:n * 48], e[:n], outs[k][0][:n], outs[k][1][:n])
+        ns.append(n)
+    rx.sync()
+    for k, s in enumerate(streams):
+        want = foa.find_alignments(s)
+        assert ns[k] == want.size, (k, ns[k], want.size)
+        ends = foa.alignment_ends(want, s.size)
+        opsdu, ores = po.decode_batch_f32(s, want, ends, slot_bytes=512, threads=4)
+        r = outs[k][1][:ns[k]].cpu().numpy()
+        assert np.array_equal(r, ores.view(np.int32).reshape(-1, 4)), k
+        ok = r[:, 0] == 0
+        assert ok.sum() >= 20 and np.array_equal(outs[k][0][:ns[k]].cpu().numpy()[ok], opsdu[ok]), k
+    # (c) an empty stream: nothing queued, _end reports 0
+    assert rx._lib.foa_rx_sync_dev_begin(rx._h, t_iq[0].data_ptr(), 0, sets[0][0].data_ptr(), sets[0][1].data_ptr(), cap) == 0
+    assert rx.sync_dev_end() == 0
+
+
 def test_device_sync_edge_inputs(rx):
     """Streams too short to hold a window, all-zero input (0/0 everywhere: never above threshold) and noise only:
     the device stage agrees with the host restatement and writes nothing it should not."""
