@@ -639,11 +639,14 @@ def extra_legs(args, rx, dev, iq, descs, ends, real, psdu_dev_path, res_dev_path
         for _ in range(8):                               # at least once per rotating work set of the library: each sizes its buffers on first use
             fn()
         rx.sync(); torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        rx.sync(); torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / reps
+        rounds = []                                      # median of three rounds of `reps`: one host hiccup inside a 3 ms region is not the figure
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            rx.sync(); torch.cuda.synchronize()
+            rounds.append((time.perf_counter() - t0) / reps)
+        return sorted(rounds)[1]
 
     # ---- config 2 end to end: pageable host memory in, H2D of 8 B/sample + D2H of the PSDUs inside the timed region ----
     try:

@@ -211,6 +211,7 @@ struct foa_rx {
                                  // call parity (below); false: front end on the third stream, walk + finish on the second (the round-1 arrangement)
     int fe_hold = 1;             // pipelined path: 1 = header, scan and data symbols of call k+1 wait for the chain-back walk of call k-1;
                                  // 2 = only the data-symbol kernel does; 0 = nothing is held back (A/B measurement)
+    int sync_flags_kind = 1;     // k_sync_flags (1) or, in the cross-check build, k_sync_flags_direct (0)
     int frontend_kind = -1;      // 1: one lane per symbol (frontend_lps.h), 0: one wave per symbol, 2: four lanes per symbol (frontend_q4.h);
                                  // -1: the default, 2
     WorkSet sets[kSets];         // up to depth + 1 are in use at any time (below); one more keeps the call before them readable (timings)
@@ -473,6 +474,12 @@ int foa_rx_set_option(foa_rx *rx, const char *name, int64_t value)
         if (value < -1 || value > 2) return fail(FOA_E_INVALID, "frontend must be -1 (by context), 0 (wave per symbol), 1 (lane per symbol) or 2 (quad per symbol)");
         if (!FOA_XCHECK && (value == 0 || value == 1)) return fail(FOA_E_INVALID, "frontend %d is a cross-check kernel: it is only in libfun_ofdm_amd_xcheck.so (make xcheck)", (int)value);
         rx->frontend_kind = (int)value;
+        return FOA_OK;
+    }
+    if (!strcmp(name, "sync_flags")) {
+        if (value < 0 || value > 1) return fail(FOA_E_INVALID, "sync_flags must be 1 (grouped tail / head sums) or 0 (direct sums)");
+        if (!FOA_XCHECK && value == 0) return fail(FOA_E_INVALID, "sync_flags 0 is a cross-check kernel: it is only in libfun_ofdm_amd_xcheck.so (make xcheck)");
+        rx->sync_flags_kind = (int)value;
         return FOA_OK;
     }
     return fail(FOA_E_INVALID, "unknown option '%s'", name);
@@ -890,7 +897,12 @@ static int sync_dev_issue(foa_rx *rx, const float *d_iq, size_t n_samples, foa_f
     // kernels may still be reading the descriptor buffers a caller reuses from round to round)
     if (st != rx->stream && rx->lanes && rx->w->used && rx->w->piped) HIP_TRY(hipStreamWaitEvent(st, rx->w->ev[3], 0));
     const float2 *iq = (const float2 *)d_iq;
-    hipLaunchKernelGGL(k_sync_flags, dim3((unsigned)((n + kFlagSamples - 1) / kFlagSamples)), dim3(256), 0, st, iq, n, rx->sy_flags.p);
+#if FOA_XCHECK
+    if (rx->sync_flags_kind == 0)
+        hipLaunchKernelGGL(k_sync_flags_direct, dim3((unsigned)((n + kFlagSamples - 1) / kFlagSamples)), dim3(256), 0, st, iq, n, rx->sy_flags.p);
+    else
+#endif
+    hipLaunchKernelGGL(k_sync_flags, dim3((unsigned)((n + kFlagSamples - 1) / kFlagSamples)), dim3(64), 0, st, iq, n, rx->sy_flags.p, n_words);
     hipLaunchKernelGGL(k_sync_sts_end, dim3(n_blocks), dim3(kSyncBlockWords), 0, st, rx->sy_flags.p, n_words, 0, rx->sy_cnt.p, rx->sy_off.p, rx->sy_x.p, ccap);
     hipLaunchKernelGGL(k_sync_scan, dim3(1), dim3(1024), 0, st, rx->sy_cnt.p, n_blocks, rx->sy_off.p, rx->sy_n.p);
     hipLaunchKernelGGL(k_sync_sts_end, dim3(n_blocks), dim3(kSyncBlockWords), 0, st, rx->sy_flags.p, n_words, 1, rx->sy_cnt.p, rx->sy_off.p, rx->sy_x.p, ccap);

@@ -3,7 +3,7 @@
 // What the host restatement (sync_host.h) does sample by sample, restructured for a GPU:
 //   k_sync_flags     frame_detector.cpp:51-66: lag-16 autocorrelation / power over a 16-sample window, threshold 0.9.
 //                    The reference keeps running sums (sum -= old; sum += new, circular_accumulator.h:88-95) whose
-//                    rounding errors drift for ever; here every sample's window is summed directly, so values agree
+//                    rounding errors drift for ever; here every sample's window is a sum of its own sixteen terms, so values agree
 //                    to ~1e-15 relative and decisions differ only when the normalised correlation lies within that
 //                    distance of the threshold (and on exactly-zero input, where the reference's leftovers decide;
 //                    there this version gives the clean 0/0 = NaN -> "below").
@@ -33,15 +33,95 @@ struct SyncCand {
 __device__ __forceinline__ cpx widen(float2 v) { return cpx{ (double)v.x, (double)v.y }; }
 
 constexpr int kFlagSamples = 1024;   // samples per block of k_sync_flags
+constexpr int kFlagGroupBytes = 144; // LDS bytes per group of 16 samples (128 + 16 of padding): a lane stride of 144 B serves ds_read_b128 without bank conflicts
 
 // flags[w] bit i = (|corr_sum| / pow_sum > 0.9) at sample 32*w + i.
-// The window of sample i holds the products of positions i-15 .. i, and a product belongs to sixteen windows: each
-// block forms the products of its 1024 + 15 positions once (three doubles each, in LDS) and every thread then adds
-// its sixteen in the order the direct sum used (oldest first), so the sums are the same doubles as before at 54
-// instead of 192 fp64 operations per sample.  |S| / P > 0.9 is decided on S.S against 0.81 P.P wherever that is clear by a
-// margin of 1e-9 (the rounding of hypot and of the division is 1e-15); only the rest takes hypot() and the division.
-// A wave's 64 verdicts leave as one ballot.
-__global__ __launch_bounds__(256) void k_sync_flags(const float2 *__restrict__ iq, int64_t n, uint32_t *__restrict__ flags)
+// The window of sample i holds the products x[j] conj(x[j-16]) and |x[j]|^2 of positions i-15 .. i, and a product belongs to
+// sixteen windows.  One wave takes 1024 samples and every lane owns SIXTEEN CONSECUTIVE windows: those that start in its group of
+// 16 product slots (slot s = position base - 15 + s).  Such a window is the tail of the lane's own group plus the head of the next
+// one, so the lane forms the products of the two groups, the running tail sums of the first (15 additions per quantity), the
+// running head sums of the second (14) and adds them pairwise (15): 2.75 additions per window and quantity where a direct sum of
+// sixteen takes 15.  No subtraction is involved -- every window is still a plain sum of its own sixteen terms, in a fixed order, so
+// nothing drifts and a huge sample is forgotten the moment it leaves the window (unlike the reference's running accumulator) -- and
+// the sums agree with any other order of the same terms to ~1e-15 relative.
+// The samples reach the lanes through LDS: the wave loads its 1024 + 47 positions once, coalesced, and each lane reads back the 48
+// it needs (the products themselves would be three doubles per position: three times the LDS, a third of the resident waves).
+// |S| / P > 0.9 is decided on S.S against 0.81 P.P wherever that is clear by a margin of 1e-9 (the rounding of hypot and of the
+// division is 1e-15); only the rest takes hypot() and the division.  A lane's sixteen verdicts leave as one 16-bit store.
+__global__ __launch_bounds__(64, 3) void k_sync_flags(const float2 *__restrict__ iq, int64_t n, uint32_t *__restrict__ flags, int64_t n_words)
+{
+#pragma clang fp contract(off)
+    constexpr int kGroups = kFlagSamples / 16 + 2;                           // group g = positions base - 31 + 16 g .. + 15; lane l reads groups l, l+1, l+2
+    constexpr int kRounds = (kGroups * 16 + 63) / 64;
+    __shared__ __attribute__((aligned(16))) uint8_t raw[(kRounds * 4 + 1) * kFlagGroupBytes];
+    const int lane = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * kFlagSamples;
+    {
+        float2 v[kRounds];
+#pragma unroll
+        for (int m = 0; m < kRounds; m++) {
+            const int64_t j = base - 31 + lane + 64 * m;
+            v[m] = (j >= 0 && j < n) ? iq[j] : float2{ 0.f, 0.f };
+        }
+#pragma unroll
+        for (int m = 0; m < kRounds; m++) {
+            const int rel = lane + 64 * m;
+            *(float2 *)(raw + (rel >> 4) * kFlagGroupBytes + (rel & 15) * 8) = v[m];
+        }
+    }
+    __syncthreads();
+    const float4 *g = (const float4 *)(raw + lane * kFlagGroupBytes);       // 9 float4 per group (the ninth is padding)
+    // products of slot r of the own group: x = g1[r], 16 back = g0[r]; of the next group: x = g2[r], 16 back = g1[r]
+    float2 g0[16], g1[16];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const float4 u = g[k], w = g[9 + k];
+        g0[2 * k] = float2{ u.x, u.y }; g0[2 * k + 1] = float2{ u.z, u.w };
+        g1[2 * k] = float2{ w.x, w.y }; g1[2 * k + 1] = float2{ w.z, w.w };
+    }
+    double T[3][16];                                                         // T[q][r]: slots r .. 15 of the own group
+    {
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+#pragma unroll
+        for (int r = 15; r >= 0; r--) {
+            const cpx a = widen(g1[r]), b = widen(g0[r]);
+            const double p0 = a.x * b.x + a.y * b.y, p1 = a.y * b.x - a.x * b.y, p2 = a.x * a.x + a.y * a.y;      // a * conj(b), |a|^2
+            if (r == 15) { t0 = p0; t1 = p1; t2 = p2; }
+            else { t0 = p0 + t0; t1 = p1 + t1; t2 = p2 + t2; }
+            T[0][r] = t0; T[1][r] = t1; T[2][r] = t2;
+        }
+    }
+    uint32_t mask = 0;
+    const int64_t i0 = base + 16 * lane;
+    double h0 = 0.0, h1 = 0.0, h2 = 0.0;                                     // slots 0 .. r-1 of the next group
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        double Sx = T[0][r], Sy = T[1][r], P = T[2][r];
+        if (r > 0) {
+            float2 xa;
+            if ((r - 1) % 2 == 0) { const float4 u = g[18 + (r - 1) / 2]; xa = float2{ u.x, u.y }; }
+            else { const float4 u = g[18 + (r - 1) / 2]; xa = float2{ u.z, u.w }; }
+            const cpx a = widen(xa), b = widen(g1[r - 1]);
+            const double p0 = a.x * b.x + a.y * b.y, p1 = a.y * b.x - a.x * b.y, p2 = a.x * a.x + a.y * a.y;
+            if (r == 1) { h0 = p0; h1 = p1; h2 = p2; }
+            else { h0 = h0 + p0; h1 = h1 + p1; h2 = h2 + p2; }
+            Sx += h0; Sy += h1; P += h2;
+        }
+        const double q = Sx * Sx + Sy * Sy, lim = 0.81 * (P * P);
+        bool above;
+        if (q > lim * (1.0 + 1e-9)) above = true;
+        else if (q < lim * (1.0 - 1e-9) || P == 0.0) above = false;         // no power: 0/0 or NaN/0, never above
+        else above = hypot(Sx, Sy) / P > 0.9;                                // too close to call (or not finite): the reference's expression
+        if (above && i0 + r < n) mask |= 1u << r;
+    }
+    const int64_t h16 = i0 >> 4;                                             // half-word of the flag array (little endian: bit i of word w = sample 32 w + i)
+    if (h16 < 2 * n_words) ((uint16_t *)flags)[h16] = (uint16_t)mask;
+}
+
+#if FOA_XCHECK
+// The first arrangement, kept in the cross-check build (option "sync_flags" 0): 256 threads per 1024 samples, every thread adds the
+// sixteen terms of a window directly, oldest first -- 15 additions and 16 LDS reads per window and quantity.
+__global__ __launch_bounds__(256) void k_sync_flags_direct(const float2 *__restrict__ iq, int64_t n, uint32_t *__restrict__ flags)
 {
 #pragma clang fp contract(off)
     __shared__ double pr[kFlagSamples + 16], pi[kFlagSamples + 16], pw[kFlagSamples + 16];
@@ -71,8 +151,8 @@ __global__ __launch_bounds__(256) void k_sync_flags(const float2 *__restrict__ i
         const double q = S.x * S.x + S.y * S.y, lim = 0.81 * (P * P);
         bool above;
         if (q > lim * (1.0 + 1e-9)) above = true;
-        else if (q < lim * (1.0 - 1e-9) || P == 0.0) above = false;         // no power: 0/0 or NaN/0, never above
-        else above = hypot(S.x, S.y) / P > 0.9;                              // too close to call (or not finite): the reference's expression
+        else if (q < lim * (1.0 - 1e-9) || P == 0.0) above = false;
+        else above = hypot(S.x, S.y) / P > 0.9;
         const uint64_t m = __ballot(i < n && above);
         const int lane = t & 63;
         const int64_t w = i >> 5;
@@ -80,6 +160,7 @@ __global__ __launch_bounds__(256) void k_sync_flags(const float2 *__restrict__ i
         if (lane == 32 && i < n) flags[w] = (uint32_t)(m >> 32);
     }
 }
+#endif
 
 // STS_END candidates of one block of flag words: count (pass 0) or write in order at offsets[block] (pass 1)
 __global__ __launch_bounds__(kSyncBlockWords) void k_sync_sts_end(const uint32_t *__restrict__ flags, int64_t n_words, int pass,

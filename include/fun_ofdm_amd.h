@@ -112,6 +112,8 @@ int foa_rx_reserve(foa_rx *rx, size_t n_samples, size_t n_frames);
  *   "frontend"    2 = four lanes per data symbol (frontend_q4.h), -1 (default) = 2: fastest alone, and its small waves run under the
  *                 previous call's forward pass when calls are pipelined; cross-check build: 0 = one wave per data symbol,
  *                 1 = one lane per data symbol; all three give bit-identical results
+ *   "sync_flags"  foa_rx_sync_dev's frame_detector kernel: 1 (default, the only shipped value) = a lane owns sixteen consecutive windows and sums
+ *                 them as tail of one group + head of the next; cross-check build: 0 = every window summed directly, term by term
  *   "record_soft" keep the depunctured soft bytes for foa_rx_get_taps (default 1; 0 saves their HBM writes)
  *   "record_eq"   keep the equalised carriers for foa_rx_get_taps (default 0) */
 int foa_rx_set_option(foa_rx *rx, const char *name, int64_t value);

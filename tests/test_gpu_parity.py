@@ -9,23 +9,25 @@ REL_TOL = 1e-4     # north_star: FFT / equaliser intermediates within 1e-4 relat
 
 class _RxPair:
     """The product library's receiver, and -- for the options that select a kernel the product does not ship ("viterbi" 0 / 1,
-    "frontend" 0 / 1: independent implementations kept as cross-checks, csrc/foa_common.h FOA_XCHECK) -- a receiver of the
+    "frontend" 0 / 1, "sync_flags" 0: independent implementations kept as cross-checks, csrc/foa_common.h FOA_XCHECK) -- a receiver of the
     cross-check build.  Every other call goes to whichever the options last selected, every option to both."""
 
     def __init__(self):
         import fun_ofdm_amd as foa
         self._prod, self._x = foa.Receiver(0), foa.Receiver(0, xcheck=True)
-        self._v, self._f = 2, -1
+        self._v, self._f, self._s = 2, -1, 1
 
     def _cur(self):
-        return self._x if (self._v != 2 or self._f in (0, 1)) else self._prod
+        return self._x if (self._v != 2 or self._f in (0, 1) or self._s == 0) else self._prod
 
     def set_option(self, name, value):
         if name == "viterbi":
             self._v = int(value)
         if name == "frontend":
             self._f = int(value)
-        if name in ("viterbi", "frontend"):
+        if name == "sync_flags":
+            self._s = int(value)
+        if name in ("viterbi", "frontend", "sync_flags"):
             self._x.set_option(name, value)
             if self._cur() is self._prod:
                 self._prod.set_option(name, value)
@@ -53,7 +55,7 @@ def test_product_library_does_not_carry_the_cross_check_kernels():
     import fun_ofdm_amd as foa
     r = foa.Receiver(0)
     try:
-        for name, value in (("viterbi", 0), ("viterbi", 1), ("frontend", 0), ("frontend", 1)):
+        for name, value in (("viterbi", 0), ("viterbi", 1), ("frontend", 0), ("frontend", 1), ("sync_flags", 0)):
             with pytest.raises(foa.FoaError):
                 r.set_option(name, value)
         r.set_option("viterbi", 2)
@@ -599,12 +601,16 @@ def test_device_sync_at_the_detection_threshold(rx, po):
     cap = s.size // 300 + 64
     t_desc = torch.zeros(cap * 48, dtype=torch.uint8, device=dev)
     t_ends = torch.zeros(cap, dtype=torch.int64, device=dev)
-    n = rx.sync_dev(t_iq, t_desc, t_ends)
-    got = t_desc.cpu().numpy()[:n * 48].view(foa.frame_desc_dtype)
-    assert n == want.size, (n, want.size)
-    assert np.array_equal(got["lts1_pos"], want["lts1_pos"]) and np.array_equal(got["rot_start"], want["rot_start"])
-    for k in ("c", "s", "c_prev", "s_prev"):
-        assert np.abs(got[k] - want[k]).max() < 1e-12, k
+    for kind in (1, 0):                         # the product's flag kernel (grouped tail / head sums), then the cross-check build's direct sums
+        rx.set_option("sync_flags", kind)
+        t_desc.zero_(); t_ends.zero_()
+        n = rx.sync_dev(t_iq, t_desc, t_ends)
+        got = t_desc.cpu().numpy()[:n * 48].view(foa.frame_desc_dtype)
+        assert n == want.size, (kind, n, want.size)
+        assert np.array_equal(got["lts1_pos"], want["lts1_pos"]) and np.array_equal(got["rot_start"], want["rot_start"]), kind
+        for k in ("c", "s", "c_prev", "s_prev"):
+            assert np.abs(got[k] - want[k]).max() < 1e-12, (kind, k)
+    rx.set_option("sync_flags", 1)
     # ... and the host restatement is the oracle's (= the compiled reference's, tests/test_oracle_vs_ref.py)
     assert np.array_equal(po.find_alignments_f32(s)["lts1_pos"], want["lts1_pos"])
 
