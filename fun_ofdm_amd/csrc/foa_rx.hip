@@ -923,6 +923,7 @@ extern "C" {
 int foa_rx_sync_dev_begin(foa_rx *rx, const float *d_iq, size_t n_samples, foa_frame_desc *d_descs, int64_t *d_ends, size_t cap)
 {
     if (!rx || !d_iq || !d_descs || !d_ends) return fail(FOA_E_INVALID, "NULL argument");
+    if (rx->open_stream) return fail(FOA_E_STATE, "a stream engine owns this handle (and its pre-sync scratch): destroy the stream first");
     if (rx->sy_open) return fail(FOA_E_STATE, "a pre-sync is already in flight on this handle: foa_rx_sync_dev_end first");
     if (n_samples > 0x7FFFFFFFull * 16) return fail(FOA_E_INVALID, "stream too long for one call");
     HIP_TRY(hipSetDevice(rx->device));

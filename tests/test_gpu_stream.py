@@ -163,6 +163,10 @@ def test_one_stream_per_handle_and_handle_destroyed_first(po):
     st = foa.Stream(r, 8192, 2)
     with pytest.raises(FoaError):
         foa.Stream(r, 8192, 0)
+    import torch
+    t_iq = torch.zeros((4096, 2), dtype=torch.float32, device="cuda:0")
+    with pytest.raises(FoaError):                      # the engine owns the handle's pre-sync scratch too
+        r.sync_dev(t_iq, torch.zeros(64 * 48, dtype=torch.uint8, device="cuda:0"), torch.zeros(64, dtype=torch.int64, device="cuda:0"))
     got = st.push(s) + st.flush()
     assert got == pays
     st.close()
