@@ -67,6 +67,7 @@ def parse_args(argv=None):
     ap.add_argument("--fe-hold", type=int, default=-1, help="A/B: library option fe_hold (-1: library default)")
     ap.add_argument("--depth", type=int, default=-1, help="A/B: library option depth (-1: library default = by grid size)")
     ap.add_argument("--lanes", type=int, default=-1, help="A/B: library option lanes (-1: library default)")
+    ap.add_argument("--walk-lane", type=int, default=-1, help="A/B: library option walk_lane (-1: library default)")
     ap.add_argument("--legs-frames", type=int, default=1000, help="frames per rate of the config-3 leg")
     ap.add_argument("--timing-age", type=int, default=4, help="pipelined steps: the per-kernel HIP-event times read inside the timed loop are those of the "
                     "call this many calls back (2..4): the further back, the more calls the host may run ahead of the GPU")
@@ -283,6 +284,8 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
         rx.set_option("fe_hold", args.fe_hold)
     if args.lanes >= 0:
         rx.set_option("lanes", args.lanes)
+    if args.walk_lane >= 0:
+        rx.set_option("walk_lane", args.walk_lane)
     if args.depth >= 0:
         rx.set_option("depth", args.depth)
     rx.set_option("pipeline", 0 if args.no_pipeline else 1)

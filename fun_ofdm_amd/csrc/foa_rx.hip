@@ -211,6 +211,7 @@ struct foa_rx {
                                  // call parity (below); false: front end on the third stream, walk + finish on the second (the round-1 arrangement)
     int fe_hold = 1;             // pipelined path: 1 = header, scan and data symbols of call k+1 wait for the chain-back walk of call k-1;
                                  // 2 = only the data-symbol kernel does; 0 = nothing is held back (A/B measurement)
+    int walk_on_lane = 1;        // lanes: the chain-back walk runs on the call's lane (1) or with the finish on the second stream, behind the forward pass's event (0; A/B)
     int sync_flags_kind = 1;     // k_sync_flags (1) or, in the cross-check build, k_sync_flags_direct (0)
     int frontend_kind = -1;      // 1: one lane per symbol (frontend_lps.h), 0: one wave per symbol, 2: four lanes per symbol (frontend_q4.h);
                                  // -1: the default, 2
@@ -298,7 +299,7 @@ int flush_pending(foa_rx *rx, hipEvent_t after_front_end)
     foa_rx::Pending &p = rx->pending;
     if (!p.valid) return FOA_OK;
     hipStream_t sb = rx->stream2;
-    if (p.lanes) {
+    if (p.lanes && rx->walk_on_lane) {
         // the walk follows its forward pass on the call's own lane -- no event between them -- and the next call of that lane
         // queues its front end behind it; the stitch/CRC kernel, which nothing on the loop waits for, goes to the second stream
         if (after_front_end) HIP_TRY(hipStreamWaitEvent(p.lane, after_front_end, 0));
@@ -476,6 +477,7 @@ int foa_rx_set_option(foa_rx *rx, const char *name, int64_t value)
         rx->frontend_kind = (int)value;
         return FOA_OK;
     }
+    if (!strcmp(name, "walk_lane")) { int rc0 = drain(rx); if (rc0) return rc0; rx->walk_on_lane = value != 0; return FOA_OK; }
     if (!strcmp(name, "sync_flags")) {
         if (value < 0 || value > 1) return fail(FOA_E_INVALID, "sync_flags must be 1 (grouped tail / head sums) or 0 (direct sums)");
         if (!FOA_XCHECK && value == 0) return fail(FOA_E_INVALID, "sync_flags 0 is a cross-check kernel: it is only in libfun_ofdm_amd_xcheck.so (make xcheck)");

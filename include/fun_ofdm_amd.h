@@ -105,6 +105,8 @@ int foa_rx_reserve(foa_rx *rx, size_t n_samples, size_t n_frames);
  *   "lanes"       pipelined calls: 1 (default) = a call's front end, forward pass and chain-back walk run on ONE stream per call parity,
  *                 so that the loop that sets the step has no event packet in it; 0 = front end on a third stream, walk and finish
  *                 on a second one (A/B)
+ *   "walk_lane"   lanes: 1 (default) = the chain-back walk follows its forward pass on the call's lane; 0 = it runs on the second stream with the
+ *                 finish, behind the forward pass's event (A/B: 2 % slower, profiles/r03_ab_walk_lane.txt)
  *   "depth"       lanes: how many calls' loops are in flight -- 0 (default) = by grid size: 2, or 4 for calls of up to 2048 frames, whose
  *                 forward pass leaves most SIMDs a single wave (1 000-frame batches decode 40-50 % faster in steady state); 2, 3, 4 = fixed (A/B).  More
  *                 than two lanes need more hardware queues than the runtime's default of four: GPU_MAX_HW_QUEUES=8 in the environment
