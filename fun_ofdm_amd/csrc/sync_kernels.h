@@ -48,6 +48,29 @@ constexpr int kFlagGroupBytes = 144; // LDS bytes per group of 16 samples (128 +
 // it needs (the products themselves would be three doubles per position: three times the LDS, a third of the resident waves).
 // |S| / P > 0.9 is decided on S.S against 0.81 P.P wherever that is clear by a margin of 1e-9 (the rounding of hypot and of the
 // division is 1e-15); only the rest takes hypot() and the division.  A lane's sixteen verdicts leave as one 16-bit store.
+// The rare window the quick test cannot call: summed again term by term, oldest first, the way circular_accumulator.h:88-95 takes its
+// samples in -- a product (or a power term) that is NaN counts as zero there (`if(sample != sample) sample = 0`, for a complex sample:
+// either part), so a NaN in the stream costs the reference the two products it is part of and nothing else, and this stage likewise.
+// (An INFINITE sample is another matter: the reference's running sum turns NaN when it leaves the window and stays NaN for good;
+// here the window is simply not above threshold while it holds one.)
+__device__ __forceinline__ bool sync_flag_slow(const uint8_t *raw, int lane, int r)
+{
+#pragma clang fp contract(off)
+    auto sample = [&](int t) -> cpx {                                        // t = 0 .. 47: position base - 31 + 16 lane + t
+        return widen(*(const float2 *)(raw + (lane + (t >> 4)) * kFlagGroupBytes + (t & 15) * 8));
+    };
+    cpx S = { 0.0, 0.0 };
+    double P = 0.0;
+    for (int m = 0; m < 16; m++) {
+        const cpx a = sample(16 + r + m), b = sample(r + m);
+        double pr = a.x * b.x + a.y * b.y, pi = a.y * b.x - a.x * b.y, pw = a.x * a.x + a.y * a.y;
+        if (pr != pr || pi != pi) { pr = 0.0; pi = 0.0; }
+        if (pw != pw) pw = 0.0;
+        S.x += pr; S.y += pi; P += pw;
+    }
+    return hypot(S.x, S.y) / P > 0.9;                                        // 0/0 and NaN/x are not above
+}
+
 __global__ __launch_bounds__(64, 3) void k_sync_flags(const float2 *__restrict__ iq, int64_t n, uint32_t *__restrict__ flags, int64_t n_words)
 {
 #pragma clang fp contract(off)
@@ -72,11 +95,10 @@ __global__ __launch_bounds__(64, 3) void k_sync_flags(const float2 *__restrict__
     __syncthreads();
     const float4 *g = (const float4 *)(raw + lane * kFlagGroupBytes);       // 9 float4 per group (the ninth is padding)
     // products of slot r of the own group: x = g1[r], 16 back = g0[r]; of the next group: x = g2[r], 16 back = g1[r]
-    float2 g0[16], g1[16];
+    float2 g1[16];
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        const float4 u = g[k], w = g[9 + k];
-        g0[2 * k] = float2{ u.x, u.y }; g0[2 * k + 1] = float2{ u.z, u.w };
+        const float4 w = g[9 + k];
         g1[2 * k] = float2{ w.x, w.y }; g1[2 * k + 1] = float2{ w.z, w.w };
     }
     double T[3][16];                                                         // T[q][r]: slots r .. 15 of the own group
@@ -84,14 +106,15 @@ __global__ __launch_bounds__(64, 3) void k_sync_flags(const float2 *__restrict__
         double t0 = 0.0, t1 = 0.0, t2 = 0.0;
 #pragma unroll
         for (int r = 15; r >= 0; r--) {
-            const cpx a = widen(g1[r]), b = widen(g0[r]);
+            const float4 u = g[r / 2];                                       // (group 0 is read as it is used: its sixteen samples need not all be live)
+            const cpx a = widen(g1[r]), b = widen((r & 1) ? float2{ u.z, u.w } : float2{ u.x, u.y });
             const double p0 = a.x * b.x + a.y * b.y, p1 = a.y * b.x - a.x * b.y, p2 = a.x * a.x + a.y * a.y;      // a * conj(b), |a|^2
             if (r == 15) { t0 = p0; t1 = p1; t2 = p2; }
             else { t0 = p0 + t0; t1 = p1 + t1; t2 = p2 + t2; }
             T[0][r] = t0; T[1][r] = t1; T[2][r] = t2;
         }
     }
-    uint32_t mask = 0;
+    uint32_t mask = 0, slow = 0;
     const int64_t i0 = base + 16 * lane;
     double h0 = 0.0, h1 = 0.0, h2 = 0.0;                                     // slots 0 .. r-1 of the next group
 #pragma unroll
@@ -111,8 +134,13 @@ __global__ __launch_bounds__(64, 3) void k_sync_flags(const float2 *__restrict__
         bool above;
         if (q > lim * (1.0 + 1e-9)) above = true;
         else if (q < lim * (1.0 - 1e-9) || P == 0.0) above = false;         // no power: 0/0 or NaN/0, never above
-        else above = hypot(Sx, Sy) / P > 0.9;                                // too close to call (or not finite): the reference's expression
+        else { above = false; slow |= 1u << r; }                             // too close to call, or not finite: settled below
         if (above && i0 + r < n) mask |= 1u << r;
+    }
+    while (slow) {                                                           // (rare: kept out of the loop above, whose registers it would claim)
+        const int r = __ffs(slow) - 1;
+        slow &= slow - 1;
+        if (sync_flag_slow(raw, lane, r) && i0 + r < n) mask |= 1u << r;
     }
     const int64_t h16 = i0 >> 4;                                             // half-word of the flag array (little endian: bit i of word w = sample 32 w + i)
     if (h16 < 2 * n_words) ((uint16_t *)flags)[h16] = (uint16_t)mask;

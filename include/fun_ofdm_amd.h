@@ -219,7 +219,10 @@ int64_t foa_sync_settled(const foa_sync *s);
  * 0.9 -- and the reference's running sums never quite forget a huge sample: after a glitch of >= ~1e10 times the
  * signal amplitude its frame_detector tags residue artefacts for the rest of the stream (circular_accumulator.h:88-95), which
  * this stage does not reproduce (it finds the real frames only; foa_sync_push_* reproduces the reference there as well;
- * tests/test_gpu_parity.py::test_device_sync_large_dynamic_range).  d_iq must be complete when the call is made (like the input of foa_rx_decode_frames_dev: with
+ * tests/test_gpu_parity.py::test_device_sync_large_dynamic_range).  A NaN sample is taken in as the reference takes it -- the two
+ * products it is part of count as zero (circular_accumulator.h:91) -- so descriptors agree wherever it falls; an INFINITE sample
+ * blinds the reference's detector for the rest of the stream (Inf - Inf = NaN stays in its running sum), this stage for the 32
+ * samples whose windows hold it (test_device_sync_non_finite_samples).  d_iq must be complete when the call is made (like the input of foa_rx_decode_frames_dev: with
  * calls pipelined the stage runs on the library's third stream, under the forward pass of a decode call in flight, and
  * is not ordered behind foa_rx_stream()); d_descs / d_ends may be handed to the next decode call straight away.
  * FOA_E_INVALID if more than cap alignments are found, FOA_E_NOMEM if the stream holds more STS_END candidates than

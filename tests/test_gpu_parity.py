@@ -697,6 +697,67 @@ def test_device_sync_edge_inputs(rx):
         assert (got[n * 48:] == 0xA5).all() and (t_ends.cpu().numpy()[n:] == -7).all()
 
 
+def test_device_sync_non_finite_samples(rx, po):
+    """NaN and infinite samples.  A NaN costs the reference exactly the two products it is part of: circular_accumulator.h:88-95
+    takes a NaN sample in as zero.  The device stage does the same (a window whose quick test is not finite is summed again term by
+    term under that rule), so its descriptors equal the reference's with a NaN in a gap, in a short training sequence, in a long
+    training sequence and in the payload.  An INFINITE sample is different: the reference's running sums turn NaN when it leaves
+    the window and stay NaN for good -- frame_detector tags nothing behind it (the host restatement reproduces that) --, while the
+    device stage sums every window from its own sixteen terms and finds the frames behind it: its descriptors equal the
+    reference's on the stream with that one sample zeroed.  Same class of deliberate, documented difference as the glitch below."""
+    import torch
+    import fun_ofdm_amd as foa
+    from fun_ofdm_amd import synth
+    dev = torch.device("cuda", 0)
+    pays = synth.splitmix64_bytes(78, 8, 150)
+    iq, _ = synth.make_stream(synth.build_frames(pays, 5), 4096, 300, 25.0, seed=4)
+    clean = foa.find_alignments(iq)
+    assert clean.size == 8
+
+    def device(stream):
+        t_iq = torch.from_numpy(stream.view(np.float32).reshape(-1, 2)).to(dev)
+        t_desc = torch.zeros(64 * 48, dtype=torch.uint8, device=dev)
+        t_ends = torch.zeros(64, dtype=torch.int64, device=dev)
+        n = rx.sync_dev(t_iq, t_desc, t_ends)
+        return t_desc.cpu().numpy()[:n * 48].view(foa.frame_desc_dtype).copy(), t_iq, t_desc, t_ends, n
+
+    def same(got, want):
+        if got.size != want.size or not (np.array_equal(got["lts1_pos"], want["lts1_pos"]) and np.array_equal(got["rot_start"], want["rot_start"])):
+            return False
+        return all(np.abs(got[k] - want[k]).max() < 1e-12 for k in ("c", "s", "c_prev", "s_prev")) if got.size else True
+
+    gap = 3 * 4096 + 3000                                # behind the fourth frame (150 bytes at 18 Mbps end well before)
+    start = 4 * 4096 + 300                               # first sample of the fifth frame
+    # NaN: the reference's rule, reproduced -- wherever it falls (gap, STS, the STS/LTS boundary, LTS, payload; one part or both)
+    for pos in (gap, start + 40, start + 100, start + 150, start + 158, start + 161, start + 200, start + 290, start + 700):
+        for bad in (complex(np.nan, 0.0), complex(0.3, np.nan), complex(np.nan, np.nan)):
+            g = iq.copy()
+            g[pos] = bad
+            host = foa.find_alignments(g)
+            assert host.tobytes() == po.find_alignments_f32(g).tobytes()
+            got = device(g)[0]
+            assert same(got, host), (pos, bad, got["lts1_pos"], host["lts1_pos"])
+    assert foa.find_alignments(np.where(np.arange(iq.size) == gap, np.complex64(complex(np.nan, 0)), iq).astype(np.complex64)).size == 8
+    # infinite: the reference goes blind, the device stage does not
+    for bad in (complex(np.inf, 0.0), complex(-np.inf, np.nan), complex(1.0, -np.inf)):
+        g = iq.copy()
+        g[gap] = bad
+        z = iq.copy()
+        z[gap] = 0
+        want = foa.find_alignments(z)
+        assert want.tobytes() == clean.tobytes()         # (the zeroed sample changes no decision)
+        host = foa.find_alignments(g)
+        assert host.tobytes() == po.find_alignments_f32(g).tobytes()
+        assert host.size == 4                            # nothing behind the sample
+        got, t_iq, t_desc, t_ends, n = device(g)
+        assert n == 8 and same(got, want)
+        t_psdu = torch.zeros((n, 256), dtype=torch.uint8, device=dev)
+        t_res = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+        rx.decode_frames_dev(t_iq, t_desc[:n * 48], t_ends[:n], t_psdu, t_res)
+        rx.sync()
+        assert (t_res.cpu().numpy()[:, 0] == 0).all() and np.array_equal(t_psdu.cpu().numpy()[:, :150], pays)
+
+
 def test_device_sync_large_dynamic_range(rx, po):
     """One huge sample (an ADC glitch) in front of normal frames.  frame_detector's running sums (circular_accumulator.h:88-95:
     sum -= old; sum += new) never forget such a sample exactly -- after 1e10 or more the residue of the cancelled power term
