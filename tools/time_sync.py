@@ -1,5 +1,5 @@
 """Times foa_rx_sync_dev alone (blocking call, stream resident) on a synthetic config-2-like stream and checks its descriptors
-against the cross-check build's direct-sum flag kernel (option sync_flags 0).  Usage: python3 tools/time_sync.py [frames [product]]"""
+against the cross-check build's direct-sum flag kernel (option sync_flags 0).  Usage: python3 tools/time_sync.py [frames [product|host]]"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -36,3 +36,9 @@ if only_product:
     sys.exit(0)
 a, b = out["grouped"], out["direct(xcheck)"]
 print("same descriptors and ends as the direct-sum kernel:", a[0] == b[0] and bool(torch.equal(a[1], b[1])) and bool(torch.equal(a[2], b[2])))
+if len(sys.argv) > 2 and sys.argv[2] == "host":                        # the host restatement (= the reference's decisions) over the same stream
+    h_iq = iq.cpu().numpy().reshape(-1).view(np.complex64)
+    t0 = time.perf_counter(); want = foa.find_alignments(h_iq); th = time.perf_counter() - t0
+    got = a[1].cpu().numpy().view(foa.frame_desc_dtype)
+    print("host pre-sync %.2f s; same alignments: %s; largest phasor difference %.2e" % (th, got.size == want.size and np.array_equal(got["lts1_pos"], want["lts1_pos"])
+          and np.array_equal(got["rot_start"], want["rot_start"]), max(np.abs(got[k] - want[k]).max() for k in ("c", "s", "c_prev", "s_prev"))))
