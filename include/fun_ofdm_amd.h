@@ -255,7 +255,7 @@ typedef struct foa_stream foa_stream;
  * foa_stream_push_f64_owned).  The engine's threads are confined to the block of eight consecutive CPUs the creating thread runs
  * on (the cores that share its last-level cache on the hosts measured; several times faster than threads spread over two
  * sockets); the environment variable FOA_STREAM_AFFINITY=0 leaves them to the scheduler.  Measured on a 2 x EPYC 9575F host:
- * 4 Mi-sample batches carry 3.2-3.4 Gsample/s of complex<double> through process_samples with four helpers and 4.3-4.7 with eight (more than
+ * 4 Mi-sample batches carry 3.2-3.4 Gsample/s of complex<double> through process_samples with four helpers and 4.0-4.8 with eight (more than
  * four alternate between the caller's block of eight CPUs and its neighbour; FOA_STREAM_AFFINITY=1 keeps all on one) (profiles/).
  * One stream per handle: a second create while one is open fails with FOA_E_STATE (the engine's submitter thread owns the handle's
  * streams and work sets); destroying the HANDLE first stops the engine -- every later call on the stream then fails with FOA_E_STATE
