@@ -63,6 +63,9 @@ __device__ __forceinline__ uint32_t pk_sub_wrap(uint32_t a, uint32_t b)
 #ifndef FOA_RN_PRIO
 #define FOA_RN_PRIO 0      // priority of a wave while it renormalises (0: unchanged)
 #endif
+#ifndef FOA_FWD_PRIO
+#define FOA_FWD_PRIO 3     // priority of the forward pass's waves over its guests' at the issue arbiter (0: unchanged; 1 .. 3 and 4 + p measured: profiles/r03_ab_fwd_prio.txt)
+#endif
 #ifndef FOA_MIN16
 #define FOA_MIN16 1
 #endif
@@ -313,6 +316,9 @@ __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd3(const FrameInfo
     __shared__ uint4 bml_all[kFwdWaves][4 * kChunk3];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint4 *bml = bml_all[wave];
+#if FOA_FWD_PRIO
+    __builtin_amdgcn_s_setprio(FOA_FWD_PRIO & 3);      // (A/B: the forward pass's waves ahead of its guests' at the issue arbiter; 4 + p: p, and 3 over the last third of the frame)
+#endif
     const int fA = 2 * (blockIdx.x * kFwdWaves + wave), fB = fA + 1;
     if (fA >= n_frames) return;
     const FrameInfo ia = info[fA];
@@ -407,6 +413,9 @@ __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd3(const FrameInfo
     };
     for (int n0 = 0; n0 < N; n0 += kChunk3) {                             // n0 mod 6 == 0: phase = chunk-relative index mod 6
         const int nn = min(kChunk3, N - n0);
+#if FOA_FWD_PRIO & 4
+        if (3 * n0 >= 2 * N && 3 * (n0 - kChunk3) < 2 * N) __builtin_amdgcn_s_setprio(3);
+#endif
         put(kChunk3);
         get(n0 + kChunk3 + 6);
         if (n0 > 0) store_block(n0 - 16, late);
