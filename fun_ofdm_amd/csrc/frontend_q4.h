@@ -124,13 +124,15 @@ void k_data_symbols_q4(const float2 *__restrict__ iq, const foa_frame_desc *__re
                        uint16_t *__restrict__ sp, double2 *__restrict__ eq_tap)
 {
     __shared__ Q4Shared sh;
-    // In the pipelined path this kernel and the chain-back run one after the other under a neighbouring call's forward pass
-    // and together take longer than it does, so this one gets the issue slots first (measured: 1.41 -> 1.38 ms per step;
-    // raising the chain-back kernels as well gives 1.40, raising the forward pass instead 1.41).
+    // (Rounds 1 and 2 ran this kernel at priority 2, which paid under the three-stream arrangement of the time.  With two lanes it costs
+    // the step 1-1.5 %: what matters is that these waves do NOT go ahead of the forward pass's -- forward pass at 2 or 3, this kernel at
+    // 0 .. 3 below or level with it, or no priorities at all, all measure the same; profiles/r03_ab_fwd_prio.txt.  No priorities, then.)
 #ifndef FOA_Q4_PRIO
-#define FOA_Q4_PRIO 2
+#define FOA_Q4_PRIO 0
 #endif
+#if FOA_Q4_PRIO
     __builtin_amdgcn_s_setprio(FOA_Q4_PRIO);
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, qd = lane >> 2, m = lane & 3;
     const int64_t total = min(totals[0], totals[3]);
     if ((int64_t)blockIdx.x * kQ4Waves * 16 >= total) return;       // the grid is sized by an upper bound: surplus blocks leave at once
