@@ -775,7 +775,8 @@ def extra_legs(args, rx, dev, iq, descs, ends, real, psdu_dev_path, res_dev_path
             e_desc, e_end = torch.zeros_like(d_desc), torch.zeros_like(d_end)
             sets5 = [(d_desc, d_end), (e_desc, e_end)]
             ref_desc, ref_end = d_desc.clone(), d_end.clone()
-            for n_p in (8, 6):
+            dtps = []
+            for n_p in (8, 6, 6, 6):                     # one warm round, then the median of three
                 rx.sync(); torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 rx.sync_dev_begin(stream, *sets5[0])
@@ -786,8 +787,9 @@ def extra_legs(args, rx, dev, iq, descs, ends, real, psdu_dev_path, res_dev_path
                     dsc, en = sets5[kk % 2]
                     rx.decode_frames_dev(stream, dsc[:nf * 48], en[:nf], d_psdu[:nf], d_res[:nf])
                 rx.sync(); torch.cuda.synchronize()
-                dtp = (time.perf_counter() - t0) / n_p
-            piped5 = {"ms_sync_plus_decode": round(dtp * 1e3, 3), "Msamples_per_s": round(total / dtp / 1e6, 1), "passes": n_p,
+                dtps.append((time.perf_counter() - t0) / n_p)
+            dtp = sorted(dtps[1:])[1]
+            piped5 = {"ms_sync_plus_decode": round(dtp * 1e3, 3), "Msamples_per_s": round(total / dtp / 1e6, 1), "passes": n_p, "protocol": "median of 3 rounds",
                       "same_descriptors_as_blocking_call": nf == m and bool(torch.equal(e_desc[:m * 48], ref_desc[:m * 48])) and bool(torch.equal(e_end[:m], ref_end[:m]))
                       and bool(torch.equal(d_desc[:m * 48], ref_desc[:m * 48])),
                       "same_results_as_blocking_call": bool(np.array_equal(d_res[:m].cpu().numpy(), r)) and bool(np.array_equal(d_psdu[:m].cpu().numpy(), hp)),
