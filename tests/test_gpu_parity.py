@@ -670,7 +670,17 @@ def test_device_sync_in_two_halves_pipelined_with_decode(rx, po):
         assert np.array_equal(r, ores.view(np.int32).reshape(-1, 4)), k
         ok = r[:, 0] == 0
         assert ok.sum() >= 20 and np.array_equal(outs[k][0][:ns[k]].cpu().numpy()[ok], opsdu[ok]), k
-    # (c) an empty stream: nothing queued, _end reports 0
+    # (c) a capacity too small for the stream: the count is refused at _end (FOA_E_INVALID), nothing is written beyond the capacity, and the
+    # handle takes the next pre-sync as if nothing had happened
+    small_d = torch.full((5 * 48 + 64,), 0xA5, dtype=torch.uint8, device=dev)
+    small_e = torch.full((5 + 8,), -7, dtype=torch.int64, device=dev)
+    assert rx._lib.foa_rx_sync_dev_begin(rx._h, t_iq[0].data_ptr(), t_iq[0].shape[0], small_d.data_ptr(), small_e.data_ptr(), 5) == 0
+    with pytest.raises(foa.FoaError):
+        rx.sync_dev_end()
+    assert (small_d[5 * 48:] == 0xA5).all() and (small_e[5:] == -7).all()
+    rx.sync_dev_begin(t_iq[0], *sets[0])
+    assert rx.sync_dev_end() == nb and torch.equal(sets[0][0][:nb * 48], b_desc[:nb * 48])
+    # (d) an empty stream: nothing queued, _end reports 0
     assert rx._lib.foa_rx_sync_dev_begin(rx._h, t_iq[0].data_ptr(), 0, sets[0][0].data_ptr(), sets[0][1].data_ptr(), cap) == 0
     assert rx.sync_dev_end() == 0
 
