@@ -56,6 +56,11 @@ def test_bench_single_rank_line_has_the_contract_fields():
     assert all(r["gpu_equals_cpu_on_all"] is True for r in rows)
     c5 = legs["config5_stream"]
     assert c5["psdu_bit_exact"] is True and c5["frames_ok"] >= 3900 and c5["gpu_equals_cpu_on_all"] is True
+    assert c5["cpu_checked_alignments"] == c5["alignments"]
+    p5 = c5["pipelined"]                                  # pre-sync in two halves (foa_rx_sync_dev_begin / _end) under the decode calls
+    assert p5["same_descriptors_as_blocking_call"] is True and p5["same_results_as_blocking_call"] is True and p5["ms_sync_plus_decode"] > 0
+    ws = out["config"]["incl_device_pre_sync"]
+    assert ws["same_results_as_host_sync"] is True and ws["pipelined"]["same_results_as_host_sync"] is True
     ps = legs["process_samples_api"]
     assert ps["same_list_as_batch_path"] is True and ps["packets"] == ps["batch_path_payloads"]
 
