@@ -301,22 +301,30 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
     # back and queued its successor late)
     LAG = 4
     n_out = LAG + 2 if multi else 1
-    out_psdu = [torch.zeros((m, PAYLOAD), dtype=torch.uint8, device=dev) for _ in range(n_out)]
+    # (one row more than alignments: row m is never written and stays zero -- the slot of a frame the detector missed)
+    out_full = [torch.zeros((m + 1, PAYLOAD), dtype=torch.uint8, device=dev) for _ in range(n_out)]
+    out_psdu = [t[:m] for t in out_full]
     out_res = [torch.zeros((m, 4), dtype=torch.int32, device=dev) for _ in range(n_out)]
-    d_real = torch.from_numpy(real).to(dev)
-    d_which = torch.from_numpy(which).to(dev)
     gathered = [None]
     read_done = [None] * n_out
     n_gathers = [0]
+    if multi:
+        # local frame slot -> alignment row (a frame the detector missed -> the zero row, like a CRC failure): one index_select per
+        # step puts the PSDUs in local frame order; its destination and rank 0's receive buffers are allocated once
+        perm = np.full(args.frames, m, np.int64)
+        perm[which] = real
+        d_perm = torch.from_numpy(perm).to(dev)
+        local_bufs = [torch.zeros((args.frames, PAYLOAD), dtype=torch.uint8, device=dev) for _ in range(2)]
+        recv = shard.GatherBuffers(n_global, PAYLOAD, world, cdev) if rank == 0 else None
 
     def gather_now(i):
-        # slots in local frame order (a frame the detector missed leaves a zero slot, like a CRC failure)
-        buf = out_psdu[i]
-        local = torch.zeros((args.frames, PAYLOAD), dtype=torch.uint8, device=dev)
-        local.index_copy_(0, d_which, buf.index_select(0, d_real))
+        local = local_bufs[n_gathers[0] % 2]             # (the gather before last, which read this buffer, is complete: same stream)
+        torch.index_select(out_full[i], 0, d_perm, out=local)
         read_done[i] = _CpuEvent() if on_cpu else torch.cuda.Event()
         read_done[i].record()
-        gathered[0] = shard.gather_psdus(local.to(cdev), n_global, rank, world, force_collective=multi)
+        # rank 0 reads the gathered slots in global frame order through a strided view of its receive buffer; the contiguous
+        # tensor is only formed for the check after the clock has stopped
+        gathered[0] = shard.gather_psdus(local.to(cdev), n_global, rank, world, force_collective=multi, buffers=recv, materialize=False)
         n_gathers[0] += 1
 
     issued = [0]          # steps queued since the last finish_steps()
@@ -495,7 +503,7 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
         ok_frames = int(oks.item())
         if rank == 0:
             # the gathered slots are in global frame order: rows of rank 0's own frames must equal its local result
-            g = gathered[0].cpu().numpy()
+            g = gathered[0].reshape(-1, PAYLOAD)[:n_global].cpu().numpy()      # [m_max, world, slot] view -> global frame order
             exact = exact and g.shape == (n_global, PAYLOAD) and bool(np.array_equal(g[0::world][which][okm], pays[which][okm]))
             all_pays = synth.splitmix64_bytes(SEED_BASE, n_global, PAYLOAD)
             nz = g.any(axis=1)                           # frames whose CRC failed leave their slot zeroed

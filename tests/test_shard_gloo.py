@@ -29,12 +29,21 @@ def _worker(rank, world, port, n_global, slot, q):
     from fun_ofdm_amd import shard
     ids = shard.local_frame_ids(n_global, rank, world)
     out = shard.gather_psdus(_fake_psdu(ids, slot), n_global, rank, world)
+    # the same through receive buffers allocated once, twice over (reuse), read in global order through the strided view
+    bufs = shard.GatherBuffers(n_global, slot, world, torch.device("cpu")) if rank == 0 else None
+    views = []
+    for rep in range(2):
+        v = shard.gather_psdus((_fake_psdu(ids, slot) + rep).to(torch.uint8), n_global, rank, world, buffers=bufs, materialize=False)
+        views.append(None if v is None else v.reshape(-1, slot)[:n_global].clone())
+    mat = shard.gather_psdus(_fake_psdu(ids, slot), n_global, rank, world, buffers=bufs)
     dist.barrier()
     if rank == 0:
         want = _fake_psdu(torch.arange(n_global), slot)
-        q.put(bool(torch.equal(out, want)) and out.shape == (n_global, slot))
+        ok = bool(torch.equal(out, want)) and out.shape == (n_global, slot)
+        ok = ok and bool(torch.equal(views[0], want)) and bool(torch.equal(views[1], (want + 1).to(torch.uint8))) and bool(torch.equal(mat, want))
+        q.put(ok)
     else:
-        assert out is None
+        assert out is None and views == [None, None] and mat is None
     dist.destroy_process_group()
 
 
