@@ -74,6 +74,7 @@ _SIGS = {
     "foa_sync_push_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "foa_sync_push_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "foa_sync_settled": (C.c_int64, [C.c_void_p]),
+    "foa_sync_set_call": (C.c_int, [C.c_void_p, C.c_int64]),
     "foa_fft_forward_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "foa_conv_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]),
     "foa_channel_estimate_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

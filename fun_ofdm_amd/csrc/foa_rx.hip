@@ -211,6 +211,7 @@ struct foa_rx {
                                  // call parity (below); false: front end on the third stream, walk + finish on the second (the round-1 arrangement)
     int fe_hold = 1;             // pipelined path: 1 = header, scan and data symbols of call k+1 wait for the chain-back walk of call k-1;
                                  // 2 = only the data-symbol kernel does; 0 = nothing is held back (A/B measurement)
+    int64_t sync_call = kSyncCallDefault;    // pre-sync: the reference receiver's call size to decide timing_sync.cpp:99 by (csrc/sync_host.h); 0 = as one call
     int walk_on_lane = 1;        // lanes: the chain-back walk runs on the call's lane (1) or with the finish on the second stream, behind the forward pass's event (0; A/B)
     int sync_flags_kind = 1;     // k_sync_flags (1) or, in the cross-check build, k_sync_flags_direct (0)
     int frontend_kind = -1;      // 1: one lane per symbol (frontend_lps.h), 0: one wave per symbol, 2: four lanes per symbol (frontend_q4.h);
@@ -478,6 +479,11 @@ int foa_rx_set_option(foa_rx *rx, const char *name, int64_t value)
         return FOA_OK;
     }
     if (!strcmp(name, "walk_lane")) { int rc0 = drain(rx); if (rc0) return rc0; rx->walk_on_lane = value != 0; return FOA_OK; }
+    if (!strcmp(name, "sync_call")) {
+        if (value != 0 && value <= 160) return fail(FOA_E_INVALID, "sync_call must be 0 (decide as one call over the whole stream) or > 160 (timing_sync.cpp:55)");
+        rx->sync_call = value;
+        return FOA_OK;
+    }
     if (!strcmp(name, "sync_flags")) {
         if (value < 0 || value > 1) return fail(FOA_E_INVALID, "sync_flags must be 1 (grouped tail / head sums) or 0 (direct sums)");
         if (!FOA_XCHECK && value == 0) return fail(FOA_E_INVALID, "sync_flags 0 is a cross-check kernel: it is only in libfun_ofdm_amd_xcheck.so (make xcheck)");
@@ -881,7 +887,8 @@ int foa_rx_get_decisions(foa_rx *rx, size_t frame, uint64_t *out, size_t cap, si
 // The launching half of foa_rx_sync_dev: every kernel of the pre-sync stage queued on the side stream, nothing waited for.  The counts
 // stay on the device in rx->sy_n ([0] STS_END candidates, [3] alignments found); *ccap_out = the candidate capacity they are checked
 // against.  (The stream engine queues this for batch k+1 while batch k decodes and reads the counts later.)
-static int sync_dev_issue(foa_rx *rx, const float *d_iq, size_t n_samples, foa_frame_desc *d_descs, int64_t *d_ends, size_t cap, int32_t *ccap_out)
+// origin: stream index of d_iq[0] (the stream engine's buffers start inside the stream; a one-shot call's starts it)
+static int sync_dev_issue(foa_rx *rx, const float *d_iq, size_t n_samples, foa_frame_desc *d_descs, int64_t *d_ends, size_t cap, int32_t *ccap_out, int64_t origin = 0)
 {
     const int64_t n = (int64_t)n_samples, n_words = (n + 31) / 32;
     const int n_blocks = (int)((n_words + kSyncBlockWords - 1) / kSyncBlockWords);
@@ -910,7 +917,7 @@ static int sync_dev_issue(foa_rx *rx, const float *d_iq, size_t n_samples, foa_f
     hipLaunchKernelGGL(k_sync_sts_end, dim3(n_blocks), dim3(kSyncBlockWords), 0, st, rx->sy_flags.p, n_words, 1, rx->sy_cnt.p, rx->sy_off.p, rx->sy_x.p, ccap);
     // one wave per candidate; the count stays on the device: fixed grids stride over it (k_sync_finish reports overflow)
     const int lts_grid = (int)std::min<int64_t>(ccap, 16384);
-    hipLaunchKernelGGL(k_sync_lts, dim3(lts_grid), dim3(64), 0, st, iq, n, rx->sy_x.p, rx->sy_n.p, ccap, rx->sy_cand.p);
+    hipLaunchKernelGGL(k_sync_lts, dim3(lts_grid), dim3(64), 0, st, iq, n, rx->sy_x.p, rx->sy_n.p, ccap, rx->sy_cand.p, origin, rx->sync_call);
     const int kb = (ccap + 255) / 256;       // blocks of the keep / emit stage; their counts reuse the STS_END stage's count buffers
     hipLaunchKernelGGL(k_sync_keep, dim3(kb), dim3(256), 0, st, rx->sy_cand.p, rx->sy_n.p, ccap, rx->sy_keep.p, rx->sy_cnt.p);
     hipLaunchKernelGGL(k_sync_scan, dim3(1), dim3(1024), 0, st, rx->sy_cnt.p, kb, rx->sy_off.p, rx->sy_n.p + 3);
@@ -1004,6 +1011,13 @@ void foa_sync_destroy(foa_sync *s) { delete s; }
 int foa_sync_push_f32(foa_sync *s, const float *iq, size_t n, foa_frame_desc *out, size_t cap, size_t *n_out) { return sync_push(s, iq, n, out, cap, n_out); }
 int foa_sync_push_f64(foa_sync *s, const double *iq, size_t n, foa_frame_desc *out, size_t cap, size_t *n_out) { return sync_push(s, iq, n, out, cap, n_out); }
 int64_t foa_sync_settled(const foa_sync *s) { return s ? s->impl.settled() : 0; }
+int foa_sync_set_call(foa_sync *s, int64_t call)
+{
+    if (!s) return fail(FOA_E_INVALID, "NULL argument");
+    if (call != 0 && call <= 160) return fail(FOA_E_INVALID, "call must be 0 (decide as one call over the whole stream) or > 160 (timing_sync.cpp:55)");
+    s->impl.set_call(call);
+    return FOA_OK;
+}
 
 // ---- stage-level entry points ---------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_fft_vectors(double2 *__restrict__ v, int n_vec)

@@ -104,7 +104,7 @@ struct StreamGpu {
         const int64_t L = foa::kStreamLongest, n_buf = C + n_new, pushed = staged_samples + n_new;
         const int64_t start = pushed - n_new - C;                    // stream index of the buffer's first sample
         const int64_t cut = final ? pushed + 1 : pushed - L;        // this batch decodes the alignments whose STS_END sample lies in [cut_prev, cut)
-        int rc = sync_dev_issue(rx, d, (size_t)n_buf, (foa_frame_desc *)d_desc[k].p, d_ends[k].p, desc_cap, &ccap[k]);
+        int rc = sync_dev_issue(rx, d, (size_t)n_buf, (foa_frame_desc *)d_desc[k].p, d_ends[k].p, desc_cap, &ccap[k], start);
         if (rc) return rc;
         hipLaunchKernelGGL(foa::k_stream_select, dim3(1), dim3(64), 0, st, (foa_frame_desc *)d_desc[k].p, rx->sy_n.p, (int32_t)desc_cap, cut_prev - start, cut - start,
                            d_prev.p, sel_dev.p + 4 * k);

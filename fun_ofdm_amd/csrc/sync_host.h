@@ -7,8 +7,9 @@
 // It never touches sample values (the rotation itself is applied in-kernel), so it only has to
 // reproduce the blocks' DECISIONS; it does that with the same operation order in fp64.
 //
-// Both blocks are chunk-size independent (their carry-overs make a chunked run equal to a one-shot run),
-// so push() may be called with any chunk sizes.
+// Both blocks are chunk-size independent (their carry-overs make a chunked run equal to a one-shot run) up to one line of
+// timing_sync (`if(lts_offset < 0) break;`, relative to a call's buffer): that one is decided here for the call size of the
+// reference's own receiver (4096; set_call), whatever the sizes push() is called with.
 #pragma once
 
 #include <algorithm>
@@ -82,6 +83,18 @@ inline void make_preamble(std::complex<double> *out)
     out[160] = std::complex<double>(-0.078, 0.0);
 }
 
+// Index of stream sample xs in the working buffer of the reference call that walks over it (timing_sync.cpp:57-69: a call's buffer
+// is the 160 samples before it + its own `call` samples, and it walks the first `call` of them); call = 0: one call for the whole stream.
+constexpr int64_t kSyncCallDefault = 4096;             // receiver.h:16 NUM_RX_SAMPLES
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int64_t sync_call_index(int64_t xs, int64_t call)
+{
+    const int64_t v = xs + 160;
+    return call > 0 ? ((v % call) + call) % call : v;
+}
+
 class SyncHost {
 public:
     SyncHost() : lts_conj_(64)
@@ -127,9 +140,15 @@ public:
             const int lim = std::min((int)peaks.size(), 5);
             for (int t = 0; t < lim; t++) {
                 if (std::abs(peaks[0].second - peaks[t].second) != 64) continue;
-                const int lts_offset = std::min(peaks[0].second, peaks[t].second) - 32;
-                if (lts_offset < 0) break;
-                hist_[lts_offset + 24].tag = kLts1;               // may overwrite a pending STS_END
+                const int lts_offset = std::min(peaks[0].second, peaks[t].second) - 32;       // index into hist_; may be negative here
+                // timing_sync.cpp:99 `if(lts_offset < 0) break;` is relative to the working buffer of the CALL that examines this
+                // STS_END (160 carried-over samples + the call's own): the reference drops an alignment whose LTS guard interval
+                // would start before that buffer.  Which sample a call's buffer starts with depends on how the stream is cut into
+                // calls -- the reference's receiver cuts it every NUM_RX_SAMPLES = 4096 (receiver.h:16) -- not on how it is pushed
+                // here: x's index in that buffer is (stream index + 160) mod call.
+                const int64_t x_in = sync_call_index(origin + (int64_t)x, call_);
+                if (x_in + (int64_t)lts_offset - (int64_t)x < 0) break;
+                if (lts_offset + 24 >= 0) hist_[lts_offset + 24].tag = kLts1;           // may overwrite a pending STS_END (one behind x is never read again)
                 hist_[lts_offset + 24 + 64].tag = kLts2;
                 const std::complex<double> v = hist_[lts_offset + 32 + 128 - 1].v * lts_conj_[63];
                 const double prev = phase_acc_;
@@ -148,6 +167,9 @@ public:
         consumed_ += (int64_t)n;
     }
 
+    // The call size of the reference's receiver to decide by (timing_sync.cpp:99, above); 0: as ONE call over the whole stream would.
+    void set_call(int64_t call) { call_ = call; }
+
     // Everything up to this stream index has been walked by timing_sync (alignments whose STS_END lies
     // before it have been reported).
     int64_t settled() const { return consumed_ - (int64_t)kCarry; }
@@ -156,6 +178,7 @@ public:
 private:
     enum { kNone = 0, kStsStart = 1, kStsEnd = 2, kLts1 = 4, kLts2 = 5 };
     static constexpr size_t kCarry = 160;
+    int64_t call_ = kSyncCallDefault;
     struct Tagged { std::complex<double> v{ 0, 0 }; int tag = 0; };
 
     // frame_detector.cpp:51-84, one sample

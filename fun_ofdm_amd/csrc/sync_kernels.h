@@ -18,6 +18,7 @@
 #pragma once
 
 #include "frontend_kernels.h"
+#include "sync_host.h"
 
 namespace foa {
 
@@ -278,8 +279,9 @@ __device__ __forceinline__ void wave_argmax(double &v, int &p)
 }
 
 // timing_sync.cpp:69-113 for one STS_END candidate per wave
+// origin: stream index of iq[0]; call: the reference receiver's call size to decide timing_sync.cpp:99 by (sync_host.h), 0 = one call
 __global__ __launch_bounds__(64) void k_sync_lts(const float2 *__restrict__ iq, int64_t n, const int64_t *__restrict__ cand_x, const int32_t *__restrict__ n_cand,
-                                                  int32_t cap, SyncCand *__restrict__ out)
+                                                  int32_t cap, SyncCand *__restrict__ out, int64_t origin, int64_t call)
 {
 #pragma clang fp contract(off)
     const int lane = threadIdx.x, nc = min(*n_cand, cap);
@@ -329,7 +331,8 @@ __global__ __launch_bounds__(64) void k_sync_lts(const float2 *__restrict__ iq, 
         if (abs(pk[0] - pk[t]) != 64) continue;
         // positions are relative to x; the reference's working buffer starts 160 samples before the stream
         const int64_t lts_offset = x + min(pk[0], pk[t]) - 32;
-        if (lts_offset < -160) break;
+        // timing_sync.cpp:99: the LTS guard interval would start before the working buffer of the call that walks over x
+        if (sync_call_index(origin + x, call) + min(pk[0], pk[t]) - 32 < 0) break;
         const cpx a = at(lts_offset + 159);
         const cpx m = cmul(a, cpx{ g_tab.lts_conj_re[63], g_tab.lts_conj_im[63] });
         const double phase = atan2(m.y, m.x);            // timing_sync.cpp:113

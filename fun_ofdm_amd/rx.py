@@ -272,9 +272,12 @@ class Sync:
     """Streaming frame_detector + timing_sync on the host (foa_sync_*): push raw samples, get alignment
     descriptors with stream-absolute positions."""
 
-    def __init__(self):
+    def __init__(self, call=4096):
+        """call: the reference receiver's call size by which timing_sync.cpp:99 is decided (foa_sync_set_call); 0 = as one call."""
         self._h = C.c_void_p()
         check(lib().foa_sync_create(C.byref(self._h)))
+        if call != 4096:
+            check(lib().foa_sync_set_call(self._h, int(call)))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -305,9 +308,9 @@ class Sync:
         return int(lib().foa_sync_settled(self._h))
 
 
-def find_alignments(iq, flush=True):
+def find_alignments(iq, flush=True, call=4096):
     """One-shot sync over a whole stream (plus 160 zeros so that the tail is examined)."""
-    s = Sync()
+    s = Sync(call)
     d = [s.push(iq)]
     if flush:
         z = np.zeros(4096, iq.dtype if iq.dtype in (np.complex64, np.complex128) else np.complex64)

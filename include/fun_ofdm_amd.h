@@ -114,6 +114,8 @@ int foa_rx_reserve(foa_rx *rx, size_t n_samples, size_t n_frames);
  *   "frontend"    2 = four lanes per data symbol (frontend_q4.h), -1 (default) = 2: fastest alone, and its small waves run under the
  *                 previous call's forward pass when calls are pipelined; cross-check build: 0 = one wave per data symbol,
  *                 1 = one lane per data symbol; all three give bit-identical results
+ *   "sync_call"   foa_rx_sync_dev / the stream engine: the reference call size by which timing_sync.cpp:99 is decided (foa_sync_set_call, below);
+ *                 default 4096 = receiver.h:16, 0 = as one call over the whole stream.  foa_rx_sync_dev takes d_iq[0] as stream index 0.
  *   "sync_flags"  foa_rx_sync_dev's frame_detector kernel: 1 (default, the only shipped value) = a lane owns sixteen consecutive windows and sums
  *                 them as tail of one group + head of the next; cross-check build: 0 = every window summed directly, term by term
  *   "record_soft" keep the depunctured soft bytes for foa_rx_get_taps (default 1; 0 saves their HBM writes)
@@ -211,6 +213,13 @@ int foa_sync_push_f32(foa_sync *s, const float *iq, size_t n_samples, foa_frame_
 int foa_sync_push_f64(foa_sync *s, const double *iq, size_t n_samples, foa_frame_desc *out, size_t cap, size_t *n_out);
 /* Stream index up to which timing_sync has looked (it trails the input by 160 samples). */
 int64_t foa_sync_settled(const foa_sync *s);
+/* One line of timing_sync depends on how the stream is cut into CALLS: `if(lts_offset < 0) break;` (timing_sync.cpp:99) drops an
+ * alignment whose LTS guard interval would start before the working buffer of the call that walks over its STS_END -- with the STS_END
+ * tag usually a sample or two late, that is a frame whose STS ends exactly 160 samples before a call boundary.  The reference's receiver
+ * cuts the stream every NUM_RX_SAMPLES = 4096 (receiver.h:16), and that is what the pre-sync decides by -- on the host and on the device,
+ * whatever the chunk sizes it is fed with -- unless told otherwise: call = the reference call size to reproduce (> 160), or 0 = decide
+ * as ONE call over the whole stream would (no alignment is ever dropped for that reason).  Device side: option "sync_call". */
+int foa_sync_set_call(foa_sync *s, int64_t call);
 
 /* The same two blocks on the DEVICE, over a stream that is already resident in HBM: fills d_descs / d_ends (device
  * pointers, capacity cap) in stream order and returns the number of alignments in *n_found (synchronises).  The decisions

@@ -14,7 +14,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, __file__.rsplit("/", 2)[0])
+sys.path.insert(0, __file__.rsplit("/", 3)[0])
 import fun_ofdm_amd as foa                      # noqa: E402
 from fun_ofdm_amd import synth                  # noqa: E402
 from oracle import pyoracle as po               # noqa: E402

@@ -707,6 +707,57 @@ def test_device_sync_edge_inputs(rx):
         assert (got[n * 48:] == 0xA5).all() and (t_ends.cpu().numpy()[n:] == -7).all()
 
 
+def test_device_sync_decides_timing_sync_99_by_the_reference_call_size(rx, po):
+    """The device pre-sync drops the alignment the reference drops at a boundary of its 4096-sample calls (`if(lts_offset < 0) break;`,
+    timing_sync.cpp:99; tests/test_synth.py has the host side of this), keeps it when told to decide as one call (option
+    "sync_call" 0), and a stream engine fed in chunks of any size drops the same frame."""
+    import torch
+    import fun_ofdm_amd as foa
+    from fun_ofdm_amd import synth
+    dev = torch.device("cuda", 0)
+    pays = synth.splitmix64_bytes(31, 3, 100)
+    iq, _ = synth.make_stream(synth.build_frames(pays, 5), pitch=3000, lead=500, snr_db=25.0, seed=8)
+    base = foa.find_alignments(iq, call=0)
+    x = int(base["rot_start"][1])
+    rel = int(base["lts1_pos"][1]) - 24 + 32 - x
+    assert base.size == 3 and 0 < rel < 32
+
+    def device(stream):
+        t_iq = torch.from_numpy(stream.view(np.float32).reshape(-1, 2)).to(dev)
+        t_desc = torch.zeros(64 * 48, dtype=torch.uint8, device=dev)
+        t_ends = torch.zeros(64, dtype=torch.int64, device=dev)
+        n = rx.sync_dev(t_iq, t_desc, t_ends)
+        return t_desc.cpu().numpy()[:n * 48].view(foa.frame_desc_dtype).copy()
+
+    dropped_somewhere = False
+    for late in range(0, 4):
+        pad = (-(x + 160) + late) % 4096
+        s = np.concatenate([np.zeros(pad, np.complex64), iq])
+        want = po.find_alignments_f32(s)
+        dropped = late + rel < 32
+        dropped_somewhere |= dropped
+        assert want.size == (2 if dropped else 3)
+        got = device(s)
+        assert got.size == want.size and np.array_equal(got["lts1_pos"], want["lts1_pos"]) and np.array_equal(got["rot_start"], want["rot_start"]), late
+        rx.set_option("sync_call", 0)
+        assert device(s).size == 3
+        rx.set_option("sync_call", 4096)
+        if dropped:                                      # the stream engine: absolute positions, not buffer positions, decide
+            r = foa.Receiver(0)
+            st = foa.Stream(r, 8192, 2)
+            got_p, i, rng = [], 0, np.random.default_rng(late)
+            while i < s.size:
+                n = int(rng.integers(1, 5000))
+                got_p += st.push(s[i:i + n])
+                i += n
+            got_p += st.flush()
+            st.close(); r.close()
+            assert got_p == [pays[0].tobytes(), pays[2].tobytes()]
+    assert dropped_somewhere
+    with pytest.raises(foa.FoaError):
+        rx.set_option("sync_call", 100)
+
+
 def test_device_sync_non_finite_samples(rx, po):
     """NaN and infinite samples.  A NaN costs the reference exactly the two products it is part of: circular_accumulator.h:88-95
     takes a NaN sample in as zero.  The device stage does the same (a window whose quick test is not finite is summed again term by

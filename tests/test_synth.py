@@ -61,6 +61,49 @@ def test_host_sync_equals_oracle_sync(po, golden):
     assert foa.find_alignments(iq.astype(np.complex128)).tobytes() == want.tobytes()
 
 
+def _same_alignments(a, b):
+    return a.size == b.size and np.array_equal(a["lts1_pos"], b["lts1_pos"]) and np.array_equal(a["rot_start"], b["rot_start"]) and \
+        (a.size == 0 or max(np.abs(a[k] - b[k]).max() for k in ("c", "s", "c_prev", "s_prev")) < 1e-12)
+
+
+def test_host_sync_decides_timing_sync_99_by_the_reference_call_size(po):
+    """`if(lts_offset < 0) break;` (timing_sync.cpp:99) is relative to the working buffer of the call that walks over an STS_END: the
+    reference drops an alignment whose LTS guard interval would start before it -- with the STS_END tag a sample or two late (the usual
+    case), a frame whose STS_END is the first sample a call walks over, i.e. lies 160 samples before a call boundary.  The reference's
+    receiver makes its calls 4096 samples long (receiver.h:16), and so does the oracle's one-shot.  The host restatement must drop the
+    same frame, HOWEVER it is pushed; told to decide as one call (call = 0) it keeps it."""
+    pays = synth.splitmix64_bytes(31, 3, 100)
+    frames = synth.build_frames(pays, 5)
+    iq, _ = synth.make_stream(frames, pitch=3000, lead=500, snr_db=25.0, seed=8)
+    base = foa.find_alignments(iq, call=0)
+    assert base.size == 3
+    x = int(base["rot_start"][1])                        # STS_END sample of the middle frame
+    rel = int(base["lts1_pos"][1]) - 24 + 32 - x         # its strongest LTS peak, relative to x
+    assert 0 < rel < 32                                  # the tag is late: the guard interval starts before x
+    hits = 0
+    for late in range(0, 4):                             # x lands on input index 0, 1, 2, 3 of a call's buffer
+        pad = (-(x + 160) + late) % 4096
+        s = np.concatenate([np.zeros(pad, np.complex64), iq])
+        want = po.find_alignments_f32(s)                 # the reference's blocks, 4096 samples per call
+        dropped = late + rel < 32
+        hits += dropped
+        assert want.size == (2 if dropped else 3), (late, rel, want.size)
+        assert _same_alignments(foa.find_alignments(s), want), late
+        assert foa.find_alignments(s, call=0).size == 3
+        rng = np.random.default_rng(late)
+        sy, got, i = foa.Sync(), [], 0
+        while i < s.size:                                # pushed in pieces that have nothing to do with 4096
+            n = int(rng.integers(1, 7000))
+            got.append(sy.push(s[i:i + n]))
+            i += n
+        got.append(sy.push(np.zeros(4096, np.complex64)))
+        got = np.concatenate(got)
+        assert _same_alignments(got[got["lts1_pos"] < s.size], want), late
+        # another call size moves the boundary: 4000-sample calls keep the frame here, and drop it where THEIR boundary falls
+        assert foa.find_alignments(s, call=4000).size == 3 or (x + pad + 160 - late) % 4000 < 4
+    assert hits >= 1
+
+
 def test_library_exports_every_declared_symbol():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     hdr = open(os.path.join(root, "include", "fun_ofdm_amd.h")).read()
