@@ -2,7 +2,7 @@
 SAME descriptors: true alignments shifted by a few samples (so that SIGNAL fields decode to other rates and lengths, or not at all),
 phasors off the unit circle, ends cut anywhere (truncated frames), positions in noise, in the middle of payloads, at the very start
 and end of the stream; SNR from 4 dB up.  Status, rate, length, symbol count and every PSDU that passes must be identical.
-Usage (GPU box, from the repo root): python3 tests/manual/stress_decode.py [first seed] [last seed]"""
+Usage (GPU box, from the repo root): python3 tests/manual/stress_decode.py [first seed] [last seed] [amplitude exponent range, default 0.5]"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -13,6 +13,7 @@ from oracle import pyoracle as po
 
 lo = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 hi = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+amp = float(sys.argv[3]) if len(sys.argv) > 3 else 0.5
 rx = foa.Receiver(0)
 bad = 0
 tot = 0
@@ -22,7 +23,7 @@ for seed in range(lo, hi):
     parts = [np.zeros(int(rng.integers(0, 500)), complex)]
     for i in range(int(rng.integers(2, 25))):
         pay = synth.splitmix64_bytes(seed * 1000 + i, 1, int(rng.choice((0, 1, int(rng.integers(2, 300)), int(rng.integers(300, 1500))))))[0]
-        f = synth.build_frames(pay[None, :], int(rng.integers(0, 11)))[0] * np.exp(1j * rng.uniform(0, 6.28)) * 10 ** rng.uniform(-0.5, 0.5)
+        f = synth.build_frames(pay[None, :], int(rng.integers(0, 11)))[0] * np.exp(1j * rng.uniform(0, 6.28)) * 10 ** rng.uniform(-amp, amp)
         if rng.random() < 0.5:
             f = f * np.exp(2j * np.pi * rng.uniform(-4500, 4500) * np.arange(f.size) / 20e6)
         snr = rng.uniform(4.0, 30.0)
