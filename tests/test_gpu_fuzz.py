@@ -1,0 +1,42 @@
+"""Short runs of the random differential checkers of tests/manual/ (the long runs are recorded in profiles/r03_soak.txt): every
+random input must come out of the HIP path exactly as it comes out of the oracle.  GPU only."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "manual"))
+
+
+def test_random_streams_presync_device_host_and_oracle_agree(po):
+    """Device pre-sync (blocking and in two halves), host restatement and the oracle's blocks in 4096-sample calls: the same alignments on
+    random streams (frames at 3 .. 30 dB, gaps from none, ends anywhere, a NaN sample in a fifth of them), the frames the reference drops at
+    its call boundaries (timing_sync.cpp:99) included."""
+    import stress_sync
+    tot, bad, host_bad = stress_sync.run(100, 260)
+    assert bad == 0 and host_bad == 0 and tot > 800
+
+
+def test_random_streams_stream_engine_equals_oracle_chain(po):
+    """process_samples on the device (random push and batch sizes) against the oracle's receiver_chain: equal ordered payload lists."""
+    import stress_stream
+    tot, bad = stress_stream.run(200, 300)
+    assert bad == 0 and tot > 300
+
+
+def test_random_soft_byte_blocks_through_the_viterbi_path(po):
+    """Seven soft-byte distributions, 1 .. 32 900 data bits, 1 .. 9 blocks per call, random chain-back segmentation: the oracle's decoder,
+    and the compiled reference's when oracle/_ref is there."""
+    import stress_viterbi
+    nblocks, bad, _ = stress_viterbi.run(40000, 40150)
+    assert bad == 0 and nblocks > 400
+
+
+def test_perturbed_alignment_descriptors_decode_like_the_oracle(po):
+    """Shifted positions, phasors off the unit circle, ends cut anywhere, positions at random -- also with frame amplitudes over twelve decades."""
+    import stress_decode
+    tot, passed, bad = stress_decode.run(50000, 50150)
+    assert bad == 0 and tot > 1500 and passed > 100
+    tot, passed, bad = stress_decode.run(51000, 51060, 6.0)
+    assert bad == 0 and tot > 300
