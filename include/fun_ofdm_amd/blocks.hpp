@@ -327,6 +327,16 @@ public:
     receiver_chain(const receiver_chain &) = delete;
     receiver_chain &operator=(const receiver_chain &) = delete;
 
+    // One line of the reference depends on how ITS caller cuts the stream into calls: timing_sync.cpp:99 drops a frame whose STS_END is the
+    // first sample a call walks over (include/fun_ofdm_amd.h, foa_sync_set_call).  This chain decides it for the call size of the
+    // reference's own receiver, 4096 samples (receiver.h:16), whatever the sizes process_samples() is called with; a caller that replaces a
+    // reference fed with another call size says so here before the first call (0: never drop a frame for that reason).
+    void set_reference_call_size(long long samples)
+    {
+        if (sync_) check(foa_sync_set_call(sync_, samples), "foa_sync_set_call");
+        check(foa_rx_set_option(dev_.get(), "sync_call", samples), "foa_rx_set_option");
+    }
+
     // Same signature and meaning as fun::receiver_chain::process_samples (src/receiver_chain.cpp:106-126): feed the
     // next chunk of the 20 MS/s stream, get the payloads of the frames that completed, in stream order.  A frame is
     // returned by the call that delivers its last sample (the reference returns it five calls later).

@@ -77,6 +77,7 @@ int main()
     }
     for (int k : { 1, 3, 8 }) {
         fun_amd::receiver_chain rc(0, k);
+        rc.set_reference_call_size(4096);
         payloads_t got;
         for (size_t x = 0; x < stream.size(); x += 4096) {
             const size_t n = std::min((size_t)4096, stream.size() - x);

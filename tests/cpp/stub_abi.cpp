@@ -80,6 +80,8 @@ void foa_sync_destroy(foa_sync *s) { delete s; }
 int foa_sync_push_f32(foa_sync *s, const float *iq, size_t n, foa_frame_desc *out, size_t cap, size_t *n_out) { return sync_push(s, iq, n, out, cap, n_out); }
 int foa_sync_push_f64(foa_sync *s, const double *iq, size_t n, foa_frame_desc *out, size_t cap, size_t *n_out) { return sync_push(s, iq, n, out, cap, n_out); }
 int64_t foa_sync_settled(const foa_sync *s) { return s ? s->impl.settled() : 0; }
+int foa_sync_set_call(foa_sync *s, int64_t call) { if (!s) return FOA_E_INVALID; s->impl.set_call(call); return FOA_OK; }
+int foa_rx_set_option(foa_rx *, const char *, int64_t) { return FOA_OK; }
 
 // foa_stream_*: the wrapper logic of fun_amd::receiver_chain's device mode is what runs here; the engine itself (batches on the
 // GPU) is replaced by "collect everything, pre-sync on the host and decode with the oracle at the flush"
