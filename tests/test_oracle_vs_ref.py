@@ -120,3 +120,35 @@ def test_blocks_on_noisy_cfo_stream():
         assert np.array_equal(g["tag"], h["tag"]) and np.array_equal(g["samples"], h["samples"], equal_nan=True)
         got += dec.work(g)
     assert len(got) == 5
+
+
+def test_timing_sync_drops_the_frame_at_a_call_boundary_like_the_real_one():
+    """timing_sync.cpp:99 (`if(lts_offset < 0) break;`) in the COMPILED reference: a frame whose STS_END tag is the first sample a
+    4096-sample call walks over, and a sample late, is dropped -- and found again when the same stream is shifted by four samples.
+    The oracle's blocks agree tag for tag; this is the behaviour the library's pre-sync reproduces by stream index
+    (tests/test_synth.py, tests/test_gpu_parity.py)."""
+    import fun_ofdm_amd as foa
+    from fun_ofdm_amd import synth
+    pays = synth.splitmix64_bytes(31, 3, 100)
+    iq, _ = synth.make_stream(synth.build_frames(pays, 5), pitch=3000, lead=500, snr_db=25.0, seed=8)
+    base = foa.find_alignments(iq, call=0)
+    x = int(base["rot_start"][1])
+    rel = int(base["lts1_pos"][1]) - 24 + 32 - x
+    assert base.size == 3 and 0 < rel < 32
+    found = {}
+    for late in (0, 4 + 32):
+        pad = (-(x + 160) + late) % 4096
+        s = np.concatenate([np.zeros(pad), iq.astype(np.complex128)])
+        n = (s.size // 4096 + 2) * 4096
+        s = np.concatenate([s, np.zeros(n - s.size)])
+        fd_o, ts_o, fd_r, ts_r = po.FrameDetector(), po.TimingSync(), R.Block("frame_detector"), R.Block("timing_sync")
+        lts1 = 0
+        for c in range(0, n, 4096):
+            a, b = fd_o.work(s[c:c + 4096]), fd_r.work(s[c:c + 4096])
+            assert np.array_equal(a["tag"], b["tag"])
+            u, v = ts_o.work(a), ts_r.work(b)
+            assert np.array_equal(u["tag"], v["tag"]) and np.array_equal(u["sample"], v["sample"])
+            lts1 += int(np.count_nonzero(v["tag"] == 4))               # LTS1 tags written by the real timing_sync
+        found[late] = lts1
+        assert po.find_alignments_f32(s.astype(np.complex64)).size == lts1
+    assert found == {0: 2, 36: 3}
