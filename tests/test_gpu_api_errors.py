@@ -87,3 +87,33 @@ def test_every_entry_point_refuses_bad_arguments(po):
     psdu, r = rx.decode_frames_host(iq, d, e, slot_bytes=128)
     assert [psdu[k, :100].tobytes() for k in on] == [q.tobytes() for q in pays] and all(r["status"][k] == 0 for k in on)
     rx.close()
+
+
+def test_handles_are_independent_across_threads():
+    """One handle per thread (the header's threading contract): four threads decode different batches at the same time on the same
+    device, each through its own foa_rx; every batch comes out as it does alone."""
+    import threading
+    import fun_ofdm_amd as foa
+    from fun_ofdm_amd import synth
+
+    def work(seed, out):
+        rx = foa.Receiver(0)
+        rng = np.random.default_rng(seed)
+        res = []
+        for k in range(12):
+            pays = synth.splitmix64_bytes(seed * 100 + k, int(rng.integers(5, 150)), int(rng.integers(10, 600)))
+            iq, _ = synth.make_stream(synth.build_frames(pays, int(rng.choice((0, 5, 8, 10)))), 4096 * 5, 200, 25.0, seed=seed + k)
+            d = foa.find_alignments(iq)
+            psdu, r = rx.decode_frames_host(iq, d, foa.alignment_ends(d, iq.size))
+            ok = np.nonzero(r["status"] == 0)[0]
+            res.append([psdu[i, :r["length"][i]].tobytes() for i in ok] == [p.tobytes() for p in pays])
+        rx.close()
+        out[seed] = res
+
+    out = {}
+    th = [threading.Thread(target=work, args=(s, out)) for s in (1, 2, 3, 4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert sorted(out) == [1, 2, 3, 4] and all(all(r) for r in out.values())
