@@ -1,7 +1,7 @@
 """Dev container only (needs /root/reference compiled into oracle/_ref): random streams through the COMPILED reference's
 frame_detector, timing_sync, channel_est and phase_tracker against the oracle's restatements of them, call by call, tag for tag and
 sample for sample (4096 samples per call like the reference's receiver; fft_symbols between them is the oracle's on both sides -- the
-reference's needs FFTW); and random blocks through the compiled codec pieces (puncture / interleave / modulate / demodulate /
+reference's needs FFTW); and random blocks through the compiled codec pieces (puncture / depuncture / interleave / deinterleave / modulate / demodulate /
 conv_encode / conv_decode) against the oracle's.  This pins the ORACLE; the HIP path is pinned against the oracle on the GPU box.
 Usage: python3 tests/manual/stress_oracle_vs_ref.py [first seed] [last seed]"""
 import os
@@ -65,6 +65,15 @@ def run(lo, hi):
         ok = ok and np.array_equal(po.conv_decode(soft, nb), R.conv_decode(soft, nb))
         car = (rng.normal(size=96) + 1j * rng.normal(size=96)) * 10 ** rng.uniform(-3, 3)
         ok = ok and np.array_equal(po.demodulate(car, rate), R.demodulate(car, rate))
+        rp = po.rate_params(rate)
+        k = int(rng.integers(1, 9))
+        by = rng.integers(0, 256, rp["cbps"] * k, dtype=np.uint8)
+        ok = ok and np.array_equal(po.deinterleave(by), R.deinterleave(by)) and np.array_equal(po.interleave(by), R.interleave(by))
+        ok = ok and np.array_equal(po.depuncture(by, rate), R.depuncture(by, rate))
+        bits = rng.integers(0, 2, rp["dbps"] * 2 * k, dtype=np.uint8)
+        ok = ok and np.array_equal(po.puncture(bits, rate), R.puncture(bits, rate))
+        mb = rng.integers(0, 2, rp["cbps"] * k, dtype=np.uint8)
+        ok = ok and np.array_equal(po.modulate(mb, rate), R.modulate(mb, rate))
         if not ok:
             bad += 1
             print("FAIL seed", seed)
