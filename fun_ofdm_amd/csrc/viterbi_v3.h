@@ -61,7 +61,7 @@ __device__ __forceinline__ uint32_t pk_sub_wrap(uint32_t a, uint32_t b)
 #define FOA_ADD_FIRST 1
 #endif
 #ifndef FOA_RN_PRIO
-#define FOA_RN_PRIO 0      // priority of a wave while it renormalises (0: unchanged)
+#define FOA_RN_PRIO 1      // priority of a wave while it renormalises (0: unchanged; profiles/r03_ab_renorm_prio.txt)
 #endif
 #ifndef FOA_FWD_PRIO
 #define FOA_FWD_PRIO 0     // priority of the forward pass's waves (A/B only: 1 .. 3, 4 + p = p and 3 over the last third of a frame; profiles/r03_ab_fwd_prio.txt)
