@@ -336,6 +336,9 @@ __global__ __launch_bounds__(64) void k_header(const float2 *__restrict__ iq, co
     __shared__ cpx lds[64];
     __shared__ uint8_t dem[48];
     __shared__ uint64_t decs[24];
+#if defined(FOA_HDR_PRIO) && FOA_HDR_PRIO
+    __builtin_amdgcn_s_setprio(FOA_HDR_PRIO);          // (A/B only)
+#endif
     const int f = blockIdx.x, lane = threadIdx.x;
     if (f >= n_frames) return;
     const foa_frame_desc d = descs[f];

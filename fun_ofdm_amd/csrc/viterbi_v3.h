@@ -63,6 +63,9 @@ __device__ __forceinline__ uint32_t pk_sub_wrap(uint32_t a, uint32_t b)
 #ifndef FOA_RN_PRIO
 #define FOA_RN_PRIO 1      // priority of a wave while it renormalises (0: unchanged; profiles/r03_ab_renorm_prio.txt)
 #endif
+#ifndef FOA_WALK_PRIO
+#define FOA_WALK_PRIO 0    // priority of the chain-back walk's waves (A/B only; profiles/r03_ab_renorm_prio.txt)
+#endif
 #ifndef FOA_FWD_PRIO
 #define FOA_FWD_PRIO 0     // priority of the forward pass's waves (A/B only: 1 .. 3, 4 + p = p and 3 over the last third of a frame; profiles/r03_ab_fwd_prio.txt)
 #endif
@@ -515,6 +518,9 @@ __global__ __launch_bounds__(64) void k_tb_walk(const FrameInfo *__restrict__ in
                                                 uint32_t *__restrict__ decoded, uint16_t *__restrict__ tb_state, int S, int L)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tb[kTbRing * kTbBlockBytes];
+#if FOA_WALK_PRIO
+    __builtin_amdgcn_s_setprio(FOA_WALK_PRIO);         // (A/B only)
+#endif
     const int lane = threadIdx.x, g = blockIdx.x * 64 + lane;
     const int n_seg = (int)totals[4];
     if (blockIdx.x * 64 >= n_seg) return;
