@@ -43,6 +43,9 @@ static void on_packets(std::vector<std::vector<unsigned char> > packets)
 
 int main(int argc, char **argv)
 {
+    // the host process's part of the set-up (include/fun_ofdm_amd.h, foa_recommended_hw_queues): the HIP runtime fixes its hardware queues
+    // when it starts, i.e. before the library is first called
+    ::setenv("GPU_MAX_HW_QUEUES", std::to_string(foa_recommended_hw_queues()).c_str(), 0);
     std::string path, format = "fc32", out;
     int chunk = 4096, device = 0, async_calls = 0, narrow_threads = 0;
     size_t device_batch = 0;

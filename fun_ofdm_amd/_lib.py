@@ -36,6 +36,8 @@ _SIGS = {
     "foa_version": (C.c_int, []),
     "foa_last_error": (C.c_char_p, []),
     "foa_device_count": (C.c_int, []),
+    "foa_recommended_hw_queues": (C.c_int, []),
+    "foa_rx_notes": (C.c_char_p, [C.c_void_p]),
     "foa_rx_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "foa_rx_destroy": (None, [C.c_void_p]),
     "foa_rx_reserve": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t]),

@@ -197,6 +197,9 @@ struct foa_rx {
                                        // data symbols (lanes off)
     hipStream_t stream4 = nullptr;     // the second lane of pipelined calls (the first is `stream`)
     hipStream_t stream5 = nullptr, stream6 = nullptr;      // third and fourth lane, used for small grids (option "depth")
+    int hw_queues = 4, max_depth = 4;  // hardware queues the runtime was started with, as far as the environment tells (foa_rx_create), and the depth they allow
+    std::string notes;                 // non-fatal remarks about how the handle is set up (foa_rx_notes)
+    int64_t sync_origin = 0;           // one-shot device pre-sync: stream index of d_iq[0] (option "sync_origin")
     int depth = 0;                     // lanes: how many calls' loops are in flight; 0 = by grid size (2, or 4 below kDeepBelow frames)
     int depth_saved = -1;              // (the stream engine pins 2 while a stream is open and restores this)
     unsigned n_calls = 0;              // pipelined decode calls made so far (a call's lane is n_calls mod depth)
@@ -357,13 +360,14 @@ int foa_device_count(void)
     return n;
 }
 
+int foa_recommended_hw_queues(void) { return 8; }
+
+const char *foa_rx_notes(foa_rx *rx) { return rx ? rx->notes.c_str() : ""; }
+
 int foa_rx_create(foa_rx **out, int device)
 {
     if (!out) return fail(FOA_E_INVALID, "out is NULL");
     *out = nullptr;
-    // six streams want six hardware queues (lane_stream above); the runtime reads this when it starts, so it only takes effect in a
-    // process whose first HIP call is this one -- others set it themselves
-    (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(FOA_E_NO_DEVICE, "no HIP device (this library has no CPU path)");
     if (device < 0 || device >= n) return fail(FOA_E_INVALID, "device %d out of range (0..%d)", device, n - 1);
@@ -373,6 +377,22 @@ int foa_rx_create(foa_rx **out, int device)
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(FOA_E_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
     foa_rx *rx = new foa_rx();
     rx->device = device;
+    // Six streams want six hardware queues (lane_stream above).  The runtime reads GPU_MAX_HW_QUEUES once, when it starts, so it is the
+    // HOST PROCESS that sets it (foa_recommended_hw_queues(); bench.py and examples/foa_sim.cpp do) -- a library does not edit its
+    // host's environment.  What the variable says now is all that can be known here: with fewer than six queues four lanes would
+    // share queues and run one after the other, so small grids then keep two loops in flight and the handle says so (foa_rx_notes).
+    {
+        const char *q = getenv("GPU_MAX_HW_QUEUES");
+        rx->hw_queues = (q && atoi(q) > 0) ? atoi(q) : 4;             // (the runtime's default)
+        if (rx->hw_queues < 6) {
+            rx->max_depth = 2;
+            char buf[320];
+            snprintf(buf, sizeof buf, "GPU_MAX_HW_QUEUES is %s (%d hardware queues): decode calls of fewer than %d frames keep 2 loops in flight instead of 4 "
+                     "(20-30 %% slower for such batches); set GPU_MAX_HW_QUEUES=%d in the environment before the HIP runtime starts. ",
+                     q ? "set low" : "unset", rx->hw_queues, kDeepBelow, foa_recommended_hw_queues());
+            rx->notes += buf;
+        }
+    }
     HIP_TRY(hipStreamCreateWithFlags(&rx->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&rx->stream2, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&rx->stream3, hipStreamNonBlocking));
@@ -469,6 +489,8 @@ int foa_rx_set_option(foa_rx *rx, const char *name, int64_t value)
     if (!strcmp(name, "depth")) {
         if (value != 0 && (value < 2 || value > 4)) return fail(FOA_E_INVALID, "depth must be 0 (by grid size), 2, 3 or 4");
         rx->depth = (int)value;
+        if (value > rx->max_depth && rx->notes.find("option depth") == std::string::npos)
+            rx->notes += "option depth exceeds what the hardware queues the runtime started with can run side by side: lanes will share queues. ";
         return FOA_OK;
     }
     if (!strcmp(name, "lanes")) { int rc0 = drain(rx); if (rc0) return rc0; rx->lanes = value != 0; return FOA_OK; }
@@ -481,7 +503,14 @@ int foa_rx_set_option(foa_rx *rx, const char *name, int64_t value)
     if (!strcmp(name, "walk_lane")) { int rc0 = drain(rx); if (rc0) return rc0; rx->walk_on_lane = value != 0; return FOA_OK; }
     if (!strcmp(name, "sync_call")) {
         if (value != 0 && value <= 160) return fail(FOA_E_INVALID, "sync_call must be 0 (decide as one call over the whole stream) or > 160 (timing_sync.cpp:55)");
+        if (rx->open_stream) return fail(FOA_E_STATE, "sync_call cannot change while a stream engine is open on the handle (its submitter thread reads it)");
         rx->sync_call = value;
+        return FOA_OK;
+    }
+    if (!strcmp(name, "sync_origin")) {
+        if (value < 0) return fail(FOA_E_INVALID, "sync_origin is a stream index (>= 0)");
+        if (rx->open_stream) return fail(FOA_E_STATE, "sync_origin cannot change while a stream engine is open on the handle");
+        rx->sync_origin = value;
         return FOA_OK;
     }
     if (!strcmp(name, "sync_flags")) {
@@ -545,7 +574,7 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
     // scan and data symbols of call k+2, forward pass k+2 -- is then one in-order stream with no event packet in it; with the front
     // end on the third stream and the walk on the second, every hand-over between them cost 20-26 us, about 90 us per loop.
     const bool lanes = piped && rx->lanes;
-    const int depth = !lanes ? 2 : rx->depth > 0 ? rx->depth : (n_frames < (size_t)kDeepBelow ? 4 : 2);
+    const int depth = !lanes ? 2 : rx->depth > 0 ? rx->depth : (n_frames < (size_t)kDeepBelow ? std::min(4, rx->max_depth) : 2);
     hipStream_t st_fwd = piped ? lane_stream(rx, (int)(rx->n_calls++ % (unsigned)depth)) : rx->stream;
     hipStream_t st = piped ? (lanes ? st_fwd : rx->stream3) : rx->stream;
     // Under one forward pass first the chain-back walk of the call before, then the front end of the call after: the two
@@ -940,13 +969,13 @@ int foa_rx_sync_dev_begin(foa_rx *rx, const float *d_iq, size_t n_samples, foa_f
     if (!rx->sy_done) HIP_TRY(hipEventCreateWithFlags(&rx->sy_done, hipEventDisableTiming));
     rx->sy_pin[0] = rx->sy_pin[1] = rx->sy_pin[2] = rx->sy_pin[3] = 0;
     rx->sy_cap = cap; rx->sy_ccap = 0;
-    rx->sy_open = true;
-    if (n_samples == 0 || cap == 0) { rx->sy_cap = 0; return FOA_OK; }          // (nothing queued; _end reports 0)
-    { int rc = sync_dev_issue(rx, d_iq, n_samples, d_descs, d_ends, cap, &rx->sy_ccap); if (rc) { rx->sy_open = false; return rc; } }
+    if (n_samples == 0 || cap == 0) { rx->sy_cap = 0; rx->sy_open = true; return FOA_OK; }          // (nothing queued; _end reports 0)
+    { int rc = sync_dev_issue(rx, d_iq, n_samples, d_descs, d_ends, cap, &rx->sy_ccap, rx->sync_origin); if (rc) return rc; }
     hipStream_t st = side_stream(rx);
     HIP_TRY(hipMemcpyAsync(rx->sy_pin, rx->sy_n.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(rx->sy_done, st));
     HIP_TRY(hipGetLastError());
+    rx->sy_open = true;              // only now: a pre-sync whose launch failed half-way is not "in flight" (its _end would report an empty batch as a success)
     return FOA_OK;
 }
 

@@ -87,6 +87,7 @@ public:
     int push(const T *iq, size_t n, release_fn release, void *ctx)
     {
         const int64_t st0 = stats_on_ ? now_ns() : 0;
+        caller_seq_.fetch_add(1, std::memory_order_relaxed);
         release_parked();
         const int rc = push_impl(iq, n, release, ctx);
         if (stats_on_) { st_push_ns_ += now_ns() - st0; st_pushes_++; }
@@ -99,7 +100,10 @@ public:
         if (finished_) { if (release) release(ctx); return -5; }
         if (int e = error_flag_.load(std::memory_order_acquire)) { if (release) release(ctx); return e; }
         Owner *own = nullptr;
-        if (release) { own = new Owner; own->refs.store(1, std::memory_order_relaxed); own->release = release; own->ctx = ctx; }
+        if (release) {
+            own = new Owner; own->refs.store(1, std::memory_order_relaxed); own->release = release; own->ctx = ctx;
+            own->big = n * (sizeof(T) * 2) >= kBigOwner;
+        }
         const bool defer = own != nullptr && !helpers_.empty();
         int rc = 0;
         while (n && !rc) {
@@ -109,8 +113,15 @@ public:
             Task t;
             t.src = iq; t.is_double = sizeof(T) == sizeof(double); t.dst = be_->staging(slot) + 2 * fill_; t.n = take; t.slot = slot; t.owner = own; t.landed = nullptr;
             if (defer) {
-                own->refs.fetch_add(1, std::memory_order_relaxed);
-                if (!try_push(t)) { st_inline_++; run_task(t, true); }           // the queue is full: the helpers are behind, narrow this one here
+                // in slices of kPiece samples, each with its own reference to the buffer: a call of a million samples is then narrowed by
+                // every helper at once instead of by one (round 3: calls of >= 65536 samples ran at the rate of ONE helper), and the
+                // caller still returns without touching a sample
+                for (size_t o = 0; o < take; o += kPiece) {
+                    Task p = t;
+                    p.src = (const char *)t.src + o * (2 * sizeof(T)); p.dst = t.dst + 2 * o; p.n = std::min(kPiece, take - o);
+                    own->refs.fetch_add(1, std::memory_order_relaxed);
+                    if (!try_push(p)) { st_inline_++; run_task(p, true); }       // the queue is full: the helpers are behind, narrow this one here
+                }
             } else if (!helpers_.empty() && take >= 65536) {
                 split_and_wait(t);
             } else {
@@ -127,6 +138,7 @@ public:
 
     int flush()
     {
+        caller_seq_.fetch_add(1, std::memory_order_relaxed);
         release_parked();
         if (finished_) return 0;
         publish();
@@ -139,7 +151,9 @@ public:
     // 1: *out = the payloads of the oldest finished batch; 0: nothing finished (wait: and nothing outstanding); < 0: error
     int take(bool wait, StreamReady *out)
     {
+        caller_seq_.fetch_add(1, std::memory_order_relaxed);
         release_parked();
+        if (wait) publish();                                   // (a caller about to sleep must not sit on unpublished tasks)
         // (the common call -- "anything finished?" after every push -- answers from one atomic, without the lock)
         if (!wait && ready_n_.load(std::memory_order_acquire) == 0) return error_flag_.load(std::memory_order_acquire);
         std::unique_lock<std::mutex> lk(m_);
@@ -194,7 +208,13 @@ private:
         (void)pthread_setaffinity_np(submitter_.native_handle(), sizeof want, &want);
 #endif
     }
-    struct Owner { std::atomic<int> refs; release_fn release; void *ctx; Owner *next; };
+    struct Owner { std::atomic<int> refs; release_fn release; void *ctx; Owner *next; bool big; };
+    // A buffer of kBigOwner bytes or more is the allocator's own mapping (glibc: mmap from 128 KB), no arena is involved in freeing it, and
+    // giving it back costs a munmap -- a quarter of a microsecond per page: 0.1-0.3 s for the 3.5 GB of a 220 M-sample capture handed over
+    // in calls of 65536 samples or more.  Parked for the caller (below) that was the caller's time, and the reason why such calls ran at
+    // 0.64-0.70 Gsample/s in round 3 against 4 with calls of 4096; the helper that drops the last reference releases such a buffer itself.
+    static constexpr size_t kBigOwner = 128 * 1024;
+    static constexpr size_t kPiece = 16384;          // samples per narrowing task of a large push
     struct Task { const void *src; bool is_double; float *dst; size_t n; int slot; Owner *owner; std::atomic<int64_t> *landed; };
     struct Cell { std::atomic<uint64_t> seq; Task task; };
     static constexpr size_t kRing = 1 << 14;
@@ -207,7 +227,7 @@ private:
     void drop_owner(Owner *o, bool on_caller = true)
     {
         if (!o || o->refs.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
-        if (on_caller) { release_now(o); return; }
+        if (on_caller || o->big) { release_now(o); return; }
         Owner *h = parked_.load(std::memory_order_relaxed);
         do { o->next = h; } while (!parked_.compare_exchange_weak(h, o, std::memory_order_release, std::memory_order_relaxed));
     }
@@ -263,7 +283,7 @@ private:
     // a large push without ownership: the helpers share it, the caller waits until it is through
     void split_and_wait(const Task &t)
     {
-        const size_t piece = 16384;
+        const size_t piece = kPiece;
         std::atomic<int64_t> landed(0);
         for (size_t o = 0; o < t.n; o += piece) {
             Task p = t;
@@ -285,20 +305,31 @@ private:
     // of the queue, i.e. the very line the caller writes next, and with the helpers on other core complexes every such store first
     // has to pull the line back from them -- at 4096-sample pushes that was most of the caller's two microseconds.  Whatever is
     // written but not yet published goes out when a batch closes, on flush() and on every error path; samples of an OPEN batch may
-    // therefore sit unnarrowed (and owned buffers unreleased) until the next few pushes -- nothing waits for an open batch.
+    // therefore sit unnarrowed (and owned buffers unreleased) until the next few pushes, or, when the caller makes no further call at all,
+    // until the submitter thread notices (within half a millisecond; tests/cpp/stream_core_test.cpp, pooled producer).
     static constexpr uint64_t kPublish = 16;
     bool try_push(const Task &t)
     {
-        Cell &c = ring_[tail_ & (kRing - 1)];
-        if (c.seq.load(std::memory_order_acquire) != tail_) { publish(); return false; }             // full
+        const uint64_t tail = tail_.load(std::memory_order_relaxed);                                   // (the caller is the only writer)
+        Cell &c = ring_[tail & (kRing - 1)];
+        if (c.seq.load(std::memory_order_acquire) != tail) { publish(); return false; }              // full
         c.task = t;
-        tail_++;
-        if (tail_ - pub_ >= kPublish) publish();
+        tail_.store(tail + 1, std::memory_order_release);
+        if (tail + 1 - pub_.load(std::memory_order_relaxed) >= kPublish) publish();
         return true;
     }
+    // Makes every written cell visible.  The caller does it every kPublish cells and wherever it is about to wait; the SUBMITTER does it
+    // too, when cells have sat unpublished over two of its wake-ups while the caller made no call (a producer with a bounded pool of
+    // buffers waits for them to come back without calling anything: round 3's core then held on to its last < kPublish buffers for
+    // good).  Hence the claim: a range [pub_, tail_) belongs to whoever moves pub_ over it.
     void publish()
     {
-        for (; pub_ < tail_; pub_++) ring_[pub_ & (kRing - 1)].seq.store(pub_ + 1, std::memory_order_release);
+        const uint64_t t = tail_.load(std::memory_order_acquire);
+        uint64_t p = pub_.load(std::memory_order_relaxed);
+        while (p < t) {
+            if (!pub_.compare_exchange_weak(p, t, std::memory_order_acq_rel, std::memory_order_relaxed)) continue;
+            for (; p < t; p++) ring_[p & (kRing - 1)].seq.store(p + 1, std::memory_order_release);
+        }
     }
     bool try_pop(Task &t)
     {
@@ -379,6 +410,8 @@ private:
         std::deque<uint64_t> flight;
         std::deque<Staged> staged;
         int64_t staged_n = 0;                                        // batches staged so far (this thread only)
+        bool tidy = false, had_left = false;
+        uint64_t seen_seq = 0;
         for (;;) {
             int slot = -1;
             int64_t n_new = 0;
@@ -395,9 +428,17 @@ private:
                     // (timed: a helper's nudge can fall between the test above and the wait; shorter while an upload or a batch is in flight)
                     const bool busy = !staged.empty() || !flight.empty();
                     cv_sub_.wait_until(lk, std::chrono::system_clock::now() + std::chrono::microseconds(busy ? 40 : 200));   // (system clock: pthread_cond_timedwait, which ThreadSanitizer knows)
-                    if (busy) break;                                 // nothing to stage yet: see whether an upload or a batch in flight has finished
+                    // the caller's leftovers: cells it has written but not published, buffers parked for it to release.  Both are the
+                    // caller's to deal with at its next call -- unless there is none: leftovers seen at two wake-ups in a row with no call
+                    // in between (>= 40 us) are dealt with here
+                    const uint64_t cs = caller_seq_.load(std::memory_order_relaxed);
+                    const bool left = pub_.load(std::memory_order_relaxed) != tail_.load(std::memory_order_relaxed) || parked_.load(std::memory_order_relaxed) != nullptr;
+                    tidy = left && had_left && cs == seen_seq;
+                    had_left = left; seen_seq = cs;
+                    if (busy || tidy) break;                         // nothing to stage yet: see whether an upload or a batch in flight has finished
                 }
             }
+            if (tidy) { publish(); release_parked(); tidy = false; }
             int rc = 0;
             if (slot >= 0) {
                 // a device buffer is written again kSlots batches later: at most kSlots - 1 batches staged or in flight, the one
@@ -462,7 +503,8 @@ private:
     std::mutex m_;
     std::condition_variable cv_work_, cv_sub_, cv_ready_, cv_room_;
     std::vector<Cell> ring_;
-    uint64_t tail_ = 0, pub_ = 0;                    // producer (caller) only: cells written / cells made visible
+    std::atomic<uint64_t> tail_{ 0 }, pub_{ 0 };     // cells written (the caller alone writes it) / cells made visible (whoever claims the range)
+    std::atomic<uint64_t> caller_seq_{ 0 };          // bumped by every push / flush / take: lets the submitter see that the caller has gone quiet
     std::atomic<uint64_t> head_{ 0 };
     std::deque<StreamReady> ready_;
     std::atomic<int64_t> done_[kSlots] = {};

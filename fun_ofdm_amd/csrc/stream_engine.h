@@ -317,6 +317,25 @@ int foa_stream_create(foa_rx *rx, size_t batch_samples, int narrow_threads, foa_
 
 }  // extern "C"
 
+// Everything the stream itself allocated, given back; idempotent (every pointer is cleared), so that it serves the normal shutdown, a
+// creation that failed half-way -- whichever allocation it failed at -- and a destroy after either.
+static void stream_free_buffers(StreamGpu &g)
+{
+    for (int i = 0; i < foa::kStreamBufs; i++) {
+        if (g.pin[i]) (void)hipHostFree(g.pin[i]);
+        g.pin[i] = nullptr;
+        g.dev[i].release(); g.d_desc[i].release(); g.d_ends[i].release();
+        if (g.in_done[i]) (void)hipEventDestroy(g.in_done[i]);
+        if (g.sel_done[i]) (void)hipEventDestroy(g.sel_done[i]);
+        g.in_done[i] = g.sel_done[i] = nullptr;
+    }
+    if (g.st_in) (void)hipStreamDestroy(g.st_in);
+    g.st_in = nullptr;
+    if (g.sel) (void)hipHostFree(g.sel);
+    g.sel = nullptr;
+    g.sel_dev.release(); g.d_prev.release();
+}
+
 // Stops the engine and gives everything it holds on the device back; the handle is the caller's again.  Idempotent: foa_rx_destroy
 // calls it for a stream that is still open (its threads use the handle), and the owner's later foa_stream_destroy then only frees
 // the shell -- every other foa_stream_* call on such a stream fails with FOA_E_STATE.
@@ -335,19 +354,7 @@ void foa_stream_shutdown(foa_stream *s)
     if (g.rx->depth_saved >= 0) { g.rx->depth = g.rx->depth_saved; g.rx->depth_saved = -1; }
     // the job slots of batches nobody took are released
     while (!g.flight.empty()) { foa::StreamReady r; if (g.collect(g.flight.front().handle, true, &r) <= 0) break; }
-    for (int i = 0; i < foa::kStreamBufs; i++) {
-        if (g.pin[i]) (void)hipHostFree(g.pin[i]);
-        g.pin[i] = nullptr;
-        g.dev[i].release(); g.d_desc[i].release(); g.d_ends[i].release();
-        if (g.in_done[i]) (void)hipEventDestroy(g.in_done[i]);
-        if (g.sel_done[i]) (void)hipEventDestroy(g.sel_done[i]);
-        g.in_done[i] = g.sel_done[i] = nullptr;
-    }
-    if (g.st_in) (void)hipStreamDestroy(g.st_in);
-    g.st_in = nullptr;
-    if (g.sel) (void)hipHostFree(g.sel);
-    g.sel = nullptr;
-    g.sel_dev.release(); g.d_prev.release();
+    stream_free_buffers(g);
 }
 
 extern "C" {
@@ -356,18 +363,11 @@ void foa_stream_destroy(foa_stream *s)
 {
     if (!s) return;
     if (s->core) foa_stream_shutdown(s);
-    else if (s->gpu.rx == nullptr || s->gpu.st_in) {
-        // (creation failed half-way: no engine yet, but buffers may exist)
-        StreamGpu &g = s->gpu;
-        for (int i = 0; i < foa::kStreamBufs; i++) {
-            if (g.pin[i]) (void)hipHostFree(g.pin[i]);
-            g.dev[i].release(); g.d_desc[i].release(); g.d_ends[i].release();
-            if (g.in_done[i]) (void)hipEventDestroy(g.in_done[i]);
-            if (g.sel_done[i]) (void)hipEventDestroy(g.sel_done[i]);
-        }
-        if (g.st_in) (void)hipStreamDestroy(g.st_in);
-        if (g.sel) (void)hipHostFree(g.sel);
-        g.sel_dev.release(); g.d_prev.release();
+    else {
+        // no engine: creation failed half-way (buffers may exist, whichever allocation it failed at), or the stream was shut down already
+        // (nothing is left: the call is a no-op then)
+        if (s->gpu.rx) (void)hipSetDevice(s->gpu.rx->device);
+        stream_free_buffers(s->gpu);
     }
     delete s;
 }

@@ -69,6 +69,9 @@ __device__ __forceinline__ uint32_t pk_sub_wrap(uint32_t a, uint32_t b)
 #ifndef FOA_FWD_PRIO
 #define FOA_FWD_PRIO 0     // priority of the forward pass's waves (A/B only: 1 .. 3, 4 + p = p and 3 over the last third of a frame; profiles/r03_ab_fwd_prio.txt)
 #endif
+#if FOA_RN_PRIO && (FOA_FWD_PRIO & 4)
+#error "FOA_FWD_PRIO 4 + p (priority 3 over the last third of a frame) and FOA_RN_PRIO do not combine: a renormalisation would end at priority p"
+#endif
 #ifndef FOA_MIN16
 #define FOA_MIN16 1
 #endif
@@ -155,7 +158,7 @@ __device__ __forceinline__ uint32_t fwd3_renorm(uint32_t Mn, uint32_t s0)
         Mn -= adj;
     }
 #if FOA_RN_PRIO
-    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(FOA_FWD_PRIO & 3);      // back to the wave's own priority (0 in the product; the A/B builds with FOA_FWD_PRIO keep theirs)
 #endif
     return Mn;
 }

@@ -47,6 +47,10 @@ class Receiver:
     def set_option(self, name, value):
         self._check(self._lib.foa_rx_set_option(self._h, name.encode(), int(value)))
 
+    def notes(self):
+        """Non-fatal remarks about the handle's set-up (e.g. too few hardware queues for four lanes); "" if none."""
+        return (self._lib.foa_rx_notes(self._h) or b"").decode()
+
     def reserve(self, n_samples, n_frames):
         self._check(self._lib.foa_rx_reserve(self._h, int(n_samples), int(n_frames)))
 

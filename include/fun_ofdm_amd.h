@@ -77,8 +77,19 @@ const char *foa_last_error(void);
 /* number of HIP devices visible, or a negative FOA_E_* */
 int foa_device_count(void);
 
-/* Create a receiver on HIP device `device` (its own non-blocking stream). */
+/* The library runs a call's stages on up to six HIP streams (two to four lanes of pipelined decode calls, one for the stitch / CRC
+ * kernels, one for copies and the pre-sync).  Streams only overlap when they sit on different hardware queues, and the HIP runtime
+ * fixes their number when it STARTS: GPU_MAX_HW_QUEUES, default 4.  The library does not touch its host's environment; a host that
+ * wants small batches (< 2049 frames per call) at full speed sets GPU_MAX_HW_QUEUES to this value (8) before its first HIP call --
+ * bench.py and examples/foa_sim.cpp do.  With fewer than six queues such calls keep two loops in flight instead of four (20-30 %
+ * slower for those batches; config 2-sized calls are not affected) and foa_rx_notes() says so. */
+int foa_recommended_hw_queues(void);
+
+/* Create a receiver on HIP device `device` (its own non-blocking streams). */
 int foa_rx_create(foa_rx **out, int device);
+/* Non-fatal remarks about how the handle is set up ("" if none), e.g. too few hardware queues for four lanes.  Valid until the handle
+ * is destroyed. */
+const char *foa_rx_notes(foa_rx *rx);
 void foa_rx_destroy(foa_rx *rx);
 
 /* Pre-size the device workspace for streams of up to n_samples samples holding up to n_frames
@@ -115,7 +126,11 @@ int foa_rx_reserve(foa_rx *rx, size_t n_samples, size_t n_frames);
  *                 previous call's forward pass when calls are pipelined; cross-check build: 0 = one wave per data symbol,
  *                 1 = one lane per data symbol; all three give bit-identical results
  *   "sync_call"   foa_rx_sync_dev / the stream engine: the reference call size by which timing_sync.cpp:99 is decided (foa_sync_set_call, below);
- *                 default 4096 = receiver.h:16, 0 = as one call over the whole stream.  foa_rx_sync_dev takes d_iq[0] as stream index 0.
+ *                 default 4096 = receiver.h:16, 0 = as one call over the whole stream.  FOA_E_STATE while a stream engine is open.
+ *   "sync_origin" foa_rx_sync_dev / _begin: the stream index of d_iq[0] (default 0).  The rule above is decided by ABSOLUTE stream index
+ *                 ((index of STS_END + 160) mod sync_call), so a caller that pre-synchronises one stream in consecutive batches sets this
+ *                 to each batch's offset in the stream (or starts every batch on a multiple of sync_call, or sets sync_call 0);
+ *                 otherwise frames are dropped at batch-relative positions the reference never drops them at
  *   "sync_flags"  foa_rx_sync_dev's frame_detector kernel: 1 (default, the only shipped value) = a lane owns sixteen consecutive windows and sums
  *                 them as tail of one group + head of the next; cross-check build: 0 = every window summed directly, term by term
  *   "record_soft" keep the depunctured soft bytes for foa_rx_get_taps (default 1; 0 saves their HBM writes)
@@ -269,7 +284,10 @@ typedef struct foa_stream foa_stream;
  * One stream per handle: a second create while one is open fails with FOA_E_STATE (the engine's submitter thread owns the handle's
  * streams and work sets); destroying the HANDLE first stops the engine -- every later call on the stream then fails with FOA_E_STATE
  * and foa_stream_destroy only frees it.  Samples pushed with foa_stream_push_f64_owned into a batch that is still open may stay
- * un-narrowed (and their buffers unreleased) until a few more pushes, a flush or the destroy: nothing waits for an open batch. */
+ * un-narrowed (and their buffers unreleased) until a few more pushes, a flush or the destroy -- or, if the caller makes no further call
+ * (a producer that waits for its pool of buffers to come back), for at most about half a millisecond: the engine's submitter thread
+ * then publishes and releases what is left.  Buffers of 128 KB and more are released on the helper thread that narrowed their last
+ * slice (they are the allocator's own mappings: giving them back is a munmap, which would otherwise be the caller's time). */
 int foa_stream_create(foa_rx *rx, size_t batch_samples, int narrow_threads, foa_stream **out);
 void foa_stream_destroy(foa_stream *s);
 /* The next n_samples of the stream (interleaved re,im).  Returns when they are copied; submits a batch whenever one is full

@@ -129,6 +129,58 @@ int main()
         while ((t = core.take(true, &r)) == 1) {}
         CHECK(rc == -3 || t == -3, "the backend's error was not reported (push/flush %d, take %d)", rc, t);
     }
+    {   // a producer with a bounded POOL of buffers, smaller than the queue's publishing stride: it hands over what it has
+        // and then waits for buffers to come back WITHOUT calling into the engine -- they must come back all the same
+        FakeGpu gpu(1 << 20);                       // one open batch, never full: nothing closes it
+        foa::StreamCore<FakeGpu> core(&gpu, 1 << 20, 2);
+        g_released = 0;
+        for (int i = 0; i < 8; i++) {
+            auto *v = new std::vector<double>(2 * 4096, 0.5);
+            CHECK(core.push(v->data(), 4096, release_vec, v) == 0, "push failed");
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        while (g_released < 8 && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(3)) std::this_thread::sleep_for(std::chrono::microseconds(200));
+        const double ms = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3;
+        CHECK(g_released == 8, "a pooled producer got %d of 8 buffers back while it made no call (%.0f ms)", (int)g_released, ms);
+        printf("pooled producer: 8 of 8 handed-over buffers back after %.2f ms without a call\n", ms);
+        // ... and one that polls take(false) meanwhile
+        g_released = 0;
+        for (int i = 0; i < 5; i++) {
+            auto *v = new std::vector<double>(2 * 1000, 0.5);
+            CHECK(core.push(v->data(), 1000, release_vec, v) == 0, "push failed");
+        }
+        foa::StreamReady r;
+        const auto t1 = std::chrono::steady_clock::now();
+        while (g_released < 5 && std::chrono::steady_clock::now() - t1 < std::chrono::seconds(3)) { (void)core.take(false, &r); std::this_thread::sleep_for(std::chrono::microseconds(50)); }
+        CHECK(g_released == 5, "a polling producer got %d of 5 buffers back", (int)g_released);
+        CHECK(core.flush() == 0, "flush failed");
+        while (core.take(true, &r) == 1) r = foa::StreamReady();
+    }
+    {   // handed-over buffers far larger than a narrowing task (a call of a million samples): sliced, every sample in place, released once
+        const int64_t B = 300000;
+        const size_t total = 2500000, chunk = 1 << 20;
+        std::vector<float> want(2 * total);
+        FakeGpu gpu(B);
+        g_released = 0;
+        int handed = 0;
+        {
+            foa::StreamCore<FakeGpu> core(&gpu, B, 3);
+            foa::StreamReady r;
+            for (size_t o = 0; o < total; o += chunk) {
+                const size_t n = std::min(chunk, total - o);
+                auto *v = new std::vector<double>(2 * n);
+                for (size_t i = 0; i < 2 * n; i++) { (*v)[i] = (double)(float)((2 * o + i) % 100003) / 8.0; want[2 * o + i] = (float)(*v)[i]; }
+                handed++;
+                CHECK(core.push(v->data(), n, release_vec, v) == 0, "push failed");
+                while (core.take(false, &r) == 1) r = foa::StreamReady();
+            }
+            CHECK(core.flush() == 0, "flush failed");
+            while (core.take(true, &r) == 1) r = foa::StreamReady();
+        }
+        CHECK(g_released == handed, "released %d of %d large buffers", (int)g_released, handed);
+        CHECK(gpu.received == want, "samples of the large handed-over calls differ");
+        printf("large handed-over calls: %d buffers of up to %zu samples, all in place\n", handed, chunk);
+    }
     printf(failures ? "FAILED (%d)\n" : "OK\n", failures);
     return failures ? 1 : 0;
 }
