@@ -134,47 +134,117 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(iq, descs, ends, pays, budget_s=18.0):
-    """The oracle (a port of the reference's per-frame path: fft_symbols..frame_decoder on one alignment) timed on this
-    host's cores on a bounded sample of the same workload.  SURVEY 8d protocol: >= 3 repetitions, the median is the
-    figure; CPU model and thread count stated."""
+def viterbi_ns_per_step(po):
+    """ns per trellis step of the three CPU forward passes there are: the oracle's scalar model (the CHECKER), its SSE form (what the
+    baseline below times) and, where oracle/_ref travelled, the reference's own compiled decoder (src/viterbi.cpp:208-457; incl. its chain-back)."""
+    rng = np.random.default_rng(5)
+    nsteps = 8424
+    sym = rng.integers(0, 256, 2 * nsteps, dtype=np.uint8)
+    out = {}
+
+    def per_step(fn, reps):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        return round((time.perf_counter() - t0) / reps / nsteps * 1e9, 1)
+    out["oracle_scalar_model"] = per_step(lambda: po.viterbi_forward(sym, nsteps), 10)
+    out["oracle_simd"] = per_step(lambda: po.viterbi_forward_simd(sym, nsteps), 100)
+    out["reference_compiled_sse"] = None
+    try:
+        if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libfun_ofdm_ref.so")):
+            out["reference_compiled_sse"] = per_step(lambda: po.Ref.conv_decode(sym, nsteps - 6), 50)
+    except Exception:
+        pass
+    out["what"] = "8424 steps (one 54 Mbps / 1024-byte frame) of random soft bytes, single thread; simd = %s" % po.lib().fo_viterbi_simd_kind().decode()
+    return out
+
+
+def cpu_baseline(iq, descs, ends, pays, wall_s=2.0):
+    """The oracle's per-alignment path (fft_symbols .. frame_decoder on one alignment, a port of the reference's) timed on this host's
+    cores on the same workload -- with the Viterbi forward pass in its SSE form (fo_viterbi_forward_simd, asserted equal to the scalar
+    model here and in tests/), pre-spawned workers, per-thread scratch, as many threads as the process may run on.  SURVEY 8d protocol: >= 3
+    repetitions, the median is the figure; CPU model, thread count, per-thread rate and parallel efficiency stated.  (Round 3 timed the
+    scalar model at 0.15 Msample/s per thread; VERDICT round 3: not a credible stand-in for the reference's CPU path.)"""
     from oracle import pyoracle as po
-    cores = os.cpu_count() or 1
-    # size the sample from a quick probe so that the three repetitions together stay near budget_s
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    real_all = np.nonzero((descs["lts1_pos"] - (LEAD + 184)) % PITCH == 0)[0]
+
+    def in_frame(n):          # in-frame samples among the first n alignments
+        return int(np.count_nonzero(real_all < n)) * FRAME_SAMPLES
+
+    # ---- one thread: the per-thread rate (a sample sized for about wall_s) ----
+    one = po.Pool(1)
+    n_probe = min(descs.size, 64)
     t0 = time.perf_counter()
-    po.decode_batch_f32(iq, descs[:cores], ends[:cores], slot_bytes=PAYLOAD, threads=cores)
+    one.decode(iq, descs[:n_probe], ends[:n_probe], slot_bytes=PAYLOAD)
     probe = time.perf_counter() - t0
-    n = int(min(descs.size, max(cores, cores * (budget_s / 3.0) / max(probe, 1e-3))))
-    n_samp = int(ends[n - 1])
+    n1 = int(min(descs.size, max(n_probe, n_probe * wall_s / max(probe, 1e-4))))
+    runs1 = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        one.decode(iq, descs[:n1], ends[:n1], slot_bytes=PAYLOAD)
+        runs1.append(time.perf_counter() - t0)
+    one.close()
+    rate1 = in_frame(n1) / sorted(runs1)[1] / 1e6
+    # ---- all threads: whole passes over the workload's alignments, repeated until a repetition lasts about wall_s (a burst of a few
+    # milliseconds does not even get every thread onto a core) ----
+    pool = po.Pool(cores)
+    n = descs.size
+    psdu, res = pool.decode(iq, descs, ends, slot_bytes=PAYLOAD)              # warm-up pass = the results the GPU is checked against
+    t0 = time.perf_counter()
+    pool.decode(iq, descs, ends, slot_bytes=PAYLOAD)
+    one_pass = time.perf_counter() - t0
+    passes = int(max(1, min(400, round(wall_s / max(one_pass, 1e-4)))))
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.5 * wall_s:                            # untimed: lets every worker reach a core (shared, virtualised hosts
+        pool.decode(iq, descs, ends, slot_bytes=PAYLOAD)                      # take a good fraction of a second to run a burst of threads in parallel)
     runs = []
     for _ in range(3):
         t0 = time.perf_counter()
-        psdu, res = po.decode_batch_f32(iq[:n_samp], descs[:n], ends[:n], slot_bytes=PAYLOAD, threads=cores)
+        for _ in range(passes):
+            pool.decode(iq, descs, ends, slot_bytes=PAYLOAD)
         runs.append(time.perf_counter() - t0)
-    dt = sorted(runs)[1]
-    real = np.nonzero((descs["lts1_pos"][:n] - (LEAD + 184)) % PITCH == 0)[0]
-    in_frame = real.size * FRAME_SAMPLES
-    out = dict(value=in_frame / dt / 1e6, unit="Msamples/s", cores=cores, threads=cores, cpu_model=cpu_model(), kind="port",
-               protocol="median of 3 repetitions", runs_s=[round(v, 3) for v in runs],
-               sample="%d of the workload's alignments (%d frames, %d samples fed), oracle fo_decode_batch_f32 on %d threads, %.2f s per repetition"
-                      % (n, real.size, n_samp, cores, dt),
-               note="a port: the reference itself needs FFTW3 and Boost, which this image does not have (oracle/Makefile builds "
-                    "the ten reference translation units that need neither and the port is pinned against them)")
+    pool.close()
+    dt = sorted(runs)[1] / passes
+    value = in_frame(n) / dt / 1e6
+    # the timed decoder against the CHECKER (scalar model, one allocation-happy decoder per frame) on a sample
+    n_chk = int(min(n, max(64, 2 * cores)))
+    cp, cr = po.decode_batch_f32(iq[:int(ends[n_chk - 1])], descs[:n_chk], ends[:n_chk], slot_bytes=PAYLOAD, threads=cores)
+    equal = bool(np.array_equal(cr.view(np.int32), res[:n_chk].view(np.int32)) and np.array_equal(cp, psdu[:n_chk]))
+    out = dict(value=round(value, 1), unit="Msamples/s", cores=cores, threads=cores, cpu_model=cpu_model(), kind="port",
+               per_thread_single={"value": round(rate1, 2), "unit": "Msamples/s", "alignments": n1, "runs_s": [round(v, 3) for v in runs1]},
+               parallel_efficiency=round(value / (cores * rate1), 3),
+               protocol="median of 3 repetitions of %d whole passes over the workload's alignments (one warm-up pass before)" % passes,
+               runs_s=[round(v, 3) for v in runs],
+               viterbi_ns_per_step=viterbi_ns_per_step(po),
+               timed_decoder_equals_scalar_checker={"alignments": n_chk, "equal": equal},
+               sample="all %d alignments of the workload (%d frames, %d samples fed) x %d passes per repetition, oracle fo_pool_decode on %d threads "
+                      "(SSE forward pass, per-thread scratch), %.3f s per pass" % (n, real_all.size, int(ends[n - 1]), passes, cores, dt),
+               note="a port: the reference itself needs FFTW3 and Boost, which this image does not have (oracle/Makefile builds the ten reference "
+                    "translation units that need neither and the port is pinned against them); its Viterbi is timed beside ours in viterbi_ns_per_step "
+                    "where oracle/_ref is present.  parallel_efficiency = value / (threads x per_thread_single); the hosts are shared")
+    if not equal:
+        out["error"] = "the timed decoder and the scalar checker disagree"
     # the reference's own structure for comparison (SURVEY 8d): process_samples() over six block threads + the caller,
     # 4096-sample chunks, pre-sync included -- one chain, >= 2000 frames, median of 3
     try:
         nf = min(len(pays), 2000)
         rs, got = [], []
-        for _ in range(3):
-            chain = po.ReceiverChain(threaded=True)
-            t0 = time.perf_counter()
-            got = chain.run_stream(iq[:nf * PITCH], chunk=4096)
-            rs.append(time.perf_counter() - t0)
+        po.lib().fo_set_timed_simd_viterbi(1)             # a TIMED leg: the chain's frame_decoder with the SSE forward pass, like the reference's
+        try:
+            for _ in range(3):
+                chain = po.ReceiverChain(threaded=True)
+                t0 = time.perf_counter()
+                got = chain.run_stream(iq[:nf * PITCH], chunk=4096)
+                rs.append(time.perf_counter() - t0)
+        finally:
+            po.lib().fo_set_timed_simd_viterbi(0)
         dt_c = sorted(rs)[1]
         out["reference_structure"] = {"value": round(nf * FRAME_SAMPLES / dt_c / 1e6, 2), "unit": "Msamples/s", "threads": 7, "protocol": "median of 3 repetitions",
                                       "runs_s": [round(v, 3) for v in rs],
                                       "sample": "%d frames through the oracle's receiver_chain (frame_detector .. frame_decoder as "
-                                                "six block threads, 4096-sample calls), %d payloads out, %.2f s per repetition" % (nf, len(got), dt_c)}
+                                                "six block threads, 4096-sample calls, SSE Viterbi forward pass), %d payloads out, %.2f s per repetition" % (nf, len(got), dt_c)}
     except Exception as e:                                # the headline baseline above does not depend on this leg
         out["reference_structure"] = {"error": str(e)}
     return out, psdu, res, n
@@ -574,26 +644,32 @@ def roofline(args, kms, n_real, ms_per_step, piped, probe):
     one lane slot of v_pk_add_u16 / v_pk_min_u16 / v_pk_sub_u16 performs TWO counted ops and the peak for them is
     N_SIMD x f x 64 lanes x 2 / (clocks per packed wave64 instruction) -- with the guide's figures (SIMD-32: 32 plain lane-ops
     per clock and SIMD, 2.4 GHz; a packed instruction takes twice the clocks and does twice the ops) 1024 x 32 x 2.4e9 = 78.6 T/s.
-    Consecutive forward passes overlap (two streams), so a launch lasts longer than a step: the PRIMARY figure divides by the
-    step time (what the machine sustains); the per-launch figure the contract defines is given next to it."""
+    Consecutive forward passes overlap (two streams), so a launch lasts longer than a step: `frac` is the per-launch figure the tier
+    defines (ops of one launch / its own duration / peak); the step-rate figure (what the machine sustains) is `frac_at_step_rate`."""
     fwd_kernel = {0: "k_viterbi_v1", 1: "k_viterbi_fwd2", 2: "k_viterbi_fwd3"}[args.viterbi]
     t_k = kms["viterbi_fwd"] * 1e-3                      # average launch duration, live from HIP events on the kernel's own stream
     t_step = ms_per_step * 1e-3 if piped else t_k        # calls in line: one launch at a time, the launch IS the kernel's share of the step
     steps = n_real * 39 * 216                            # trellis steps per launch (frames found x 39 symbols x 216)
     alg_ops = steps * ALG_LANE_OPS_PER_STEP              # SURVEY 8d: (256 + 32) ops per step
     peak = N_SIMD * 32 * 2.4e9                           # MI355X_MICROARCH.md: 4 SIMD-32 per CU, 256 CUs, 2.4 GHz
-    r = {"bound": "valu", "kernel": fwd_kernel, "achieved": round(alg_ops / t_step / 1e12, 3), "peak": round(peak / 1e12, 2), "unit": "T ops/s",
-         "frac": round(alg_ops / t_step / peak, 4),
+    # frac as the tier defines it: algorithmic ops of ONE launch / that launch's own average duration / peak.  The step-rate figure (one
+    # launch per ms_per_step: what the machine sustains while consecutive launches overlap on two queues) is kept beside it.
+    r = {"bound": "valu", "kernel": fwd_kernel, "achieved": round(alg_ops / t_k / 1e12, 3), "peak": round(peak / 1e12, 2), "unit": "T ops/s",
+         "frac": round(alg_ops / t_k / peak, 4),
          "definition": "algorithmic integer ops (SURVEY 8d: 64 states x (2 saturating adds + min + compare) + 32 branch metrics = 288 per trellis "
-                       "step and frame) x %d steps per launch / %s; peak = 1024 SIMD-32 x 32 lane-ops per clock x 2.4 GHz (MI355X_MICROARCH.md; "
-                       "a packed-u16 instruction does two of the counted ops per lane in twice the clocks: the same peak)"
-                       % (steps, "ms_per_step (one launch per step; consecutive launches overlap on two streams)" if piped else "average launch duration"),
+                       "step and frame) x %d steps per launch / the launch's own average duration (HIP events on the kernel's stream, live in this run); "
+                       "peak = 1024 SIMD-32 x 32 lane-ops per clock x 2.4 GHz (MI355X_MICROARCH.md; a packed-u16 instruction does two of the counted ops "
+                       "per lane in twice the clocks: the same peak).  Steps are counted for the %d frames the workload holds; the launch also decodes "
+                       "the alignments timing_sync places on noise (alignments_decoded_per_gpu in config), whose SIGNAL fails: no trellis steps, so "
+                       "the count is exact for the forward pass and conservative for the call" % (steps, n_real),
          "algorithmic_ops_per_launch": int(alg_ops), "avg_kernel_ms": round(kms["viterbi_fwd"], 4),
-         "per_launch": {"achieved": round(alg_ops / t_k / 1e12, 3), "frac": round(alg_ops / t_k / peak, 4),
-                        "what": "the same ops / the launch's own duration (HIP events on its stream); below the step-rate figure when launches overlap"}}
+         "frac_at_step_rate": {"achieved": round(alg_ops / t_step / 1e12, 3), "frac": round(alg_ops / t_step / peak, 4),
+                               "what": "the same ops / ms_per_step: a throughput figure -- two launches overlap on two hardware queues, so a launch lasts "
+                                       "longer than a step (rounds 2-3 reported this one as `frac`)" if piped else "calls in line: equal to frac"}}
     if probe:
         live_peak = probe["pk_u16"]["wave_instr_per_s"] * 64 * 2
-        r["peak_measured_live"] = {"value": round(live_peak / 1e12, 2), "unit": "T ops/s", "frac": round(alg_ops / t_step / live_peak, 4),
+        r["peak_measured_live"] = {"value": round(live_peak / 1e12, 2), "unit": "T ops/s", "frac": round(alg_ops / t_k / live_peak, 4),
+                                   "frac_at_step_rate": round(alg_ops / t_step / live_peak, 4),
                                    "clk_per_packed_wave_instr": round(probe["pk_u16"]["clk_per_wave_instr"], 3), "ghz": round(probe["pk_u16"]["ghz"], 3),
                                    "clk_per_plain_vop2_wave_instr": round(probe["vop2_u32"]["clk_per_wave_instr"], 3),
                                    "source": "foa_rx_probe_issue in THIS run on THIS device: 8 waves per SIMD issuing v_pk_add_u16 clamp for a fixed window"}

@@ -314,11 +314,18 @@ void fo_viterbi_chainback(const uint64_t *decisions, uint8_t *data, int data_bit
     }
 }
 
+/* 0 (default, the CHECKER): fo_conv_decode runs the scalar model.  1: the SSE forward pass (identical decision words) -- set only
+ * around TIMED CPU legs of bench.py (the reference-shaped chain), never while anything is being checked. */
+static int g_conv_simd = 0;
+void fo_set_timed_simd_viterbi(int on) { __atomic_store_n(&g_conv_simd, on ? 1 : 0, __ATOMIC_RELEASE); }
+void fo_viterbi_forward_simd(const uint8_t *symbols, int nsteps, uint64_t *decisions, uint8_t *metrics);
+
 void fo_conv_decode(const uint8_t *symbols, uint8_t *data, int data_bits)
 {
     int nsteps = data_bits + 6;
     uint64_t *dec = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(nsteps > 0 ? nsteps : 1));
-    fo_viterbi_forward(symbols, nsteps, dec, NULL, NULL);
+    if (__atomic_load_n(&g_conv_simd, __ATOMIC_ACQUIRE)) fo_viterbi_forward_simd(symbols, nsteps, dec, NULL);
+    else fo_viterbi_forward(symbols, nsteps, dec, NULL, NULL);
     fo_viterbi_chainback(dec, data, data_bits);
     free(dec);
 }
@@ -478,20 +485,40 @@ size_t fo_encode_data(const uint8_t *payload, int length, int rate, fo_c64 *out)
     return n;
 }
 
-int fo_decode_data(const fo_c64 *in, int rate, int length, uint8_t *payload, uint8_t *soft, uint8_t *decoded_out)
+/* Scratch of one worker of the timed CPU baseline (fo_pool, below): every buffer fo_decode_data and fo_decode_alignment_f32 would
+ * otherwise malloc per frame, sized for the longest frame (1369 symbols of 24 bits at 6 Mbps .. 152 symbols of 216 at 54 Mbps: at most
+ * 4095 + 6 bytes = 32 856 + padding bits, i.e. 33 048 trellis steps).  With a scratch the Viterbi forward pass is the SIMD one. */
+#define FO_MAX_STEPS 33264
+#define FO_MAX_SYMS 1372
+struct fo_scratch {
+    uint8_t dem[FO_MAX_SYMS * 288 + 64], dei[FO_MAX_SYMS * 288 + 64], dep[2 * FO_MAX_STEPS + 64];
+    uint8_t dec[FO_MAX_STEPS / 8 + 16], des[FO_MAX_STEPS / 8 + 16];
+    uint64_t decisions[FO_MAX_STEPS + 8];
+    fo_c64 car[FO_MAX_SYMS * 48];
+};
+
+void fo_viterbi_forward_simd(const uint8_t *symbols, int nsteps, uint64_t *decisions, uint8_t *metrics);
+
+static int decode_data_impl(const fo_c64 *in, int rate, int length, uint8_t *payload, uint8_t *soft, uint8_t *decoded_out, struct fo_scratch *sc)
 {
     const fo_rate_params *rp = &RATE_TABLE[rate];
     int nsym = fo_num_symbols(rate, length);
     int nbits = nsym * rp->dbps, nbytes = nbits / 8;
     size_t ncar = (size_t)nsym * 48, ncoded = ncar * (size_t)rp->bpsc;
-    uint8_t *dem = (uint8_t *)malloc(ncoded + 48), *dei = (uint8_t *)malloc(ncoded + 48);
-    uint8_t *dep = (uint8_t *)malloc((size_t)nbits * 2 + 48);
+    uint8_t *dem = sc ? sc->dem : (uint8_t *)malloc(ncoded + 48), *dei = sc ? sc->dei : (uint8_t *)malloc(ncoded + 48);
+    uint8_t *dep = sc ? sc->dep : (uint8_t *)malloc((size_t)nbits * 2 + 48);
     fo_demodulate(in, ncar, rate, dem);
     fo_deinterleave(dem, ncoded, dei);
     size_t nd = fo_depuncture(dei, ncoded, rate, dep);
     if (soft) memcpy(soft, dep, nd);
-    uint8_t *dec = (uint8_t *)calloc((size_t)nbytes + 8, 1), *des = (uint8_t *)calloc((size_t)nbytes + 8, 1);
-    fo_conv_decode(dep, dec, nbits - 6);
+    uint8_t *dec = sc ? sc->dec : (uint8_t *)calloc((size_t)nbytes + 8, 1), *des = sc ? sc->des : (uint8_t *)calloc((size_t)nbytes + 8, 1);
+    if (sc) {
+        memset(dec, 0, (size_t)nbytes + 8); memset(des, 0, (size_t)nbytes + 8);
+        fo_viterbi_forward_simd(dep, nbits, sc->decisions, NULL);          /* = fo_conv_decode with the SIMD forward pass */
+        fo_viterbi_chainback(sc->decisions, dec, nbits - 6);
+    } else {
+        fo_conv_decode(dep, dec, nbits - 6);
+    }
     fo_scramble(dec, des, (size_t)nbytes);
     if (decoded_out) memcpy(decoded_out, des, (size_t)nbytes);
     uint32_t crc = fo_crc32(des, (size_t)(2 + length));
@@ -499,8 +526,13 @@ int fo_decode_data(const fo_c64 *in, int rate, int length, uint8_t *payload, uin
                      ((uint32_t)des[4 + length] << 16) | ((uint32_t)des[5 + length] << 24);
     int ok = given == crc;
     if (ok && payload) memcpy(payload, des + 2, (size_t)length);
-    free(dem); free(dei); free(dep); free(dec); free(des);
+    if (!sc) { free(dem); free(dei); free(dep); free(dec); free(des); }
     return ok;
+}
+
+int fo_decode_data(const fo_c64 *in, int rate, int length, uint8_t *payload, uint8_t *soft, uint8_t *decoded_out)
+{
+    return decode_data_impl(in, rate, length, payload, soft, decoded_out, NULL);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -962,16 +994,19 @@ const fo_payloads *fo_receiver_chain_process_samples(fo_receiver_chain *c, const
 /* ------------------------------------------------------------------------------------------ */
 /* the hot path in isolation                                                                   */
 /* ------------------------------------------------------------------------------------------ */
-void fo_decode_alignment_f32(const float *iq, int64_t end, const fo_frame_desc *d, uint8_t *psdu,
-                             fo_frame_result *res, fo_c64 *hinv, fo_c64 *eq, uint8_t *soft, fo_c64 *fftout)
+static void decode_alignment_impl(const float *iq, int64_t end, const fo_frame_desc *d, uint8_t *psdu,
+                                  fo_frame_result *res, fo_c64 *hinv, fo_c64 *eq, uint8_t *soft, fo_c64 *fftout, struct fo_scratch *sc)
 {
     ensure_tables();
     res->status = FO_ST_HEADER_FAIL; res->rate = -1; res->length = 0; res->num_symbols = 0;
     int64_t p = d->lts1_pos;
     cplx rot = CMPLX(d->c, d->s), rot_prev = CMPLX(d->c_prev, d->s_prev);
     fo_tagged_vec64 v;
-    fo_channel_est *ce = fo_channel_est_new();
-    fo_phase_tracker *pt = fo_phase_tracker_new();
+    fo_channel_est ce_obj; fo_phase_tracker pt_obj;       /* (as fo_channel_est_new / fo_phase_tracker_new leave them) */
+    memset(&ce_obj, 0, sizeof ce_obj); memset(&pt_obj, 0, sizeof pt_obj);
+    for (int j = 0; j < 64; j++) ce_obj.est[j].re = 1.0;
+    fo_channel_est *ce = &ce_obj;
+    fo_phase_tracker *pt = &pt_obj;
     fo_tagged_vec64 eqv; fo_tagged_vec48 dv;
     fo_c64 *car = NULL;
     int rate = -1, length = 0, nsym = 0;
@@ -994,18 +1029,23 @@ void fo_decode_alignment_f32(const float *iq, int64_t end, const fo_frame_desc *
         if (sym == 0) {
             if (!fo_decode_header(dv.samples, &rate, &length, &nsym)) { rate = -1; break; }
             res->rate = rate; res->length = length; res->num_symbols = nsym;
-            car = (fo_c64 *)malloc(sizeof(fo_c64) * 48 * (size_t)nsym);
+            car = sc ? sc->car : (fo_c64 *)malloc(sizeof(fo_c64) * 48 * (size_t)nsym);
         } else {
             memcpy(car + (size_t)(sym - 1) * 48, dv.samples, sizeof dv.samples);
             if (sym == nsym) {
-                int ok = fo_decode_data(car, rate, length, psdu, soft, NULL);
+                int ok = decode_data_impl(car, rate, length, psdu, soft, NULL, sc);
                 res->status = ok ? FO_ST_OK : FO_ST_CRC_FAIL;
                 break;
             }
         }
     }
-    free(car);
-    fo_channel_est_free(ce); fo_phase_tracker_free(pt);
+    if (!sc) free(car);
+}
+
+void fo_decode_alignment_f32(const float *iq, int64_t end, const fo_frame_desc *d, uint8_t *psdu,
+                             fo_frame_result *res, fo_c64 *hinv, fo_c64 *eq, uint8_t *soft, fo_c64 *fftout)
+{
+    decode_alignment_impl(iq, end, d, psdu, res, hinv, eq, soft, fftout, NULL);
 }
 
 size_t fo_find_alignments_f32(const float *iq, int64_t n, fo_frame_desc *out, size_t cap)
@@ -1071,4 +1111,173 @@ void fo_decode_batch_f32(const float *iq, int64_t n, const fo_frame_desc *descs,
     for (int t = 0; t < threads; t++) pthread_create(&th[t], NULL, batch_worker, &j);
     for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
     free(th);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* the timed CPU baseline (bench.py `cpu_baseline`): the same per-alignment path, made fast the */
+/* way the reference's own CPU path is fast                                                    */
+/* ------------------------------------------------------------------------------------------ */
+/* viterbi.cpp:208-457 keeps its 64 uint8 path metrics in four SSE registers; fo_viterbi_forward above is the readable
+ * scalar model of it and stays the CHECKER.  What is TIMED as "the CPU" must not be an order of magnitude slower than the
+ * reference's decoder, so this is the same recursion on sixteen butterflies per instruction, written from the scalar model
+ * (tests/test_oracle_golden.py asserts equal decision words and metrics on random, saturating and erased inputs; where the
+ * reference's compiled decoder is present, tests/test_oracle_vs_ref.py compares against it too).
+ * Layout: v[0..3] = metrics of states 0-15, 16-31, 32-47, 48-63.  Butterfly i (0..31) reads states i and i+32 and writes 2i
+ * and 2i+1: for i = 0..15 that is (v0, v2) -> interleaved into new v0, v1; for i = 16..31 (v1, v3) -> new v2, v3. */
+#if defined(__x86_64__) || defined(__i386__)
+#include <smmintrin.h>
+
+void fo_viterbi_forward_simd(const uint8_t *symbols, int nsteps, uint64_t *decisions, uint8_t *metrics)
+{
+    uint8_t b0[32], b1[32], init[64];
+    for (int i = 0; i < 32; i++) {                 /* viterbi.cpp:86-91 */
+        b0[i] = fo_parity((unsigned)((2 * i) & 121)) ? 255 : 0;
+        b1[i] = fo_parity((unsigned)((2 * i) & 91)) ? 255 : 0;
+    }
+    for (int i = 0; i < 64; i++) init[i] = 63;     /* viterbi.cpp:71-78 */
+    init[0] = 0;
+    const __m128i B0a = _mm_loadu_si128((const __m128i *)b0), B0b = _mm_loadu_si128((const __m128i *)(b0 + 16));
+    const __m128i B1a = _mm_loadu_si128((const __m128i *)b1), B1b = _mm_loadu_si128((const __m128i *)(b1 + 16));
+    const __m128i k63 = _mm_set1_epi8(63);
+    __m128i v0 = _mm_loadu_si128((const __m128i *)init), v1 = _mm_loadu_si128((const __m128i *)(init + 16)),
+            v2 = _mm_loadu_si128((const __m128i *)(init + 32)), v3 = _mm_loadu_si128((const __m128i *)(init + 48));
+    const int run = 2 * (nsteps / 2);               /* viterbi.cpp:209: an odd last step is dropped */
+    for (int t = run; t < nsteps; t++) decisions[t] = 0;
+    for (int t = 0; t < run; t++) {
+        const __m128i s0 = _mm_set1_epi8((char)symbols[2 * t]), s1 = _mm_set1_epi8((char)symbols[2 * t + 1]);
+        /* ((s0 ^ B0) + (s1 ^ B1) + 1) >> 1 is the rounding average; then >> 2, & 63 */
+        const __m128i ma = _mm_and_si128(_mm_srli_epi16(_mm_avg_epu8(_mm_xor_si128(s0, B0a), _mm_xor_si128(s1, B1a)), 2), k63);
+        const __m128i mb = _mm_and_si128(_mm_srli_epi16(_mm_avg_epu8(_mm_xor_si128(s0, B0b), _mm_xor_si128(s1, B1b)), 2), k63);
+        const __m128i ca = _mm_sub_epi8(k63, ma), cb = _mm_sub_epi8(k63, mb);
+        /* butterflies 0..15 */
+        __m128i a0 = _mm_adds_epu8(v0, ma), a1 = _mm_adds_epu8(v2, ca), c0 = _mm_adds_epu8(v0, ca), c1 = _mm_adds_epu8(v2, ma);
+        __m128i na = _mm_min_epu8(a0, a1), nc = _mm_min_epu8(c0, c1);
+        __m128i da = _mm_cmpeq_epi8(na, a1), dc = _mm_cmpeq_epi8(nc, c1);          /* upper <= lower */
+        const __m128i n0 = _mm_unpacklo_epi8(na, nc), n1 = _mm_unpackhi_epi8(na, nc);
+        uint64_t d = (uint64_t)(unsigned)_mm_movemask_epi8(_mm_unpacklo_epi8(da, dc)) | (uint64_t)(unsigned)_mm_movemask_epi8(_mm_unpackhi_epi8(da, dc)) << 16;
+        /* butterflies 16..31 */
+        a0 = _mm_adds_epu8(v1, mb); a1 = _mm_adds_epu8(v3, cb); c0 = _mm_adds_epu8(v1, cb); c1 = _mm_adds_epu8(v3, mb);
+        na = _mm_min_epu8(a0, a1); nc = _mm_min_epu8(c0, c1);
+        da = _mm_cmpeq_epi8(na, a1); dc = _mm_cmpeq_epi8(nc, c1);
+        const __m128i n2 = _mm_unpacklo_epi8(na, nc), n3 = _mm_unpackhi_epi8(na, nc);
+        d |= (uint64_t)(unsigned)_mm_movemask_epi8(_mm_unpacklo_epi8(da, dc)) << 32 | (uint64_t)(unsigned)_mm_movemask_epi8(_mm_unpackhi_epi8(da, dc)) << 48;
+        decisions[t] = d;
+        v0 = n0; v1 = n1; v2 = n2; v3 = n3;
+        if ((unsigned)(_mm_extract_epi8(v0, 0) & 255) > 210u) {                    /* viterbi.cpp:314-332,438-456 */
+            __m128i m = _mm_min_epu8(_mm_min_epu8(v0, v1), _mm_min_epu8(v2, v3));
+            m = _mm_min_epu8(m, _mm_srli_epi16(m, 8));                              /* low byte of every 16-bit lane: min of the pair; high byte 0 */
+            m = _mm_minpos_epu16(_mm_and_si128(m, _mm_set1_epi16(0x00FF)));
+            const __m128i mn = _mm_set1_epi8((char)(_mm_extract_epi16(m, 0) & 255));
+            v0 = _mm_sub_epi8(v0, mn); v1 = _mm_sub_epi8(v1, mn); v2 = _mm_sub_epi8(v2, mn); v3 = _mm_sub_epi8(v3, mn);
+        }
+    }
+    if (metrics) {
+        _mm_storeu_si128((__m128i *)metrics, v0); _mm_storeu_si128((__m128i *)(metrics + 16), v1);
+        _mm_storeu_si128((__m128i *)(metrics + 32), v2); _mm_storeu_si128((__m128i *)(metrics + 48), v3);
+    }
+}
+const char *fo_viterbi_simd_kind(void) { return "sse4.1, 16 butterflies per instruction"; }
+#else
+void fo_viterbi_forward_simd(const uint8_t *symbols, int nsteps, uint64_t *decisions, uint8_t *metrics)
+{
+    fo_viterbi_forward(symbols, nsteps, decisions, metrics, NULL);
+}
+const char *fo_viterbi_simd_kind(void) { return "scalar (no SSE4.1 on this host)"; }
+#endif
+
+/* A pool of pre-spawned workers, each with its own scratch (no allocation per frame), frames handed out eight at a time
+ * from one atomic counter.  fo_pool_decode blocks until the batch is done and may be called any number of times. */
+struct fo_pool {
+    int threads;
+    pthread_t *th;
+    struct fo_scratch **scratch;
+    pthread_mutex_t mu;
+    pthread_cond_t go, done;
+    unsigned long epoch;
+    int running, quit;
+    /* the batch in hand */
+    const float *iq; const fo_frame_desc *descs; const int64_t *ends; size_t n_frames;
+    uint8_t *psdu; size_t slot; fo_frame_result *res;
+    size_t next;          /* (atomic) */
+};
+
+struct pool_arg { fo_pool *p; int i; };
+
+static void pool_run(fo_pool *p, struct fo_scratch *sc)
+{
+    for (;;) {
+        const size_t lo = __atomic_fetch_add(&p->next, 8, __ATOMIC_RELAXED);
+        if (lo >= p->n_frames) break;
+        const size_t hi = lo + 8 < p->n_frames ? lo + 8 : p->n_frames;
+        for (size_t f = lo; f < hi; f++)
+            decode_alignment_impl(p->iq, p->ends[f], &p->descs[f], p->psdu + f * p->slot, &p->res[f], NULL, NULL, NULL, NULL, sc);
+    }
+}
+
+static void *pool_worker(void *arg)
+{
+    struct pool_arg *a = (struct pool_arg *)arg;
+    fo_pool *p = a->p; const int i = a->i;
+    free(a);
+    unsigned long seen = 0;
+    for (;;) {
+        pthread_mutex_lock(&p->mu);
+        while (!p->quit && p->epoch == seen) pthread_cond_wait(&p->go, &p->mu);
+        if (p->quit) { pthread_mutex_unlock(&p->mu); break; }
+        seen = p->epoch;
+        pthread_mutex_unlock(&p->mu);
+        pool_run(p, p->scratch[i]);
+        pthread_mutex_lock(&p->mu);
+        if (--p->running == 0) pthread_cond_signal(&p->done);
+        pthread_mutex_unlock(&p->mu);
+    }
+    return NULL;
+}
+
+fo_pool *fo_pool_new(int threads)
+{
+    ensure_tables();
+    if (threads < 1) threads = 1;
+    fo_pool *p = (fo_pool *)calloc(1, sizeof(fo_pool));
+    p->threads = threads;
+    p->th = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
+    p->scratch = (struct fo_scratch **)calloc((size_t)threads, sizeof(struct fo_scratch *));
+    pthread_mutex_init(&p->mu, NULL); pthread_cond_init(&p->go, NULL); pthread_cond_init(&p->done, NULL);
+    for (int i = 0; i < threads; i++) {
+        p->scratch[i] = (struct fo_scratch *)malloc(sizeof(struct fo_scratch));
+        if (i == 0) continue;                    /* worker 0 is the calling thread */
+        struct pool_arg *a = (struct pool_arg *)malloc(sizeof *a);
+        a->p = p; a->i = i;
+        pthread_create(&p->th[i], NULL, pool_worker, a);
+    }
+    return p;
+}
+
+void fo_pool_free(fo_pool *p)
+{
+    if (!p) return;
+    pthread_mutex_lock(&p->mu); p->quit = 1; pthread_cond_broadcast(&p->go); pthread_mutex_unlock(&p->mu);
+    for (int i = 1; i < p->threads; i++) pthread_join(p->th[i], NULL);
+    for (int i = 0; i < p->threads; i++) free(p->scratch[i]);
+    free(p->scratch); free(p->th);
+    pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->go); pthread_cond_destroy(&p->done);
+    free(p);
+}
+
+int fo_pool_threads(const fo_pool *p) { return p->threads; }
+
+void fo_pool_decode(fo_pool *p, const float *iq, const fo_frame_desc *descs, const int64_t *ends, size_t n_frames,
+                    uint8_t *psdu, size_t slot_bytes, fo_frame_result *res)
+{
+    pthread_mutex_lock(&p->mu);
+    p->iq = iq; p->descs = descs; p->ends = ends; p->n_frames = n_frames; p->psdu = psdu; p->slot = slot_bytes; p->res = res;
+    __atomic_store_n(&p->next, 0, __ATOMIC_RELAXED);
+    p->running = p->threads - 1;
+    p->epoch++;
+    pthread_cond_broadcast(&p->go);
+    pthread_mutex_unlock(&p->mu);
+    pool_run(p, p->scratch[0]);
+    pthread_mutex_lock(&p->mu);
+    while (p->running > 0) pthread_cond_wait(&p->done, &p->mu);
+    pthread_mutex_unlock(&p->mu);
 }

@@ -203,6 +203,22 @@ size_t fo_find_alignments_f32(const float *iq, int64_t n, fo_frame_desc *out, si
 void fo_decode_batch_f32(const float *iq, int64_t n, const fo_frame_desc *descs, const int64_t *ends,
                          size_t n_frames, uint8_t *psdu, size_t slot_bytes, fo_frame_result *res, int threads);
 
+/* ---- the TIMED CPU baseline of bench.py (never the checker: the functions above are) ----
+ * fo_viterbi_forward_simd: fo_viterbi_forward on sixteen butterflies per SSE instruction, the way the reference's own decoder
+ * (viterbi.cpp:208-457) is laid out; identical decision words and metrics (asserted in tests/).  metrics may be NULL.
+ * fo_pool: pre-spawned workers with per-thread scratch decoding a batch of alignments like fo_decode_batch_f32, with the SIMD
+ * forward pass and no allocation per frame; identical results (asserted in tests/ and by bench.py on every timed sample). */
+void fo_viterbi_forward_simd(const uint8_t *symbols, int nsteps, uint64_t *decisions, uint8_t *metrics);
+const char *fo_viterbi_simd_kind(void);
+/* 1: fo_conv_decode (and with it the block chain's frame_decoder) uses the SSE forward pass -- for TIMED legs only; 0 (default): the scalar model */
+void fo_set_timed_simd_viterbi(int on);
+typedef struct fo_pool fo_pool;
+fo_pool *fo_pool_new(int threads);
+void fo_pool_free(fo_pool *);
+int fo_pool_threads(const fo_pool *);
+void fo_pool_decode(fo_pool *, const float *iq, const fo_frame_desc *descs, const int64_t *ends, size_t n_frames,
+                    uint8_t *psdu, size_t slot_bytes, fo_frame_result *res);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,6 +77,9 @@ def lib():
             "fo_frame_decoder_stats": (vp, [vp]),
             "fo_receiver_chain_new": (vp, []), "fo_receiver_chain_new_threaded": (vp, []), "fo_receiver_chain_free": (None, [vp]),
             "fo_receiver_chain_process_samples": (vp, [vp, vp, sz]), "fo_receiver_chain_decoder_stats": (vp, [vp]),
+            "fo_viterbi_forward_simd": (None, [vp, i32, vp, vp]), "fo_viterbi_simd_kind": (C.c_char_p, []), "fo_set_timed_simd_viterbi": (None, [i32]),
+            "fo_pool_new": (vp, [i32]), "fo_pool_free": (None, [vp]), "fo_pool_threads": (i32, [vp]),
+            "fo_pool_decode": (None, [vp, vp, vp, vp, sz, vp, sz, vp]),
             "fo_decode_alignment_f32": (None, [vp, i64, vp, vp, vp, vp, vp, vp, vp]),
             "fo_find_alignments_f32": (sz, [vp, i64, vp, sz]),
             "fo_decode_batch_f32": (None, [vp, i64, vp, vp, sz, vp, sz, vp, i32]),
@@ -162,6 +165,41 @@ def viterbi_forward(symbols, nsteps):
     stats = np.zeros(2, np.uint64)
     lib().fo_viterbi_forward(_ptr(s), nsteps, _ptr(dec), _ptr(met), _ptr(stats))
     return dec, met, stats
+
+
+def viterbi_forward_simd(symbols, nsteps):
+    """The SIMD forward pass of the TIMED CPU baseline (fo_viterbi_forward_simd): must equal viterbi_forward bit for bit."""
+    s = np.ascontiguousarray(symbols, np.uint8)
+    dec = np.zeros(max(nsteps, 1), np.uint64)
+    met = np.zeros(64, np.uint8)
+    lib().fo_viterbi_forward_simd(_ptr(s), nsteps, _ptr(dec), _ptr(met))
+    return dec[:nsteps], met
+
+
+class Pool:
+    """Pre-spawned workers with per-thread scratch: the batch decoder bench.py times as the CPU baseline (SIMD forward pass, no
+    allocation per frame).  Same results as decode_batch_f32."""
+
+    def __init__(self, threads):
+        self.h = lib().fo_pool_new(int(threads))
+        self.threads = int(lib().fo_pool_threads(self.h))
+
+    def decode(self, iq, descs, ends, slot_bytes=4096):
+        iq = np.ascontiguousarray(iq, np.complex64)
+        descs = np.ascontiguousarray(descs, frame_desc)
+        ends = np.ascontiguousarray(ends, np.int64)
+        n = descs.size
+        psdu = np.zeros((n, slot_bytes), np.uint8)
+        res = np.zeros(n, frame_result)
+        lib().fo_pool_decode(self.h, _ptr(iq), _ptr(descs), _ptr(ends), n, _ptr(psdu), slot_bytes, _ptr(res))
+        return psdu, res
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().fo_pool_free(self.h)
+            self.h = None
+
+    __del__ = close
 
 
 def viterbi_chainback(decisions, data_bits):

@@ -1,4 +1,4 @@
-"""Short runs of the random differential checkers of tests/manual/ (the long runs are recorded in profiles/r03_soak.txt): every
+"""Short runs of the random differential checkers of tests/manual/ (the long runs are recorded in profiles/r03_soak.txt and profiles/r04_soak.txt): every
 random input must come out of the HIP path exactly as it comes out of the oracle.  GPU only."""
 import os
 import sys
@@ -40,3 +40,15 @@ def test_perturbed_alignment_descriptors_decode_like_the_oracle(po):
     assert bad == 0 and tot > 1500 and passed > 100
     tot, passed, bad = stress_decode.run(51000, 51060, 6.0)
     assert bad == 0 and tot > 300
+
+
+def test_colliding_frames_and_false_alarms_inside_frames_equal_the_block_chain(po):
+    """fft_symbols.cpp:41-50 / channel_est.cpp:77-81 / frame_decoder.cpp:52-68: a preamble inside a frame -- the second frame weaker, equal or
+    stronger, its SIGNAL valid or garbled, its LTS1 anywhere in the first frame or late in its last symbol, bare preambles, pile-ups.  The
+    ordered payload list of the batch path (host and device pre-sync), of the stream engine and of fun_amd::receiver_chain::process_samples
+    in its three modes against the oracle's BLOCK-LEVEL chain, which models the partial-vector flush."""
+    import stress_collide
+    tot, n_al, bad = stress_collide.run_gpu(1000, 1060, cpp=True)
+    assert not bad and n_al > 100 and tot > 15, (tot, n_al, bad)
+    tot, n_al, bad = stress_collide.run_gpu(2000, 2200)
+    assert not bad and n_al > 350, (tot, n_al, bad)

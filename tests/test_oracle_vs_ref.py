@@ -34,6 +34,17 @@ def test_viterbi_random_blocks():
         assert np.array_equal(po.conv_decode(s, nb), R.conv_decode(s, nb)), (it, nb)
 
 
+def test_simd_forward_pass_against_the_compiled_reference_decoder():
+    """The oracle's SSE forward pass (the TIMED CPU baseline) + chain-back against src/viterbi.cpp compiled in place."""
+    rng = np.random.default_rng(31)
+    for nb in (18, 100, 8418, 20002):
+        n = nb + 6
+        for s in (rng.integers(0, 256, 2 * n, dtype=np.uint8), rng.choice(np.array([0, 255, 127], np.uint8), 2 * n),
+                  (po.conv_encode(rng.integers(0, 256, nb // 8 + 2, dtype=np.uint8), nb).astype(np.uint8) * 255)):
+            dec, _ = po.viterbi_forward_simd(s, n)
+            assert np.array_equal(po.viterbi_chainback(dec, nb), po.Ref.conv_decode(s, nb)), nb
+
+
 def test_viterbi_long_punctured_blocks():
     # 4092-byte 9 Mbps shape: 32 796 trellis steps, erasures every third pair (SURVEY fact 4)
     rng = np.random.default_rng(12)
