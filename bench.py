@@ -69,6 +69,8 @@ def parse_args(argv=None):
     ap.add_argument("--lanes", type=int, default=-1, help="A/B: library option lanes (-1: library default)")
     ap.add_argument("--walk-lane", type=int, default=-1, help="A/B: library option walk_lane (-1: library default)")
     ap.add_argument("--legs-frames", type=int, default=1000, help="frames per rate of the config-3 leg")
+    ap.add_argument("--no-fill-legs", action="store_true", help="skip the machine-filling and mixed-call tables of config 3 (tens of GB of workspaces)")
+    ap.add_argument("--fill-frames", type=int, default=10240, help="frames per rate of the machine-filling table (10 240 = five forward-pass waves per SIMD)")
     ap.add_argument("--timing-age", type=int, default=4, help="pipelined steps: the per-kernel HIP-event times read inside the timed loop are those of the "
                     "call this many calls back (2..4): the further back, the more calls the host may run ahead of the GPU")
     ap.add_argument("--no-self-check", action="store_true", help="skip the alone-speed leg and the issue probe (profiling: keeps their launches out of the kernel averages)")
@@ -160,6 +162,28 @@ def viterbi_ns_per_step(po):
     return out
 
 
+def cgroup_cpu_quota():
+    """CPUs' worth of time the container may use per period (cgroup v2 cpu.max, v1 cpu.cfs_quota_us), or None if unlimited / not visible."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(int(q) / int(p), 2)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else round(q / p, 2)
+    except (OSError, ValueError):
+        return None
+
+
+def usable_threads():
+    """Threads worth starting for a CPU leg: the affinity mask, cut to the container's CPU quota where one is visible."""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    q = cgroup_cpu_quota()
+    return max(1, min(aff, int(q + 0.5))) if q else aff
+
+
 def cpu_baseline(iq, descs, ends, pays, wall_s=2.0):
     """The oracle's per-alignment path (fft_symbols .. frame_decoder on one alignment, a port of the reference's) timed on this host's
     cores on the same workload -- with the Viterbi forward pass in its SSE form (fo_viterbi_forward_simd, asserted equal to the scalar
@@ -167,7 +191,8 @@ def cpu_baseline(iq, descs, ends, pays, wall_s=2.0):
     repetitions, the median is the figure; CPU model, thread count, per-thread rate and parallel efficiency stated.  (Round 3 timed the
     scalar model at 0.15 Msample/s per thread; VERDICT round 3: not a credible stand-in for the reference's CPU path.)"""
     from oracle import pyoracle as po
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = cgroup_cpu_quota()
     real_all = np.nonzero((descs["lts1_pos"] - (LEAD + 184)) % PITCH == 0)[0]
 
     def in_frame(n):          # in-frame samples among the first n alignments
@@ -187,10 +212,28 @@ def cpu_baseline(iq, descs, ends, pays, wall_s=2.0):
         runs1.append(time.perf_counter() - t0)
     one.close()
     rate1 = in_frame(n1) / sorted(runs1)[1] / 1e6
-    # ---- all threads: whole passes over the workload's alignments, repeated until a repetition lasts about wall_s (a burst of a few
-    # milliseconds does not even get every thread onto a core) ----
-    pool = po.Pool(cores)
+    # ---- how many threads?  As many as the process may RUN on: its affinity mask says 256 on the GPU boxes of this pool, the container's
+    # CPU quota (cgroup cpu.max) about 8 -- 256 threads then share 8 CPUs' worth of time and each pass pays for 256 wake-ups (round 3's
+    # "3 % parallel efficiency").  The quota where it is visible, and in any case a probe: one pass per candidate count, the fastest wins ----
     n = descs.size
+    cands = sorted(set(c for c in (1, 2, 4, 8, 16, 32, 64, 128, affinity, int(quota + 0.5) if quota else 0) if 1 <= c <= affinity))
+    probe_rows, best = [], (0.0, 1)
+    for c in cands:
+        pl = po.Pool(c)
+        pl.decode(iq, descs[:min(n, 8 * c)], ends[:min(n, 8 * c)], slot_bytes=PAYLOAD)
+        t0 = time.perf_counter()
+        pl.decode(iq, descs, ends, slot_bytes=PAYLOAD)
+        d1 = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        pl.decode(iq, descs, ends, slot_bytes=PAYLOAD)
+        d1 = min(d1, time.perf_counter() - t0)
+        pl.close()
+        r = in_frame(n) / d1 / 1e6
+        probe_rows.append({"threads": c, "Msamples_per_s": round(r, 1)})
+        if r > best[0] * 1.03:                                                 # (more threads only for a real gain)
+            best = (r, c)
+    cores = best[1]
+    pool = po.Pool(cores)
     psdu, res = pool.decode(iq, descs, ends, slot_bytes=PAYLOAD)              # warm-up pass = the results the GPU is checked against
     t0 = time.perf_counter()
     pool.decode(iq, descs, ends, slot_bytes=PAYLOAD)
@@ -213,6 +256,7 @@ def cpu_baseline(iq, descs, ends, pays, wall_s=2.0):
     cp, cr = po.decode_batch_f32(iq[:int(ends[n_chk - 1])], descs[:n_chk], ends[:n_chk], slot_bytes=PAYLOAD, threads=cores)
     equal = bool(np.array_equal(cr.view(np.int32), res[:n_chk].view(np.int32)) and np.array_equal(cp, psdu[:n_chk]))
     out = dict(value=round(value, 1), unit="Msamples/s", cores=cores, threads=cores, cpu_model=cpu_model(), kind="port",
+               affinity_cpus=affinity, cgroup_cpu_quota=quota, thread_count_probe=probe_rows,
                per_thread_single={"value": round(rate1, 2), "unit": "Msamples/s", "alignments": n1, "runs_s": [round(v, 3) for v in runs1]},
                parallel_efficiency=round(value / (cores * rate1), 3),
                protocol="median of 3 repetitions of %d whole passes over the workload's alignments (one warm-up pass before)" % passes,
@@ -223,7 +267,8 @@ def cpu_baseline(iq, descs, ends, pays, wall_s=2.0):
                       "(SSE forward pass, per-thread scratch), %.3f s per pass" % (n, real_all.size, int(ends[n - 1]), passes, cores, dt),
                note="a port: the reference itself needs FFTW3 and Boost, which this image does not have (oracle/Makefile builds the ten reference "
                     "translation units that need neither and the port is pinned against them); its Viterbi is timed beside ours in viterbi_ns_per_step "
-                    "where oracle/_ref is present.  parallel_efficiency = value / (threads x per_thread_single); the hosts are shared")
+                    "where oracle/_ref is present.  cores = the thread count the probe found fastest (the affinity mask names every CPU of the host, "
+                    "the container's share of them is smaller); parallel_efficiency = value / (threads x per_thread_single); the hosts are shared")
     if not equal:
         out["error"] = "the timed decoder and the scalar checker disagree"
     # the reference's own structure for comparison: process_samples() over six block threads + the caller,
@@ -752,50 +797,130 @@ def extra_legs(args, rx, dev, iq, descs, ends, real, psdu_dev_path, res_dev_path
         legs["end_to_end_host_pointers"] = {"error": str(e)}
 
     # ---- config 3: the 8 standard rates x 4092-byte payloads (PSDU incl. CRC = 4096 bytes) ----
+    # Three tables: "small batch" = SURVEY 8d's 1 000 frames per rate in calls of their own (500 forward-pass waves on
+    # 1 024 SIMDs: what is measured is the latency of a lone wave, not the machine); "machine filling" = per rate, the frame count that
+    # gives five forward-pass waves per SIMD (10 240), or as many as the workspaces allow (they are sized for the worst case of 216 trellis
+    # steps per 80 samples: 14 bytes per step and work set); "mixed" = one call holding 1 000 frames of each of the eight rates.  Every
+    # alignment of every row is checked against the CPU: the scalar checker on the small-batch rows (the 143 CRC failures of the 9 Mbps
+    # leg included), the pool decoder (SSE forward pass, asserted equal to the scalar model) on all alignments of the large rows plus
+    # the scalar checker on their first 256.
+    def c3_workload(rate, n, length, seed):
+        pays = synth.splitmix64_bytes(0x0FD3 + rate, n, length)
+        frames = rx.tx_build_frames(torch.from_numpy(pays).to(dev), rate)
+        s = frames.shape[1]
+        pitch = -(-(s + 576) // 4096) * 4096
+        d_iq = rx.tx_channel(frames, pitch, 176, 25.0, seed=seed)
+        del frames
+        return pays, d_iq, int(s), int(pitch)
+
+    def c3_decode_and_check(d_iq, pays_of, length, reps, big):
+        """pays_of(lts1_pos array) -> (mask of alignments that are real frames, their payloads)."""
+        n_s = d_iq.shape[0]
+        cap = n_s // 512 + 64
+        d_desc = torch.zeros(cap * 48, dtype=torch.uint8, device=dev)
+        d_end = torch.zeros(cap, dtype=torch.int64, device=dev)
+        m = rx.sync_dev(d_iq, d_desc, d_end)
+        d_psdu = torch.zeros((m, length), dtype=torch.uint8, device=dev)
+        d_res = torch.zeros((m, 4), dtype=torch.int32, device=dev)
+        dt = timed(lambda: rx.decode_frames_dev(d_iq, d_desc[:m * 48], d_end[:m], d_psdu, d_res), reps)   # (steady state: the loops in flight fill and drain)
+        r = d_res.cpu().numpy()
+        d = d_desc.cpu().numpy()[:m * 48].view(foa.frame_desc_dtype)
+        gp = d_psdu.cpu().numpy()
+        on_mask, want = pays_of(d["lts1_pos"])
+        on = np.nonzero(on_mask)[0]
+        okm = r[on, 0] == 0
+        exact = bool(np.array_equal(gp[on][okm], want[okm]))
+        e = d_end[:m].cpu().numpy()
+        h_iq = d_iq[:int(e[-1])].cpu().numpy().reshape(-1).view(np.complex64)
+        thr = usable_threads()
+        row = {}
+        if big:
+            pool = po.Pool(thr)
+            pool.decode(h_iq, d[:min(m, 4 * thr)], e[:min(m, 4 * thr)], slot_bytes=length)
+            t0 = time.perf_counter()
+            opsdu, ores = pool.decode(h_iq, d, e, slot_bytes=length)
+            dt_cpu = time.perf_counter() - t0
+            pool.close()
+            k2 = min(m, 256)
+            sp2, sr2 = po.decode_batch_f32(h_iq[:int(e[k2 - 1])], d[:k2], e[:k2], slot_bytes=length, threads=thr)
+            row["scalar_checker_on_first"] = {"alignments": int(k2), "equal_to_gpu": bool(np.array_equal(sr2.view(np.int32).reshape(-1, 4), r[:k2]) and
+                                                                                     np.array_equal(sp2[r[:k2, 0] == 0], gp[:k2][r[:k2, 0] == 0]))}
+            row["cpu_decoder"] = "fo_pool_decode (SSE forward pass)"
+        else:
+            t0 = time.perf_counter()
+            opsdu, ores = po.decode_batch_f32(h_iq, d, e, slot_bytes=length, threads=thr)
+            dt_cpu = time.perf_counter() - t0
+            row["cpu_decoder"] = "fo_decode_batch_f32 (the scalar checker)"
+        same = bool(np.array_equal(ores.view(np.int32).reshape(-1, 4), r))
+        okk = r[:, 0] == 0
+        same = same and bool(np.array_equal(opsdu[okk], gp[okk]))
+        row.update({"alignments": int(m), "frames_found": int(on.size), "crc_ok": int(np.count_nonzero(okm)), "psdu_bit_exact": exact, "gpu_equals_cpu_on_all": same,
+                    "cpu_checked_alignments": int(m), "cpu_crc_fail": int(np.count_nonzero(ores["status"] == foa.ST_CRC_FAIL)),
+                    "gpu_crc_fail": int(np.count_nonzero(r[:, 0] == foa.ST_CRC_FAIL)), "ms": round(dt * 1e3, 3), "cpu_s": round(dt_cpu, 3), "cpu_threads": thr})
+        del d_psdu, d_res, d_desc, d_end
+        return row, on.size, dt, dt_cpu
+
     try:
         n, length, rows = args.legs_frames, 4092, []
         for rate in STD:
-            pays = synth.splitmix64_bytes(0x0FD3 + rate, n, length)
-            frames = rx.tx_build_frames(torch.from_numpy(pays).to(dev), rate)
-            s = frames.shape[1]
-            pitch = -(-(s + 576) // 4096) * 4096
-            d_iq = rx.tx_channel(frames, pitch, 176, 25.0, seed=300 + rate)
-            del frames
-            cap = n * pitch // 512 + 64
-            d_desc = torch.zeros(cap * 48, dtype=torch.uint8, device=dev)
-            d_end = torch.zeros(cap, dtype=torch.int64, device=dev)
-            m = rx.sync_dev(d_iq, d_desc, d_end)
-            d_psdu = torch.zeros((m, length), dtype=torch.uint8, device=dev)
-            d_res = torch.zeros((m, 4), dtype=torch.int32, device=dev)
-            dt = timed(lambda: rx.decode_frames_dev(d_iq, d_desc[:m * 48], d_end[:m], d_psdu, d_res), 24)   # (steady state: four loops in flight fill and drain)
-            r = d_res.cpu().numpy()
-            d = d_desc.cpu().numpy()[:m * 48].view(foa.frame_desc_dtype)
-            on = np.nonzero((d["lts1_pos"] - 360) % pitch == 0)[0]
-            ok = on[r[on, 0] == 0]
-            exact = bool(np.array_equal(d_psdu.cpu().numpy()[ok], pays[(d["lts1_pos"][ok] - 360) // pitch]))
-            # CPU oracle, same status and PSDUs, on ALL alignments of every rate (the 9 Mbps leg is the one whose long frames fail their
-            # CRC now and then at 25 dB: parity = the same failures); the same call, timed, is the per-rate CPU figure (decode only, all
-            # host threads, one repetition)
-            k = m
-            e = d_end[:k].cpu().numpy()
-            h_iq = d_iq[:int(e[-1])].cpu().numpy().reshape(-1).view(np.complex64)
-            thr = os.cpu_count() or 1
-            t0 = time.perf_counter()
-            opsdu, ores = po.decode_batch_f32(h_iq, d[:k], e, slot_bytes=length, threads=thr)
-            dt_cpu = time.perf_counter() - t0
-            same = bool(np.array_equal(ores.view(np.int32).reshape(-1, 4), r[:k]))
-            okk = r[:k, 0] == 0
-            same = same and bool(np.array_equal(opsdu[okk], d_psdu[:k].cpu().numpy()[okk]))
-            on_k = int(np.count_nonzero((d["lts1_pos"][:k] - 360) % pitch == 0))
-            rows.append({"rate_enum": rate, "mbps": foa.RATE_MBPS[rate], "frame_samples": int(s), "frames_found": int(on.size), "crc_ok": int(ok.size),
-                         "psdu_bit_exact": exact, "gpu_equals_cpu_on_all" if k == m else "gpu_equals_cpu_on_%d" % k: same, "cpu_checked_alignments": int(k),
-                         "cpu_crc_fail": int(np.count_nonzero(ores["status"] == foa.ST_CRC_FAIL)), "gpu_crc_fail_same_sample": int(np.count_nonzero(r[:k, 0] == foa.ST_CRC_FAIL)),
-                         "ms": round(dt * 1e3, 3), "Msamples_per_s": round(on.size * s / dt / 1e6, 1),
-                         "cpu_Msamples_per_s": round(on_k * s / dt_cpu / 1e6, 1), "cpu_threads": thr})
-            del d_iq, d_psdu, d_res, d_desc, d_end
-        legs["config3_rate_sweep"] = {"frames_per_rate": n, "payload_bytes": length, "snr_db": 25.0, "counted_samples": "in-frame", "rates": rows}
+            pays, d_iq, s, pitch = c3_workload(rate, n, length, 300 + rate)
+            row, found, dt, dt_cpu = c3_decode_and_check(d_iq, lambda pos, pays=pays, pitch=pitch: ((pos - 360) % pitch == 0, pays[((pos - 360) // pitch)[(pos - 360) % pitch == 0]]), length, 24, False)
+            row.update({"rate_enum": rate, "mbps": foa.RATE_MBPS[rate], "frame_samples": s, "Msamples_per_s": round(found * s / dt / 1e6, 1),
+                        "cpu_Msamples_per_s": round(found * s / dt_cpu / 1e6, 1)})
+            rows.append(row)
+            del d_iq
+        legs["config3_rate_sweep"] = {"table": "small batch", "frames_per_rate": n, "payload_bytes": length, "snr_db": 25.0, "counted_samples": "in-frame", "rates": rows,
+                                      "reading": "%d frames per call = %d forward-pass waves on 1 024 SIMDs: a lone wave's latency sets the time, four calls' loops in flight "
+                                                 "(option depth); the machine-filling figures are in config3_machine_filling" % (n, n // 2)}
     except Exception as e:
-        legs["config3_rate_sweep"] = {"error": str(e)}
+        legs["config3_rate_sweep"] = {"error": str(e)[-300:]}
+    if not args.no_fill_legs:
+        try:
+            length, rows, budget = 4092, [], 300 * 1000 * 1000
+            for rate in STD:
+                s0 = 320 + 80 * (1 + po.num_symbols(rate, length))
+                pitch0 = -(-(s0 + 576) // 4096) * 4096
+                nfill = int(min(args.fill_frames, budget // pitch0))
+                pays, d_iq, s, pitch = c3_workload(rate, nfill, length, 400 + rate)
+                row, found, dt, dt_cpu = c3_decode_and_check(d_iq, lambda pos, pays=pays, pitch=pitch: ((pos - 360) % pitch == 0, pays[((pos - 360) // pitch)[(pos - 360) % pitch == 0]]), length, 6, True)
+                row.update({"rate_enum": rate, "mbps": foa.RATE_MBPS[rate], "frames": nfill, "forward_waves_per_simd": round(nfill / 2 / 1024, 2), "frame_samples": s,
+                            "Msamples_per_s": round(found * s / dt / 1e6, 1), "cpu_Msamples_per_s": round(found * s / dt_cpu / 1e6, 1)})
+                if nfill < args.fill_frames:
+                    row["fewer_than_five_waves_because"] = "10 240 such frames are %d M samples; a call's workspaces are sized for the worst case (216 trellis steps per 80 samples, 14 B per step, several sets in rotation)" % (10240 * pitch0 // 1000000)
+                rows.append(row)
+                del d_iq
+                torch.cuda.empty_cache()
+            legs["config3_machine_filling"] = {"table": "machine filling", "payload_bytes": length, "snr_db": 25.0, "counted_samples": "in-frame", "rates": rows}
+        except Exception as e:
+            legs["config3_machine_filling"] = {"error": str(e)[-300:]}
+        # one call holding all eight rates (1 000 frames each, 4092-byte payloads): what a mixed-rate capture of long frames costs
+        try:
+            length, parts, metas, base = 4092, [], [], 0
+            for rate in STD:
+                pays, d_iq, s, pitch = c3_workload(rate, args.legs_frames, length, 500 + rate)
+                parts.append(d_iq)
+                metas.append((base, base + d_iq.shape[0], pitch, s, pays))
+                base += d_iq.shape[0]
+            d_all = torch.cat(parts)
+            del parts, d_iq
+
+            def pays_of(pos):
+                mask = np.zeros(pos.size, bool)
+                want = np.zeros((pos.size, length), np.uint8)
+                for lo, hi, pitch, s, pays in metas:
+                    inr = (pos >= lo) & (pos < hi) & ((pos - lo - 360) % pitch == 0)
+                    mask |= inr
+                    want[inr] = pays[(pos[inr] - lo - 360) // pitch]
+                return mask, want[mask]
+            row, found, dt, dt_cpu = c3_decode_and_check(d_all, pays_of, length, 6, True)
+            in_frame = sum(args.legs_frames * s for _, _, _, s, _ in metas)
+            row.update({"frames": 8 * args.legs_frames, "samples_fed": int(d_all.shape[0]), "Msamples_per_s": round(in_frame / dt / 1e6, 1),
+                        "cpu_Msamples_per_s": round(in_frame / dt_cpu / 1e6, 1), "what": "one call: %d frames of each of the eight rates, 4092-byte payloads, 25 dB" % args.legs_frames})
+            legs["config3_mixed_call"] = row
+            del d_all
+            torch.cuda.empty_cache()
+        except Exception as e:
+            legs["config3_mixed_call"] = {"error": str(e)[-300:]}
 
     # ---- config 5: one continuous stream, frames cycling the 8 rates back to back, CFO within +-4 kHz, pre-sync on the device ----
     try:

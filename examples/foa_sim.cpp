@@ -1,35 +1,61 @@
 // foa_sim -- offline receiver over a raw I/Q file (the shape of the reference's examples/test_sim.cpp
 // with the simulated channel replaced by a capture).
 //
-//   foa_sim <iq file> [--format fc32|fc64] [--chunk N] [--device D] [--async K] [--device-batch B [--narrow-threads T]]
-//                     [--preload] [--out FILE]
+//   foa_sim <iq file> [--format fc32|fc64] [--chunk N] [--device D] [--async K] [--device-batch B [--narrow-threads T] [--devices D0,D1,..]]
+//                     [--preload [--warm-batches W] [--pace MSPS] [--latency PITCH LEAD SAMPLES]] [--out FILE]
 //
 // Feeds the file through fun_amd::receiver (sample source -> receiver_chain::process_samples -> callback) in chunks of N
 // samples (default 4096, the reference's NUM_RX_SAMPLES) and writes every received PSDU to FILE (default: stdout summary
 // only) as a record: 4-byte little-endian length, then the bytes.  --async K: decode in asynchronous batches submitted
 // every K calls (fun_amd::receiver_chain's streaming mode) instead of synchronously in every call.  --device-batch B: the
 // whole of process_samples() on the device in batches of B samples (pre-sync kernels included; the mode for rates far
-// above real time), T helper threads narrowing large calls to float.  --preload: read the capture into memory first (as
+// above real time), T helper threads narrowing large calls to float; --devices D0,D1,..: those batches dealt over several devices (batch k on
+// the (k mod n)-th of the list; a device may be listed twice), payloads in stream order all the same.  --preload: read the capture into memory first (as
 // the complex<double> chunks process_samples() takes) and time the receive loop alone: "x.y Msamples/s through
 // process_samples" is then the rate of the drop-in API itself, without the file read and the float -> double widening of
-// this program's own source.
+// this program's own source.  With --preload: --warm-batches W (default 2 in device mode) feeds W batches of silence before the clock
+// starts, so that the timed loop meets a running pipeline (threads on their cores, every buffer touched) rather than a cold one;
+// --pace MSPS hands the chunks over at MSPS million samples per second of wall-clock time instead of as fast as they are taken (a
+// radio's pace: 20; the engine's latency under a given load); --latency PITCH LEAD SAMPLES reports how long after the call that
+// delivered a frame's last sample its payload came back (frame k of the capture occupies samples [k*PITCH + LEAD, k*PITCH + LEAD +
+// SAMPLES) and carries k in its first four payload bytes, little-endian: tools/bench_stream.py builds such captures).
 //
 // build:  g++ -O2 -std=c++17 examples/foa_sim.cpp -Iinclude -Lfun_ofdm_amd/csrc -lfun_ofdm_amd -lpthread -o foa_sim
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 
 #include <fun_ofdm_amd/blocks.hpp>
+#if defined(__GLIBC__)
+#include <malloc.h>
+#endif
 
 static std::FILE *g_out = nullptr;
 static size_t g_packets = 0, g_bytes = 0, g_calls = 0;
 
+// --latency: call_time[c] = when the c-th timed process_samples() call was made; a frame's latency = now - the time of the call
+// that delivered its last sample
+static std::vector<double> g_call_time;
+static std::vector<double> g_latency_ms;
+static long long g_lat_pitch = 0, g_lat_lead = 0, g_lat_samples = 0;
+static int g_lat_chunk = 0;
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 static void on_packets(std::vector<std::vector<unsigned char> > packets)
 {
     g_calls++;
+    const double t = g_lat_pitch ? now_s() : 0.0;
     for (const auto &p : packets) {
+        if (g_lat_pitch && p.size() >= 4) {
+            const long long k = (long long)p[0] | (long long)p[1] << 8 | (long long)p[2] << 16 | (long long)p[3] << 24;
+            const long long last = k * g_lat_pitch + g_lat_lead + g_lat_samples - 1;
+            const size_t call = (size_t)(last / g_lat_chunk);
+            if (call < g_call_time.size()) g_latency_ms.push_back((t - g_call_time[call]) * 1e3);
+        }
         g_packets++;
         g_bytes += p.size();
         if (g_out) {
@@ -46,10 +72,23 @@ int main(int argc, char **argv)
     // the host process's part of the set-up (include/fun_ofdm_amd.h, foa_recommended_hw_queues): the HIP runtime fixes its hardware queues
     // when it starts, i.e. before the library is first called
     ::setenv("GPU_MAX_HW_QUEUES", std::to_string(foa_recommended_hw_queues()).c_str(), 0);
+#if defined(__GLIBC__)
+    // A caller that hands process_samples() megabyte-sized vectors at gigabytes per second must not have its allocator give every one of
+    // them back to the kernel: glibc serves requests above its mmap threshold (128 KB until the first such block is freed, then whatever
+    // that block's size was) with a mapping of their own, and freeing 3.5 GB of those costs 0.2-0.3 s of munmap -- page by page, under the
+    // process's mmap lock -- which is where calls of >= 65 536 samples spent their time in round 3 (0.64-0.70 Gsample/s against 4 with
+    // calls of 4096 samples, whose 64 KB vectors come from the heap).  A long-running receiver reaches the same state by itself (the
+    // threshold adapts to the sizes it frees); --preload allocates every chunk before it frees the first, so it says so up front.
+    mallopt(M_MMAP_THRESHOLD, 32 * 1024 * 1024);
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
+#endif
     std::string path, format = "fc32", out;
     int chunk = 4096, device = 0, async_calls = 0, narrow_threads = 0;
     size_t device_batch = 0;
     bool preload = false;
+    std::vector<int> devices;                   // --devices 0,1,..: device mode over several devices (batch k on devices[k mod n])
+    int warm_batches = -1;
+    double pace_msps = 0.0;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         if (a == "--format" && i + 1 < argc) format = argv[++i];
@@ -60,6 +99,10 @@ int main(int argc, char **argv)
         else if (a == "--device-batch" && i + 1 < argc) device_batch = (size_t)std::atoll(argv[++i]);
         else if (a == "--narrow-threads" && i + 1 < argc) narrow_threads = std::atoi(argv[++i]);
         else if (a == "--preload") preload = true;
+        else if (a == "--devices" && i + 1 < argc) { for (const char *q = argv[++i]; *q;) { devices.push_back(std::atoi(q)); while (*q && *q != ',') q++; if (*q == ',') q++; } }
+        else if (a == "--warm-batches" && i + 1 < argc) warm_batches = std::atoi(argv[++i]);
+        else if (a == "--pace" && i + 1 < argc) pace_msps = std::atof(argv[++i]);
+        else if (a == "--latency" && i + 3 < argc) { g_lat_pitch = std::atoll(argv[++i]); g_lat_lead = std::atoll(argv[++i]); g_lat_samples = std::atoll(argv[++i]); }
         else if (path.empty() && a[0] != '-') path = a;
         else { std::fprintf(stderr, "usage: foa_sim <iq file> [--format fc32|fc64] [--chunk N] [--device D] [--async K] [--device-batch B] [--narrow-threads T] [--preload] [--out FILE]\n"); return 2; }
     }
@@ -76,17 +119,46 @@ int main(int argc, char **argv)
             std::vector<std::complex<double> > buf;
             size_t total = 0;
             while (src.get_samples(chunk, buf)) { chunks.push_back(buf); total += buf.size(); }
-            fun_amd::receiver_chain chain(device, async_calls, device_batch, narrow_threads);
+            std::unique_ptr<fun_amd::receiver_chain> chain_p(devices.empty() ? new fun_amd::receiver_chain(device, async_calls, device_batch, narrow_threads)
+                                                                             : new fun_amd::receiver_chain(devices, device_batch, narrow_threads));
+            fun_amd::receiver_chain &chain = *chain_p;
             chain.process_samples(std::vector<std::complex<double> >(512));            // creates the handle outside the timed loop
+            // ... and the engine's pipeline: W batches of silence (no frames, no payloads) before the clock starts, so that the timed loop
+            // does not pay for threads that are not on a core yet and buffers nobody has touched (single runs varied 3.1-4.4 Gsample/s cold)
+            if (warm_batches < 0) warm_batches = device_batch > 0 ? 2 : 0;
+            if (warm_batches > 0 && device_batch > 0) {
+                const size_t warm = (size_t)warm_batches * device_batch;
+                for (size_t o = 0; o < warm; o += (size_t)chunk) chain.process_samples(std::vector<std::complex<double> >((size_t)chunk));
+            }
+            g_lat_chunk = chunk;
+            g_call_time.reserve(chunks.size() + 2);
             const auto t0 = std::chrono::steady_clock::now();
-            for (auto &c : chunks) { on_packets(chain.process_samples(std::move(c))); }
+            const double t0s = now_s();
+            size_t fed = 0;
+            for (auto &c : chunks) {
+                if (pace_msps > 0.0) { const double due = t0s + (double)fed / (pace_msps * 1e6); while (now_s() < due) {} }
+                fed += c.size();
+                if (g_lat_pitch) g_call_time.push_back(now_s());
+                on_packets(chain.process_samples(std::move(c)));
+            }
             on_packets(chain.process_samples(std::vector<std::complex<double> >(512)));   // silence lets the pre-sync settle
             on_packets(chain.flush());
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             std::printf("%.1f Msamples/s through process_samples (%zu samples in %.4f s, %zu calls of %d)\n", total / dt / 1e6, total, dt, chunks.size(), chunk);
+            if (g_lat_pitch && !g_latency_ms.empty()) {
+                std::sort(g_latency_ms.begin(), g_latency_ms.end());
+                const size_t m = g_latency_ms.size();
+                std::printf("payload latency ms: p50 %.3f p90 %.3f p99 %.3f max %.3f (%zu payloads; from the call that delivered a frame's last sample to the call that returned its payload)\n",
+                            g_latency_ms[m / 2], g_latency_ms[m * 9 / 10], g_latency_ms[std::min(m - 1, m * 99 / 100)], g_latency_ms[m - 1], m);
+            }
         } else {
-            fun_amd::receiver rx(on_packets, &src, device, chunk, async_calls, device_batch, narrow_threads);
-            rx.wait_finished();
+            if (devices.empty()) {
+                fun_amd::receiver rx(on_packets, &src, device, chunk, async_calls, device_batch, narrow_threads);
+                rx.wait_finished();
+            } else {
+                fun_amd::receiver rx(on_packets, &src, devices, chunk, device_batch, narrow_threads);
+                rx.wait_finished();
+            }
         }
         if (g_out) std::fclose(g_out);
         std::printf("%zu packets, %zu bytes, %zu calls of %d samples\n", g_packets, g_bytes, g_calls, chunk);

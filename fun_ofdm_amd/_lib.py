@@ -71,6 +71,16 @@ _SIGS = {
     "foa_stream_ready": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "foa_stream_take": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "foa_stream_stats": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "foa_shard_create": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),
+    "foa_shard_destroy": (None, [C.c_void_p]),
+    "foa_shard_devices": (C.c_int, [C.c_void_p]),
+    "foa_shard_push_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "foa_shard_push_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "foa_shard_push_f64_owned": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "foa_shard_flush": (C.c_int, [C.c_void_p]),
+    "foa_shard_ready": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "foa_shard_take": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "foa_shard_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "foa_sync_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "foa_sync_destroy": (None, [C.c_void_p]),
     "foa_sync_push_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),

@@ -1009,6 +1009,7 @@ int foa_stream_push_f64_owned(struct foa_stream *s, const double *iq, size_t n_s
 }  // extern "C" (reopened below)
 
 #include "stream_engine.h"
+#include "shard_engine.h"
 
 // ---- host-side pre-sync ---------------------------------------------------------------------------
 struct foa_sync {

@@ -37,6 +37,81 @@ constexpr int kStreamBufs = 6;                      // device sample buffers / p
 
 }  // namespace foa
 
+// Queue the decode of m alignments of a batch buffer through a job slot of the asynchronous host entry (page-locked mirror, D2H behind the
+// finish kernel); *ticket identifies the job for stream_collect_job.  Shared by the single-device engine below and the multi-device one
+// (shard_engine.h).  t_prep (may be null): ns spent finding and sizing the job slot.
+static int stream_decode_batch(foa_rx *rx, const float *d, size_t n_buf, const foa_frame_desc *descs, const int64_t *ends, size_t m, size_t slot_bytes,
+                               uint64_t *ticket, int64_t *t_prep)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    const bool piped = rx->pipeline && rx->viterbi_kind == 2;
+    HostJob *job = nullptr;
+    for (auto &j : rx->jobs) if (!j.busy) { job = &j; break; }
+    if (!job) return fail(FOA_E_STATE, "internal: no free job slot");
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_res = up(m * slot_bytes), total = o_res + up(m * sizeof(foa_frame_result));
+    // (twice what this batch needs: the number of frames differs a little from batch to batch, and growing a buffer means a
+    // hipFree, which waits for the whole device -- with exact sizes that was 0.4-0.9 ms of the submitter's time per batch)
+    const size_t roomy = (2 * total + ((size_t)1 << 20)) & ~(((size_t)1 << 20) - 1);
+    int rc;
+    if (job->dev.n < total && (rc = job->dev.ensure(roomy))) return rc;
+    if (job->pin_cap < total) {
+        if (job->pin) (void)hipHostFree(job->pin);
+        job->pin = nullptr; job->pin_cap = 0;
+        HIP_TRY(hipHostMalloc((void **)&job->pin, roomy, hipHostMallocDefault));
+        job->pin_cap = roomy;
+    }
+    if (!job->done) HIP_TRY(hipEventCreateWithFlags(&job->done, hipEventDisableTiming));
+    // (the slots are not cleared: collect reads the payload of a frame only where the result says it passed)
+    job->total = total; job->o_psdu = 0; job->o_res = o_res; job->n_frames = m; job->slot_bytes = slot_bytes; job->copy_queued = false;
+    rx->attach_job = piped ? job : nullptr;
+    if (t_prep) *t_prep += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    rc = foa_rx_decode_frames_dev(rx, d, n_buf, descs, ends, m, job->dev.p, slot_bytes, (foa_frame_result *)(job->dev.p + o_res));
+    rx->attach_job = nullptr;
+    if (rc) return rc;
+    if (!piped) {
+        HIP_TRY(hipMemcpyAsync(job->pin, job->dev.p, total, hipMemcpyDeviceToHost, rx->stream));
+        HIP_TRY(hipEventRecord(job->done, rx->stream));
+        job->copy_queued = true;
+    }
+    job->busy = true;
+    job->ticket = rx->next_ticket++;
+    *ticket = job->ticket;
+    return FOA_OK;
+}
+
+// The job behind `ticket`: 1 = complete, its CRC-passing payloads appended to *out in frame order and the slot released; 0 = not yet
+// (only with wait false); < 0 error.  by_status[5]: alignments per FOA_ST_* of the batch.
+static int stream_collect_job(foa_rx *rx, uint64_t ticket, size_t n_frames, bool wait, foa::StreamReady *out, uint64_t by_status[5])
+{
+    HostJob *job = nullptr;
+    const int rc = job_ready(rx, ticket, wait, &job);
+    if (rc <= 0) return rc;
+    // straight out of the job's page-locked mirror: only the payload bytes of the frames that passed move again
+    const foa_frame_result *res = (const foa_frame_result *)(job->pin + job->o_res);
+    const uint8_t *ps = job->pin + job->o_psdu;
+    size_t bytes = 0, n_ok = 0;
+    for (size_t i = 0; i < n_frames; i++) {
+        const int st = res[i].status;
+        if (st >= 0 && st < 5) by_status[st]++;
+        if (st == FOA_ST_OK) { bytes += (size_t)res[i].length; n_ok++; }
+    }
+    const size_t at = out->bytes.size(), at_len = out->len.size();
+    out->bytes.resize(at + bytes);
+    out->len.resize(at_len + n_ok);
+    uint8_t *dst = out->bytes.data() + at;
+    uint32_t *dl = out->len.data() + at_len;
+    for (size_t i = 0; i < n_frames; i++) {
+        const foa_frame_result &r = res[i];
+        if (r.status != FOA_ST_OK) continue;
+        *dl++ = (uint32_t)r.length;
+        memcpy(dst, ps + i * job->slot_bytes, (size_t)r.length);
+        dst += r.length;
+    }
+    job->busy = false;
+    return 1;
+}
+
 // The GPU side of one stream: everything here except staging() runs on the core's submitter thread.
 struct StreamGpu {
     foa_rx *rx = nullptr;
@@ -131,7 +206,6 @@ struct StreamGpu {
         const int64_t n_buf = C + n_new, pushed = submitted_samples + n_new;
         HIP_TRY(hipSetDevice(rx->device));
         float *d = dev[k].p;
-        const bool piped = rx->pipeline && rx->viterbi_kind == 2;
         int64_t t0 = now_ns();
         HIP_TRY(hipEventSynchronize(sel_done[k]));                   // (through already when the core asked uploaded(); the staging slot is free again)
         t_sync += now_ns() - t0;
@@ -144,39 +218,8 @@ struct StreamGpu {
         InFlight fl;
         fl.handle = next_handle++; fl.n_frames = m; fl.ticket = 0;
         if (m) {
-            // outputs go through a job slot of the asynchronous host entry (page-locked mirror, D2H behind the finish kernel)
-            HostJob *job = nullptr;
-            for (auto &j : rx->jobs) if (!j.busy) { job = &j; break; }
-            if (!job) return fail(FOA_E_STATE, "internal: no free job slot");
-            auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-            const size_t o_res = up(m * slot_bytes), total = o_res + up(m * sizeof(foa_frame_result));
-            // (twice what this batch needs: the number of frames differs a little from batch to batch, and growing a buffer means a
-            // hipFree, which waits for the whole device -- with exact sizes that was 0.4-0.9 ms of the submitter's time per batch)
-            const size_t roomy = (2 * total + ((size_t)1 << 20)) & ~(((size_t)1 << 20) - 1);
-            if (job->dev.n < total && (rc = job->dev.ensure(roomy))) return rc;
-            if (job->pin_cap < total) {
-                if (job->pin) (void)hipHostFree(job->pin);
-                job->pin = nullptr; job->pin_cap = 0;
-                HIP_TRY(hipHostMalloc((void **)&job->pin, roomy, hipHostMallocDefault));
-                job->pin_cap = roomy;
-            }
-            if (!job->done) HIP_TRY(hipEventCreateWithFlags(&job->done, hipEventDisableTiming));
-            // (the slots are not cleared: collect() reads the payload of a frame only where the result says it passed)
-            job->total = total; job->o_psdu = 0; job->o_res = o_res; job->n_frames = m; job->slot_bytes = slot_bytes; job->copy_queued = false;
-            rx->attach_job = piped ? job : nullptr;
-            t_prep += now_ns() - t0;
-            rc = foa_rx_decode_frames_dev(rx, d, (size_t)n_buf, (const foa_frame_desc *)d_desc[k].p + i0, d_ends[k].p + i0, m, job->dev.p, slot_bytes,
-                                          (foa_frame_result *)(job->dev.p + o_res));
-            rx->attach_job = nullptr;
+            rc = stream_decode_batch(rx, d, (size_t)n_buf, (const foa_frame_desc *)d_desc[k].p + i0, d_ends[k].p + i0, m, slot_bytes, &fl.ticket, &t_prep);
             if (rc) return rc;
-            if (!piped) {
-                HIP_TRY(hipMemcpyAsync(job->pin, job->dev.p, total, hipMemcpyDeviceToHost, rx->stream));
-                HIP_TRY(hipEventRecord(job->done, rx->stream));
-                job->copy_queued = true;
-            }
-            job->busy = true;
-            job->ticket = rx->next_ticket++;
-            fl.ticket = job->ticket;
             alignments.fetch_add(m);
         }
         t_decode += now_ns() - t0;
@@ -195,34 +238,11 @@ struct StreamGpu {
         if (f.n_frames) {
             (void)hipSetDevice(rx->device);
             const int64_t t0 = now_ns();
-            HostJob *job = nullptr;
-            const int rc = job_ready(rx, f.ticket, wait, &job);
+            uint64_t by_status[5] = { 0, 0, 0, 0, 0 };
+            const int rc = stream_collect_job(rx, f.ticket, f.n_frames, wait, out, by_status);
             if (rc < 0) { flight.pop_front(); return keep_error(rc); }
             if (rc == 0) { t_collect_wait += now_ns() - t0; return 0; }
-            // straight out of the job's page-locked mirror: only the payload bytes of the frames that passed move again
-            const foa_frame_result *res = (const foa_frame_result *)(job->pin + job->o_res);
-            const uint8_t *ps = job->pin + job->o_psdu;
-            size_t bytes = 0, n_ok = 0;
-            uint64_t by_status[5] = { 0, 0, 0, 0, 0 };
-            for (size_t i = 0; i < f.n_frames; i++) {
-                const int st = res[i].status;
-                if (st >= 0 && st < 5) by_status[st]++;
-                if (st == FOA_ST_OK) { bytes += (size_t)res[i].length; n_ok++; }
-            }
             for (int k = 0; k < 5; k++) if (by_status[k]) status_count[k].fetch_add(by_status[k], std::memory_order_relaxed);
-            const size_t at = out->bytes.size(), at_len = out->len.size();
-            out->bytes.resize(at + bytes);
-            out->len.resize(at_len + n_ok);
-            uint8_t *dst = out->bytes.data() + at;
-            uint32_t *dl = out->len.data() + at_len;
-            for (size_t i = 0; i < f.n_frames; i++) {
-                const foa_frame_result &r = res[i];
-                if (r.status != FOA_ST_OK) continue;
-                *dl++ = (uint32_t)r.length;
-                memcpy(dst, ps + i * job->slot_bytes, (size_t)r.length);
-                dst += r.length;
-            }
-            job->busy = false;
             t_collect += now_ns() - t0;
         }
         flight.pop_front();

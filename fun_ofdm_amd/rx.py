@@ -272,6 +272,62 @@ class Stream:
                     batches=int(a[6]), samples=int(a[7]))
 
 
+class Shard(Stream):
+    """The stream engine over several devices (foa_shard_*): batch k of the stream on device devices[k mod n]; payloads in stream order.
+    A device may be listed more than once (two handles sharing it)."""
+
+    def __init__(self, devices, batch_samples, narrow_threads=0, xcheck=False):
+        self._lib = lib(xcheck)
+        self._h = C.c_void_p()
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        self._check(self._lib.foa_shard_create(devs, len(devices), int(batch_samples), int(narrow_threads), C.byref(self._h)))
+        self.n_devices = len(devices)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.foa_shard_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def push(self, iq):
+        iq = np.ascontiguousarray(iq)
+        if iq.dtype == np.complex64:
+            self._check(self._lib.foa_shard_push_f32(self._h, _vp(iq), iq.size))
+        else:
+            iq = iq.astype(np.complex128, copy=False)
+            self._check(self._lib.foa_shard_push_f64(self._h, _vp(iq), iq.size))
+        return self.take()
+
+    def flush(self):
+        self._check(self._lib.foa_shard_flush(self._h))
+        return self.take(wait=True)
+
+    def take(self, wait=False):
+        out = []
+        while True:
+            n, nb = C.c_size_t(0), C.c_size_t(0)
+            rc = self._lib.foa_shard_ready(self._h, 1 if wait else 0, C.byref(n), C.byref(nb))
+            if rc < 0:
+                self._check(rc)
+            if rc == 0:
+                return out
+            buf = np.zeros(max(nb.value, 1), np.uint8)
+            lens = np.zeros(max(n.value, 1), np.uint32)
+            self._check(self._lib.foa_shard_take(self._h, _vp(buf), _vp(lens)))
+            o = 0
+            for k in range(n.value):
+                out.append(buf[o:o + int(lens[k])].tobytes())
+                o += int(lens[k])
+
+    def stats(self):
+        a = np.zeros(8, np.uint64)
+        per = np.zeros(self.n_devices, np.uint64)
+        self._check(self._lib.foa_shard_stats(self._h, _vp(a), _vp(per), self.n_devices))
+        return dict(ok=int(a[0]), header_fail=int(a[1]), crc_fail=int(a[2]), truncated=int(a[3]), no_space=int(a[4]), alignments=int(a[5]),
+                    batches=int(a[6]), samples=int(a[7]), per_device_alignments=[int(x) for x in per])
+
+
 class Sync:
     """Streaming frame_detector + timing_sync on the host (foa_sync_*): push raw samples, get alignment
     descriptors with stream-absolute positions."""

@@ -308,6 +308,32 @@ int foa_stream_take(foa_stream *s, uint8_t *payloads, uint32_t *lengths);
 /* out[0..4]: alignments per FOA_ST_* status so far (taken batches), [5] alignments submitted, [6] batches, [7] samples pushed */
 int foa_stream_stats(const foa_stream *s, uint64_t out[8]);
 
+/* ---- the same stream engine over SEVERAL devices (BASELINE config 4's frame sharding, behind the C ABI) -----------------------------
+ *
+ * foa_shard_* is foa_stream_* with a list of devices: batch k of the stream goes to device k mod n_devices -- upload, pre-sync,
+ * decode and copy back on that device, through a receiver handle the shard creates for it -- so n_devices consecutive batches are in
+ * work at once, and the CRC-passing payloads still come out in stream order (foa_shard_ready / _take, batch by batch).  Every batch
+ * buffer is filled from the host (the carry of 112 640 samples before the batch included), so no device reads another device's memory and
+ * there is no collective: what crosses from one batch to the next is the phasor timing_sync left in force (timing_sync.cpp:113-125),
+ * sixteen bytes the host hands from device to device in stream order (fun_ofdm_amd/csrc/shard_core.h; its ordering logic runs against
+ * device doubles at 1, 2, 3 and 8 devices in tests/cpp/shard_core_test.cpp).  The payload list equals foa_stream_*'s and the reference
+ * chain's (tests/test_gpu_stream.py runs it with the one device a test box has, listed once and twice).  A device may be listed more
+ * than once (two handles on one device share it).  NOT measured on a multi-GPU node: none was available to the builder.
+ * Threads, ownership of handed-over buffers and the meaning of every call are those of the foa_stream_* functions of the same name. */
+typedef struct foa_shard foa_shard;
+int foa_shard_create(const int *devices, int n_devices, size_t batch_samples, int narrow_threads, foa_shard **out);
+void foa_shard_destroy(foa_shard *s);
+int foa_shard_devices(const foa_shard *s);
+int foa_shard_push_f32(foa_shard *s, const float *iq, size_t n_samples);
+int foa_shard_push_f64(foa_shard *s, const double *iq, size_t n_samples);
+int foa_shard_push_f64_owned(foa_shard *s, const double *iq, size_t n_samples, void (*release)(void *), void *ctx);
+int foa_shard_flush(foa_shard *s);
+int foa_shard_ready(foa_shard *s, int wait, size_t *n_payloads, size_t *n_bytes);
+int foa_shard_take(foa_shard *s, uint8_t *payloads, uint32_t *lengths);
+/* out[0..7] as foa_stream_stats (summed over the devices); per_device_alignments (may be NULL): alignments decoded by each of the
+ * first n_devices entries of the device list */
+int foa_shard_stats(const foa_shard *s, uint64_t out[8], uint64_t *per_device_alignments, int n_devices);
+
 /* ---- stage-level entry points (one per replaced fun::block, for the per-block adaptors) ---- */
 
 /* fft::forward over n_vec vectors of 64 complex doubles (host pointers, in place): unscaled DFT with

@@ -318,10 +318,20 @@ public:
     {
         if (device_batch_ == 0) check(foa_sync_create(&sync_), "foa_sync_create");
     }
+    // SEVERAL devices (BASELINE config 4 behind process_samples): device mode with batch k of the stream on devices[k mod n] (foa_shard_*,
+    // include/fun_ofdm_amd.h) -- n consecutive batches in work at once, one receiver handle per entry of the list (a device may be listed
+    // twice), payloads in stream order as ever.  Same payloads as every other mode.
+    receiver_chain(const std::vector<int> &devices, size_t device_batch_samples, int narrow_threads = 0)
+        : dev_(devices.empty() ? 0 : devices[0]), sync_(nullptr), base_(0), batch_calls_(0), calls_(0), stream_(nullptr), device_batch_(device_batch_samples),
+          narrow_threads_(narrow_threads), devices_(devices)
+    {
+        if (devices_.empty() || device_batch_ == 0) throw std::invalid_argument("receiver_chain: a device list needs at least one device and a batch size");
+    }
     ~receiver_chain()
     {
         try { while (!jobs_.empty()) collect_front(true, nullptr); } catch (...) {}
         if (stream_) foa_stream_destroy(stream_);
+        if (shard_) foa_shard_destroy(shard_);
         if (sync_) foa_sync_destroy(sync_);
     }
     receiver_chain(const receiver_chain &) = delete;
@@ -333,6 +343,7 @@ public:
     // reference fed with another call size says so here before the first call (0: never drop a frame for that reason).
     void set_reference_call_size(long long samples)
     {
+        if (!devices_.empty()) throw std::runtime_error("receiver_chain: the multi-device mode decides by the reference's own call size (4096)");
         if (sync_) check(foa_sync_set_call(sync_, samples), "foa_sync_set_call");
         check(foa_rx_set_option(dev_.get(), "sync_call", samples), "foa_rx_set_option");
     }
@@ -483,24 +494,32 @@ private:
     std::vector<std::vector<unsigned char> > process_device(std::vector<std::complex<double> > &samples, bool final)
     {
         std::vector<std::vector<unsigned char> > out;
-        if (stream_ && stream_over_) { foa_stream_destroy(stream_); stream_ = nullptr; stream_over_ = false; }     // a new stream after a flush
-        if (!stream_) check(foa_stream_create(dev_.get(), device_batch_, narrow_threads_, &stream_), "foa_stream_create");
+        const bool multi = !devices_.empty();
+        if (stream_over_) {                                             // a new stream after a flush
+            if (stream_) { foa_stream_destroy(stream_); stream_ = nullptr; }
+            if (shard_) { foa_shard_destroy(shard_); shard_ = nullptr; }
+            stream_over_ = false;
+        }
+        if (multi && !shard_) check(foa_shard_create(devices_.data(), (int)devices_.size(), device_batch_, narrow_threads_, &shard_), "foa_shard_create");
+        if (!multi && !stream_) check(foa_stream_create(dev_.get(), device_batch_, narrow_threads_, &stream_), "foa_stream_create");
         if (!samples.empty()) {
             // process_samples owns its argument (by value, src/receiver_chain.h:56): hand the buffer to the engine instead of
             // narrowing it here -- its helper threads do that while the caller fetches the next chunk
             std::vector<std::complex<double> > *own = new std::vector<std::complex<double> >(std::move(samples));
-            check(foa_stream_push_f64_owned(stream_, reinterpret_cast<const double *>(own->data()), own->size(), &receiver_chain::release_vector, own),
-                  "foa_stream_push_f64_owned");
+            if (multi) check(foa_shard_push_f64_owned(shard_, reinterpret_cast<const double *>(own->data()), own->size(), &receiver_chain::release_vector, own), "foa_shard_push_f64_owned");
+            else check(foa_stream_push_f64_owned(stream_, reinterpret_cast<const double *>(own->data()), own->size(), &receiver_chain::release_vector, own),
+                       "foa_stream_push_f64_owned");
         }
-        if (final) check(foa_stream_flush(stream_), "foa_stream_flush");
+        if (final) { if (multi) check(foa_shard_flush(shard_), "foa_shard_flush"); else check(foa_stream_flush(stream_), "foa_stream_flush"); }
         for (;;) {
             size_t n = 0, bytes = 0;
-            const int rc = foa_stream_ready(stream_, final ? 1 : 0, &n, &bytes);
-            if (rc < 0) check(rc, "foa_stream_ready");
+            const int rc = multi ? foa_shard_ready(shard_, final ? 1 : 0, &n, &bytes) : foa_stream_ready(stream_, final ? 1 : 0, &n, &bytes);
+            if (rc < 0) check(rc, multi ? "foa_shard_ready" : "foa_stream_ready");
             if (rc == 0) break;
             take_bytes_.resize(bytes ? bytes : 1);
             take_len_.resize(n ? n : 1);
-            check(foa_stream_take(stream_, take_bytes_.data(), take_len_.data()), "foa_stream_take");
+            if (multi) check(foa_shard_take(shard_, take_bytes_.data(), take_len_.data()), "foa_shard_take");
+            else check(foa_stream_take(stream_, take_bytes_.data(), take_len_.data()), "foa_stream_take");
             size_t o = 0;
             for (size_t i = 0; i < n; i++) {
                 out.push_back(std::vector<unsigned char>(take_bytes_.begin() + o, take_bytes_.begin() + o + take_len_[i]));
@@ -533,6 +552,8 @@ private:
     long calls_;
     std::deque<job> jobs_;
     foa_stream *stream_;              // device mode
+    foa_shard *shard_ = nullptr;      // device mode over several devices
+    std::vector<int> devices_;
     bool stream_over_ = false;
     size_t device_batch_;
     int narrow_threads_;
@@ -612,6 +633,12 @@ public:
              size_t device_batch_samples = 0, int narrow_threads = 0)
         : callback_(callback), source_(source), chain_(device, async_batch_calls, device_batch_samples, narrow_threads), n_(num_rx_samples), token_(true),
           stop_(false), finished_(false)
+    {
+        thread_ = std::thread(&receiver::receiver_chain_loop, this);
+    }
+    // the same over several devices (receiver_chain's device-list mode)
+    receiver(callback_t callback, sample_source *source, const std::vector<int> &devices, int num_rx_samples, size_t device_batch_samples, int narrow_threads = 0)
+        : callback_(callback), source_(source), chain_(devices, device_batch_samples, narrow_threads), n_(num_rx_samples), token_(true), stop_(false), finished_(false)
     {
         thread_ = std::thread(&receiver::receiver_chain_loop, this);
     }

@@ -100,6 +100,20 @@ int main()
         for (auto &p : rest) got.push_back(p);
         CHECK(got == want, "device-mode process_samples payloads differ (%zu vs %zu)", got.size(), want.size());
     }
+    {   // ... and its device-list mode (foa_shard_* behind it), a second stream after a flush included
+        fun_amd::receiver_chain rc(std::vector<int>{ 0, 0, 1 }, 65536, 2);
+        for (int round = 0; round < 2; round++) {
+            payloads_t got;
+            for (size_t x = 0; x < stream.size(); x += 10000) {
+                const size_t n = std::min((size_t)10000, stream.size() - x);
+                payloads_t r = rc.process_samples(std::vector<std::complex<double> >(stream.begin() + x, stream.begin() + x + n));
+                for (auto &p : r) got.push_back(p);
+            }
+            payloads_t rest = rc.flush();
+            for (auto &p : rest) got.push_back(p);
+            CHECK(got == want, "device-list process_samples payloads differ (round %d: %zu vs %zu)", round, got.size(), want.size());
+        }
+    }
     for (int async_calls : { 0, 4 }) {
         g_rx_packets.clear();
         g_rx_calls = 0;

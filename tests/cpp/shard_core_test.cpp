@@ -1,0 +1,154 @@
+// shard_core_test.cpp -- one stream dealt over N devices (fun_ofdm_amd/csrc/shard_core.h) against device doubles: batch k must go to
+// device k mod N with exactly the C samples before it as its carry, the selection of batch k must be queued only after batch k-1's has
+// finished and with the phasor that one reported, payloads must come back in stream order whatever the devices' speeds.  CPU only; run
+// under ThreadSanitizer and AddressSanitizer + UBSan by tools/run_sanitizers.sh.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+
+#include "../../fun_ofdm_amd/csrc/shard_core.h"
+
+static int failures = 0;
+#define CHECK(cond, ...) do { if (!(cond)) { failures++; printf("FAIL %s:%d: ", __FILE__, __LINE__); printf(__VA_ARGS__); printf("\n"); } } while (0)
+
+// what every device double reports to
+struct World {
+    int64_t B, C, L;
+    std::vector<float> stream;                      // the samples as pushed (interleaved re, im), for checking carries
+    std::mutex m;
+    int64_t uploads = 0, selects_queued = 0, selects_done = 0, decodes = 0;
+    int64_t next_select_batch = 0;                  // the chain: selections must be queued in batch order, each after the previous finished
+    double last_phasor[2] = { 1.0, 0.0 };
+    std::vector<int> device_of_batch;
+    int bad = 0;
+};
+
+struct FakeDev {
+    World *w; int id; int n_dev;
+    struct Buf { int64_t batch = -1, n_new = 0, start = 0, lo = 0, hi = 0; int polls = 0; bool selected = false; double prev[2] = { 0, 0 }; };
+    Buf buf[6];
+    std::deque<std::pair<uint64_t, int64_t> > flight;      // (handle, batch)
+    uint64_t next = 1;
+    int slow;                                       // polls until a selection / a batch reports done
+    FakeDev(World *world, int i, int n, int slowness) : w(world), id(i), n_dev(n), slow(slowness) {}
+
+    int upload(int slot, const float *carry, const float *batch, int64_t n_new, int64_t start)
+    {
+        std::lock_guard<std::mutex> lk(w->m);
+        const int64_t k = w->uploads++;
+        w->device_of_batch.push_back(id);
+        if (id != (int)(k % n_dev)) { w->bad++; printf("batch %lld went to device %d\n", (long long)k, id); }
+        // the carry: the C samples before the batch (zeros before the stream's start); the batch: the next n_new samples of the stream
+        const int64_t b0 = start + w->C;            // stream index of the batch's first sample
+        for (int64_t i = 0; i < w->C; i++) {
+            const int64_t x = start + i;
+            const float re = x < 0 ? 0.0f : w->stream[2 * x], im = x < 0 ? 0.0f : w->stream[2 * x + 1];
+            if (carry[2 * i] != re || carry[2 * i + 1] != im) { w->bad++; printf("batch %lld: carry sample %lld differs\n", (long long)k, (long long)i); break; }
+        }
+        for (int64_t i = 0; i < n_new; i++)
+            if (batch[2 * i] != w->stream[2 * (b0 + i)] || batch[2 * i + 1] != w->stream[2 * (b0 + i) + 1]) { w->bad++; printf("batch %lld: sample %lld differs\n", (long long)k, (long long)i); break; }
+        buf[slot] = Buf();
+        buf[slot].batch = k; buf[slot].n_new = n_new; buf[slot].start = start;
+        return 0;
+    }
+    int select(int slot, int64_t lo, int64_t hi, const double prev[2])
+    {
+        std::lock_guard<std::mutex> lk(w->m);
+        Buf &b = buf[slot];
+        if (b.batch != w->next_select_batch || w->selects_done != b.batch) { w->bad++; printf("selection of batch %lld queued out of turn (%lld done)\n", (long long)b.batch, (long long)w->selects_done); }
+        if (prev[0] != w->last_phasor[0] || prev[1] != w->last_phasor[1]) { w->bad++; printf("batch %lld got the wrong phasor\n", (long long)b.batch); }
+        // the selection window in stream coordinates must tile the stream: [cut(k-1), cut(k))
+        b.lo = lo + b.start; b.hi = hi + b.start;
+        b.prev[0] = prev[0]; b.prev[1] = prev[1];
+        w->selects_queued++;
+        w->next_select_batch++;
+        return 0;
+    }
+    int selected(int slot, double last[2])
+    {
+        Buf &b = buf[slot];
+        if (++b.polls < slow) return 0;
+        std::lock_guard<std::mutex> lk(w->m);
+        // every third batch "finds no alignment": the phasor passes through unchanged
+        if (b.batch % 3 == 2) { last[0] = b.prev[0]; last[1] = b.prev[1]; }
+        else { last[0] = 0.001 * (double)(b.batch + 1); last[1] = (double)id; }
+        w->last_phasor[0] = last[0]; w->last_phasor[1] = last[1];
+        w->selects_done++;
+        b.selected = true;
+        return 1;
+    }
+    int decode(int slot, int64_t n_new, uint64_t *handle)
+    {
+        std::lock_guard<std::mutex> lk(w->m);
+        Buf &b = buf[slot];
+        if (!b.selected || n_new != b.n_new) { w->bad++; printf("batch %lld decoded before its selection was through\n", (long long)b.batch); }
+        w->decodes++;
+        flight.push_back(std::make_pair(next, b.batch));
+        *handle = next++;
+        return 0;
+    }
+    int collect(uint64_t h, bool wait, foa::StreamReady *out)
+    {
+        if (flight.empty() || flight.front().first != h) return -5;
+        static thread_local int polls = 0;
+        if (!wait && ++polls % (slow + 1)) return 0;
+        const int64_t k = flight.front().second;
+        out->len.push_back(8);
+        out->bytes.resize(8);
+        memcpy(out->bytes.data(), &k, 8);
+        flight.pop_front();
+        return 1;
+    }
+};
+
+static void run(int n_dev, int64_t B, int64_t C, int64_t L, size_t total, unsigned seed, size_t max_push, int helpers)
+{
+    std::mt19937 rng(seed);
+    World w;
+    w.B = B; w.C = C; w.L = L;
+    w.stream.resize(2 * total);
+    for (size_t i = 0; i < w.stream.size(); i++) w.stream[i] = (float)((int)(rng() % 20001) - 10000) / 64.0f;
+    std::vector<FakeDev *> devs;
+    for (int i = 0; i < n_dev; i++) devs.push_back(new FakeDev(&w, i, n_dev, 1 + (int)(rng() % 5)));
+    std::vector<std::vector<float> > stage(6, std::vector<float>(2 * B)), carry(6, std::vector<float>(2 * C));
+    float *sp[6], *cp[6];
+    for (int i = 0; i < 6; i++) { sp[i] = stage[i].data(); cp[i] = carry[i].data(); }
+    std::vector<int64_t> order;
+    {
+        foa::ShardBackend<FakeDev> be(devs, B, C, L, sp, cp);
+        foa::StreamCore<foa::ShardBackend<FakeDev> > core(&be, B, helpers);
+        auto drain = [&](bool wait) {
+            foa::StreamReady r;
+            while (core.take(wait, &r) == 1) { int64_t k; memcpy(&k, r.bytes.data(), 8); order.push_back(k); r = foa::StreamReady(); }
+        };
+        size_t o = 0;
+        while (o < total) {
+            const size_t n = std::min(total - o, (size_t)(1 + rng() % max_push));
+            CHECK(core.push(w.stream.data() + 2 * o, n, nullptr, nullptr) == 0, "push failed");
+            o += n;
+            if (rng() % 3 == 0) drain(false);
+        }
+        CHECK(core.flush() == 0, "flush failed");
+        drain(true);
+    }
+    const size_t want = total / B + 1;
+    CHECK(order.size() == want, "%zu batches came back, expected %zu", order.size(), want);
+    for (size_t k = 0; k < order.size(); k++) CHECK(order[k] == (int64_t)k, "batch %lld came back in place %zu", (long long)order[k], k);
+    CHECK(w.bad == 0, "%d violations", w.bad);
+    CHECK(w.uploads == (int64_t)want && w.selects_done == (int64_t)want && w.decodes == (int64_t)want, "uploads %lld, selections %lld, decodes %lld of %zu",
+          (long long)w.uploads, (long long)w.selects_done, (long long)w.decodes, want);
+    for (auto *d : devs) delete d;
+    printf("%d devices, B %lld, C %lld, %zu samples, pushes up to %zu, %d helpers: %zu batches in order\n", n_dev, (long long)B, (long long)C, total, max_push, helpers, order.size());
+}
+
+int main()
+{
+    run(1, 4096, 1000, 600, 100000, 1, 3000, 0);
+    run(2, 4096, 1000, 600, 300000, 2, 9000, 2);
+    run(8, 4096, 6000, 4000, 500000, 3, 20000, 3);          // a carry longer than a batch: it spans several batches
+    run(8, 65536, 20000, 9000, 3000000, 4, 300000, 4);      // config 4's device count
+    run(3, 5000, 700, 300, 65000, 5, 100, 1);               // total a multiple of the batch: the final batch is empty
+    printf(failures ? "FAILED (%d)\n" : "OK\n", failures);
+    return failures ? 1 : 0;
+}

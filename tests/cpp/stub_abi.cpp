@@ -139,6 +139,21 @@ int foa_stream_take(foa_stream *s, uint8_t *payloads, uint32_t *lengths)
 }
 int foa_stream_stats(const foa_stream *, uint64_t out[8]) { memset(out, 0, 8 * sizeof(uint64_t)); return FOA_OK; }
 
+// foa_shard_*: the same stand-in behind the multi-device entry points (what is exercised here is blocks.hpp's device-list mode)
+struct foa_shard { foa_stream st; int n; };
+int foa_shard_create(const int *devices, int n, size_t batch, int, foa_shard **out) { if (!devices || n < 1 || batch < 4096) return FOA_E_INVALID; *out = new foa_shard(); (*out)->n = n; return FOA_OK; }
+void foa_shard_destroy(foa_shard *s) { delete s; }
+int foa_shard_devices(const foa_shard *s) { return s->n; }
+int foa_shard_push_f32(foa_shard *s, const float *iq, size_t n) { return foa_stream_push_f32(&s->st, iq, n); }
+int foa_shard_push_f64(foa_shard *s, const double *iq, size_t n) { return foa_stream_push_f64(&s->st, iq, n); }
+int foa_shard_push_f64_owned(foa_shard *s, const double *iq, size_t n, void (*release)(void *), void *ctx) { return foa_stream_push_f64_owned(&s->st, iq, n, release, ctx); }
+int foa_shard_flush(foa_shard *s) { return foa_stream_flush(&s->st); }
+int foa_shard_ready(foa_shard *s, int w, size_t *np, size_t *nb) { return foa_stream_ready(&s->st, w, np, nb); }
+int foa_shard_take(foa_shard *s, uint8_t *p, uint32_t *l) { return foa_stream_take(&s->st, p, l); }
+int foa_shard_stats(const foa_shard *, uint64_t out[8], uint64_t *, int) { memset(out, 0, 8 * sizeof(uint64_t)); return FOA_OK; }
+int foa_recommended_hw_queues(void) { return 8; }
+const char *foa_rx_notes(foa_rx *) { return ""; }
+
 // the per-block adaptors are not part of this run; their entry points only have to link
 int foa_fft_forward_f64(foa_rx *, double *, size_t) { return FOA_E_NO_DEVICE; }
 int foa_channel_estimate_f64(foa_rx *, const double *, double *, size_t) { return FOA_E_NO_DEVICE; }

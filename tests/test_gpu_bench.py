@@ -33,27 +33,35 @@ def test_bench_two_ranks_decode_and_gather():
 
 
 def test_bench_single_rank_line_has_the_contract_fields():
-    out = _bench("--frames", "600", "--steps", "4", "--warmup", "2", "--legs-frames", "40")
+    out = _bench("--frames", "600", "--steps", "4", "--warmup", "2", "--legs-frames", "40", "--fill-frames", "96")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
               "config", "roofline", "cpu_baseline"):
         assert k in out, k
     assert out["n_gpus"] == 1 and out["config"]["psdu_bit_exact"] is True
     rf = out["roofline"]
     assert rf["bound"] == "valu" and 0 < rf["frac"] < 1 and rf["hbm"]["unit"] == "GB/s" and rf["kernel"] == "k_viterbi_fwd3"
-    assert 70 < rf["peak"] < 85 and 0 < rf["per_launch"]["frac"] <= rf["frac"] * 1.5
+    assert 70 < rf["peak"] < 85 and 0 < rf["frac"] <= rf["frac_at_step_rate"]["frac"] * 1.5      # frac: per launch (the tier's definition)
+    assert abs(rf["frac"] - rf["algorithmic_ops_per_launch"] / (rf["avg_kernel_ms"] * 1e-3) / (rf["peak"] * 1e12)) < 2e-3
     live = rf["peak_measured_live"]                        # the issue probe ran in this process: packed instructions at ~4 clocks, plain VOP2 at ~2
     assert 3.5 < live["clk_per_packed_wave_instr"] < 4.8 and 1.8 < live["clk_per_plain_vop2_wave_instr"] < 2.6 and 1.5 < live["ghz"] < 2.6
     rp = out["repeats"]
     assert rp["regions"] == 3 and rp["min"] <= rp["median"] <= rp["max"] and rp["forward_live_over_alone"] > 0.5
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and len(cb["runs_s"]) == 3 and cb["cpu_model"]
+    assert cb["timed_decoder_equals_scalar_checker"]["equal"] is True and cb["per_thread_single"]["value"] > 1.0 and 0 < cb["parallel_efficiency"] < 1.5
+    assert cb["viterbi_ns_per_step"]["oracle_simd"] < cb["viterbi_ns_per_step"]["oracle_scalar_model"]
     legs = out["legs"]
     assert legs["end_to_end_host_pointers"]["same_results_as_device_path"] is True
     rows = legs["config3_rate_sweep"]["rates"]
     assert [r["rate_enum"] for r in rows] == [0, 2, 3, 5, 6, 8, 9, 10]
     assert all(r["psdu_bit_exact"] and r["crc_ok"] >= 30 for r in rows) and all(v for r in rows for k, v in r.items() if k.startswith("gpu_equals_cpu"))
-    assert all(r["cpu_Msamples_per_s"] > 0 and r["cpu_crc_fail"] == r["gpu_crc_fail_same_sample"] for r in rows)
-    assert all(r["gpu_equals_cpu_on_all"] is True for r in rows)
+    assert all(r["cpu_Msamples_per_s"] > 0 and r["cpu_crc_fail"] == r["gpu_crc_fail"] for r in rows)
+    assert all(r["gpu_equals_cpu_on_all"] is True for r in rows) and legs["config3_rate_sweep"]["table"] == "small batch"
+    fill = legs["config3_machine_filling"]["rates"]
+    assert [r["rate_enum"] for r in fill] == [0, 2, 3, 5, 6, 8, 9, 10] and all(r["frames"] == 96 for r in fill)
+    assert all(r["psdu_bit_exact"] and r["gpu_equals_cpu_on_all"] is True and r["scalar_checker_on_first"]["equal_to_gpu"] is True for r in fill)
+    mixed = legs["config3_mixed_call"]
+    assert mixed["frames"] == 8 * 40 and mixed["psdu_bit_exact"] is True and mixed["gpu_equals_cpu_on_all"] is True and mixed["crc_ok"] >= 8 * 40 - 12
     c5 = legs["config5_stream"]
     assert c5["psdu_bit_exact"] is True and c5["frames_ok"] >= 3900 and c5["gpu_equals_cpu_on_all"] is True
     assert c5["cpu_checked_alignments"] == c5["alignments"]

@@ -176,3 +176,91 @@ def test_one_stream_per_handle_and_handle_destroyed_first(po):
     with pytest.raises(FoaError):
         st2.push(s[4000:])
     st2.close()
+
+
+# ---- the same engine over several devices (foa_shard_*): one test box has one GPU, so the device list names it once, twice, three times
+# (handles sharing it); what is tested is the dealing of batches, the host-side carries and the phasor chain through the handles ----
+@pytest.mark.parametrize("devices,batch,chunk", [([0], 4096, 4096), ([0, 0], 4096, 1000), ([0, 0], 20000, 4096), ([0, 0, 0], 65536, 7777),
+                                                 ([0, 0], 1 << 18, 4096), ([0, 0], 1 << 22, 100000)])
+def test_shard_engine_equals_reference_chain(mixed, devices, batch, chunk):
+    import fun_ofdm_amd as foa
+    iq, pays, want = mixed
+    sh = foa.Shard(devices, batch, narrow_threads=2)
+    got = []
+    try:
+        for a in range(0, iq.size, chunk):
+            got += sh.push(iq[a:a + chunk])
+        got += sh.flush()
+        stats = sh.stats()
+    finally:
+        sh.close()
+    assert got == want, (devices, batch, chunk, len(got), len(want))
+    assert stats["samples"] == iq.size and stats["ok"] == len(want) and stats["batches"] == iq.size // batch + 1
+    assert sum(stats["per_device_alignments"]) == stats["alignments"]
+    if len(devices) > 1 and stats["batches"] > 4:
+        assert all(v > 0 for v in stats["per_device_alignments"])          # every handle did part of the work
+
+
+def test_shard_engine_phasor_chain_across_devices(po):
+    """Long silences between frames with CFO: the first frame after a silence longer than the carry finds no alignment before it in its own
+    buffer, so the phasor timing_sync had left in force comes from a batch that ANOTHER handle decoded (shard_core.h)."""
+    import fun_ofdm_amd as foa
+    rng = np.random.default_rng(63)
+    sigma = np.sqrt(0.0124 / (2 * 10 ** 2.5))
+    parts = []
+    for i in range(6):
+        a, _ = _stream(po, rng, [(int(rng.choice((0, 5, 10))), int(rng.integers(20, 600))) for _ in range(2)], gap=(0, 200), cfo_hz=4000.0)
+        parts += [a, ((rng.normal(size=130000) + 1j * rng.normal(size=130000)) * sigma).astype(np.complex64)]
+    iq = np.concatenate(parts)
+    want = po.ReceiverChain().run_stream(iq.astype(np.complex128))
+    assert len(want) >= 10
+    for devices, batch in (([0, 0], 32768), ([0, 0, 0], 16384)):
+        sh = foa.Shard(devices, batch)
+        try:
+            got = sh.push(iq) + sh.flush()
+        finally:
+            sh.close()
+        assert got == want, (devices, batch)
+
+
+def test_shard_engine_second_preamble_inside_a_frame_and_api_edges(po):
+    from test_gpu_cpp_adaptors import _collision_stream
+    import fun_ofdm_amd as foa
+    for case in ("valid", "invalid"):
+        iq, pays = _collision_stream(po, case, 5)
+        want = po.ReceiverChain().run_stream(iq.astype(np.complex128))
+        sh = foa.Shard([0, 0], 4096)
+        try:
+            got = sh.push(iq) + sh.flush()
+            with pytest.raises(foa.FoaError):
+                sh.push(np.zeros(10, np.complex64))             # no pushes after the flush
+        finally:
+            sh.close()
+        assert got == want, case
+    with pytest.raises(foa.FoaError):
+        foa.Shard([0], 100)                                     # batch too small
+    with pytest.raises(foa.FoaError):
+        foa.Shard([], 4096)                                     # no device
+    with pytest.raises(foa.FoaError):
+        foa.Shard([0, 99], 4096)                                # no such device
+
+
+def test_process_samples_over_a_device_list_through_the_cpp_chain(tmp_path, po, mixed):
+    """fun_amd::receiver_chain(std::vector<int> devices, ...) behind examples/foa_sim --devices: the same ordered payloads."""
+    import fun_ofdm_amd as foa
+    iq, pays, want = mixed
+    exe = str(tmp_path / "foa_sim")
+    libdir = os.path.dirname(foa.library_path())
+    subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "examples", "foa_sim.cpp"), "-I", os.path.join(ROOT, "include"),
+                    "-L", libdir, "-lfun_ofdm_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lpthread", "-o", exe], check=True)
+    src, out = str(tmp_path / "cap.fc32"), str(tmp_path / "psdus")
+    iq.tofile(src)
+    for extra in (["--devices", "0,0", "--device-batch", "30000"], ["--devices", "0,0,0", "--device-batch", "65536", "--narrow-threads", "2", "--preload", "--chunk", "65536"]):
+        r = subprocess.run([exe, src, "--format", "fc32", "--out", out] + extra, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        raw, recs, o = open(out, "rb").read(), [], 0
+        while o < len(raw):
+            n = int.from_bytes(raw[o:o + 4], "little")
+            recs.append(raw[o + 4:o + 4 + n])
+            o += 4 + n
+        assert recs == want, extra

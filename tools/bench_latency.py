@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""fun_amd::receiver_chain::process_samples in device mode: throughput AND payload latency against the batch size.
+A capture of back-to-back 54 Mbps frames whose payloads carry their frame number goes through examples/foa_sim --preload
+  (a) as fast as it is taken, in calls of 4096 / 65536 / 1 Mi samples (the large calls that ran at the rate of one helper in round 3),
+  (b) for B in {64 Ki, 256 Ki, 1 Mi, 4 Mi}: as fast as it is taken, and PACED at 20 x and 100 x real time (400 / 2000 Msample/s of wall
+      clock), with the latency from the call that delivered a frame's last sample to the call that returned its payload.
+The reference returns a payload five 4096-sample calls after its last sample (receiver_chain.cpp:106-126): 1.02 ms at 20 Msample/s.
+One JSON line per run.  usage: tools/bench_latency.py [frames] > gpurun_out/latency.jsonl"""
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+import fun_ofdm_amd as foa                      # noqa: E402
+from fun_ofdm_amd import synth                  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 60000
+rx = foa.Receiver(0)
+pays = synth.splitmix64_bytes(0xB57, n, 1024)
+pays[:, :4] = np.arange(n, dtype="<u4").view(np.uint8).reshape(n, 4)          # the frame number: foa_sim --latency reads it back
+frames = rx.tx_build_frames(torch.from_numpy(pays).to("cuda:0"), 10)
+s = frames.shape[1]
+PITCH, LEAD = s + 160, 80
+iq = rx.tx_channel(frames, PITCH, LEAD, 25.0, seed=5).cpu().numpy().reshape(-1).view(np.complex64)
+rx.close()
+cap = "/tmp/stream_lat.fc32"
+iq.tofile(cap)
+exe = "/tmp/foa_sim_lat"
+libdir = os.path.dirname(foa.library_path())
+subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "examples", "foa_sim.cpp"), "-I", os.path.join(ROOT, "include"), "-L", libdir,
+                "-lfun_ofdm_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lpthread", "-o", exe], check=True)
+want = n                                          # (a few frames at 25 dB may fail their CRC: reported, not asserted)
+
+
+def run(name, extra, reps=1):
+    out = []
+    for _ in range(reps):
+        r = subprocess.run([exe, cap, "--format", "fc32", "--preload", "--latency", str(PITCH), str(LEAD), str(s)] + extra, capture_output=True, text=True, timeout=600)
+        m = re.search(r"([\d.]+) Msamples/s through process_samples \((\d+) samples in ([\d.]+) s, (\d+) calls of (\d+)\)", r.stdout)
+        lat = re.search(r"payload latency ms: p50 ([\d.]+) p90 ([\d.]+) p99 ([\d.]+) max ([\d.]+) \((\d+) payloads", r.stdout)
+        p = re.search(r"(\d+) packets", r.stdout)
+        if not m:
+            print(json.dumps({"mode": name, "error": (r.stdout + r.stderr)[-400:]}), flush=True)
+            return
+        out.append((float(m.group(1)), m, lat, p))
+    out.sort(key=lambda t: t[0])
+    rate, m, lat, p = out[len(out) // 2]
+    rec = {"mode": name, "args": extra, "Msamples_per_s": rate, "x_realtime_20MSps": round(rate / 20.0, 1), "seconds": float(m.group(3)), "calls": int(m.group(4)),
+           "chunk": int(m.group(5)), "packets": int(p.group(1)) if p else None, "frames_sent": n}
+    if reps > 1:
+        rec["runs_Msamples_per_s"] = [t[0] for t in out]
+        rec["spread"] = round((out[-1][0] - out[0][0]) / out[len(out) // 2][0], 3)
+    if lat:
+        rec["latency_ms"] = {"p50": float(lat.group(1)), "p90": float(lat.group(2)), "p99": float(lat.group(3)), "max": float(lat.group(4)), "payloads": int(lat.group(5))}
+    print(json.dumps(rec), flush=True)
+
+
+# (a) call size, batches of 4 Mi samples, eight helpers; three runs each (median, spread)
+for chunk in (4096, 65536, 1 << 20):
+    run("device 4M, calls of %d, 8 helpers, as fast as taken" % chunk, ["--chunk", str(chunk), "--device-batch", str(1 << 22), "--narrow-threads", "8"], reps=3)
+run("device 4M, calls of 4096, 8 helpers, no warm-up batches (round 3's protocol)", ["--chunk", "4096", "--device-batch", str(1 << 22), "--narrow-threads", "8", "--warm-batches", "0"], reps=3)
+# (b) batch size x pace
+for B in (1 << 16, 1 << 18, 1 << 20, 1 << 22):
+    for pace in (0, 400, 2000):
+        extra = ["--chunk", "4096", "--device-batch", str(B), "--narrow-threads", "8"] + (["--pace", str(pace)] if pace else [])
+        run("device %dK, calls of 4096, %s" % (B >> 10, ("paced at %d Msample/s (%d x real time)" % (pace, pace // 20)) if pace else "as fast as taken"), extra)
