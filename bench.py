@@ -221,12 +221,13 @@ def cpu_baseline(iq, descs, ends, pays, wall_s=2.0):
     for c in cands:
         pl = po.Pool(c)
         pl.decode(iq, descs[:min(n, 8 * c)], ends[:min(n, 8 * c)], slot_bytes=PAYLOAD)
-        t0 = time.perf_counter()
-        pl.decode(iq, descs, ends, slot_bytes=PAYLOAD)
-        d1 = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        pl.decode(iq, descs, ends, slot_bytes=PAYLOAD)
-        d1 = min(d1, time.perf_counter() - t0)
+        # sustained, not a burst: passes for at least 0.4 s (a CPU quota is enforced per 100 ms period: one 50 ms pass on twice the
+        # quota's threads looks twice as fast as the container can keep up)
+        t0, k = time.perf_counter(), 0
+        while k < 2 or time.perf_counter() - t0 < 0.4:
+            pl.decode(iq, descs, ends, slot_bytes=PAYLOAD)
+            k += 1
+        d1 = (time.perf_counter() - t0) / k
         pl.close()
         r = in_frame(n) / d1 / 1e6
         probe_rows.append({"threads": c, "Msamples_per_s": round(r, 1)})

@@ -45,6 +45,16 @@ int fail(int code, const char *fmt, ...)
         if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? FOA_E_NOMEM : FOA_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+// Every entry point that queues work starts here: select the handle's device and FORGET whatever error an earlier HIP call on this
+// thread left behind -- a failed call of ours that was already reported, a polled hipEventQuery, or another library's probing (PyTorch
+// asks about peers a one-GPU box does not have: "invalid device ordinal").  The launch checks below (hipGetLastError after the kernels
+// are queued) must report THIS call's errors only; round 4 found a transmit-side test failing on a stale one.
+static inline hipError_t enter_device(int device)
+{
+    (void)hipGetLastError();
+    return hipSetDevice(device);
+}
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
@@ -446,7 +456,7 @@ void foa_rx_destroy(foa_rx *rx)
 int foa_rx_reserve(foa_rx *rx, size_t n_samples, size_t n_frames)
 {
     if (!rx) return fail(FOA_E_INVALID, "rx is NULL");
-    HIP_TRY(hipSetDevice(rx->device));
+    HIP_TRY(enter_device(rx->device));
     { int rc0 = drain(rx); if (rc0) return rc0; }
     WorkSet *keep = rx->w;
     int rc = FOA_OK;
@@ -552,7 +562,7 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
     if (n_frames == 0) { rx->last_frames = 0; return FOA_OK; }
     if (!d_iq || !d_descs || !d_ends || !d_psdu || !d_results) return fail(FOA_E_INVALID, "NULL device pointer");
     if (n_frames > 0x7FFFFFF0u) return fail(FOA_E_INVALID, "too many frames");
-    HIP_TRY(hipSetDevice(rx->device));
+    HIP_TRY(enter_device(rx->device));
     // Two work sets take turns when the finish runs on its own stream: this call's front end and forward pass may then
     // start while the previous call's chain-back is still reading the other set.
     const bool piped = rx->pipeline && rx->viterbi_kind == 2;
@@ -665,7 +675,7 @@ int foa_rx_decode_frames_host(foa_rx *rx, const float *iq, size_t n_samples, con
     if (!rx) return fail(FOA_E_INVALID, "rx is NULL");
     if (n_frames == 0) return FOA_OK;
     if (!iq || !descs || !ends || !psdu || !results) return fail(FOA_E_INVALID, "NULL pointer");
-    HIP_TRY(hipSetDevice(rx->device));
+    HIP_TRY(enter_device(rx->device));
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t o_iq = 0, o_desc = o_iq + up(n_samples * 8), o_end = o_desc + up(n_frames * sizeof(foa_frame_desc)),
            o_psdu = o_end + up(n_frames * 8), o_res = o_psdu + up(n_frames * slot_bytes), total = o_res + up(n_frames * sizeof(foa_frame_result));
@@ -694,7 +704,7 @@ int foa_rx_submit_host(foa_rx *rx, const float *iq, size_t n_samples, const foa_
 {
     if (!rx || !ticket) return fail(FOA_E_INVALID, "NULL argument");
     if (n_frames == 0 || !iq || !descs || !ends) return fail(FOA_E_INVALID, "empty call or NULL pointer");
-    HIP_TRY(hipSetDevice(rx->device));
+    HIP_TRY(enter_device(rx->device));
     HostJob *job = nullptr;
     for (auto &j : rx->jobs) if (!j.busy) { job = &j; break; }
     if (!job) return fail(FOA_E_STATE, "%d calls are in flight: collect the oldest first", kMaxJobs);
@@ -747,7 +757,7 @@ static int job_ready(foa_rx *rx, uint64_t ticket, bool wait, HostJob **out)
     HostJob *job = nullptr;
     for (auto &j : rx->jobs) if (j.busy && j.ticket == ticket) { job = &j; break; }
     if (!job) return fail(FOA_E_INVALID, "unknown ticket");
-    HIP_TRY(hipSetDevice(rx->device));
+    HIP_TRY(enter_device(rx->device));
     if (!job->copy_queued) {
         // its chain-back + finish is still the pending one: queue it (it would otherwise wait for the next call)
         if (!(rx->pending.valid && rx->pending.job == job)) return fail(FOA_E_STATE, "internal: job without a pending finish");
@@ -822,7 +832,7 @@ int foa_rx_kernel_ms_age(foa_rx *rx, int age, float out_ms[6])
 int foa_rx_probe_issue(foa_rx *rx, double out[6])
 {
     if (!rx || !out) return fail(FOA_E_INVALID, "NULL argument");
-    HIP_TRY(hipSetDevice(rx->device));
+    HIP_TRY(enter_device(rx->device));
     { int rc0 = drain(rx); if (rc0) return rc0; }
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, rx->device));
@@ -864,7 +874,7 @@ int foa_rx_get_taps(foa_rx *rx, size_t n_frames, double *hinv, double *eq, size_
     if (!rx) return fail(FOA_E_INVALID, "rx is NULL");
     if (n_frames != rx->last_frames || n_frames == 0) return fail(FOA_E_STATE, "n_frames does not match the last decode call");
     if (eq && !rx->record_eq) return fail(FOA_E_STATE, "set option record_eq=1 before the decode call to get eq");
-    HIP_TRY(hipSetDevice(rx->device));
+    HIP_TRY(enter_device(rx->device));
     { int rc0 = drain(rx); if (rc0) return rc0; }
     std::vector<FrameInfo> info(n_frames);
     HIP_TRY(hipMemcpy(info.data(), rx->w->info.p, n_frames * sizeof(FrameInfo), hipMemcpyDeviceToHost));
@@ -900,7 +910,7 @@ int foa_rx_get_decisions(foa_rx *rx, size_t frame, uint64_t *out, size_t cap, si
 {
     if (!rx || !out || !n_steps) return fail(FOA_E_INVALID, "NULL argument");
     if (frame >= rx->last_frames) return fail(FOA_E_STATE, "frame index beyond the last decode call");
-    HIP_TRY(hipSetDevice(rx->device));
+    HIP_TRY(enter_device(rx->device));
     { int rc0 = drain(rx); if (rc0) return rc0; }
     FrameInfo fi;
     HIP_TRY(hipMemcpy(&fi, rx->w->info.p + frame, sizeof fi, hipMemcpyDeviceToHost));
@@ -964,7 +974,7 @@ int foa_rx_sync_dev_begin(foa_rx *rx, const float *d_iq, size_t n_samples, foa_f
     if (rx->open_stream) return fail(FOA_E_STATE, "a stream engine owns this handle (and its pre-sync scratch): destroy the stream first");
     if (rx->sy_open) return fail(FOA_E_STATE, "a pre-sync is already in flight on this handle: foa_rx_sync_dev_end first");
     if (n_samples > 0x7FFFFFFFull * 16) return fail(FOA_E_INVALID, "stream too long for one call");
-    HIP_TRY(hipSetDevice(rx->device));
+    HIP_TRY(enter_device(rx->device));
     if (!rx->sy_pin) HIP_TRY(hipHostMalloc((void **)&rx->sy_pin, 4 * sizeof(int32_t), hipHostMallocDefault));
     if (!rx->sy_done) HIP_TRY(hipEventCreateWithFlags(&rx->sy_done, hipEventDisableTiming));
     rx->sy_pin[0] = rx->sy_pin[1] = rx->sy_pin[2] = rx->sy_pin[3] = 0;
@@ -986,7 +996,7 @@ int foa_rx_sync_dev_end(foa_rx *rx, size_t *n_found)
     if (!rx->sy_open) return fail(FOA_E_STATE, "no pre-sync in flight (foa_rx_sync_dev_begin first)");
     rx->sy_open = false;
     if (rx->sy_cap == 0) return FOA_OK;
-    HIP_TRY(hipSetDevice(rx->device));
+    HIP_TRY(enter_device(rx->device));
     HIP_TRY(hipEventSynchronize(rx->sy_done));
     if (rx->sy_pin[0] > rx->sy_ccap) return fail(FOA_E_NOMEM, "too many STS_END candidates (%d)", rx->sy_pin[0]);
     if ((size_t)rx->sy_pin[3] > rx->sy_cap) return fail(FOA_E_INVALID, "cap too small: %d alignments found", rx->sy_pin[3]);
@@ -1065,7 +1075,7 @@ int foa_fft_forward_f64(foa_rx *rx, double *vectors, size_t n_vec)
 {
     if (!rx || !vectors) return fail(FOA_E_INVALID, "NULL argument");
     if (n_vec == 0) return FOA_OK;
-    HIP_TRY(hipSetDevice(rx->device));
+    HIP_TRY(enter_device(rx->device));
     { int rc0 = drain(rx); if (rc0) return rc0; }                     // rx->scratch may still be read by a call in flight
     size_t bytes = n_vec * 64 * sizeof(double2);
     int rc = rx->scratch.ensure(bytes);
@@ -1083,7 +1093,7 @@ int foa_conv_decode(foa_rx *rx, const uint8_t *symbols, uint8_t *data, int data_
     if (data_bits < 1 || data_bits > 8 * (kMaxDecodedBytes - 8)) return fail(FOA_E_INVALID, "data_bits out of range");
     if (n_blocks == 0) return FOA_OK;
     if (n_blocks > 0xFFFFu) return fail(FOA_E_INVALID, "at most 65535 blocks per call");
-    HIP_TRY(hipSetDevice(rx->device));
+    HIP_TRY(enter_device(rx->device));
     { int rc0 = drain(rx); if (rc0) return rc0; }                     // this entry point reuses the work set of the batch calls
     const size_t nsteps = (size_t)data_bits + 6, sym_bytes = n_blocks * 2 * nsteps, nbytes = (size_t)((data_bits + 7) / 8), out_bytes = n_blocks * nbytes;
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -1149,7 +1159,7 @@ int foa_channel_estimate_f64(foa_rx *rx, const double *lts_pairs, double *hinv, 
 {
     if (!rx || !lts_pairs || !hinv) return fail(FOA_E_INVALID, "NULL argument");
     if (n == 0) return FOA_OK;
-    HIP_TRY(hipSetDevice(rx->device));
+    HIP_TRY(enter_device(rx->device));
     { int rc0 = drain(rx); if (rc0) return rc0; }                     // rx->scratch may still be read by a call in flight
     const size_t in_b = n * 128 * sizeof(double2), out_b = n * 64 * sizeof(double2);
     int rc = rx->scratch.ensure(in_b + out_b);
@@ -1168,7 +1178,7 @@ int foa_equalize_f64(foa_rx *rx, double *vectors, size_t n_vec, const double *hi
     if (n_vec == 0) return FOA_OK;
     for (size_t i = 0; i < n_vec; i++)
         if (hinv_index[i] < 0 || (size_t)hinv_index[i] >= n_hinv) return fail(FOA_E_INVALID, "hinv_index[%zu] out of range", i);
-    HIP_TRY(hipSetDevice(rx->device));
+    HIP_TRY(enter_device(rx->device));
     { int rc0 = drain(rx); if (rc0) return rc0; }                     // rx->scratch may still be read by a call in flight
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t v_b = n_vec * 64 * sizeof(double2), h_b = n_hinv * 64 * sizeof(double2), i_b = n_vec * sizeof(int32_t);
@@ -1189,7 +1199,7 @@ int foa_phase_track_f64(foa_rx *rx, const double *vectors, const int32_t *symbol
 {
     if (!rx || !vectors || !symbol_count || !out48) return fail(FOA_E_INVALID, "NULL argument");
     if (n_vec == 0) return FOA_OK;
-    HIP_TRY(hipSetDevice(rx->device));
+    HIP_TRY(enter_device(rx->device));
     { int rc0 = drain(rx); if (rc0) return rc0; }                     // rx->scratch may still be read by a call in flight
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t v_b = n_vec * 64 * sizeof(double2), c_b = n_vec * sizeof(int32_t), o_b = n_vec * 48 * sizeof(double2);
@@ -1209,7 +1219,7 @@ int foa_decode_header_f64(foa_rx *rx, const double *carriers48, size_t n, foa_fr
 {
     if (!rx || !carriers48 || !results) return fail(FOA_E_INVALID, "NULL argument");
     if (n == 0) return FOA_OK;
-    HIP_TRY(hipSetDevice(rx->device));
+    HIP_TRY(enter_device(rx->device));
     { int rc0 = drain(rx); if (rc0) return rc0; }                     // rx->scratch may still be read by a call in flight
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t c_b = n * 48 * sizeof(double2), r_b = n * sizeof(foa_frame_result);
@@ -1228,7 +1238,7 @@ int foa_decode_data_f64(foa_rx *rx, const double *carriers, const uint64_t *carr
 {
     if (!rx || !carriers || !carrier_off || !results || !psdu) return fail(FOA_E_INVALID, "NULL argument");
     if (n_frames == 0) return FOA_OK;
-    HIP_TRY(hipSetDevice(rx->device));
+    HIP_TRY(enter_device(rx->device));
     { int rc0 = drain(rx); if (rc0) return rc0; }                     // this entry point reuses the work set of the batch calls
     DeviceTables tab;
     build_tables(&tab);
@@ -1308,7 +1318,7 @@ int foa_tx_build_frames_dev(foa_rx *rx, const uint8_t *d_payloads, size_t payloa
     if ((!d_payloads && length > 0) || !d_frames) return fail(FOA_E_INVALID, "NULL device pointer");
     if (payload_pitch < (size_t)length) return fail(FOA_E_INVALID, "payload_pitch smaller than length");
     if (n_frames > 0x7FFFFFF0u / (size_t)(nsym + 1)) return fail(FOA_E_INVALID, "too many frames for one call");
-    HIP_TRY(hipSetDevice(rx->device));
+    HIP_TRY(enter_device(rx->device));
     const size_t stride = ((size_t)nbytes + 1 + 15) & ~(size_t)15;
     int rc = rx->scratch.ensure(n_frames * stride);
     if (rc) return rc;
@@ -1329,7 +1339,7 @@ int foa_tx_channel_dev(foa_rx *rx, const double *d_frames, size_t n_frames, size
     if (n_frames == 0) return FOA_OK;
     if (!d_frames || !d_iq) return fail(FOA_E_INVALID, "NULL device pointer");
     if (lead + frame_samples > pitch) return fail(FOA_E_INVALID, "lead + frame_samples exceeds the pitch");
-    HIP_TRY(hipSetDevice(rx->device));
+    HIP_TRY(enter_device(rx->device));
     // sigma^2 per real component = P_ref / (2 10^(SNR/10)), P_ref = 0.0124
     const double sigma = std::sqrt(0.0124 / (2.0 * std::pow(10.0, snr_db / 10.0)));
     const int64_t total = (int64_t)n_frames * (int64_t)pitch;

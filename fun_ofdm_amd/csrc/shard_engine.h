@@ -21,6 +21,8 @@ struct ShardDev {
     hipStream_t st_in = nullptr;
     DevBuf<double> d_prev;
     DevBuf<int32_t> sel_dev;
+    DevBuf<int32_t> syn_dev;                         // per buffer: the pre-sync's counts (rx->sy_n) as they stood when ITS kernels finished -- the
+                                                     // selection is queued later, possibly behind the pre-sync of the handle's next batch, which reuses the scratch
     int32_t *sel = nullptr;                          // page-locked: per buffer { STS_END candidates, alignments found, first of the batch, count }
     double *ph = nullptr;                            // page-locked: per buffer { phasor handed in (2), phasor in force after the batch (2) }
     int32_t ccap[foa::kStreamBufs] = {};
@@ -42,7 +44,7 @@ struct ShardDev {
     {
         rx = handle; B = batch;
         desc_cap = (size_t)((foa::kStreamCarry + B) / 300 + 64);
-        HIP_TRY(hipSetDevice(rx->device));
+        HIP_TRY(enter_device(rx->device));
         int rc = FOA_OK;
         for (int i = 0; i < foa::kStreamBufs && !rc; i++) {
             rc = dev[i].ensure((size_t)(foa::kStreamCarry + B) * 2);
@@ -55,6 +57,7 @@ struct ShardDev {
         if (!rc && hipHostMalloc((void **)&sel, (size_t)foa::kStreamBufs * 4 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) rc = fail(FOA_E_NOMEM, "hipHostMalloc failed");
         if (!rc && hipHostMalloc((void **)&ph, (size_t)foa::kStreamBufs * 4 * sizeof(double), hipHostMallocDefault) != hipSuccess) rc = fail(FOA_E_NOMEM, "hipHostMalloc failed");
         if (!rc) rc = sel_dev.ensure((size_t)foa::kStreamBufs * 4);
+        if (!rc) rc = syn_dev.ensure((size_t)foa::kStreamBufs * 8);
         if (!rc) rc = d_prev.ensure(2);
         // everything a batch will need is allocated here, not by the first batches that need it (stream_engine.h)
         if (!rc) rc = foa_rx_reserve(rx, (size_t)(foa::kStreamCarry + B), (size_t)((foa::kStreamCarry + B) / 1200 + 64));
@@ -78,7 +81,7 @@ struct ShardDev {
         if (sel) (void)hipHostFree(sel);
         if (ph) (void)hipHostFree(ph);
         sel = nullptr; ph = nullptr;
-        sel_dev.release(); d_prev.release();
+        sel_dev.release(); d_prev.release(); syn_dev.release();
     }
 
     // ---- the Dev interface of shard_core.h (submitter thread only) ----
@@ -86,7 +89,7 @@ struct ShardDev {
     int upload_impl(int k, const float *carry, const float *batch, int64_t n_new, int64_t start)
     {
         const int64_t C = foa::kStreamCarry;
-        HIP_TRY(hipSetDevice(rx->device));
+        HIP_TRY(enter_device(rx->device));
         float *d = dev[k].p;
         HIP_TRY(hipMemcpyAsync(d, carry, (size_t)C * 8, hipMemcpyHostToDevice, st_in));
         if (n_new) HIP_TRY(hipMemcpyAsync(d + 2 * C, batch, (size_t)n_new * 8, hipMemcpyHostToDevice, st_in));
@@ -96,17 +99,18 @@ struct ShardDev {
         n_buf[k] = C + n_new;
         int rc = sync_dev_issue(rx, d, (size_t)n_buf[k], (foa_frame_desc *)d_desc[k].p, d_ends[k].p, desc_cap, &ccap[k], start);
         if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(syn_dev.p + 8 * k, rx->sy_n.p, 8 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
         HIP_TRY(hipGetLastError());
         return FOA_OK;
     }
     int select(int k, int64_t lo, int64_t hi, const double prev[2]) { return keep(select_impl(k, lo, hi, prev)); }
     int select_impl(int k, int64_t lo, int64_t hi, const double prev[2])
     {
-        HIP_TRY(hipSetDevice(rx->device));
+        HIP_TRY(enter_device(rx->device));
         hipStream_t st = side_stream(rx);
         ph[4 * k] = prev[0]; ph[4 * k + 1] = prev[1];
         HIP_TRY(hipMemcpyAsync(d_prev.p, ph + 4 * k, 2 * sizeof(double), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(foa::k_stream_select, dim3(1), dim3(64), 0, st, (foa_frame_desc *)d_desc[k].p, rx->sy_n.p, (int32_t)desc_cap, lo, hi, d_prev.p, sel_dev.p + 4 * k);
+        hipLaunchKernelGGL(foa::k_stream_select, dim3(1), dim3(64), 0, st, (foa_frame_desc *)d_desc[k].p, syn_dev.p + 8 * k, (int32_t)desc_cap, lo, hi, d_prev.p, sel_dev.p + 4 * k);
         HIP_TRY(hipMemcpyAsync(sel + 4 * k, sel_dev.p + 4 * k, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(ph + 4 * k + 2, d_prev.p, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipEventRecord(sel_done[k], st));
@@ -124,7 +128,7 @@ struct ShardDev {
     int decode(int k, int64_t n_new, uint64_t *handle) { (void)n_new; return keep(decode_impl(k, handle)); }
     int decode_impl(int k, uint64_t *handle)
     {
-        HIP_TRY(hipSetDevice(rx->device));
+        HIP_TRY(enter_device(rx->device));
         const int32_t *q = sel + 4 * k;
         if (q[0] > ccap[k]) return fail(FOA_E_NOMEM, "too many STS_END candidates (%d)", q[0]);
         if ((size_t)q[1] > desc_cap) return fail(FOA_E_INVALID, "internal: %d alignments in one batch buffer", q[1]);

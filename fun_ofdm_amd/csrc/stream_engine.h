@@ -166,7 +166,7 @@ struct StreamGpu {
     {
         const int64_t C = foa::kStreamCarry;
         const int kp = (k + foa::kStreamBufs - 1) % foa::kStreamBufs;
-        HIP_TRY(hipSetDevice(rx->device));
+        HIP_TRY(enter_device(rx->device));
         float *d = dev[k].p;
         if (n_staged == 0) HIP_TRY(hipMemsetAsync(d, 0, (size_t)C * 8, st_in));                     // silence before the stream
         else HIP_TRY(hipMemcpyAsync(d, dev[kp].p + 2 * B, (size_t)C * 8, hipMemcpyDeviceToDevice, st_in));   // (every batch but the last is full)
@@ -204,7 +204,7 @@ struct StreamGpu {
     {
         const int64_t C = foa::kStreamCarry;
         const int64_t n_buf = C + n_new, pushed = submitted_samples + n_new;
-        HIP_TRY(hipSetDevice(rx->device));
+        HIP_TRY(enter_device(rx->device));
         float *d = dev[k].p;
         int64_t t0 = now_ns();
         HIP_TRY(hipEventSynchronize(sel_done[k]));                   // (through already when the core asked uploaded(); the staging slot is free again)
@@ -280,7 +280,7 @@ int foa_stream_create(foa_rx *rx, size_t batch_samples, int narrow_threads, foa_
     if (narrow_threads < 0 || narrow_threads > 64) return fail(FOA_E_INVALID, "narrow_threads must lie in [0, 64]");
     // one stream per handle: its submitter thread owns the handle's streams, work sets and job slots until the stream is destroyed
     if (rx->open_stream) return fail(FOA_E_STATE, "a stream is already open on this handle: destroy it first (one engine per handle)");
-    HIP_TRY(hipSetDevice(rx->device));
+    HIP_TRY(enter_device(rx->device));
     { int rc0 = drain(rx); if (rc0) return rc0; }
     foa_stream *s = new foa_stream();
     StreamGpu &g = s->gpu;

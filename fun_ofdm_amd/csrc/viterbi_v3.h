@@ -354,10 +354,32 @@ __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd3(const FrameInfo
     // (Measured: these ~17 extra VALU and 4 extra LDS instructions per 48 steps cost the kernel 4.7 %; hand-placed
     // ds_write2_b32 pairs instead of the compiler's stores, or v_perm byte gathers, made it slower still.)
     uint32_t pa = 0, pb = 0;
+#ifndef FOA_TRIM
+#define FOA_TRIM 1       // 1: the chunk's loads and stores are buffer instructions (scalar descriptor + per-lane offset + scalar chunk offset): no vector
+                         // instruction forms an address or tests a bound (round 4); 0: flat addresses, the compiler's arithmetic
+#endif
+#if FOA_TRIM
+    // Soft pairs come in and decision words go out through BUFFER instructions: base address and extent in a scalar resource descriptor, the
+    // lane's byte offset in one VGPR that never changes, the chunk's position in a scalar offset -- no vector instruction forms an
+    // address (the flat-address form spent nine per chunk on it, and three registers), and a lane whose step lies beyond its frame's last
+    // one needs no test: a load outside the descriptor's extent returns zero (the soft pair of "no more steps").  The compiler's own
+    // builtins, so that its wait-count bookkeeping sees the loads (a first version issued global_load ... saddr from inline asm: put()
+    // read the registers before the data had landed, every chain-back segment was re-walked, 8 ms per step).
+    constexpr int kRsrcFlags = 0x00020000;          // gfx9 raw buffer, dword 3: DATA_FORMAT 32 (as composable_kernel's CK_BUFFER_RESOURCE_3RD_DWORD for gfx90a / gfx94x / gfx950)
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)spA, 0, 2 * TA, kRsrcFlags);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void *)spB, 0, 2 * TB, kRsrcFlags);
+    const int lane2 = 2 * lane;
+    auto get = [&](int t0) {
+        // soft pairs of steps t0 .. t0+47 of both frames (lanes 48..63 fetch the next sixteen, unused); beyond a frame's end: 0
+        pa = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rsA, lane2, 2 * t0, 0);
+        pb = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rsB, lane2, 2 * t0, 0);
+    };
+#else
     auto get = [&](int t0) {
         pa = (lane < kChunk3 && t0 + lane < TA) ? (uint32_t)spA[t0 + lane] : 0u;
         pb = (lane < kChunk3 && t0 + lane < TB) ? (uint32_t)spB[t0 + lane] : 0u;
     };
+#endif
     const uint32_t bml_addr = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)bml + 64u * (uint32_t)lane;
     auto put = [&](int cnt) {
         __builtin_amdgcn_wave_barrier();
@@ -399,15 +421,29 @@ __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd3(const FrameInfo
     // next wait for loads: old enough), the third one chunk LATE, behind the next chunk's loads, as all three were in round 2.  Three
     // live registers instead of nine; the accumulators need no initialisation either (eight steps overwrite all the bits the word takes,
     // and bits at or beyond a frame's last step are forced to 1 by the store).
+#if FOA_TRIM
+    const int slot2 = 2 * (63 - lane);                                    // byte offset of this lane's word inside a 16-step block (slot p's word sits at index 63 - p)
+    const __amdgpu_buffer_rsrc_t rdA = __builtin_amdgcn_make_buffer_rsrc((void *)dA, 0, 8 * NAtop, kRsrcFlags);      // 8 bytes of decisions per step
+    const __amdgpu_buffer_rsrc_t rdB = __builtin_amdgcn_make_buffer_rsrc((void *)dB, 0, 8 * NBtop, kRsrcFlags);
+#endif
     auto store_block = [&](int b0, uint32_t w) {
         if constexpr (FOA_ABL & 16) { if (w == 0x12345678u) dA[lane] = 1; return; }
         if (__builtin_expect(b0 < NAtop, 1)) {             // (said so that the stores stay in line: as unlikely blocks each cost two taken branches)
             const int v = NA - b0;
-            dA[(size_t)(b0 >> 4) * 64 + 63 - lane] = (uint16_t)(w | (v >= 16 ? 0u : v <= 0 ? 0xFFFFu : 0xFFFFu << v));
+            const uint32_t word = w | (v >= 16 ? 0u : v <= 0 ? 0xFFFFu : 0xFFFFu << v);
+#if FOA_TRIM
+            __builtin_amdgcn_raw_buffer_store_b16((uint16_t)word, rdA, slot2, 128 * (b0 >> 4), 0);
+#else
+            dA[(size_t)(b0 >> 4) * 64 + 63 - lane] = (uint16_t)word;
+#endif
         }
         if (__builtin_expect(b0 < NBtop, 1)) {
             const int v = NB - b0;
+#if FOA_TRIM
+            __builtin_amdgcn_raw_buffer_store_b16((uint16_t)((w >> 16) | (v >= 16 ? 0u : v <= 0 ? 0xFFFFu : 0xFFFFu << v)), rdB, slot2, 128 * (b0 >> 4), 0);
+#else
             dB[(size_t)(b0 >> 4) * 64 + 63 - lane] = (uint16_t)((w >> 16) | (v >= 16 ? 0u : v <= 0 ? 0xFFFFu : 0xFFFFu << v));
+#endif
         }
     };
     uint32_t late = 0u;

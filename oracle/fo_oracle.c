@@ -1281,3 +1281,142 @@ void fo_pool_decode(fo_pool *p, const float *iq, const fo_frame_desc *descs, con
     while (p->running > 0) pthread_cond_wait(&p->done, &p->mu);
     pthread_mutex_unlock(&p->mu);
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* the blocks behind timing_sync fed with a GIVEN list of alignments, and the batch restatement */
+/* of what they do with it (round 4: the partial-vector flush of fft_symbols.cpp:41-50)          */
+/* ------------------------------------------------------------------------------------------ */
+/* fo_chain_from_tags_f32: the tagged, rotated sample stream timing_sync would hand on for these alignments -- LTS1 at lts1_pos, LTS2
+ * 64 later (a later alignment's tag overwrites an earlier one at the same sample, as in timing_sync.cpp:105-106), every sample
+ * multiplied by the phasor in force at its index (timing_sync.cpp:121-125: (c, s) of the latest alignment whose rot_start it has
+ * reached, (c_prev, s_prev) of the first one before that) -- through fft_symbols, channel_est, phase_tracker and frame_decoder in one
+ * call each.  The ground truth for what a batch decoder must deliver for the same descriptors. */
+void fo_chain_from_tags_f32(const float *iq, int64_t n, const fo_frame_desc *descs, size_t n_al, fo_payloads *out)
+{
+    ensure_tables();
+    fo_tagged_sample *ts = (fo_tagged_sample *)calloc((size_t)(n > 0 ? n : 1), sizeof(fo_tagged_sample));
+    size_t a = 0;                                       /* alignments whose rot_start has been reached */
+    cplx rot = n_al ? CMPLX(descs[0].c_prev, descs[0].s_prev) : CMPLX(1.0, 0.0);
+    for (int64_t i = 0; i < n; i++) {
+        while (a < n_al && descs[a].rot_start <= i) { rot = CMPLX(descs[a].c, descs[a].s); a++; }
+        ts[i].sample = from_c(CMPLX((double)iq[2 * i], (double)iq[2 * i + 1]) * rot);
+        ts[i].tag = FO_NONE;
+    }
+    for (size_t j = 0; j < n_al; j++) {
+        const int64_t p = descs[j].lts1_pos;
+        if (p >= 0 && p < n) ts[p].tag = FO_LTS1;
+        if (p + 64 >= 0 && p + 64 < n) ts[p + 64].tag = FO_LTS2;
+    }
+    fo_fft_symbols *fs = fo_fft_symbols_new(); fo_channel_est *ce = fo_channel_est_new();
+    fo_phase_tracker *pt = fo_phase_tracker_new(); fo_frame_decoder *dec = fo_frame_decoder_new();
+    fo_tagged_vec64 *v = (fo_tagged_vec64 *)malloc(sizeof(fo_tagged_vec64) * ((size_t)n / 64 + n_al + 8));
+    const size_t nv = fo_fft_symbols_work(fs, ts, (size_t)n, v);
+    fo_tagged_vec64 *e = (fo_tagged_vec64 *)malloc(sizeof(fo_tagged_vec64) * (nv + 1));
+    const size_t ne = fo_channel_est_work(ce, v, nv, e);
+    fo_tagged_vec48 *d = (fo_tagged_vec48 *)malloc(sizeof(fo_tagged_vec48) * (ne + 1));
+    fo_phase_tracker_work(pt, e, ne, d);
+    fo_payloads_clear(out);
+    if (ne) fo_frame_decoder_work(dec, d, ne, out);
+    free(ts); free(v); free(e); free(d);
+    fo_fft_symbols_free(fs); fo_channel_est_free(ce); fo_phase_tracker_free(pt); fo_frame_decoder_free(dec);
+}
+
+/* What those blocks do, restated per alignment (the shape a batch decoder has).  Alignment j, LTS1 at p, ends at e = the next
+ * alignment's LTS1 (or the end of the stream).  fft_symbols emits for it: the two LTS vectors, then the vectors of the complete
+ * symbol windows [p + 144 + 80 k, + 64), k = 0 (SIGNAL) .. K - 1, that end by e, and -- when another LTS1 follows and the window in
+ * progress has got past its cyclic prefix (m_offset > 15, fft_symbols.cpp:46) -- ONE MORE: the first (e - p - 128) mod 80 - 16
+ * samples of window K, the rest of the vector still holding window K - 1 (the LTS2 window for K = 0).  channel_est equalises all of
+ * them with alignment j's estimate and phase_tracker counts them on (k = 0 is START_OF_FRAME).  These vectors of all alignments,
+ * in stream order, are ONE sequence: frame_decoder copies the nsym vectors that follow a valid SIGNAL into its frame wherever they
+ * come from -- the partial vector, the next alignment's SIGNAL, its data symbols if that SIGNAL is invalid -- and drops the frame
+ * when a VALID SIGNAL arrives before the last of them (frame_decoder.cpp:52-88).
+ * Alignments whose LTS windows are cut (e < p + 128) take no part (residual: pile-ups closer than 128 samples). */
+typedef struct { int32_t K, has_part, fresh, nvec, valid, rate, length, nsym; int64_t voff; fo_c64 est[64]; } v2_al;
+
+static void v2_vector(const float *iq, const fo_frame_desc *d, const v2_al *a, int k, fo_tagged_vec48 *out)
+{
+    const int64_t w0 = d->lts1_pos + 144 + 80 * (int64_t)k;
+    const int partial = a->has_part && k == a->K;
+    const cplx rot = CMPLX(d->c, d->s), rot_prev = CMPLX(d->c_prev, d->s_prev);
+    fo_tagged_vec64 v, eq;
+    for (int i = 0; i < 64; i++) {
+        const int64_t idx = (partial && i >= a->fresh) ? w0 - 80 + i : w0 + i;
+        const cplx smp = CMPLX((double)iq[2 * idx], (double)iq[2 * idx + 1]);
+        v.samples[i] = from_c(smp * (idx >= d->rot_start ? rot : rot_prev));
+    }
+    v.tag = FO_NONE; v._pad = 0;
+    fo_fft64(v.samples);
+    fo_channel_est ce;
+    memset(&ce, 0, sizeof ce);
+    memcpy(ce.est, a->est, sizeof ce.est);
+    fo_channel_est_work(&ce, &v, 1, &eq);
+    fo_phase_tracker pt; pt.symbol_count = k;
+    fo_phase_tracker_work(&pt, &eq, 1, out);
+}
+
+void fo_decode_batch_v2_f32(const float *iq, int64_t n, const fo_frame_desc *descs, size_t n_al, uint8_t *psdu, size_t slot_bytes, fo_frame_result *res)
+{
+    ensure_tables();
+    v2_al *al = (v2_al *)calloc(n_al ? n_al : 1, sizeof(v2_al));
+    int64_t voff = 0;
+    for (size_t j = 0; j < n_al; j++) {
+        v2_al *a = &al[j];
+        const fo_frame_desc *d = &descs[j];
+        const int64_t p = d->lts1_pos, e = j + 1 < n_al ? descs[j + 1].lts1_pos : n;
+        res[j].status = FO_ST_TRUNCATED; res[j].rate = -1; res[j].length = 0; res[j].num_symbols = 0;
+        a->voff = voff;
+        if (p < 0 || e < p + 128 || e > n) continue;                 /* LTS cut off: no estimate, no vectors */
+        a->K = e >= p + 208 ? (int32_t)((e - (p + 208)) / 80 + 1) : 0;
+        const int mo = (int)((e - (p + 128)) % 80);
+        a->has_part = (j + 1 < n_al) && mo > 15;
+        a->fresh = a->has_part ? mo - 16 : 0;
+        a->nvec = a->K + a->has_part;
+        voff += a->nvec;
+        /* channel_est.cpp:44-58 on the two LTS vectors */
+        fo_channel_est ce;
+        memset(&ce, 0, sizeof ce);
+        for (int w = 0; w < 2; w++) {
+            fo_tagged_vec64 v, dummy;
+            const cplx rot = CMPLX(d->c, d->s), rot_prev = CMPLX(d->c_prev, d->s_prev);
+            for (int i = 0; i < 64; i++) {
+                const int64_t idx = p + 64 * w + i;
+                v.samples[i] = from_c(CMPLX((double)iq[2 * idx], (double)iq[2 * idx + 1]) * (idx >= d->rot_start ? rot : rot_prev));
+            }
+            v.tag = w == 0 ? FO_LTS_START : FO_NONE; v._pad = 0;
+            fo_fft64(v.samples);
+            fo_channel_est_work(&ce, &v, 1, &dummy);
+        }
+        memcpy(a->est, ce.est, sizeof a->est);
+        if (a->nvec == 0) continue;                                   /* not even part of a SIGNAL vector: no START_OF_FRAME from this alignment */
+        fo_tagged_vec48 sig;
+        v2_vector(iq, d, a, 0, &sig);
+        res[j].status = FO_ST_HEADER_FAIL;
+        a->valid = fo_decode_header(sig.samples, &a->rate, &a->length, &a->nsym);
+        if (a->valid) { res[j].rate = a->rate; res[j].length = a->length; res[j].num_symbols = a->nsym; res[j].status = FO_ST_TRUNCATED; }
+    }
+    const int64_t total = voff;
+    for (size_t j = 0; j < n_al; j++) {
+        const v2_al *a = &al[j];
+        if (!a->valid) continue;
+        const int64_t first = a->voff + 1, last = a->voff + a->nsym;       /* the frame's vectors in the global sequence */
+        if (last >= total) continue;                                       /* the stream ends first: never decoded (TRUNCATED) */
+        int dropped = 0;
+        for (size_t g = j + 1; g < n_al && al[g].voff < last; g++)
+            if (al[g].nvec > 0 && al[g].valid && al[g].voff > a->voff) { dropped = 1; break; }     /* a valid SIGNAL before the frame's last vector */
+        if (dropped) continue;
+        fo_c64 *car = (fo_c64 *)malloc(sizeof(fo_c64) * 48 * (size_t)a->nsym);
+        size_t g = j;
+        for (int64_t v = first; v <= last; v++) {
+            while (g + 1 < n_al && (al[g + 1].voff <= v)) g++;             /* the alignment whose vectors include v (alignments without vectors are skipped over) */
+            size_t src = g;
+            while (al[src].nvec == 0 || al[src].voff > v) src--;           /* (an alignment with no vectors shares its voff with the next one) */
+            fo_tagged_vec48 dv;
+            v2_vector(iq, &descs[src], &al[src], (int)(v - al[src].voff), &dv);
+            memcpy(car + (size_t)(v - first) * 48, dv.samples, sizeof dv.samples);
+        }
+        const int ok = fo_decode_data(car, a->rate, a->length, psdu + j * slot_bytes, NULL, NULL);
+        res[j].status = ok ? FO_ST_OK : FO_ST_CRC_FAIL;
+        free(car);
+    }
+    free(al);
+}

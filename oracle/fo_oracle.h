@@ -203,6 +203,16 @@ size_t fo_find_alignments_f32(const float *iq, int64_t n, fo_frame_desc *out, si
 void fo_decode_batch_f32(const float *iq, int64_t n, const fo_frame_desc *descs, const int64_t *ends,
                          size_t n_frames, uint8_t *psdu, size_t slot_bytes, fo_frame_result *res, int threads);
 
+/* The blocks behind timing_sync (fft_symbols .. frame_decoder) fed with the tagged, rotated stream timing_sync WOULD produce for a
+ * given list of alignments: the ground truth for a batch decoder handed the same descriptors -- the partial-vector flush of
+ * fft_symbols.cpp:41-50 and frame_decoder's frame-in-progress logic (frame_decoder.cpp:52-88) included. */
+void fo_chain_from_tags_f32(const float *iq, int64_t n, const fo_frame_desc *descs, size_t n_al, fo_payloads *out);
+/* ... and those blocks restated per alignment, the way the device's batch path is organised (every alignment's vectors, the partial
+ * one included, form one sequence; a frame takes the nsym vectors behind its SIGNAL from wherever they come and is dropped by a valid
+ * SIGNAL among them).  ends are implied: alignment j ends at alignment j+1's lts1_pos, the last one at n.  status TRUNCATED = the frame
+ * is never delivered by the reference (stream over, or dropped), with rate / length / num_symbols as SIGNAL announced them. */
+void fo_decode_batch_v2_f32(const float *iq, int64_t n, const fo_frame_desc *descs, size_t n_al, uint8_t *psdu, size_t slot_bytes, fo_frame_result *res);
+
 /* ---- the TIMED CPU baseline of bench.py (never the checker: the functions above are) ----
  * fo_viterbi_forward_simd: fo_viterbi_forward on sixteen butterflies per SSE instruction, the way the reference's own decoder
  * (viterbi.cpp:208-457) is laid out; identical decision words and metrics (asserted in tests/).  metrics may be NULL.

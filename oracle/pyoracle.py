@@ -77,6 +77,7 @@ def lib():
             "fo_frame_decoder_stats": (vp, [vp]),
             "fo_receiver_chain_new": (vp, []), "fo_receiver_chain_new_threaded": (vp, []), "fo_receiver_chain_free": (None, [vp]),
             "fo_receiver_chain_process_samples": (vp, [vp, vp, sz]), "fo_receiver_chain_decoder_stats": (vp, [vp]),
+            "fo_chain_from_tags_f32": (None, [vp, i64, vp, sz, vp]), "fo_decode_batch_v2_f32": (None, [vp, i64, vp, sz, vp, sz, vp]),
             "fo_viterbi_forward_simd": (None, [vp, i32, vp, vp]), "fo_viterbi_simd_kind": (C.c_char_p, []), "fo_set_timed_simd_viterbi": (None, [i32]),
             "fo_pool_new": (vp, [i32]), "fo_pool_free": (None, [vp]), "fo_pool_threads": (i32, [vp]),
             "fo_pool_decode": (None, [vp, vp, vp, vp, sz, vp, sz, vp]),
@@ -492,6 +493,29 @@ def decode_batch_f32(iq, descs, ends, slot_bytes=4096, threads=1):
     psdu = np.zeros((n, slot_bytes), np.uint8)
     res = np.zeros(n, frame_result)
     lib().fo_decode_batch_f32(_ptr(iq), iq.size, _ptr(descs), _ptr(ends), n, _ptr(psdu), slot_bytes, _ptr(res), threads)
+    return psdu, res
+
+
+def chain_from_tags_f32(iq, descs):
+    """fft_symbols .. frame_decoder over the tagged, rotated stream timing_sync would hand on for these alignments: payload list."""
+    iq = np.ascontiguousarray(iq, np.complex64)
+    descs = np.ascontiguousarray(descs, frame_desc)
+    h = lib().fo_payloads_new()
+    try:
+        lib().fo_chain_from_tags_f32(_ptr(iq), iq.size, _ptr(descs), descs.size, h)
+        return _payload_list(h)
+    finally:
+        lib().fo_payloads_free(h)
+
+
+def decode_batch_v2_f32(iq, descs, slot_bytes=4096):
+    """The batch restatement with the partial-vector flush and frame_decoder's frame-in-progress logic (fo_decode_batch_v2_f32)."""
+    iq = np.ascontiguousarray(iq, np.complex64)
+    descs = np.ascontiguousarray(descs, frame_desc)
+    n = descs.size
+    psdu = np.zeros((n, slot_bytes), np.uint8)
+    res = np.zeros(n, frame_result)
+    lib().fo_decode_batch_v2_f32(_ptr(iq), iq.size, _ptr(descs), n, _ptr(psdu), slot_bytes, _ptr(res))
     return psdu, res
 
 

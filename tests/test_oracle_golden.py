@@ -219,3 +219,27 @@ def test_chain_with_the_timed_simd_viterbi_delivers_the_same_payloads(po):
     finally:
         po.lib().fo_set_timed_simd_viterbi(0)
     assert got == want == [pay.tobytes()] * 2
+
+
+def test_batch_restatement_with_the_partial_vector_flush_equals_the_blocks(po):
+    """fft_symbols.cpp:41-50 / frame_decoder.cpp:52-88 on GIVEN tag streams: the oracle's blocks fed with made-up alignments (an LTS1 late in a
+    frame's last symbol, a symbol earlier, anywhere, on noise) against the per-alignment restatement of the same rules
+    (fo_decode_batch_v2_f32: the specification of the one place where the device's batch path reports FOA_ST_TRUNCATED although the
+    reference may still deliver -- DESIGN.md 2).  On streams without cut frames it is the plain per-alignment decoder."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "manual"))
+    import stress_tags
+    tot, n_al, bad, hits = stress_tags.run_cpu(0, 120)
+    assert bad == 0 and n_al > 600 and hits > 20, (tot, n_al, bad, hits)
+    rng = np.random.default_rng(5)
+    parts = [np.zeros(300, complex)]
+    for rate in (0, 5, 8, 10):
+        parts += [po.build_frame(rng.integers(0, 256, int(rng.integers(1, 400)), dtype=np.uint8), rate), np.zeros(int(rng.integers(0, 300)), complex)]
+    s = np.concatenate(parts + [np.zeros(500, complex)])
+    s = (s + (rng.normal(size=s.size) + 1j * rng.normal(size=s.size)) * np.sqrt(0.0124 / 2 / 10 ** 2.5)).astype(np.complex64)
+    d = po.find_alignments_f32(s)
+    ends = np.append(d["lts1_pos"][1:], s.size).astype(np.int64)
+    p1, r1 = po.decode_batch_f32(s, d, ends)
+    p2, r2 = po.decode_batch_v2_f32(s, d)
+    assert d.size >= 4 and np.array_equal(r1.view(np.int32), r2.view(np.int32)) and np.array_equal(p1, p2)
+    assert po.chain_from_tags_f32(s, d) == po.ReceiverChain().run_stream(s.astype(np.complex128))
