@@ -159,10 +159,27 @@ void k_data_symbols_q4(const float2 *__restrict__ iq, const foa_frame_desc *__re
 
     // ---- samples n = m + 4u, rotated (timing_sync.cpp:124-125) ----
     cpx x[16];
+    // A data symbol's window starts 224 samples behind LTS1 and the phasor changes at most 8 behind it (rot_start), so every sample of
+    // the window takes (c, s) -- unless a caller's descriptor says otherwise, which costs nothing to honour: the wave looks once.  (The
+    // per-sample choice was a 64-bit compare and four v_cndmask_b32 on VCC per sample, sixteen times per lane: the select on VCC issues
+    // at 16 clocks per wave instruction on this part, tools/probe_issue.hip -- a seventh of the kernel's issue time for a choice that
+    // always comes out the same way.)
+#ifndef FOA_Q4_FASTROT
+#define FOA_Q4_FASTROT 1          // (0: the per-sample choice always -- A/B only)
+#endif
+    if (FOA_Q4_FASTROT && __all(!valid || start >= d.rot_start)) {
+        const cpx r = { d.c, d.s };
 #pragma unroll
-    for (int u = 0; u < 16; u++) {
-        const int64_t idx = start + m + 4 * u;
-        x[u] = valid ? load_rotated(iq, idx, d) : cpx{ 0.0, 0.0 };
+        for (int u = 0; u < 16; u++) {
+            const float2 sm = valid ? iq[start + m + 4 * u] : make_float2(0.0f, 0.0f);
+            x[u] = cmul(cpx{ (double)sm.x, (double)sm.y }, r);
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const int64_t idx = start + m + 4 * u;
+            x[u] = valid ? load_rotated(iq, idx, d) : cpx{ 0.0, 0.0 };
+        }
     }
     // ---- stage 1: operands u = s, s+4, s+8, s+12; twiddle exponent e = n = m + 4 s ----
 #pragma unroll
