@@ -328,6 +328,7 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
     import fun_ofdm_amd as foa
     from fun_ofdm_amd import shard, synth
 
+    t_run0 = time.perf_counter()
     n_dev = 0 if on_cpu else torch.cuda.device_count()        # (counting devices does not initialise the GPU)
     if backend is None:
         backend = os.environ.get("FOA_BENCH_BACKEND")
@@ -668,10 +669,15 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
             kms = {k: v / kern_n for k, v in kern.items()}
             out["roofline"] = roofline(args, kms, real.size, ms_per_step, piped, probe)
             out["kernel_ms"] = {k: round(v, 4) for k, v in kms.items()}
+    wall = {}
     if rank == 0 and not args.no_extra_legs and world == 1 and not on_cpu:
+        tw = time.perf_counter()
         out["legs"] = extra_legs(args, rx, dev, iq, descs, ends, real, psdu, res)
+        wall["extra_legs_s"] = round(time.perf_counter() - tw, 1)
     if rank == 0 and not args.no_cpu_baseline:
+        tw = time.perf_counter()
         cb, opsdu, ores, n_cb = cpu_baseline(iq, descs, ends, pays)
+        wall["cpu_baseline_s"] = round(time.perf_counter() - tw, 1)
         out["cpu_baseline"] = cb
         same = bool(np.array_equal(ores.view(np.int32).reshape(-1, 4), res[:n_cb]))
         okc = res[:n_cb, 0] == 0
@@ -679,6 +685,9 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
         out["config"]["gpu_equals_cpu_on_sample"] = same
         out["config"]["cpu_sample_alignments"] = int(n_cb)
         out["config"]["psdu_bit_exact"] = bool(exact and same)
+    if rank == 0 and out is not None:
+        wall["whole_run_s"] = round(time.perf_counter() - t_run0, 1)
+        out["bench_wall_s"] = wall                       # where this process's time went (the timed regions are a fraction of a second)
     rx.close()
     return out
 
