@@ -28,6 +28,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 
 #include <fun_ofdm_amd/blocks.hpp>
 #if defined(__GLIBC__)
@@ -123,12 +124,22 @@ int main(int argc, char **argv)
                                                                              : new fun_amd::receiver_chain(devices, device_batch, narrow_threads));
             fun_amd::receiver_chain &chain = *chain_p;
             chain.process_samples(std::vector<std::complex<double> >(512));            // creates the handle outside the timed loop
-            // ... and the engine's pipeline: W batches of silence (no frames, no payloads) before the clock starts, so that the timed loop
-            // does not pay for threads that are not on a core yet and buffers nobody has touched (single runs varied 3.1-4.4 Gsample/s cold)
-            if (warm_batches < 0) warm_batches = device_batch > 0 ? 2 : 0;
-            if (warm_batches > 0 && device_batch > 0) {
-                const size_t warm = (size_t)warm_batches * device_batch;
-                for (size_t o = 0; o < warm; o += (size_t)chunk) chain.process_samples(std::vector<std::complex<double> >((size_t)chunk));
+            // ... and the engine's pipeline: W batches' worth of the capture's own first samples (a copy), then silence until their payloads
+            // have all come back, before the clock starts -- so that the timed loop meets threads that are on their cores, buffers that have been
+            // touched and kernels that have been launched before (silence alone decodes nothing: the first real batches then paid ~15 ms of
+            // first-launch costs inside the timed region; single runs varied 3.1-4.4 Gsample/s cold).  At least two batches and 8 Mi samples:
+            // small batches go round four lanes, six staging slots and six work sets.
+            if (warm_batches < 0) warm_batches = device_batch > 0 ? (int)std::min<size_t>(128, std::max<size_t>(2, ((size_t)8 << 20) / device_batch)) : 0;
+            if (warm_batches > 0 && device_batch > 0 && !chunks.empty()) {
+                const size_t warm = std::min((size_t)warm_batches * device_batch, total);
+                size_t fed_w = 0;
+                for (size_t c = 0; fed_w < warm && c < chunks.size(); c++) { fed_w += chunks[c].size(); chain.process_samples(std::vector<std::complex<double> >(chunks[c])); }
+                const size_t quiet = 131072 + 2 * device_batch;      // past the longest frame and through the batches in flight
+                for (size_t o = 0; o < quiet; o += (size_t)chunk) chain.process_samples(std::vector<std::complex<double> >((size_t)chunk));
+                for (int idle = 0; idle < 200;) {                    // until nothing has come back for a while
+                    std::this_thread::sleep_for(std::chrono::microseconds(200));
+                    idle = chain.process_samples(std::vector<std::complex<double> >(64)).empty() ? idle + 1 : 0;
+                }
             }
             g_lat_chunk = chunk;
             g_call_time.reserve(chunks.size() + 2);

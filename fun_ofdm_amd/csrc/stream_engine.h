@@ -326,9 +326,14 @@ int foa_stream_create(foa_rx *rx, size_t batch_samples, int narrow_threads, foa_
         if (!rc && !j.done && hipEventCreateWithFlags(&j.done, hipEventDisableTiming) != hipSuccess) rc = fail(FOA_E_HIP, "hipEventCreate failed");
     }
     if (rc) { foa_stream_destroy(s); return rc; }
-    // the engine's batches are small grids, but its decode calls alternate with a pre-sync the host waits for: two loops in flight
-    // serve it better than four (2.2 against 2.0 Gsample/s through process_samples)
-    rx->depth_saved = rx->depth; rx->depth = 2;
+    // How many decode calls' loops in flight?  A batch of a million samples and more fills the machine with its forward pass: two (2.2
+    // against 2.0 Gsample/s through process_samples with four).  A SMALL batch is a handful of forward-pass waves, and one wave walks its
+    // frames' trellis at the lone-wave rate (0.65 ms for a 1024-byte frame at 54 Mbps) whatever the batch: what sets the rate of 64 Ki-sample
+    // batches is loops in flight over that latency -- 0.36 ms per batch with two -- so batches below a million samples get four where the
+    // runtime has the hardware queues for them (foa_recommended_hw_queues).  FOA_STREAM_DEPTH overrides (A/B).
+    rx->depth_saved = rx->depth;
+    rx->depth = (batch_samples <= ((size_t)1 << 20) && rx->max_depth >= 4) ? 4 : 2;
+    if (const char *e = getenv("FOA_STREAM_DEPTH")) { const int v = atoi(e); if (v >= 2 && v <= 4) rx->depth = v; }
     s->core = new foa::StreamCore<StreamGpu>(&g, g.B, narrow_threads);
     rx->open_stream = s;
     *out = s;

@@ -1,0 +1,8 @@
+#!/bin/bash
+mkdir -p gpurun_out/s7
+timeout 1500 python3 tools/bench_latency.py 60000 > gpurun_out/s7/latency.jsonl 2> gpurun_out/s7/latency.err
+python3 - <<'PY'
+import json
+for l in open('gpurun_out/s7/latency.jsonl'):
+    d=json.loads(l); print(d["mode"][:76].ljust(78), d.get("Msamples_per_s"), d.get("spread",""), d.get("latency_ms"))
+PY
