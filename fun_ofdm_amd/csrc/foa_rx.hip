@@ -210,6 +210,7 @@ struct foa_rx {
     int hw_queues = 4, max_depth = 4;  // hardware queues the runtime was started with, as far as the environment tells (foa_rx_create), and the depth they allow
     std::string notes;                 // non-fatal remarks about how the handle is set up (foa_rx_notes)
     int64_t sync_origin = 0;           // one-shot device pre-sync: stream index of d_iq[0] (option "sync_origin")
+    int64_t stream_longest = 0;        // foa_stream_create: longest frame (samples, preamble to last symbol + 192) the stream will hold; 0 = any frame the format allows
     int depth = 0;                     // lanes: how many calls' loops are in flight; 0 = by grid size (2, or 4 below kDeepBelow frames)
     int depth_saved = -1;              // (the stream engine pins 2 while a stream is open and restores this)
     unsigned n_calls = 0;              // pipelined decode calls made so far (a call's lane is n_calls mod depth)
@@ -515,6 +516,12 @@ int foa_rx_set_option(foa_rx *rx, const char *name, int64_t value)
         if (value != 0 && value <= 160) return fail(FOA_E_INVALID, "sync_call must be 0 (decide as one call over the whole stream) or > 160 (timing_sync.cpp:55)");
         if (rx->open_stream) return fail(FOA_E_STATE, "sync_call cannot change while a stream engine is open on the handle (its submitter thread reads it)");
         rx->sync_call = value;
+        return FOA_OK;
+    }
+    if (!strcmp(name, "stream_longest")) {
+        if (value != 0 && (value < 1024 || value > 110592)) return fail(FOA_E_INVALID, "stream_longest must be 0 (any frame: 110 592 samples) or lie in [1024, 110592]");
+        if (rx->open_stream) return fail(FOA_E_STATE, "stream_longest is read when a stream is created");
+        rx->stream_longest = value;
         return FOA_OK;
     }
     if (!strcmp(name, "sync_origin")) {

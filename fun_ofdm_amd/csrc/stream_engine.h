@@ -116,6 +116,7 @@ static int stream_collect_job(foa_rx *rx, uint64_t ticket, size_t n_frames, bool
 struct StreamGpu {
     foa_rx *rx = nullptr;
     int64_t B = 0;                                   // batch_samples
+    int64_t L = foa::kStreamLongest, C = foa::kStreamCarry;      // longest frame the stream may hold (+ look-ahead) and the carry it implies (option "stream_longest")
     size_t slot_bytes = 4096;
     float *pin[foa::kStreamBufs] = {};               // page-locked staging, B float2 each
     DevBuf<float> dev[foa::kStreamBufs];             // (C + B) float2 each
@@ -164,7 +165,6 @@ struct StreamGpu {
     }
     int stage_impl(int k, int64_t n_new, bool final)
     {
-        const int64_t C = foa::kStreamCarry;
         const int kp = (k + foa::kStreamBufs - 1) % foa::kStreamBufs;
         HIP_TRY(enter_device(rx->device));
         float *d = dev[k].p;
@@ -176,7 +176,7 @@ struct StreamGpu {
         // by the time the batch is submitted the host has nothing to wait for but four integers
         hipStream_t st = side_stream(rx);
         HIP_TRY(hipStreamWaitEvent(st, in_done[k], 0));
-        const int64_t L = foa::kStreamLongest, n_buf = C + n_new, pushed = staged_samples + n_new;
+        const int64_t n_buf = C + n_new, pushed = staged_samples + n_new;
         const int64_t start = pushed - n_new - C;                    // stream index of the buffer's first sample
         const int64_t cut = final ? pushed + 1 : pushed - L;        // this batch decodes the alignments whose STS_END sample lies in [cut_prev, cut)
         int rc = sync_dev_issue(rx, d, (size_t)n_buf, (foa_frame_desc *)d_desc[k].p, d_ends[k].p, desc_cap, &ccap[k], start);
@@ -202,7 +202,6 @@ struct StreamGpu {
     }
     int submit_impl(int k, int64_t n_new, bool final, uint64_t *handle)
     {
-        const int64_t C = foa::kStreamCarry;
         const int64_t n_buf = C + n_new, pushed = submitted_samples + n_new;
         HIP_TRY(enter_device(rx->device));
         float *d = dev[k].p;
@@ -286,11 +285,12 @@ int foa_stream_create(foa_rx *rx, size_t batch_samples, int narrow_threads, foa_
     StreamGpu &g = s->gpu;
     g.rx = rx;
     g.B = (int64_t)batch_samples;
-    g.desc_cap = (size_t)((foa::kStreamCarry + g.B) / 300 + 64);
+    if (rx->stream_longest > 0) { g.L = rx->stream_longest; g.C = g.L + 2048; }
+    g.desc_cap = (size_t)((g.C + g.B) / 300 + 64);
     int rc = FOA_OK;
     for (int i = 0; i < foa::kStreamBufs && !rc; i++) {
         if (hipHostMalloc((void **)&g.pin[i], (size_t)g.B * 8, hipHostMallocDefault) != hipSuccess) rc = fail(FOA_E_NOMEM, "hipHostMalloc of a %zu-byte staging buffer failed", (size_t)g.B * 8);
-        if (!rc) rc = g.dev[i].ensure((size_t)(foa::kStreamCarry + g.B) * 2);
+        if (!rc) rc = g.dev[i].ensure((size_t)(g.C + g.B) * 2);
         if (!rc) rc = g.d_desc[i].ensure(g.desc_cap * sizeof(foa_frame_desc));
         if (!rc) rc = g.d_ends[i].ensure(g.desc_cap);
         if (!rc && hipEventCreateWithFlags(&g.in_done[i], hipEventDisableTiming) != hipSuccess) rc = fail(FOA_E_HIP, "hipEventCreate failed");
@@ -309,7 +309,7 @@ int foa_stream_create(foa_rx *rx, size_t batch_samples, int narrow_threads, foa_
     // hipFree waits for the device) inside the stream cost a 53-batch capture a fifth of its time.  Work sets for a buffer's worth of
     // samples and as many frames as its shortest-plausible spacing gives, job slots for twice a 54 Mbps-dense batch (both grow if a stream
     // turns out denser).
-    if (!rc) rc = foa_rx_reserve(rx, (size_t)(foa::kStreamCarry + g.B), (size_t)((foa::kStreamCarry + g.B) / 1200 + 64));
+    if (!rc) rc = foa_rx_reserve(rx, (size_t)(g.C + g.B), (size_t)((g.C + g.B) / 1200 + 64));
     for (auto &j : rx->jobs) {
         if (rc) break;
         auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };

@@ -131,6 +131,13 @@ int foa_rx_reserve(foa_rx *rx, size_t n_samples, size_t n_frames);
  *                 ((index of STS_END + 160) mod sync_call), so a caller that pre-synchronises one stream in consecutive batches sets this
  *                 to each batch's offset in the stream (or starts every batch on a multiple of sync_call, or sets sync_call 0);
  *                 otherwise frames are dropped at batch-relative positions the reference never drops them at
+ *   "stream_longest"  read by foa_stream_create: the longest frame the stream will hold, in samples from the first preamble sample to the last data
+ *                 sample, plus 192 (timing_sync's look-ahead and the window offset).  A batch decodes the frames whose STS_END lies at least this far
+ *                 before its end, so that every frame is whole inside the batch that decodes it; the default 0 = 110 592 covers the longest frame the
+ *                 format allows (4095 bytes at 6 Mbps) and costs 5.5 ms of latency at the air's own 20 Msample/s.  A receiver that knows its traffic
+ *                 (say 1500-byte frames at 24 Mbps and up: 320 + 80 x 127 + 192 = 10 672) sets it and gets that latency back; a frame LONGER than
+ *                 this value is then reported FOA_ST_TRUNCATED (never delivered) -- a deviation from the reference the caller has asked for.
+ *                 Also shortens the carry every batch re-synchronises (stream_longest + 2048 samples), which is most of a small batch's cost.
  *   "sync_flags"  foa_rx_sync_dev's frame_detector kernel: 1 (default, the only shipped value) = a lane owns sixteen consecutive windows and sums
  *                 them as tail of one group + head of the next; cross-check build: 0 = every window summed directly, term by term
  *   "record_soft" keep the depunctured soft bytes for foa_rx_get_taps (default 1; 0 saves their HBM writes)

@@ -348,6 +348,14 @@ public:
         check(foa_rx_set_option(dev_.get(), "sync_call", samples), "foa_rx_set_option");
     }
 
+    // Device mode: the longest frame this stream will hold (samples, first preamble sample to last data sample, + 192); see option
+    // "stream_longest" in include/fun_ofdm_amd.h -- the latency knob of a receiver that knows its traffic.  Before the first call.
+    void set_stream_longest(long long samples)
+    {
+        if (!devices_.empty()) throw std::runtime_error("receiver_chain: the multi-device mode keeps the format's longest frame");
+        check(foa_rx_set_option(dev_.get(), "stream_longest", samples), "foa_rx_set_option");
+    }
+
     // Same signature and meaning as fun::receiver_chain::process_samples (src/receiver_chain.cpp:106-126): feed the
     // next chunk of the 20 MS/s stream, get the payloads of the frames that completed, in stream order.  A frame is
     // returned by the call that delivers its last sample (the reference returns it five calls later).

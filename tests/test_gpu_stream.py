@@ -264,3 +264,47 @@ def test_process_samples_over_a_device_list_through_the_cpp_chain(tmp_path, po, 
             recs.append(raw[o + 4:o + 4 + n])
             o += 4 + n
         assert recs == want, extra
+
+
+def test_stream_longest_option_keeps_the_payload_list_and_cuts_what_is_longer(rx, po):
+    """Option "stream_longest" (the latency knob): a stream whose frames all fit gives the reference chain's payload list for any batch size; a
+    frame longer than the value is reported truncated, i.e. missing from the list, and nothing else changes."""
+    import fun_ofdm_amd as foa
+    rng = np.random.default_rng(64)
+    specs = [(int(rng.choice((5, 6, 8, 9, 10))), int(rng.integers(1, 700))) for _ in range(40)]       # <= 700 bytes at >= 18 Mbps: <= 320 + 80 * 80 samples
+    iq, pays = _stream(po, rng, specs, snr_db=24.0, cfo_hz=3000.0, gap=(0, 400))
+    want = po.ReceiverChain().run_stream(iq.astype(np.complex128))
+    assert len(want) >= 36
+    longest = 320 + 80 * 81 + 192
+    rx.set_option("stream_longest", longest)
+    try:
+        for batch, chunk in ((4096, 4096), (8192, 1000), (65536, 7777), (1 << 18, 4096)):
+            st = foa.Stream(rx, batch, narrow_threads=1)
+            got = []
+            try:
+                for a in range(0, iq.size, chunk):
+                    got += st.push(iq[a:a + chunk])
+                got += st.flush()
+            finally:
+                st.close()
+            assert got == want, (batch, chunk, len(got), len(want))
+        # one frame longer than the value in the middle of the stream: it is the only one missing
+        big = po.build_frame(rng.integers(0, 256, 3000, dtype=np.uint8), 5) * np.exp(1j * 0.7)
+        sigma = np.sqrt(0.0124 / (2 * 10 ** 2.4))
+        big = (big + (rng.normal(size=big.size) + 1j * rng.normal(size=big.size)) * sigma).astype(np.complex64)
+        cut = iq.size // 2
+        while np.abs(iq[cut - 50:cut + 50]).max() > 0.05:        # a quiet spot between two frames
+            cut += 37
+        iq2 = np.concatenate([iq[:cut], np.zeros(300, np.complex64), big, np.zeros(300, np.complex64), iq[cut:]])
+        want2 = po.ReceiverChain().run_stream(iq2.astype(np.complex128))
+        assert len(want2) == len(want) + 1
+        st = foa.Stream(rx, 16384)
+        try:
+            got2 = st.push(iq2) + st.flush()
+        finally:
+            st.close()
+        assert len(got2) == len(want) and [p for p in want2 if len(p) != 3000] == got2
+        with pytest.raises(foa.FoaError):
+            rx.set_option("stream_longest", 100)
+    finally:
+        rx.set_option("stream_longest", 0)

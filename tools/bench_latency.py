@@ -66,6 +66,10 @@ def run(name, extra, reps=1):
 for chunk in (4096, 65536, 1 << 20):
     run("device 4M, calls of %d, 8 helpers, as fast as taken" % chunk, ["--chunk", str(chunk), "--device-batch", str(1 << 22), "--narrow-threads", "8"], reps=3)
 run("device 4M, calls of 4096, 8 helpers, no warm-up batches (round 3's protocol)", ["--chunk", "4096", "--device-batch", str(1 << 22), "--narrow-threads", "8", "--warm-batches", "0"], reps=3)
+# (c) the latency knob: a receiver that knows its longest frame (here 1024 bytes at 54 Mbps: 3 520 samples + 192) waits that long instead of 110 592 samples
+for B, pace in ((1 << 14, 20), (1 << 14, 100), (1 << 16, 20), (1 << 16, 100), (1 << 16, 0), (1 << 18, 400), (1 << 18, 0)):
+    extra = ["--chunk", "4096", "--device-batch", str(B), "--narrow-threads", "8", "--longest", "4096"] + (["--pace", str(pace)] if pace else [])
+    run("device %dK, stream_longest 4096, calls of 4096, %s" % (B >> 10, ("paced at %d Msample/s (%d x real time)" % (pace, pace // 20)) if pace else "as fast as taken"), extra)
 # (b) batch size x pace
 for B in (1 << 16, 1 << 18, 1 << 20, 1 << 22):
     for pace in (0, 400, 2000):
