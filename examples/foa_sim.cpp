@@ -140,10 +140,15 @@ int main(int argc, char **argv)
                 size_t fed_w = 0;
                 for (size_t c = 0; fed_w < warm && c < chunks.size(); c++) { fed_w += chunks[c].size(); chain.process_samples(std::vector<std::complex<double> >(chunks[c])); }
                 const size_t quiet = 131072 + 2 * device_batch;      // past the longest frame and through the batches in flight
-                for (size_t o = 0; o < quiet; o += (size_t)chunk) chain.process_samples(std::vector<std::complex<double> >((size_t)chunk));
-                for (int idle = 0; idle < 200;) {                    // until nothing has come back for a while
+                size_t fed_q = 0;
+                for (; fed_q < quiet; fed_q += (size_t)chunk) chain.process_samples(std::vector<std::complex<double> >((size_t)chunk));
+                // the capture proper must start on a multiple of the reference's call size: timing_sync.cpp:99 is decided by absolute stream
+                // index (include/fun_ofdm_amd.h), and the payload list is compared with a decode of the capture from index 0
+                const size_t pad = (4096 - (fed_w + fed_q) % 4096) % 4096;
+                if (pad) chain.process_samples(std::vector<std::complex<double> >(pad));
+                for (int idle = 0; idle < 200;) {                    // until nothing has come back for a while (empty calls only poll)
                     std::this_thread::sleep_for(std::chrono::microseconds(200));
-                    idle = chain.process_samples(std::vector<std::complex<double> >(64)).empty() ? idle + 1 : 0;
+                    idle = chain.process_samples(std::vector<std::complex<double> >()).empty() ? idle + 1 : 0;
                 }
             }
             g_lat_chunk = chunk;
