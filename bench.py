@@ -1091,7 +1091,8 @@ def extra_legs(args, rx, dev, iq, descs, ends, real, psdu_dev_path, res_dev_path
                                        "packets": int(pk.group(1)) if pk else None, "frames_sent": n, "runs_Msamples_per_s": [t[0] for t in runs_ps], "protocol": "median of 3 runs",
                                        "same_list_as_batch_path": bool(same_list), "batch_path_payloads": len(batch_list),
                                        "what": "fun_amd::receiver_chain::process_samples(std::vector<std::complex<double>>) in device mode: 4 Mi-sample "
-                                               "batches, 8 helper threads (two core complexes), pre-sync and decode on the GPU, payloads through the callback; capture preloaded"}
+                                               "batches, 8 helper threads (two core complexes), pre-sync and decode on the GPU, payloads through the callback; capture preloaded, the engine "
+                                               "warmed with a copy of the capture's first batches before the clock starts (foa_sim --warm-batches)"}
     except Exception as e:
         legs["process_samples_api"] = {"error": str(e)[-300:]}
     return legs
