@@ -25,6 +25,15 @@
 
 namespace foa {
 
+static inline void phasor(double phase, double &c, double &s)
+{
+#if defined(__GLIBC__)
+    ::sincos(phase, &s, &c);
+#else
+    c = std::cos(phase); s = std::sin(phase);
+#endif
+}
+
 // preamble.h:432: conj of the 64-sample long training symbol, as printed with 12 significant digits
 inline void make_lts_time_conj(std::complex<double> *out)
 {
@@ -157,8 +166,12 @@ public:
                 foa_frame_desc d;
                 d.lts1_pos = origin + lts_offset + 24;
                 d.rot_start = origin + (int64_t)x;
-                d.c = std::cos(phase_acc_); d.s = std::sin(phase_acc_);
-                d.c_prev = std::cos(prev); d.s_prev = std::sin(prev);
+                // cos and sin of ONE argument as the reference's build computes them: g++ -O3 turns the pair of calls in timing_sync.cpp:124
+                // into one sincos(), whose cosine is not always the bit pattern cos() returns (glibc; 1 ulp apart on 2 of 4 685 alignments of
+                // round 4's collision streams, where this file's separate calls -- clang keeps them separate -- were caught against the oracle,
+                // which is compiled like the reference and equals its compiled timing_sync bit for bit on those streams)
+                phasor(phase_acc_, d.c, d.s);
+                phasor(prev, d.c_prev, d.s_prev);
                 out.push_back(d);
                 break;
             }

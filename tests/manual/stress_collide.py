@@ -166,6 +166,12 @@ def run_gpu(lo, hi, cpp=False):
         d_desc = torch.zeros(cap * 48, dtype=torch.uint8, device="cuda:0")
         d_end = torch.zeros(cap, dtype=torch.int64, device="cuda:0")
         m = rx.sync_dev(d_iq, d_desc, d_end)
+        dd = d_desc.cpu().numpy()[:m * 48].view(foa.frame_desc_dtype)
+        # positions exactly, phasors to 1e-12: atan2 / cos / sin come from the device's math library there (a floating-point intermediate;
+        # the host restatement equals the oracle byte for byte, above)
+        if not (m == descs.size and np.array_equal(dd["lts1_pos"], descs["lts1_pos"]) and np.array_equal(dd["rot_start"], descs["rot_start"]) and
+                (m == 0 or max(np.abs(dd[k] - descs[k]).max() for k in ("c", "s", "c_prev", "s_prev")) < 1e-12)):
+            note("device pre-sync descriptors", seed, want, [])
         if m:
             d_psdu = torch.zeros((m, 4096), dtype=torch.uint8, device="cuda:0")
             d_res = torch.zeros((m, 4), dtype=torch.int32, device="cuda:0")
