@@ -16,6 +16,9 @@
 #include "frontend_q4.h"
 #include "viterbi_v1.h"
 #include "viterbi_v3.h"
+#if FOA_XCHECK
+#include "viterbi_v4.h"      // four states per lane: an exact alternative forward pass, measured and not adopted
+#endif
 #include "stage_kernels.h"
 #include "sync_host.h"
 #include "sync_kernels.h"
@@ -163,6 +166,7 @@ struct WorkSet {
     DevBuf<int32_t> sym2frame, seg2frame;
     DevBuf<uint16_t> tb_state;
     DevBuf<uint64_t> dec;
+    DevBuf<uint64_t> dec4;        // option "forward" = 4 while its decisions are still converted for viterbi_v3.h's chain-back: the forward pass's own layout
     DevBuf<uint16_t> sp;          // depunctured soft pairs, one per trellis step (front end -> forward pass, taps)
     DevBuf<uint32_t> decoded;
     DevBuf<int64_t> totals;
@@ -175,7 +179,7 @@ struct WorkSet {
     bool used = false, have_timing = false, piped = false;
     void release_all()
     {
-        info.release(); hinv.release(); sym2frame.release(); seg2frame.release(); tb_state.release(); dec.release(); sp.release();
+        info.release(); hinv.release(); sym2frame.release(); seg2frame.release(); tb_state.release(); dec.release(); dec4.release(); sp.release();
         decoded.release(); totals.release(); eq_sig.release(); eq_data.release();
     }
 };
@@ -214,6 +218,8 @@ struct foa_rx {
     int depth = 0;                     // lanes: how many calls' loops are in flight; 0 = by grid size (2, or 4 below kDeepBelow frames)
     int depth_saved = -1;              // (the stream engine pins 2 while a stream is open and restores this)
     unsigned n_calls = 0;              // pipelined decode calls made so far (a call's lane is n_calls mod depth)
+    int fwd_calls = 0;
+    int fwd_kind = 3;            // forward pass: 3 viterbi_v3.h (a state per lane, two frames per wave), 4 viterbi_v4.h (four states per lane, four frames per wave)
     int viterbi_kind = 2;        // 0: lane per state (viterbi_v1.h), 1: packed, serial chain-back (v2), 2: packed, segment chain-back (v3)
     int tb_segment = 960, tb_overlap = 96;   // v3 chain-back: data steps per segment / run-in steps (multiples of 96)
     bool pipeline = true;        // v3: finish of one call overlaps the next call's front end (two work sets, two streams)
@@ -283,6 +289,30 @@ int inputs_queued(foa_rx *rx, hipStream_t cs)
     if (cs == rx->stream) return FOA_OK;
     HIP_TRY(hipEventRecord(rx->in_ready, cs));
     rx->in_wait = true;
+    return FOA_OK;
+}
+
+// the forward pass of a work set's frames (option "forward")
+int launch_forward(foa_rx *rx, hipStream_t st, WorkSet *w, int nf)
+{
+#if FOA_XCHECK
+    if (rx->fwd_kind == 5 && rx->fwd_calls++ < 24) {
+        // timing experiment only (FOA_FORWARD=5, tools/gpu_v4d.sh): the first calls run viterbi_v3.h's pass, so that every work set holds valid decisions of
+        // the batch (the bench decodes the same batch every step); from then on viterbi_v4.h's pass runs WITHOUT the conversion and the chain-back reads
+        // those -- the step as it would be with a chain-back of the same cost for the new layout
+        launch_fwd3(st, w->info.p, nf, w->sp.p, w->dec.p);
+        return FOA_OK;
+    }
+    if (rx->fwd_kind >= 4) {
+        int rc = w->dec4.ensure(w->dec.n);
+        if (rc) return rc;
+        const size_t cap = w->dec.n < w->sp.n ? w->dec.n : w->sp.n;
+        launch_fwd4(st, w->info.p, nf, w->sp.p, w->dec4.p, cap);
+        if (rx->fwd_kind == 4) launch_dec4_to_dec3(st, w->info.p, nf, w->dec4.p, w->dec.p);
+        return FOA_OK;
+    }
+#endif
+    launch_fwd3(st, w->info.p, nf, w->sp.p, w->dec.p);
     return FOA_OK;
 }
 
@@ -419,6 +449,9 @@ int foa_rx_create(foa_rx **out, int device)
     DeviceTables tab;
     build_tables(&tab);
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_tab), &tab, sizeof tab));
+#if FOA_XCHECK
+    if (const char *e = getenv("FOA_FORWARD")) { const int v = atoi(e); if (v >= 3 && v <= 5) rx->fwd_kind = v; }      // (A/B runs of tools/gpu_v4*.sh; the option "forward" is the interface)
+#endif
     *out = rx;
     return FOA_OK;
 }
@@ -477,6 +510,12 @@ int foa_rx_set_option(foa_rx *rx, const char *name, int64_t value)
         if (value < 0 || value > 2) return fail(FOA_E_INVALID, "viterbi must be 0 (lane per state), 1 (packed, serial chain-back) or 2 (packed, segment chain-back)");
         if (!FOA_XCHECK && value != 2) return fail(FOA_E_INVALID, "viterbi %d is a cross-check kernel: it is only in libfun_ofdm_amd_xcheck.so (make xcheck)", (int)value);
         rx->viterbi_kind = (int)value;
+        return FOA_OK;
+    }
+    if (!strcmp(name, "forward")) {
+        if (value != 3 && value != 4) return fail(FOA_E_INVALID, "forward must be 3 (viterbi_v3.h) or 4 (viterbi_v4.h)");
+        if (!FOA_XCHECK && value != 3) return fail(FOA_E_INVALID, "forward 4 is a cross-check kernel: it is only in libfun_ofdm_amd_xcheck.so (make xcheck)");
+        rx->fwd_kind = (int)value;
         return FOA_OK;
     }
     if (!strcmp(name, "tb_segment")) {
@@ -647,7 +686,7 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
         if ((rc = flush_pending(rx, rx->w->ev[3]))) return rc;
         if (!lanes) HIP_TRY(hipStreamWaitEvent(st_fwd, rx->w->ev[3], 0));
         HIP_TRY(hipEventRecord(rx->w->ev[7], st_fwd));          // start of the forward pass (this stream idles every other step: free)
-        launch_fwd3(st_fwd, rx->w->info.p, nf, rx->w->sp.p, rx->w->dec.p);
+        if ((rc = launch_forward(rx, st_fwd, rx->w, nf))) return rc;
         HIP_TRY(hipEventRecord(rx->w->ev[5], st_fwd));
         foa_rx::Pending &p = rx->pending;
         p.valid = true; p.w = rx->w; p.nf = nf; p.S = rx->tb_segment; p.L = rx->tb_overlap; p.max_segs = max_segs; p.slot_bytes = slot_bytes;
@@ -660,8 +699,12 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
             launch_viterbi_v2(st, rx->w->info.p, nf, rx->w->sp.p, rx->w->dec.p, rx->w->decoded.p, d_psdu, slot_bytes, d_results, rx->w->ev[5]);
         else
 #endif
-            launch_viterbi_v3(st, rx->w->info.p, nf, rx->w->sp.p, rx->w->dec.p, rx->w->decoded.p, rx->w->seg2frame.p, rx->w->totals.p, rx->w->tb_state.p,
-                              max_segs, rx->tb_segment, rx->tb_overlap, d_psdu, slot_bytes, d_results, rx->w->ev[5]);
+        {
+            if ((rc = launch_forward(rx, st, rx->w, nf))) return rc;
+            HIP_TRY(hipEventRecord(rx->w->ev[5], st));
+            launch_finish3(st, st, rx->w->info.p, nf, rx->w->dec.p, rx->w->decoded.p, rx->w->seg2frame.p, rx->w->totals.p, rx->w->tb_state.p, max_segs, rx->tb_segment,
+                           rx->tb_overlap, d_psdu, slot_bytes, d_results);
+        }
         if (rx->viterbi_kind == 0) HIP_TRY(hipEventRecord(rx->w->ev[5], st));
         HIP_TRY(hipEventRecord(rx->w->ev[6], st));                     // (not separable from the forward pass on one stream)
         HIP_TRY(hipEventRecord(rx->w->ev[4], st));
@@ -1148,8 +1191,11 @@ int foa_conv_decode(foa_rx *rx, const uint8_t *symbols, uint8_t *data, int data_
                 launch_viterbi_v2(st, rx->w->info.p, (int)n_blocks, rx->w->sp.p, rx->w->dec.p, rx->w->decoded.p, nullptr, 0, nullptr, nullptr);
             else
 #endif
-                launch_viterbi_v3(st, rx->w->info.p, (int)n_blocks, rx->w->sp.p, rx->w->dec.p, rx->w->decoded.p, rx->w->seg2frame.p, rx->w->totals.p,
-                                  rx->w->tb_state.p, seg2frame.size(), rx->tb_segment, rx->tb_overlap, nullptr, 0, nullptr, nullptr);
+            {
+                if ((rc = launch_forward(rx, st, rx->w, (int)n_blocks))) return rc;
+                launch_finish3(st, st, rx->w->info.p, (int)n_blocks, rx->w->dec.p, rx->w->decoded.p, rx->w->seg2frame.p, rx->w->totals.p, rx->w->tb_state.p, seg2frame.size(),
+                               rx->tb_segment, rx->tb_overlap, nullptr, 0, nullptr);
+            }
             hipLaunchKernelGGL(k_conv_pack, dim3((unsigned)((nbytes + 255) / 256), (unsigned)n_blocks), dim3(256), 0, st, rx->w->decoded.p, rx->w->info.p,
                                (N + 7) / 8, (int)nbytes, d_out);
             HIP_TRY(hipStreamSynchronize(st));        // the host vectors above are the copies' sources
@@ -1300,8 +1346,12 @@ int foa_decode_data_f64(foa_rx *rx, const double *carriers, const uint64_t *carr
         launch_viterbi_v2(st, rx->w->info.p, (int)n_frames, rx->w->sp.p, rx->w->dec.p, rx->w->decoded.p, d_psdu, slot_bytes, d_res, nullptr);
     else
 #endif
-        launch_viterbi_v3(st, rx->w->info.p, (int)n_frames, rx->w->sp.p, rx->w->dec.p, rx->w->decoded.p, rx->w->seg2frame.p, rx->w->totals.p, rx->w->tb_state.p,
-                          seg2frame.size(), rx->tb_segment, rx->tb_overlap, d_psdu, slot_bytes, d_res, nullptr);
+    {
+        int rcf = launch_forward(rx, st, rx->w, (int)n_frames);
+        if (rcf) return rcf;
+        launch_finish3(st, st, rx->w->info.p, (int)n_frames, rx->w->dec.p, rx->w->decoded.p, rx->w->seg2frame.p, rx->w->totals.p, rx->w->tb_state.p, seg2frame.size(),
+                       rx->tb_segment, rx->tb_overlap, d_psdu, slot_bytes, d_res);
+    }
     HIP_TRY(hipMemcpyAsync(psdu, d_psdu, p_b, hipMemcpyDeviceToHost, st));
     std::vector<foa_frame_result> out(n_frames);
     HIP_TRY(hipMemcpyAsync(out.data(), d_res, r_b, hipMemcpyDeviceToHost, st));

@@ -15,10 +15,10 @@ class _RxPair:
     def __init__(self):
         import fun_ofdm_amd as foa
         self._prod, self._x = foa.Receiver(0), foa.Receiver(0, xcheck=True)
-        self._v, self._f, self._s = 2, -1, 1
+        self._v, self._f, self._s, self._fw = 2, -1, 1, 3
 
     def _cur(self):
-        return self._x if (self._v != 2 or self._f in (0, 1) or self._s == 0) else self._prod
+        return self._x if (self._v != 2 or self._f in (0, 1) or self._s == 0 or self._fw != 3) else self._prod
 
     def set_option(self, name, value):
         if name == "viterbi":
@@ -27,7 +27,9 @@ class _RxPair:
             self._f = int(value)
         if name == "sync_flags":
             self._s = int(value)
-        if name in ("viterbi", "frontend", "sync_flags"):
+        if name == "forward":
+            self._fw = int(value)
+        if name in ("viterbi", "frontend", "sync_flags", "forward"):
             self._x.set_option(name, value)
             if self._cur() is self._prod:
                 self._prod.set_option(name, value)
@@ -55,7 +57,7 @@ def test_product_library_does_not_carry_the_cross_check_kernels():
     import fun_ofdm_amd as foa
     r = foa.Receiver(0)
     try:
-        for name, value in (("viterbi", 0), ("viterbi", 1), ("frontend", 0), ("frontend", 1), ("sync_flags", 0)):
+        for name, value in (("viterbi", 0), ("viterbi", 1), ("frontend", 0), ("frontend", 1), ("sync_flags", 0), ("forward", 4)):
             with pytest.raises(foa.FoaError):
                 r.set_option(name, value)
         r.set_option("viterbi", 2)
@@ -178,6 +180,52 @@ def test_conv_decode_saturation_corner_cases(rx, po, kind):
         for b, blk in enumerate(blocks):
             assert np.array_equal(got[b], po.conv_decode(blk, nb)), (nb, b)
     _set_viterbi(rx, VITERBI_KINDS[2])
+
+
+def test_forward_pass_with_four_states_per_lane_is_exact_too(rx, po, golden):
+    """csrc/viterbi_v4.h (cross-check build only, option "forward" = 4; DESIGN.md section 4 says why it is not the product's pass): a frame per
+    16-lane row, four frames per wave, results not written back in place.  Same bits as the oracle on the reference's SSE vectors, on random,
+    saturating and erased blocks at every length class (odd lengths, one to nine blocks per call: rows of a wave with and without a frame,
+    frames of a wave with different lengths in decode_frames below)."""
+    rx.set_option("forward", 4)
+    try:
+        g = golden.viterbi_ref
+        for i, nb in enumerate(g["data_bits"]):
+            s = g["symbols"][g["sym_off"][i]:g["sym_off"][i + 1]]
+            assert np.array_equal(rx.conv_decode(s, int(nb))[0], g["decoded"][g["dec_off"][i]:g["dec_off"][i + 1]]), "KAT %d" % i
+        rng = np.random.default_rng(404)
+        for nb in (1, 2, 7, 34, 35, 40, 41, 58, 91, 1000, 1001, 8418, 32826):
+            for nblk in (1, 3, 4, 5, 9) if nb < 5000 else (2,):
+                n = 2 * (nb + 6)
+                s = rng.integers(0, 256, nblk * n, dtype=np.uint8)
+                e = np.clip(po.conv_encode(rng.integers(0, 256, (nb + 13) // 8 + 1, dtype=np.uint8), nb).astype(float) * 255 + rng.normal(0, 80, n), 0, 255)
+                s[:n] = e.astype(np.uint8)
+                s[2:n:6] = 127
+                if nblk > 1:
+                    s[n:2 * n] = rng.choice(np.array([0, 255, 127], np.uint8), n)
+                got = rx.conv_decode(s, nb, nblk)
+                for b in range(nblk):
+                    assert np.array_equal(got[b], po.conv_decode(s[b * n:(b + 1) * n], nb)), (nb, nblk, b)
+        for nb in (18, 8418):
+            blocks = _corner_blocks(po, nb, rng)
+            got = rx.conv_decode(np.concatenate(blocks), nb, len(blocks))
+            for b, blk in enumerate(blocks):
+                assert np.array_equal(got[b], po.conv_decode(blk, nb)), (nb, b)
+        # frames of different rates and lengths in one call: the four frames of a wave end at different steps
+        import fun_ofdm_amd as foa
+        lens = [40, 1500, 7, 300, 2000, 64, 900, 33, 1200, 5]
+        pays = [bytes(rng.integers(0, 256, n, dtype=np.uint8)) for n in lens]
+        frames = [po.build_frame(np.frombuffer(p, np.uint8), r) for p, r in zip(pays, (0, 10, 5, 8, 9, 1, 10, 3, 6, 10))]
+        parts = []
+        for f in frames:
+            parts += [np.zeros(300, complex), f]
+        iq = np.concatenate(parts + [np.zeros(2000, complex)]).astype(np.complex64)
+        descs = foa.find_alignments(iq)
+        assert descs.size == len(lens)
+        psdu, res = rx.decode_frames_host(iq, descs, foa.alignment_ends(descs, iq.size))
+        assert [bytes(psdu[i, :res["length"][i]]) for i in range(len(lens))] == pays and np.all(res["status"] == 0)
+    finally:
+        rx.set_option("forward", 3)
 
 
 def _corner_blocks(po, nb, rng):
