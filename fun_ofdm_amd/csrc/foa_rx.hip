@@ -297,7 +297,7 @@ int launch_forward(foa_rx *rx, hipStream_t st, WorkSet *w, int nf)
 {
 #if FOA_XCHECK
     if (rx->fwd_kind == 5 && rx->fwd_calls++ < 24) {
-        // timing experiment only (FOA_FORWARD=5, tools/gpu_v4d.sh): the first calls run viterbi_v3.h's pass, so that every work set holds valid decisions of
+        // timing experiment only (FOA_FORWARD=5, tools/exp_forward_v4.sh pipelined): the first calls run viterbi_v3.h's pass, so that every work set holds valid decisions of
         // the batch (the bench decodes the same batch every step); from then on viterbi_v4.h's pass runs WITHOUT the conversion and the chain-back reads
         // those -- the step as it would be with a chain-back of the same cost for the new layout
         launch_fwd3(st, w->info.p, nf, w->sp.p, w->dec.p);
@@ -450,7 +450,7 @@ int foa_rx_create(foa_rx **out, int device)
     build_tables(&tab);
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_tab), &tab, sizeof tab));
 #if FOA_XCHECK
-    if (const char *e = getenv("FOA_FORWARD")) { const int v = atoi(e); if (v >= 3 && v <= 5) rx->fwd_kind = v; }      // (A/B runs of tools/gpu_v4*.sh; the option "forward" is the interface)
+    if (const char *e = getenv("FOA_FORWARD")) { const int v = atoi(e); if (v >= 3 && v <= 5) rx->fwd_kind = v; }      // (A/B runs of tools/exp_forward_v4.sh; the option "forward" is the interface)
 #endif
     *out = rx;
     return FOA_OK;
