@@ -119,6 +119,7 @@ struct ShardDev {
     }
     int selected(int k, double last[2])
     {
+        (void)hipSetDevice(rx->device);                  // (the submitter thread's current device is whichever handle it served last)
         const hipError_t e = hipEventQuery(sel_done[k]);
         if (e == hipErrorNotReady) return 0;
         if (e != hipSuccess) return keep(fail(FOA_E_HIP, "hipEventQuery: %s", hipGetErrorString(e)));
