@@ -137,7 +137,19 @@ __device__ __forceinline__ bool fwd3_due(uint32_t s0)
 {
     return (~(s0 + 0x002D002Du) & 0x80008000u) != 0u;
 }
-__device__ __forceinline__ uint32_t fwd3_renorm(uint32_t Mn, uint32_t s0)
+// Both frames' state 0 at or below 147: the NEXT step cannot bring either above 210 (new[0] <= old[0] + m, m <= 63: viterbi.cpp:242-247), so that step
+// needs no test.  Adding 108 carries out of a half iff its metric exceeds 147 (as fwd3_due; a carry out of the low half can only make the answer "no").
+#ifndef FOA_TEST_SKIP
+#define FOA_TEST_SKIP 0     // A/B only.  1: a step whose predecessor showed both state-0 metrics <= 147 (a third of config 2's steps) runs without the renormalisation
+                            // test -- no v_readfirstlane; the bookkeeping is scalar.  Bit-exact, and SLOWER: the pass alone 1.00 -> 1.15 ms, a lone wave +16 %, the
+                            // pipelined step +8.5 % (profiles/r04_ab_test_skip.txt): the branch around the test is taken on a third of the steps, and a taken branch
+                            // costs a wave more than the vector instruction it saves (round 1 found the same on another kernel)
+#endif
+__device__ __forceinline__ uint32_t fwd3_safe(uint32_t s0)
+{
+    return (~(s0 + 0x006C006Cu) & 0x80008000u) == 0u ? 1u : 0u;
+}
+__device__ __forceinline__ uint32_t fwd3_renorm(uint32_t Mn, uint32_t &s0)
 {
 #if FOA_RN_PRIO
     __builtin_amdgcn_s_setprio(FOA_RN_PRIO);      // the wave's recursion stands still until this is through
@@ -151,11 +163,13 @@ __device__ __forceinline__ uint32_t fwd3_renorm(uint32_t Mn, uint32_t s0)
         uint32_t adj;
         asm("s_sub_u32 %0, %1, %2" : "=s"(adj) : "s"(wave_min_lo16(Mn)), "s"(kBias) : "scc");
         Mn -= adj;
+        s0 -= adj;                                    // (state 0 as the next step will find it: fwd3_safe)
     }
     if (s0 >= ((kRenormThr + 1u) << 16)) {
         uint32_t adj;
         asm("s_and_b32 %0, %1, 0xffff0000\n\ts_sub_u32 %0, %0, %2" : "=s"(adj) : "s"(wave_min_hi16_word(Mn)), "s"(kBias << 16) : "scc");
         Mn -= adj;
+        s0 -= adj;
     }
 #if FOA_RN_PRIO
     __builtin_amdgcn_s_setprio(FOA_FWD_PRIO & 3);      // back to the wave's own priority (0 in the product; the A/B builds with FOA_FWD_PRIO keep theirs)
@@ -231,14 +245,24 @@ __device__ __forceinline__ uint32_t fwd3_acs(uint32_t M, const uint2 w, uint32_t
 // 0.616 ms only -- what a lone wave waits for is the chain of dependent VALU instructions itself, about 14 clocks each -- and
 // at five waves per SIMD the repeated steps cost 11 %.)
 template <int PH, int J>
-__device__ __forceinline__ uint32_t fwd3_step(uint32_t M, const uint2 w, uint32_t (&acc)[6], int jdyn)
+__device__ __forceinline__ uint32_t fwd3_step(uint32_t M, const uint2 w, uint32_t (&acc)[6], int jdyn, uint32_t &skip)
 {
     uint32_t x, y;
     uint32_t Mn = fwd3_acs<PH, J>(M, w, acc, jdyn, x, y);
     if constexpr (FOA_FILE_LATE && J >= 0 && !(FOA_ABL & 1) && !(FOA_ABL & 2)) {
-        const uint32_t s0 = __builtin_amdgcn_readfirstlane(Mn);
         constexpr uint32_t m = 0x01000100u << (J & 7);
         uint32_t tmp;
+        if constexpr (FOA_TEST_SKIP) {
+            // the decisions first (ONE block for both ways through the step: two copies of it make the compiler shuffle the accumulator between them), then
+            // the test -- unless the step before left both state-0 metrics at or below 147: then nothing can be due now and no v_readfirstlane is issued
+            asm volatile("v_pk_sub_u16 %1, %2, %3\n\tv_bfi_b32 %0, %4, %1, %0" : "+v"(acc[fwd3_acc_index(J)]), "=&v"(tmp) : "v"(x), "v"(y), "s"(m));
+            if (skip) { skip = 0u; return Mn; }                 // (wave-uniform)
+            uint32_t s0 = __builtin_amdgcn_readfirstlane(Mn);
+            if (__builtin_expect(fwd3_due(s0), 0)) Mn = fwd3_renorm(Mn, s0);
+            skip = fwd3_safe(s0);
+            return Mn;
+        }
+        uint32_t s0 = __builtin_amdgcn_readfirstlane(Mn);
         // (s0 is named as an input only to keep the block behind the v_readfirstlane)
         asm volatile("v_pk_sub_u16 %1, %2, %3\n\tv_bfi_b32 %0, %4, %1, %0" : "+v"(acc[fwd3_acc_index(J)]), "=&v"(tmp) : "v"(x), "v"(y), "s"(m), "s"(s0));
         if constexpr (FOA_EXP & 2) asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(acc[5]) : "s"(0u), "v"(Mn));
@@ -246,6 +270,7 @@ __device__ __forceinline__ uint32_t fwd3_step(uint32_t M, const uint2 w, uint32_
         if (__builtin_expect(fwd3_due(s0), 0)) Mn = fwd3_renorm(Mn, s0);
         return Mn;
     }
+    skip = 0u;                                        // (steps without a recorded decision, the run-time steps of a last partial chunk, ablation builds: always tested)
     if constexpr (FOA_FILE_LATE && J >= 0 && !(FOA_ABL & 1)) {           // (ablation build without the test: file in line)
         constexpr uint32_t m = 0x01000100u << (J & 7);
         uint32_t tmp;
@@ -254,13 +279,13 @@ __device__ __forceinline__ uint32_t fwd3_step(uint32_t M, const uint2 w, uint32_
     if constexpr (FOA_EXP & 2) asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(acc[5]) : "s"(0u), "v"(Mn));          // (mask 0: acc[5] unchanged)
     if constexpr (FOA_EXP & 4) asm volatile("v_bfi_b32 %0, %1, %2, %0\n\tv_bfi_b32 %0, %1, %2, %0" : "+v"(acc[5]) : "s"(0u), "v"(Mn));
     if constexpr (FOA_ABL & 2) return Mn;
-    const uint32_t s0 = __builtin_amdgcn_readfirstlane(Mn);
+    uint32_t s0 = __builtin_amdgcn_readfirstlane(Mn);
     if constexpr (FOA_ABL & 32) { if (__builtin_expect(s0 == 0x12345678u, 0)) Mn = fwd3_renorm(Mn, s0); return Mn; }
     if constexpr (FOA_ABL & 64) {               // events at a made-up 1 step in 8; 128: the cold path without the reduction; 256: low half only
         if (__builtin_expect(((s0 >> 1) & 7u) == 0u, 0)) {
             if constexpr (FOA_ABL & 128) { uint32_t z; asm volatile("s_mov_b32 %0, 0" : "=s"(z)); Mn -= z; }
-            else if constexpr (FOA_ABL & 256) Mn = fwd3_renorm(Mn, 0xFF00FFD3u);
-            else Mn = fwd3_renorm(Mn, (s0 & 16u) ? 0xFF00FFD3u : 0xFFD3FF00u);
+            else if constexpr (FOA_ABL & 256) { uint32_t z = 0xFF00FFD3u; Mn = fwd3_renorm(Mn, z); }
+            else { uint32_t z = (s0 & 16u) ? 0xFF00FFD3u : 0xFFD3FF00u; Mn = fwd3_renorm(Mn, z); }
         }
         return Mn;
     }
@@ -283,35 +308,35 @@ struct Fwd3NoFlush { __device__ __forceinline__ void operator()(int) const {} };
 
 // flush(blk): called right behind the step that completes the 16-step block blk of the chunk (FOA_ACC2)
 template <int E0, int J0, typename Flush = Fwd3NoFlush>
-__device__ __forceinline__ uint32_t fwd3_group(uint32_t M, const uint4 *bml, const Fwd3Lane &c, uint32_t (&acc)[6], const Flush &flush = Flush())
+__device__ __forceinline__ uint32_t fwd3_group(uint32_t M, const uint4 *bml, const Fwd3Lane &c, uint32_t (&acc)[6], uint32_t &skip, const Flush &flush = Flush())
 {
     const uint2 w0 = fwd3_inc(bml, E0 + 0, c.ofs[0]), w1 = fwd3_inc(bml, E0 + 1, c.ofs[1]), w2 = fwd3_inc(bml, E0 + 2, c.ofs[2]),
                 w3 = fwd3_inc(bml, E0 + 3, c.ofs[3]), w4 = fwd3_inc(bml, E0 + 4, c.ofs[4]), w5 = fwd3_inc(bml, E0 + 5, c.ofs[5]);
-    M = fwd3_step<0, (J0 < 0 ? J0 : J0 + 0)>(M, w0, acc, 0);
+    M = fwd3_step<0, (J0 < 0 ? J0 : J0 + 0)>(M, w0, acc, 0, skip);
     if constexpr (FOA_ACC2 && J0 >= 0 && ((J0 + 0) & 15) == 15) flush((J0 + 0) >> 4);
-    M = fwd3_step<1, (J0 < 0 ? J0 : J0 + 1)>(M, w1, acc, 0);
+    M = fwd3_step<1, (J0 < 0 ? J0 : J0 + 1)>(M, w1, acc, 0, skip);
     if constexpr (FOA_ACC2 && J0 >= 0 && ((J0 + 1) & 15) == 15) flush((J0 + 1) >> 4);
-    M = fwd3_step<2, (J0 < 0 ? J0 : J0 + 2)>(M, w2, acc, 0);
+    M = fwd3_step<2, (J0 < 0 ? J0 : J0 + 2)>(M, w2, acc, 0, skip);
     if constexpr (FOA_ACC2 && J0 >= 0 && ((J0 + 2) & 15) == 15) flush((J0 + 2) >> 4);
-    M = fwd3_step<3, (J0 < 0 ? J0 : J0 + 3)>(M, w3, acc, 0);
+    M = fwd3_step<3, (J0 < 0 ? J0 : J0 + 3)>(M, w3, acc, 0, skip);
     if constexpr (FOA_ACC2 && J0 >= 0 && ((J0 + 3) & 15) == 15) flush((J0 + 3) >> 4);
-    M = fwd3_step<4, (J0 < 0 ? J0 : J0 + 4)>(M, w4, acc, 0);
+    M = fwd3_step<4, (J0 < 0 ? J0 : J0 + 4)>(M, w4, acc, 0, skip);
     if constexpr (FOA_ACC2 && J0 >= 0 && ((J0 + 4) & 15) == 15) flush((J0 + 4) >> 4);
-    M = fwd3_step<5, (J0 < 0 ? J0 : J0 + 5)>(M, w5, acc, 0);
+    M = fwd3_step<5, (J0 < 0 ? J0 : J0 + 5)>(M, w5, acc, 0, skip);
     if constexpr (FOA_ACC2 && J0 >= 0 && ((J0 + 5) & 15) == 15) flush((J0 + 5) >> 4);
     __builtin_amdgcn_sched_barrier(0);          // keep the next groups' LDS reads from being hoisted (registers)
     return M;
 }
 
-__device__ __forceinline__ uint32_t fwd3_step_dyn(uint32_t M, int j, const uint4 *bml, const Fwd3Lane &c, uint32_t (&acc)[6])
+__device__ __forceinline__ uint32_t fwd3_step_dyn(uint32_t M, int j, const uint4 *bml, const Fwd3Lane &c, uint32_t (&acc)[6], uint32_t &skip)
 {
     switch (j % 6) {
-    case 0: return fwd3_step<0, -2>(M, fwd3_inc(bml, j, c.ofs[0]), acc, j);
-    case 1: return fwd3_step<1, -2>(M, fwd3_inc(bml, j, c.ofs[1]), acc, j);
-    case 2: return fwd3_step<2, -2>(M, fwd3_inc(bml, j, c.ofs[2]), acc, j);
-    case 3: return fwd3_step<3, -2>(M, fwd3_inc(bml, j, c.ofs[3]), acc, j);
-    case 4: return fwd3_step<4, -2>(M, fwd3_inc(bml, j, c.ofs[4]), acc, j);
-    default: return fwd3_step<5, -2>(M, fwd3_inc(bml, j, c.ofs[5]), acc, j);
+    case 0: return fwd3_step<0, -2>(M, fwd3_inc(bml, j, c.ofs[0]), acc, j, skip);
+    case 1: return fwd3_step<1, -2>(M, fwd3_inc(bml, j, c.ofs[1]), acc, j, skip);
+    case 2: return fwd3_step<2, -2>(M, fwd3_inc(bml, j, c.ofs[2]), acc, j, skip);
+    case 3: return fwd3_step<3, -2>(M, fwd3_inc(bml, j, c.ofs[3]), acc, j, skip);
+    case 4: return fwd3_step<4, -2>(M, fwd3_inc(bml, j, c.ofs[4]), acc, j, skip);
+    default: return fwd3_step<5, -2>(M, fwd3_inc(bml, j, c.ofs[5]), acc, j, skip);
     }
 }
 
@@ -405,7 +430,8 @@ __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd3(const FrameInfo
     get(0);
     put(6);
     get(6);
-    M = fwd3_group<0, -1>(M, bml, c, acc);
+    uint32_t skip = 0u;
+    M = fwd3_group<0, -1>(M, bml, c, acc, skip);
     // The decision words of a chunk leave one chunk LATE (FOA_LATE_ST = 1), right behind the loads that fetch the soft pairs
     // of the chunk after: vector loads and stores share one counter on gfx950 and complete out of order with respect to each
     // other, so the wait for those loads is a wait for everything -- and with the stores queued at the end of a chunk it was
@@ -462,14 +488,15 @@ __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd3(const FrameInfo
         get(n0 + kChunk3 + 6);
         if (n0 > 0) store_block(n0 - 16, late);
         n_chunk = n0;
+        if constexpr (FOA_TEST_SKIP) skip = __builtin_amdgcn_readfirstlane(skip);      // (it IS uniform; said so that it stays on the scalar side across the loop)
         if (nn == kChunk3) {
-            M = fwd3_group<0, 0>(M, bml, c, acc, flush);   M = fwd3_group<6, 6>(M, bml, c, acc, flush);   M = fwd3_group<12, 12>(M, bml, c, acc, flush);
-            M = fwd3_group<18, 18>(M, bml, c, acc, flush); M = fwd3_group<24, 24>(M, bml, c, acc, flush); M = fwd3_group<30, 30>(M, bml, c, acc, flush);
-            M = fwd3_group<36, 36>(M, bml, c, acc, flush); M = fwd3_group<42, 42>(M, bml, c, acc, flush);
+            M = fwd3_group<0, 0>(M, bml, c, acc, skip, flush);   M = fwd3_group<6, 6>(M, bml, c, acc, skip, flush);   M = fwd3_group<12, 12>(M, bml, c, acc, skip, flush);
+            M = fwd3_group<18, 18>(M, bml, c, acc, skip, flush); M = fwd3_group<24, 24>(M, bml, c, acc, skip, flush); M = fwd3_group<30, 30>(M, bml, c, acc, skip, flush);
+            M = fwd3_group<36, 36>(M, bml, c, acc, skip, flush); M = fwd3_group<42, 42>(M, bml, c, acc, skip, flush);
         } else {
             // the last, partial chunk: blocks the steps do not reach are still stored (all ones: the store's mask)
             for (int j = 0; j < nn; j++) {
-                M = fwd3_step_dyn(M, j, bml, c, acc);
+                M = fwd3_step_dyn(M, j, bml, c, acc, skip);
                 if ((j & 15) == 15) flush(j >> 4);
             }
             for (int blk = nn >> 4; blk < 3; blk++) flush(blk);
@@ -500,11 +527,11 @@ __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd3(const FrameInfo
         if (FOA_LATE_ST && n0 > 0) store(n0 - kChunk3);
         acc[0] = acc[1] = acc[2] = acc[3] = acc[4] = acc[5] = 0xFFFFFFFFu;
         if (nn == kChunk3) {
-            M = fwd3_group<0, 0>(M, bml, c, acc);   M = fwd3_group<6, 6>(M, bml, c, acc);   M = fwd3_group<12, 12>(M, bml, c, acc);
-            M = fwd3_group<18, 18>(M, bml, c, acc); M = fwd3_group<24, 24>(M, bml, c, acc); M = fwd3_group<30, 30>(M, bml, c, acc);
-            M = fwd3_group<36, 36>(M, bml, c, acc); M = fwd3_group<42, 42>(M, bml, c, acc);
+            M = fwd3_group<0, 0>(M, bml, c, acc, skip);   M = fwd3_group<6, 6>(M, bml, c, acc, skip);   M = fwd3_group<12, 12>(M, bml, c, acc, skip);
+            M = fwd3_group<18, 18>(M, bml, c, acc, skip); M = fwd3_group<24, 24>(M, bml, c, acc, skip); M = fwd3_group<30, 30>(M, bml, c, acc, skip);
+            M = fwd3_group<36, 36>(M, bml, c, acc, skip); M = fwd3_group<42, 42>(M, bml, c, acc, skip);
         } else {
-            for (int j = 0; j < nn; j++) M = fwd3_step_dyn(M, j, bml, c, acc);
+            for (int j = 0; j < nn; j++) M = fwd3_step_dyn(M, j, bml, c, acc, skip);
         }
         // bytes 1 and 3 of a block's two accumulators: (A steps 0-7, A steps 8-15, B steps 0-7, B steps 8-15)
 #pragma unroll
