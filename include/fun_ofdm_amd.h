@@ -105,6 +105,9 @@ int foa_rx_reserve(foa_rx *rx, size_t n_samples, size_t n_frames);
  *   "viterbi"     2 = two frames per wave, chain-back in parallel segments (viterbi_v3.h; the default and the only shipped value);
  *                 cross-check build: 0 = one wave per frame, lane per state (viterbi_v1.h); 1 = two frames per wave, serial chain-back
  *                 (viterbi_v2.h)
+ *   "forward"     viterbi 2: 3 = the forward pass of viterbi_v3.h (a state per lane, two frames per wave; the default and the only shipped value);
+ *                 cross-check build: 4 = viterbi_v4.h (four states per lane, a frame per 16-lane row, four frames per wave: exact, measured, not adopted --
+ *                 DESIGN.md section 4), its decisions converted for the same chain-back
  *   "tb_segment"  viterbi 2: data steps per chain-back segment, a multiple of 96 in [96, 3072] (default 960)
  *   "tb_overlap"  viterbi 2: run-in steps above a segment, a multiple of 96 in [0, 3072] (default 96); any value gives
  *                 the same result as the serial chain-back, small values cost re-walks
