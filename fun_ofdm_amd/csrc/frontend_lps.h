@@ -75,21 +75,11 @@ __device__ __forceinline__ void qam_decode_n(double sym, double scale_d, uint32_
 }
 
 // qam.h:110-125 through the table: the three soft bytes of one axis in one dword
-// (`int pt = sym * d_scale_d` is cvttsd2si on the reference's platform: INT_MIN for NaN and for anything outside int's range, which the clamp below turns into
-// table entry 0.  v_cvt_i32_f64 saturates instead -- INT_MIN below the range as well, but INT_MAX above it and 0 for NaN --, so one ordered compare (v < 2^31,
-// false for NaN) decides between the clamped conversion and entry 0.  The compare goes to a scalar pair and the select reads it from there: as
-// `cond ? a : b` the compiler selects on VCC, which issues at 16 clocks per wave instruction on this part against 4, tools/probe_issue.hip -- two selects per carrier.)
 __device__ __forceinline__ uint32_t qam_lookup(const uint32_t *qam, double sym, double scale_d)
 {
 #pragma clang fp contract(off)
-    const double v = sym * scale_d;
-    int pt;
-    asm("v_cvt_i32_f64 %0, %1" : "=v"(pt) : "v"(v));
-    const int idx = min(max(pt, -320), 320) + 320;
-    const uint64_t in_range = __builtin_amdgcn_fcmp(v, 2147483648.0, 4 /* ordered and less than */);
-    int sel;
-    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(sel) : "v"(idx), "s"(in_range));
-    return qam[sel];
+    const int pt = trunc_to_int(sym * scale_d);
+    return qam[min(max(pt, -320), 320) + 320];
 }
 
 // LDS of one wave: staging rows for the coalesced input loads and output stores, and the look-up tables
