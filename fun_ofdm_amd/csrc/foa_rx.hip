@@ -647,7 +647,8 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
     if (rx->in_wait) { HIP_TRY(hipStreamWaitEvent(st, rx->in_ready, 0)); rx->in_wait = false; }
     HIP_TRY(hipEventRecord(rx->w->ev[0], st));
     const bool exp_skip_fe = (FOA_EXP & 8) && rx->w->used;          // timing experiment only (tools/exp_chainback.sh): what is the front end on the loop worth?
-    if (!exp_skip_fe)
+    const bool exp_skip_hdr = (FOA_EXP & 16) && rx->w->used;        // timing experiment only: the bound on what a cheaper header kernel could gain (the work set keeps the last call's results)
+    if (!exp_skip_fe && !exp_skip_hdr)
     hipLaunchKernelGGL(k_header, dim3(nf), dim3(64), 0, st, iq, d_descs, d_ends, (int64_t)n_samples, nf, rx->w->info.p, rx->w->hinv.p, eq_sig);
     HIP_TRY(hipEventRecord(rx->w->ev[1], st));
     // segments of this call: at most (total data steps)/S + one per frame; lanes beyond the real total idle
