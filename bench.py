@@ -53,10 +53,8 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--reps", type=int, default=3, help="timed regions of --steps steps each inside the one run; value = the median region")
     ap.add_argument("--frames", type=int, default=10000, help="frames per GPU (BASELINE config 2: 10000)")
-    ap.add_argument("--viterbi", type=int, default=2, help="0: lane per state, 1: packed + serial chain-back, 2: packed + segment chain-back")
-    ap.add_argument("--tb-segment", type=int, default=0, help="viterbi 2: data steps per chain-back segment (0: library default)")
-    ap.add_argument("--tb-overlap", type=int, default=-1, help="viterbi 2: run-in steps of a segment (-1: library default)")
-    ap.add_argument("--frontend", type=int, default=-1, help="-1: library default, 0: wave-per-symbol, 1: lane-per-symbol, 2: quad-per-symbol kernel")
+    ap.add_argument("--tb-segment", type=int, default=0, help="data steps per chain-back segment (0: library default)")
+    ap.add_argument("--tb-overlap", type=int, default=-1, help="run-in steps of a chain-back segment (-1: library default)")
     ap.add_argument("--tx", choices=("host", "device"), default="host",
                     help="where the synthetic frames are built: numpy on the host (default) or foa_tx_* on the device")
     ap.add_argument("--no-pipeline", action="store_true", help="finish of a step on the same stream as the rest (no overlap with the next step)")
@@ -64,10 +62,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-sync-leg", action="store_true", help="skip the extra leg with the device pre-sync (profiling: keeps its launches out of the kernel averages)")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the legs that are not `value`: host-pointer entry (H2D + D2H inside), config 3 rate sweep, config 5 stream")
-    ap.add_argument("--fe-hold", type=int, default=-1, help="A/B: library option fe_hold (-1: library default)")
     ap.add_argument("--depth", type=int, default=-1, help="A/B: library option depth (-1: library default = by grid size)")
-    ap.add_argument("--lanes", type=int, default=-1, help="A/B: library option lanes (-1: library default)")
-    ap.add_argument("--walk-lane", type=int, default=-1, help="A/B: library option walk_lane (-1: library default)")
     ap.add_argument("--legs-frames", type=int, default=1000, help="frames per rate of the config-3 leg")
     ap.add_argument("--no-fill-legs", action="store_true", help="skip the machine-filling and mixed-call tables of config 3 (tens of GB of workspaces)")
     ap.add_argument("--fill-frames", type=int, default=10240, help="frames per rate of the machine-filling table (10 240 = five forward-pass waves per SIMD)")
@@ -392,18 +387,10 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
     m = descs.size
 
     rx = make_receiver(dev_index) if make_receiver else foa.Receiver(dev_index)
-    rx.set_option("viterbi", args.viterbi)
     if args.tb_segment > 0:
         rx.set_option("tb_segment", args.tb_segment)
     if args.tb_overlap >= 0:
         rx.set_option("tb_overlap", args.tb_overlap)
-    rx.set_option("frontend", args.frontend)
-    if args.fe_hold >= 0:
-        rx.set_option("fe_hold", args.fe_hold)
-    if args.lanes >= 0:
-        rx.set_option("lanes", args.lanes)
-    if args.walk_lane >= 0:
-        rx.set_option("walk_lane", args.walk_lane)
     if args.depth >= 0:
         rx.set_option("depth", args.depth)
     rx.set_option("pipeline", 0 if args.no_pipeline else 1)
@@ -478,7 +465,7 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
     for _ in range(args.warmup):
         step()
     d_psdu, d_res = finish_steps()
-    piped = bool(args.viterbi == 2 and not args.no_pipeline)
+    piped = not args.no_pipeline
 
     def timed_region():
         """EXACTLY args.steps steps between barrier + synchronize on both sides; returns (seconds, max over ranks; per-kernel
@@ -643,7 +630,7 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
                        "frames_per_gpu": args.frames, "frame_samples": FRAME_SAMPLES, "slot_pitch_samples": PITCH,
                        "counted_samples": "in-frame only (3520/frame)", "value_all_samples_fed": round(value * PITCH / FRAME_SAMPLES, 1),
                        "x_realtime_20MSps": round(value / 20.0, 1), "psdu_bit_exact": exact, "frames_ok": ok_frames, "frames_found_by_sync_rank0": int(real.size),
-                       "alignments_decoded_per_gpu": m, "frontend_dtype": "f64", "viterbi_kernel": args.viterbi, "frontend_kernel": args.frontend,
+                       "alignments_decoded_per_gpu": m, "frontend_dtype": "f64", "viterbi_kernel": "k_viterbi_fwd3 + k_tb_walk + k_tb_finish", "frontend_kernel": "k_header + k_data_symbols_q4",
                        "steps_pipelined": piped,
                        "sharding": ("global frame i on rank i mod %d, one %s gather of PSDU slots to rank 0 per step%s"
                                     % (world, "RCCL" if backend == "nccl" else backend,
@@ -702,7 +689,7 @@ def roofline(args, kms, n_real, ms_per_step, piped, probe):
     per clock and SIMD, 2.4 GHz; a packed instruction takes twice the clocks and does twice the ops) 1024 x 32 x 2.4e9 = 78.6 T/s.
     Consecutive forward passes overlap (two streams), so a launch lasts longer than a step: `frac` is the per-launch figure the tier
     defines (ops of one launch / its own duration / peak); the step-rate figure (what the machine sustains) is `frac_at_step_rate`."""
-    fwd_kernel = {0: "k_viterbi_v1", 1: "k_viterbi_fwd2", 2: "k_viterbi_fwd3"}[args.viterbi]
+    fwd_kernel = "k_viterbi_fwd3"
     t_k = kms["viterbi_fwd"] * 1e-3                      # average launch duration, live from HIP events on the kernel's own stream
     t_step = ms_per_step * 1e-3 if piped else t_k        # calls in line: one launch at a time, the launch IS the kernel's share of the step
     steps = n_real * 39 * 216                            # trellis steps per launch (frames found x 39 symbols x 216)

@@ -11,26 +11,20 @@ class FoaError(RuntimeError):
     pass
 
 
-def library_path(xcheck=False):
-    """The product library, or (xcheck) the build that also holds the kernels kept only as cross-checks for the parity suite
-    (csrc/foa_common.h, FOA_XCHECK): tests load that one; nothing in the product path does."""
-    if xcheck:
-        return os.path.join(CSRC, "libfun_ofdm_amd_xcheck.so")
-    # FOA_LIB: alternative build of the same library (kernel A/B experiments)
+def library_path():
+    """The library (FOA_LIB: another build of it, for A/B timing on one box)."""
     return os.environ.get("FOA_LIB") or os.path.join(CSRC, "libfun_ofdm_amd.so")
 
 
 def build(force=False):
     """Compile the gfx950 library in-tree with hipcc (cross-compiles without a GPU)."""
-    for path in (library_path(), library_path(True)):
-        if force and os.path.exists(path):
-            os.remove(path)
-    subprocess.run(["make", "-s", "-C", CSRC], check=True)
+    if force:
+        subprocess.run(["make", "-s", "-C", CSRC, "clean"], check=True)
+    subprocess.run(["make", "-s", "-j", "6", "-C", CSRC], check=True)
     return library_path()
 
 
 _lib = None
-_lib_x = None
 
 _SIGS = {
     "foa_version": (C.c_int, []),
@@ -99,15 +93,23 @@ _SIGS = {
 EXPORTS = tuple(_SIGS)
 
 
-def lib(xcheck=False):
+def lib():
     """The loaded library.  There is deliberately no fallback: a missing or unloadable HIP library
     is an error."""
-    global _lib, _lib_x
-    if (_lib_x if xcheck else _lib) is None:
-        path = library_path(xcheck)
+    global _lib
+    if _lib is None:
+        path = library_path()
         if not os.path.exists(path):
             raise FoaError("%s not found: build it with fun_ofdm_amd.build() / `make -C fun_ofdm_amd/csrc` "
                            "(this package has no CPU implementation)" % path)
+        # The library keeps up to six HIP streams busy and the runtime fixes its number of hardware queues when it STARTS (default 4:
+        # lanes would share queues and small batches lose 20-30 %, include/fun_ofdm_amd.h foa_recommended_hw_queues).  This process is
+        # the library's host: say so before anything starts the runtime.  A host that has set the variable keeps its choice; one that
+        # started the runtime before importing this package is told so by Receiver (foa_rx_notes).
+        import sys
+        tc = getattr(sys.modules.get("torch"), "cuda", None)
+        if not (tc is not None and tc.is_initialized()):                # (too late otherwise: the library then sees the variable unset and says so)
+            os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
         # PyTorch-ROCm wheels bundle their own libamdhip64; two HIP runtimes in one process do not
         # coexist (the second sees no GPU).  Importing torch first makes this library bind to the
         # runtime torch already loaded, so device buffers and streams can be shared with it.
@@ -119,11 +121,8 @@ def lib(xcheck=False):
         for name, (res, args) in _SIGS.items():
             f = getattr(L, name)
             f.restype, f.argtypes = res, args
-        if xcheck:
-            _lib_x = L
-        else:
-            _lib = L
-    return _lib_x if xcheck else _lib
+        _lib = L
+    return _lib
 
 
 def check(rc, L=None):

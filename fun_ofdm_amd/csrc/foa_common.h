@@ -1,13 +1,6 @@
 // foa_common.h -- shared declarations of the gfx950 receive path (device + host side).
 #pragma once
 
-// FOA_XCHECK = 1 builds libfun_ofdm_amd_xcheck.so: the product plus the kernels kept ONLY as independent cross-checks for the parity
-// suite (viterbi_v1.h, the v2 forward / chain-back kernels, the wave-per-symbol and lane-per-symbol front ends).  The shipped
-// library (FOA_XCHECK = 0) does not contain them.
-#ifndef FOA_XCHECK
-#define FOA_XCHECK 0
-#endif
-
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -17,6 +10,7 @@ namespace foa {
 
 constexpr int kNumRates = 11;
 constexpr int kWave = 64;
+constexpr int kMaxDecodedBytes = 4128;   // num_data_bytes <= 4104 for length <= 4095 at any rate
 
 // Per-frame working record kept in HBM between the kernels of one decode call.
 struct FrameInfo {
@@ -28,7 +22,7 @@ struct FrameInfo {
     int32_t nsteps;      // trellis steps = nsym * dbps
     int64_t soft_off;    // byte offset of this frame's depunctured soft bytes (= 2 * dec_off: two per trellis step)
     int64_t dec_off;     // offset (in per-step elements) of this frame's region in the soft-pair, decision and decoded buffers
-    int32_t seg_off;     // first chain-back segment's index in the call-wide segment numbering (viterbi_v3.h)
+    int32_t seg_off;     // first chain-back segment's index in the call-wide segment numbering (viterbi_tb.h)
     int32_t reserved_;
 };
 
@@ -48,7 +42,6 @@ struct DeviceTables {
     uint8_t scramble[128];         // ppdu.cpp:256-264 feedback bit per byte index mod 127
     uint32_t crc_table[256];       // IEEE 802.3 CRC-32, reflected
     double lts_conj_re[64], lts_conj_im[64];   // preamble.h:432 LTS_TIME_DOMAIN_CONJ
-    // look-up form of the soft demapper, used by the lane-per-symbol and quad-per-symbol front ends
     uint32_t qam_lut[641];         // qam.h:110-125 for pt = -320..320 (constant outside): soft byte i in bits 8i..8i+7
     // interleaver.cpp:28-38 + puncturer.cpp:94-118 as one map per rate: demodulated byte c = carrier * bpsc + bit of a
     // symbol -> its position among the symbol's 2 * dbps depunctured soft bytes (frontend_q4.h)
@@ -56,8 +49,8 @@ struct DeviceTables {
     double preamble_re[320], preamble_im[320];   // preamble.h:24 PREAMBLE_SAMPLES (transmit side, tx_kernels.h)
 };
 
-// Filled once on the host (tables.cpp) and uploaded to __constant__ memory of each translation unit
-// that needs it.
+// Filled once on the host (rx_handle.hip); every translation unit that holds kernels keeps its own copy in __constant__ memory
+// (device_math.h) and uploads it when a handle is created.
 void build_tables(DeviceTables *t);
 
 }  // namespace foa

@@ -1,10 +1,9 @@
 // frontend_q4.h -- data symbols, FOUR LANES (one DPP quad) PER OFDM SYMBOL, sixteen symbols per wave.
 //
-// Same arithmetic and the same operation order as k_data_symbols_lps (fft_symbols.cpp:33-79 + fft.cpp:50-59,
-// channel_est.cpp:77-81, phase_tracker.cpp:83-99, modulator.cpp:108-164 / qam.h:110-125, interleaver.cpp:28-38,
-// puncturer.cpp:78-123), so the results are bit-identical to it; what changes is who holds what.
-// The lane-per-symbol kernel keeps 64 complex doubles per lane: 512 VGPRs, one wave per SIMD, VALU 17 % busy.
-// Here lane m of a quad holds the 16 samples n = m (mod 4) of its symbol:
+// Replaces, for the data symbols of every frame of a call: fft_symbols.cpp:33-79 + fft.cpp:50-59, channel_est.cpp:77-81,
+// phase_tracker.cpp:83-99, modulator.cpp:108-164 / qam.h:110-125, interleaver.cpp:28-38, puncturer.cpp:78-123 -- the same
+// arithmetic in the same operation order as the wave-wide fft64_lane of device_math.h, laid out so that a wave carries sixteen
+// symbols.  Lane m of a quad holds the 16 samples n = m (mod 4) of its symbol:
 //   * radix-4 DIF stage 1 pairs n, n+16, n+32, n+48 and stage 2 pairs n, n+4, n+8, n+12 inside every 16-block --
 //     all four operands have the same n mod 4, so both stages run in the lane's own registers;
 //   * stage 3 pairs n, n+1, n+2, n+3 = one operand per lane: a 4x4 transpose inside the quad (through LDS, 4 KB per
@@ -13,21 +12,15 @@
 //     terms live in lanes 1 and 2 and are broadcast so that every lane adds them in the reference's order;
 //   * soft bytes are scattered into the symbol's depunctured order in LDS ((carrier, bit) -> position table per
 //     rate), and leave in 8-byte stores, four trellis steps per lane and trip.
-// Measured alone (config 2): 0.31 ms against 0.34 ms for the lane-per-symbol kernel, although the fp64 butterflies issue at
-// about 6 clocks per wave instruction and the quad layout spends 1 640 VALU instructions per 16 symbols where
-// lane-per-symbol spends 4 400 per 64: its waves are small (<= 176 VGPRs against 512), so several share a SIMD and hide each
-// other's latencies, and they fit next to the forward pass of the previous call in the pipelined path.  It is the default
-// front end (option "frontend" = -1); the lane-per-symbol and wave-per-symbol kernels stay selectable and in the parity suite.
+// Its waves are small (<= 176 VGPRs), so several share a SIMD and hide each other's latencies, and they fit next to the forward
+// pass of the previous call when calls are pipelined (0.18 ms alone at config 2; HISTORY.md has the layouts it replaced).
 #pragma once
 
-#include "frontend_lps.h"
+#include "device_math.h"
 
 namespace foa {
 
-#ifndef FOA_Q4_WAVES
-#define FOA_Q4_WAVES 4
-#endif
-constexpr int kQ4Waves = FOA_Q4_WAVES;       // waves per block: FOUR, one per SIMD (10 KB of tables + 7 KB per wave = 38 KB of LDS).
+constexpr int kQ4Waves = 4;                  // waves per block: FOUR, one per SIMD (10 KB of tables + 7 KB per wave = 38 KB of LDS).
                                              // With five (a block's waves go round the SIMDs, so the fifth doubles up on one) the
                                              // kernel alone took 0.447 ms instead of 0.308 and the pipelined step 1.32 ms instead
                                              // of 1.21 (2, 3, 6 waves per block: 1.23; 8: 1.28).  The register budget does not
@@ -49,7 +42,7 @@ struct Q4Shared {
     Q4Wave w[kQ4Waves];
 };
 
-// the radix-4 butterfly of fft64_regs / fft64_lane (same association)
+// the radix-4 butterfly of fft64_lane (same association)
 __device__ __forceinline__ void q4_butterfly(cpx a, cpx b, cpx c, cpx d, cpx &y0, cpx &y1, cpx &y2, cpx &y3)
 {
     const cpx t0 = cadd(a, c), t1 = cadd(a, cneg(c));
@@ -124,15 +117,7 @@ void k_data_symbols_q4(const float2 *__restrict__ iq, const foa_frame_desc *__re
                        uint16_t *__restrict__ sp, double2 *__restrict__ eq_tap)
 {
     __shared__ Q4Shared sh;
-    // (Rounds 1 and 2 ran this kernel at priority 2, which paid under the three-stream arrangement of the time.  With two lanes it costs
-    // the step 1-1.5 %: what matters is that these waves do NOT go ahead of the forward pass's -- forward pass at 2 or 3, this kernel at
-    // 0 .. 3 below or level with it, or no priorities at all, all measure the same; profiles/r03_ab_fwd_prio.txt.  No priorities, then.)
-#ifndef FOA_Q4_PRIO
-#define FOA_Q4_PRIO 0
-#endif
-#if FOA_Q4_PRIO
-    __builtin_amdgcn_s_setprio(FOA_Q4_PRIO);
-#endif
+    // (No wave priority: what matters is that these waves do not go ahead of the forward pass's; profiles/r03_ab_fwd_prio.txt.)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, qd = lane >> 2, m = lane & 3;
     const int64_t total = min(totals[0], totals[3]);
     if ((int64_t)blockIdx.x * kQ4Waves * 16 >= total) return;       // the grid is sized by an upper bound: surplus blocks leave at once
@@ -164,10 +149,7 @@ void k_data_symbols_q4(const float2 *__restrict__ iq, const foa_frame_desc *__re
     // per-sample choice was a 64-bit compare and four v_cndmask_b32 on VCC per sample, sixteen times per lane: the select on VCC issues
     // at 16 clocks per wave instruction on this part, tools/probe_issue.hip -- a seventh of the kernel's issue time for a choice that
     // always comes out the same way.)
-#ifndef FOA_Q4_FASTROT
-#define FOA_Q4_FASTROT 1          // (0: the per-sample choice always -- A/B only)
-#endif
-    if (FOA_Q4_FASTROT && __all(!valid || start >= d.rot_start)) {
+    if (__all(!valid || start >= d.rot_start)) {
         const cpx r = { d.c, d.s };
 #pragma unroll
         for (int u = 0; u < 16; u++) {

@@ -1,5 +1,5 @@
 // shard_engine.h -- foa_shard_*: one stream dealt over several devices (include/fun_ofdm_amd.h; the logic is shard_core.h, this is its GPU
-// side).  Included by foa_rx.hip behind stream_engine.h, whose batch geometry (carry, longest frame, job slots) it shares.
+// side).  Included by rx_stream.hip behind stream_engine.h, whose batch geometry (carry, longest frame, job slots) it shares.
 //
 // Every device has its own receiver handle -- its own streams, work sets, pre-sync scratch and job slots -- created and destroyed by
 // the shard.  Batch k of the stream goes to device k mod N: two host-to-device copies (the C samples before the batch out of the host's
@@ -37,7 +37,7 @@ struct ShardDev {
     ShardDev() { for (auto &c : status_count) c.store(0); alignments.store(0); }
     int keep(int rc)
     {
-        if (rc) { std::lock_guard<std::mutex> lk(*err_m); if (err_text->empty()) *err_text = g_err; }
+        if (rc) { std::lock_guard<std::mutex> lk(*err_m); if (err_text->empty()) *err_text = last_error_text(); }
         return rc;
     }
     int init(foa_rx *handle, int64_t batch)
@@ -110,7 +110,7 @@ struct ShardDev {
         hipStream_t st = side_stream(rx);
         ph[4 * k] = prev[0]; ph[4 * k + 1] = prev[1];
         HIP_TRY(hipMemcpyAsync(d_prev.p, ph + 4 * k, 2 * sizeof(double), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(foa::k_stream_select, dim3(1), dim3(64), 0, st, (foa_frame_desc *)d_desc[k].p, syn_dev.p + 8 * k, (int32_t)desc_cap, lo, hi, d_prev.p, sel_dev.p + 4 * k);
+        launch_stream_select(st, (foa_frame_desc *)d_desc[k].p, syn_dev.p + 8 * k, (int32_t)desc_cap, lo, hi, d_prev.p, sel_dev.p + 4 * k);
         HIP_TRY(hipMemcpyAsync(sel + 4 * k, sel_dev.p + 4 * k, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(ph + 4 * k + 2, d_prev.p, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipEventRecord(sel_done[k], st));

@@ -3,9 +3,52 @@
 // element order (subcarrier index = FFT bin + 32, tagged_vector.h), so lane j = subcarrier j here.
 #pragma once
 
-#include "viterbi_v2.h"
+#include "signal_decode.h"
 
 namespace foa {
+
+constexpr int kSymWaves = 4;          // waves (symbols) per block of k_stage_demap
+
+// fft::forward (fft.cpp:50-59) on vectors of 64 complex doubles, in place: one wave per vector
+__global__ __launch_bounds__(256) void k_fft_vectors(double2 *__restrict__ v, int n_vec)
+{
+    __shared__ cpx lds_all[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= n_vec) return;
+    double2 x = v[(size_t)i * 64 + lane];
+    cpx y = fft64_lane(cpx{ x.x, x.y }, lds_all[wave], lane);
+    v[(size_t)i * 64 + lane_subcarrier(lane)] = make_double2(y.x, y.y);
+}
+
+// One data symbol's 48 derotated carriers -> the depunctured soft bytes of its dbps trellis steps, two per step (what
+// puncturer::depuncture hands viterbi::conv_decode; the forward pass forms its branch metrics from them, viterbi_fwd.h).
+// Lane with data index di >= 0 holds carrier z.  stage: 448 B of LDS private to the wave.
+// modulator.cpp:108-164 / qam.h:110-125, interleaver.cpp:28-38, puncturer.cpp:78-123.
+__device__ __forceinline__ void emit_symbol_soft(cpx z, int di, const RateRow &rr, uint8_t *stage, uint16_t *sp_dst, int lane)
+{
+    // erasures first (puncturer.cpp:98,100,114), then scatter this carrier's soft bytes
+    const int out_bytes = 2 * rr.dbps;                         // depunctured bytes of this symbol
+    if (rr.punct != 0) {
+        uint32_t *st32 = (uint32_t *)stage;
+        for (int i = lane; i < out_bytes / 4; i += 64) st32[i] = 0x7F7F7F7Fu;
+    }
+    wave_lds_sync();
+    if (di >= 0) {
+        uint8_t bits[6];
+        qam_decode(z.x, rr.numbits, rr.scale_d, bits);
+        if (rr.bpsc > 1) qam_decode(z.y, rr.numbits, rr.scale_d, bits + rr.numbits);
+        for (int b = 0; b < rr.bpsc; b++) {
+            int c = di * rr.bpsc + b;                          // demodulated byte index within the symbol
+            int dd = 48 * (c / 48) + deinterleaved_pos(c % 48);
+            stage[depunct_pos(dd, rr.punct)] = bits[b];        // symbol-local: cbps is a multiple of 12
+        }
+    }
+    wave_lds_sync();
+    uint32_t *dst = (uint32_t *)sp_dst;                        // (symbols start on 8-byte boundaries: dbps is a multiple of 4)
+    const uint32_t *st32 = (const uint32_t *)stage;
+    for (int i = lane; i < out_bytes / 4; i += 64) dst[i] = st32[i];
+}
 
 // channel_est.cpp:44-58: est = (LTS_FREQ_DOMAIN / Y1) / 2 + (LTS_FREQ_DOMAIN / Y2) / 2, one wave per LTS pair
 __global__ __launch_bounds__(64) void k_stage_chanest(const double2 *__restrict__ lts_pairs, double2 *__restrict__ hinv, int n)
@@ -84,9 +127,8 @@ __global__ __launch_bounds__(64) void k_stage_header(const double2 *__restrict__
     }
 }
 
-// viterbi::conv_decode through the packed kernels (foa_conv_decode with option "viterbi" = 1 or 2): the soft bytes of
-// block blockIdx.y go into the block's region as they are, two per trellis step -- exactly what the front end hands the
-// forward pass.
+// viterbi::conv_decode through the kernels of the batch path (foa_conv_decode): the soft bytes of block blockIdx.y go into
+// the block's region as they are, two per trellis step -- exactly what the front end hands the forward pass.
 __global__ __launch_bounds__(256) void k_conv_sp(const uint8_t *__restrict__ symbols, size_t sym_stride, int T, const FrameInfo *__restrict__ info,
                                                  uint16_t *__restrict__ sp)
 {

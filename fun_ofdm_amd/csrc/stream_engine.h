@@ -1,5 +1,5 @@
 // stream_engine.h -- receiver_chain::process_samples() with EVERYTHING on the device (SURVEY 8f #1 + #3):
-// foa_stream_* of include/fun_ofdm_amd.h.  Included by foa_rx.hip (it drives the handle's streams and work sets).
+// foa_stream_* of include/fun_ofdm_amd.h.  Host code only (rx_stream.hip); it drives the handle's streams, work sets and job slots.
 //
 // The reference runs frame_detector -> timing_sync -> fft_symbols -> ... -> frame_decoder inside every
 // process_samples() call (src/receiver_chain.cpp:106-126) on 4096-sample chunks, carrying 16 + 160 samples and the frame in
@@ -27,7 +27,15 @@
 // for that); one submitter thread makes every GPU call while the stream is open.
 #pragma once
 
+#include <algorithm>
+#include <atomic>
+#include <deque>
+#include <mutex>
+
+#include "rx_handle.h"
 #include "stream_core.h"
+
+using namespace foa;
 
 namespace foa {
 
@@ -44,7 +52,7 @@ static int stream_decode_batch(foa_rx *rx, const float *d, size_t n_buf, const f
                                uint64_t *ticket, int64_t *t_prep)
 {
     const auto t0 = std::chrono::steady_clock::now();
-    const bool piped = rx->pipeline && rx->viterbi_kind == 2;
+    const bool piped = rx->pipeline;
     HostJob *job = nullptr;
     for (auto &j : rx->jobs) if (!j.busy) { job = &j; break; }
     if (!job) return fail(FOA_E_STATE, "internal: no free job slot");
@@ -152,7 +160,7 @@ struct StreamGpu {
     int keep_error(int rc)
     {
         std::lock_guard<std::mutex> lk(err_m);
-        if (err_text.empty()) err_text = g_err;
+        if (err_text.empty()) err_text = last_error_text();
         return rc;
     }
 
@@ -181,8 +189,7 @@ struct StreamGpu {
         const int64_t cut = final ? pushed + 1 : pushed - L;        // this batch decodes the alignments whose STS_END sample lies in [cut_prev, cut)
         int rc = sync_dev_issue(rx, d, (size_t)n_buf, (foa_frame_desc *)d_desc[k].p, d_ends[k].p, desc_cap, &ccap[k], start);
         if (rc) return rc;
-        hipLaunchKernelGGL(foa::k_stream_select, dim3(1), dim3(64), 0, st, (foa_frame_desc *)d_desc[k].p, rx->sy_n.p, (int32_t)desc_cap, cut_prev - start, cut - start,
-                           d_prev.p, sel_dev.p + 4 * k);
+        launch_stream_select(st, (foa_frame_desc *)d_desc[k].p, rx->sy_n.p, (int32_t)desc_cap, cut_prev - start, cut - start, d_prev.p, sel_dev.p + 4 * k);
         HIP_TRY(hipMemcpyAsync(sel + 4 * k, sel_dev.p + 4 * k, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipEventRecord(sel_done[k], st));
         HIP_TRY(hipGetLastError());
@@ -364,7 +371,7 @@ static void stream_free_buffers(StreamGpu &g)
 // Stops the engine and gives everything it holds on the device back; the handle is the caller's again.  Idempotent: foa_rx_destroy
 // calls it for a stream that is still open (its threads use the handle), and the owner's later foa_stream_destroy then only frees
 // the shell -- every other foa_stream_* call on such a stream fails with FOA_E_STATE.
-void foa_stream_shutdown(foa_stream *s)
+void foa::stream_shutdown(foa_stream *s)
 {
     if (!s || !s->core) return;
     delete s->core;                                   // joins the helpers and the submitter: from here on this thread owns the handle
@@ -387,7 +394,7 @@ extern "C" {
 void foa_stream_destroy(foa_stream *s)
 {
     if (!s) return;
-    if (s->core) foa_stream_shutdown(s);
+    if (s->core) stream_shutdown(s);
     else {
         // no engine: creation failed half-way (buffers may exist, whichever allocation it failed at), or the stream was shut down already
         // (nothing is left: the call is a no-op then)

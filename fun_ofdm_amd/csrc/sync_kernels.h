@@ -17,7 +17,7 @@
 //                    compact in stream order, chain the "previous phasor", derive the per-alignment end.
 #pragma once
 
-#include "frontend_kernels.h"
+#include "device_math.h"
 #include "sync_host.h"
 
 namespace foa {
@@ -146,50 +146,6 @@ __global__ __launch_bounds__(64, 3) void k_sync_flags(const float2 *__restrict__
     const int64_t h16 = i0 >> 4;                                             // half-word of the flag array (little endian: bit i of word w = sample 32 w + i)
     if (h16 < 2 * n_words) ((uint16_t *)flags)[h16] = (uint16_t)mask;
 }
-
-#if FOA_XCHECK
-// The first arrangement, kept in the cross-check build (option "sync_flags" 0): 256 threads per 1024 samples, every thread adds the
-// sixteen terms of a window directly, oldest first -- 15 additions and 16 LDS reads per window and quantity.
-__global__ __launch_bounds__(256) void k_sync_flags_direct(const float2 *__restrict__ iq, int64_t n, uint32_t *__restrict__ flags)
-{
-#pragma clang fp contract(off)
-    __shared__ double pr[kFlagSamples + 16], pi[kFlagSamples + 16], pw[kFlagSamples + 16];
-    const int t = threadIdx.x;
-    const int64_t base = (int64_t)blockIdx.x * kFlagSamples;
-    auto at = [&](int64_t k) -> cpx { return (k >= 0 && k < n) ? widen(iq[k]) : cpx{ 0.0, 0.0 }; };
-    for (int s = t; s < kFlagSamples + 15; s += 256) {                      // slot s = position base - 15 + s
-        const int64_t j = base - 15 + s;
-        const cpx a = at(j), b = at(j - 16);
-        pr[s] = a.x * b.x + a.y * b.y;                                       // a * conj(b)
-        pi[s] = a.y * b.x - a.x * b.y;
-        pw[s] = a.x * a.x + a.y * a.y;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < kFlagSamples / 256; r++) {
-        const int s0 = t + 256 * r;                                          // sample base + s0: slots s0 .. s0 + 15
-        const int64_t i = base + s0;
-        cpx S = { 0.0, 0.0 };
-        double P = 0.0;
-#pragma unroll
-        for (int k = 0; k < 16; k++) {                                       // oldest product first, like a running sum would hold them
-            S.x += pr[s0 + k];
-            S.y += pi[s0 + k];
-            P += pw[s0 + k];
-        }
-        const double q = S.x * S.x + S.y * S.y, lim = 0.81 * (P * P);
-        bool above;
-        if (q > lim * (1.0 + 1e-9)) above = true;
-        else if (q < lim * (1.0 - 1e-9) || P == 0.0) above = false;
-        else above = hypot(S.x, S.y) / P > 0.9;
-        const uint64_t m = __ballot(i < n && above);
-        const int lane = t & 63;
-        const int64_t w = i >> 5;
-        if (lane == 0 && i < n) flags[w] = (uint32_t)m;
-        if (lane == 32 && i < n) flags[w] = (uint32_t)(m >> 32);
-    }
-}
-#endif
 
 // STS_END candidates of one block of flag words: count (pass 0) or write in order at offsets[block] (pass 1)
 __global__ __launch_bounds__(kSyncBlockWords) void k_sync_sts_end(const uint32_t *__restrict__ flags, int64_t n_words, int pass,

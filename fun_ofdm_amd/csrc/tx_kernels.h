@@ -13,7 +13,7 @@
 // to the conjugate.
 #pragma once
 
-#include "frontend_lps.h"
+#include "device_math.h"
 
 namespace foa {
 

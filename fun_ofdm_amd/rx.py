@@ -26,13 +26,14 @@ def _vp(a):
 class Receiver:
     """One receiver handle = one HIP stream on one device."""
 
-    def __init__(self, device=0, xcheck=False):
-        """xcheck: bind to libfun_ofdm_amd_xcheck.so, the build that also contains the cross-check kernels (options "viterbi" 0 / 1,
-        "frontend" 0 / 1) -- for the parity suite only."""
-        self._lib = lib(xcheck)
+    def __init__(self, device=0):
+        self._lib = lib()
         self._h = C.c_void_p()
         self._check(self._lib.foa_rx_create(C.byref(self._h), int(device)))
         self.device = int(device)
+        if self.notes():
+            import warnings
+            warnings.warn("fun_ofdm_amd: " + self.notes())
 
     def _check(self, rc):
         check(rc, self._lib)
@@ -276,8 +277,8 @@ class Shard(Stream):
     """The stream engine over several devices (foa_shard_*): batch k of the stream on device devices[k mod n]; payloads in stream order.
     A device may be listed more than once (two handles sharing it)."""
 
-    def __init__(self, devices, batch_samples, narrow_threads=0, xcheck=False):
-        self._lib = lib(xcheck)
+    def __init__(self, devices, batch_samples, narrow_threads=0):
+        self._lib = lib()
         self._h = C.c_void_p()
         devs = (C.c_int * len(devices))(*[int(d) for d in devices])
         self._check(self._lib.foa_shard_create(devs, len(devices), int(batch_samples), int(narrow_threads), C.byref(self._h)))

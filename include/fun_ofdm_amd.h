@@ -96,38 +96,22 @@ void foa_rx_destroy(foa_rx *rx);
  * alignments, so that later decode calls allocate nothing. */
 int foa_rx_reserve(foa_rx *rx, size_t n_samples, size_t n_frames);
 
-/* Options (results are identical for every setting; they exist for A/B measurement and diagnostics).  The production path is the
- * default of every option.  libfun_ofdm_amd.so holds ONE Viterbi path ("viterbi" 2) and ONE front end ("frontend" 2): the other values
- * select earlier, 2-10 x slower implementations of the same stages that are kept only as independent cross-checks for the parity suite
- * (three Viterbi kernels and three front ends must agree bit for bit with each other and with the oracle).  They are compiled into the
- * test-only build libfun_ofdm_amd_xcheck.so (make -C fun_ofdm_amd/csrc xcheck, -DFOA_XCHECK=1); the shipped library answers them with
- * FOA_E_INVALID.
- *   "viterbi"     2 = two frames per wave, chain-back in parallel segments (viterbi_v3.h; the default and the only shipped value);
- *                 cross-check build: 0 = one wave per frame, lane per state (viterbi_v1.h); 1 = two frames per wave, serial chain-back
- *                 (viterbi_v2.h)
- *   "forward"     viterbi 2: 3 = the forward pass of viterbi_v3.h (a state per lane, two frames per wave; the default and the only shipped value);
- *                 cross-check build: 4 = viterbi_v4.h (four states per lane, a frame per 16-lane row, four frames per wave: exact, measured, not adopted --
- *                 DESIGN.md section 4), its decisions converted for the same chain-back
- *   "tb_segment"  viterbi 2: data steps per chain-back segment, a multiple of 96 in [96, 3072] (default 960)
- *   "tb_overlap"  viterbi 2: run-in steps above a segment, a multiple of 96 in [0, 3072] (default 96); any value gives
- *                 the same result as the serial chain-back, small values cost re-walks
- *   "pipeline"    viterbi 2: consecutive decode calls form a three-stage pipeline (front end | forward pass | chain-back
- *                 and finish) over several streams and rotating work sets (default 1).  Results and their order are unchanged;
- *                 the outputs of a call are final after foa_rx_sync (or, for the call before the most recent one, after
- *                 foa_rx_wait_previous), and the INPUTS of a call must be complete when it is made and stay untouched
- *                 until then.  0 = every call runs start to end on the handle's stream.
- *   "lanes"       pipelined calls: 1 (default) = a call's front end, forward pass and chain-back walk run on ONE stream per call parity,
- *                 so that the loop that sets the step has no event packet in it; 0 = front end on a third stream, walk and finish
- *                 on a second one (A/B)
- *   "walk_lane"   lanes: 1 (default) = the chain-back walk follows its forward pass on the call's lane; 0 = it runs on the second stream with the
- *                 finish, behind the forward pass's event (A/B: 2 % slower, profiles/r03_ab_walk_lane.txt)
- *   "depth"       lanes: how many calls' loops are in flight -- 0 (default) = by grid size: 2, or 4 for calls of up to 2048 frames, whose
- *                 forward pass leaves most SIMDs a single wave (1 000-frame batches decode 40-50 % faster in steady state); 2, 3, 4 = fixed (A/B).  More
- *                 than two lanes need more hardware queues than the runtime's default of four: GPU_MAX_HW_QUEUES=8 in the environment
- *                 before the HIP runtime starts (bench.py sets it)
- *   "frontend"    2 = four lanes per data symbol (frontend_q4.h), -1 (default) = 2: fastest alone, and its small waves run under the
- *                 previous call's forward pass when calls are pipelined; cross-check build: 0 = one wave per data symbol,
- *                 1 = one lane per data symbol; all three give bit-identical results
+/* Options.  Results are identical for every setting of the first group (they exist for measurement and diagnostics); the second
+ * group says which reference behaviour the pre-sync reproduces.  Unknown names and out-of-range values: FOA_E_INVALID.
+ *   "tb_segment"  data steps per chain-back segment, a multiple of 96 in [96, 3072] (default 960)
+ *   "tb_overlap"  run-in steps above a segment, a multiple of 96 in [0, 3072] (default 96); any value gives the same result as a
+ *                 serial chain-back, small values cost re-walks (fun_ofdm_amd/csrc/viterbi_tb.h)
+ *   "pipeline"    consecutive decode calls form a three-stage pipeline (front end | forward pass | chain-back and finish) over several
+ *                 streams and rotating work sets (default 1).  Results and their order are unchanged; the outputs of a call are final
+ *                 after foa_rx_sync (or, for the call before the most recent one, after foa_rx_wait_previous), and the INPUTS of a call
+ *                 must be complete when it is made and stay untouched until then.  0 = every call runs start to end on the handle's
+ *                 stream.  (Waits for everything in flight before it switches.)
+ *   "depth"       pipelined calls: how many calls' loops are in flight -- 0 (default) = by grid size: 2, or 4 for calls of up to 2048 frames,
+ *                 whose forward pass leaves most SIMDs a single wave (1 000-frame batches decode 40-50 % faster in steady state); 2, 3, 4 =
+ *                 fixed.  More than two need more hardware queues than the runtime's default of four (foa_recommended_hw_queues)
+ *   "record_soft" keep the depunctured soft bytes for foa_rx_get_taps (default 1; 0 saves their HBM writes)
+ *   "record_eq"   keep the equalised carriers for foa_rx_get_taps (default 0)
+ *
  *   "sync_call"   foa_rx_sync_dev / the stream engine: the reference call size by which timing_sync.cpp:99 is decided (foa_sync_set_call, below);
  *                 default 4096 = receiver.h:16, 0 = as one call over the whole stream.  FOA_E_STATE while a stream engine is open.
  *   "sync_origin" foa_rx_sync_dev / _begin: the stream index of d_iq[0] (default 0).  The rule above is decided by ABSOLUTE stream index
@@ -137,14 +121,8 @@ int foa_rx_reserve(foa_rx *rx, size_t n_samples, size_t n_frames);
  *   "stream_longest"  read by foa_stream_create: the longest frame the stream will hold, in samples from the first preamble sample to the last data
  *                 sample, plus 192 (timing_sync's look-ahead and the window offset).  A batch decodes the frames whose STS_END lies at least this far
  *                 before its end, so that every frame is whole inside the batch that decodes it; the default 0 = 110 592 covers the longest frame the
- *                 format allows (4095 bytes at 6 Mbps) and costs 5.5 ms of latency at the air's own 20 Msample/s.  A receiver that knows its traffic
- *                 (say 1500-byte frames at 24 Mbps and up: 320 + 80 x 127 + 192 = 10 672) sets it and gets that latency back; a frame LONGER than
- *                 this value is then reported FOA_ST_TRUNCATED (never delivered) -- a deviation from the reference the caller has asked for.
- *                 Also shortens the carry every batch re-synchronises (stream_longest + 2048 samples), which is most of a small batch's cost.
- *   "sync_flags"  foa_rx_sync_dev's frame_detector kernel: 1 (default, the only shipped value) = a lane owns sixteen consecutive windows and sums
- *                 them as tail of one group + head of the next; cross-check build: 0 = every window summed directly, term by term
- *   "record_soft" keep the depunctured soft bytes for foa_rx_get_taps (default 1; 0 saves their HBM writes)
- *   "record_eq"   keep the equalised carriers for foa_rx_get_taps (default 0) */
+ *                 format allows (4095 bytes at 6 Mbps).  Also shortens the carry every batch re-synchronises (stream_longest + 2048 samples),
+ *                 which is most of a small batch's cost. */
 int foa_rx_set_option(foa_rx *rx, const char *name, int64_t value);
 
 /*
@@ -217,11 +195,8 @@ int foa_rx_probe_issue(foa_rx *rx, double out[6]);
 int foa_rx_get_taps(foa_rx *rx, size_t n_frames, double *hinv, double *eq, size_t eq_cap, uint64_t *eq_off,
                     uint8_t *soft, size_t soft_cap, uint64_t *soft_off);
 /* Raw decision words of one frame of the most recent decode call (debugging / unit parity of the forward
- * kernel): n_steps = num_symbols * dbps words.  Layout depends on the kernel in use: option viterbi=0 writes the
- * reference's decision_t (bit s = new state s, src/viterbi.h:36-41); viterbi=1 writes slot order (bit p of step t
- * belongs to the state whose label is the 6-bit left-rotation of p by t+1); viterbi=2 returns the raw region of the
- * transposed layout (16-bit words [block of 16 data steps][63 - slot], complemented bits, trellis steps 6.. only; see
- * fun_ofdm_amd/csrc/viterbi_v3.h). */
+ * kernel): n_steps = num_symbols * dbps words, the raw region of the forward pass's transposed layout (16-bit words
+ * [block of 16 data steps][63 - slot], complemented bits, trellis steps 6.. only; see fun_ofdm_amd/csrc/viterbi_fwd.h). */
 int foa_rx_get_decisions(foa_rx *rx, size_t frame, uint64_t *out, size_t cap, size_t *n_steps);
 
 /* ---- pre-sync: on the host (streaming) and on the device (whole resident streams), SURVEY 8f #1 ---- */

@@ -2,7 +2,7 @@
 // (tools/run_sanitizers.sh): include/fun_ofdm_amd/blocks.hpp (receiver_chain, receiver, sources) and
 // fun_ofdm_amd/csrc/sync_host.h (the streaming pre-sync behind foa_sync_*).
 // TEST INFRASTRUCTURE: the decode entry points are answered by the oracle (oracle/fo_oracle.c); nothing in the product
-// links this file.  The foa_sync_* functions are the real host code (SyncHost), wrapped exactly as foa_rx.hip wraps it.
+// links this file.  The foa_sync_* functions are the real host code (SyncHost), wrapped exactly as csrc/rx_sync.hip wraps it.
 #include <cstring>
 #include <map>
 #include <string>

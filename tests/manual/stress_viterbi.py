@@ -3,8 +3,7 @@ settings) against the oracle's decoder -- and against the compiled reference dec
 32 900 data bits (the longest PSDU), 1 .. 9 blocks per call (odd counts leave a wave with one frame), soft bytes drawn from a different distribution per
 block: uniform, pushed to the extremes, noisy codewords at random noise levels, erasure bursts, constant runs, saw-tooth ramps --
 the inputs on which uint8 saturation, the state-0 renormalisation rule and the tie rule decide the output.
-Usage (GPU box, from the repo root): python3 tests/manual/stress_viterbi.py [first seed] [last seed] [--forward4]
-(--forward4: the cross-check build's forward pass with four states per lane, csrc/viterbi_v4.h, instead of the product's)"""
+Usage (GPU box, from the repo root): python3 tests/manual/stress_viterbi.py [first seed] [last seed]"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -13,10 +12,8 @@ import fun_ofdm_amd as foa
 from oracle import pyoracle as po
 
 
-def run(lo, hi, forward4=False):
-    rx = foa.Receiver(0, xcheck=forward4)
-    if forward4:
-        rx.set_option("forward", 4)
+def run(lo, hi):
+    rx = foa.Receiver(0)
     real = po.Ref.conv_decode if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(po.__file__)), "_ref", "libfun_ofdm_ref.so")) else None
     bad = 0
     nblocks = 0
@@ -60,9 +57,8 @@ def run(lo, hi, forward4=False):
 
 
 if __name__ == "__main__":
-    f4 = "--forward4" in sys.argv
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     lo = int(args[0]) if len(args) > 0 else 0
     hi = int(args[1]) if len(args) > 1 else 100
-    nblocks, bad, with_ref = run(lo, hi, f4)
+    nblocks, bad, with_ref = run(lo, hi)
     print("seeds %d..%d done: %d blocks; blocks that differ from the oracle%s: %d" % (lo, hi - 1, nblocks, " or the compiled reference" if with_ref else "", bad))

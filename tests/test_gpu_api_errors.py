@@ -49,7 +49,7 @@ def test_every_entry_point_refuses_bad_arguments(po):
                L.foa_conv_decode(h, null, hp, 10, 1), L.foa_decode_data_f64(h, hp, null, 1, hp, hp, 64), L.foa_stream_create(h, 8192, 0, None)):
         refused(rc, E_INVALID)
     # out-of-range arguments
-    for name, value in ((b"no_such_option", 1), (b"tb_segment", 100), (b"tb_segment", 96 * 40), (b"tb_overlap", 50), (b"depth", 7), (b"fe_hold", 3),
+    for name, value in ((b"no_such_option", 1), (b"tb_segment", 100), (b"tb_segment", 96 * 40), (b"tb_overlap", 50), (b"depth", 7), (b"fe_hold", 1), (b"lanes", 1),
                         (b"frontend", 5), (b"viterbi", 3), (b"sync_call", 160), (b"sync_call", -4096), (b"sync_flags", 2)):
         refused(L.foa_rx_set_option(h, name, value), E_INVALID)
     refused(L.foa_rx_set_option(h, None, 1), E_INVALID)

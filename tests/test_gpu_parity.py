@@ -7,69 +7,30 @@ pytestmark = pytest.mark.gpu
 REL_TOL = 1e-4     # north_star: FFT / equaliser intermediates within 1e-4 relative (max-norm per symbol)
 
 
-class _RxPair:
-    """The product library's receiver, and -- for the options that select a kernel the product does not ship ("viterbi" 0 / 1,
-    "frontend" 0 / 1, "sync_flags" 0: independent implementations kept as cross-checks, csrc/foa_common.h FOA_XCHECK) -- a receiver of the
-    cross-check build.  Every other call goes to whichever the options last selected, every option to both."""
-
-    def __init__(self):
-        import fun_ofdm_amd as foa
-        self._prod, self._x = foa.Receiver(0), foa.Receiver(0, xcheck=True)
-        self._v, self._f, self._s, self._fw = 2, -1, 1, 3
-
-    def _cur(self):
-        return self._x if (self._v != 2 or self._f in (0, 1) or self._s == 0 or self._fw != 3) else self._prod
-
-    def set_option(self, name, value):
-        if name == "viterbi":
-            self._v = int(value)
-        if name == "frontend":
-            self._f = int(value)
-        if name == "sync_flags":
-            self._s = int(value)
-        if name == "forward":
-            self._fw = int(value)
-        if name in ("viterbi", "frontend", "sync_flags", "forward"):
-            self._x.set_option(name, value)
-            if self._cur() is self._prod:
-                self._prod.set_option(name, value)
-            return
-        self._prod.set_option(name, value)
-        self._x.set_option(name, value)
-
-    def __getattr__(self, name):
-        return getattr(self._cur(), name)
-
-    def close(self):
-        self._prod.close()
-        self._x.close()
-
-
 @pytest.fixture(scope="module")
 def rx():
-    r = _RxPair()
+    import fun_ofdm_amd as foa
+    r = foa.Receiver(0)
     yield r
     r.close()
 
 
-def test_product_library_does_not_carry_the_cross_check_kernels():
-    """The shipped library holds ONE Viterbi path and ONE front end; asking it for a cross-check kernel is an error, not a fallback."""
+def test_library_holds_one_implementation_of_every_stage():
+    """The library holds ONE Viterbi path and ONE front end (the cross-check kernels of rounds 1-4 are gone: the oracle and the compiled
+    reference decoder pin the product directly); the options that used to select them are unknown, not silently accepted."""
     import fun_ofdm_amd as foa
     r = foa.Receiver(0)
     try:
-        for name, value in (("viterbi", 0), ("viterbi", 1), ("frontend", 0), ("frontend", 1), ("sync_flags", 0), ("forward", 4)):
+        for name, value in (("viterbi", 2), ("viterbi", 0), ("frontend", 2), ("frontend", -1), ("sync_flags", 1), ("forward", 3), ("lanes", 1)):
             with pytest.raises(foa.FoaError):
                 r.set_option(name, value)
-        r.set_option("viterbi", 2)
-        r.set_option("frontend", 2)
-        r.set_option("frontend", -1)
     finally:
         r.close()
 
 
-# Viterbi kernel variants: 0 = lane per state; 1 = packed, serial chain-back; 2 = packed, segment chain-back with
-# (tb_segment, tb_overlap): default, no run-in at all (most segments get re-walked), short segments, one long segment
-VITERBI_KINDS = [(0, 0, 0), (1, 0, 0), (2, 960, 96), (2, 96, 0), (2, 192, 96), (2, 3072, 0)]
+# Chain-back segmentations (tb_segment, tb_overlap) of the Viterbi path: default, no run-in at all (most segments get re-walked),
+# short segments, one long segment.  (The leading 2 is the kernel generation; rounds 1-4 kept two older ones beside it.)
+VITERBI_KINDS = [(2, 960, 96), (2, 96, 0), (2, 192, 96), (2, 3072, 0)]
 
 
 def _kind_id(k):
@@ -77,10 +38,8 @@ def _kind_id(k):
 
 
 def _set_viterbi(rx, kind):
-    rx.set_option("viterbi", kind[0])
-    if kind[0] == 2:
-        rx.set_option("tb_segment", kind[1])
-        rx.set_option("tb_overlap", kind[2])
+    rx.set_option("tb_segment", kind[1])
+    rx.set_option("tb_overlap", kind[2])
 
 
 def _ends(descs, n):
@@ -102,8 +61,8 @@ def test_library_is_native_and_loaded():
 
 @pytest.mark.parametrize("kind", VITERBI_KINDS, ids=_kind_id)
 def test_conv_decode_matches_reference_sse_vectors(rx, golden, kind):
-    """Every Viterbi kernel of the batch path -- foa_conv_decode runs the one option "viterbi" selects, the production
-    k_viterbi_fwd3 / k_tb_walk / k_tb_finish included -- fed the bytes the REAL reference decoder (viterbi.cpp:208-457,
+    """The Viterbi kernels of the batch path (foa_conv_decode runs k_viterbi_fwd3 / k_tb_walk / k_tb_finish on records built on
+    the host), for several chain-back segmentations, fed the bytes the REAL reference decoder (viterbi.cpp:208-457,
     :108-146, compiled SSE) was fed: bit-exact, garbage / constant / erasure inputs included."""
     _set_viterbi(rx, kind)
     g = golden.viterbi_ref
@@ -124,7 +83,7 @@ def test_conv_decode_matches_reference_sse_vectors(rx, golden, kind):
         got = rx.conv_decode(s, nb, len(idx))
         for k, i in enumerate(idx):
             assert np.array_equal(got[k], g["decoded"][g["dec_off"][i]:g["dec_off"][i + 1]]), (nb, k)
-    _set_viterbi(rx, VITERBI_KINDS[2])
+    _set_viterbi(rx, VITERBI_KINDS[0])
 
 
 @pytest.mark.parametrize("kind", VITERBI_KINDS, ids=_kind_id)
@@ -142,7 +101,7 @@ def test_conv_decode_random_vs_oracle(rx, po, kind):
         got = rx.conv_decode(s, nb, nblk)
         for b in range(nblk):
             assert np.array_equal(got[b], po.conv_decode(s[b * n:(b + 1) * n], nb)), (nb, b)
-    _set_viterbi(rx, VITERBI_KINDS[2])
+    _set_viterbi(rx, VITERBI_KINDS[0])
 
 
 # chain-back segmentations of the production kernels for the saturation / renormalisation corner cases below
@@ -157,7 +116,7 @@ def _real_sse_decoder(po):
     return po.Ref.conv_decode if os.path.exists(path) else None
 
 
-@pytest.mark.parametrize("kind", [(0, 0, 0), (1, 0, 0)] + SEGMENTATIONS, ids=_kind_id)
+@pytest.mark.parametrize("kind", SEGMENTATIONS, ids=_kind_id)
 def test_conv_decode_saturation_corner_cases(rx, po, kind):
     """Where the uint8 saturation, the state-0 renormalisation rule and the tie rule decide the output:
     constant soft bytes (0, 255, 127 = erasures everywhere, 128), uniformly random bytes, alternating extremes, a clean
@@ -179,53 +138,7 @@ def test_conv_decode_saturation_corner_cases(rx, po, kind):
         got = rx.conv_decode(s, nb, len(blocks))
         for b, blk in enumerate(blocks):
             assert np.array_equal(got[b], po.conv_decode(blk, nb)), (nb, b)
-    _set_viterbi(rx, VITERBI_KINDS[2])
-
-
-def test_forward_pass_with_four_states_per_lane_is_exact_too(rx, po, golden):
-    """csrc/viterbi_v4.h (cross-check build only, option "forward" = 4; DESIGN.md section 4 says why it is not the product's pass): a frame per
-    16-lane row, four frames per wave, results not written back in place.  Same bits as the oracle on the reference's SSE vectors, on random,
-    saturating and erased blocks at every length class (odd lengths, one to nine blocks per call: rows of a wave with and without a frame,
-    frames of a wave with different lengths in decode_frames below)."""
-    rx.set_option("forward", 4)
-    try:
-        g = golden.viterbi_ref
-        for i, nb in enumerate(g["data_bits"]):
-            s = g["symbols"][g["sym_off"][i]:g["sym_off"][i + 1]]
-            assert np.array_equal(rx.conv_decode(s, int(nb))[0], g["decoded"][g["dec_off"][i]:g["dec_off"][i + 1]]), "KAT %d" % i
-        rng = np.random.default_rng(404)
-        for nb in (1, 2, 7, 34, 35, 40, 41, 58, 91, 1000, 1001, 8418, 32826):
-            for nblk in (1, 3, 4, 5, 9) if nb < 5000 else (2,):
-                n = 2 * (nb + 6)
-                s = rng.integers(0, 256, nblk * n, dtype=np.uint8)
-                e = np.clip(po.conv_encode(rng.integers(0, 256, (nb + 13) // 8 + 1, dtype=np.uint8), nb).astype(float) * 255 + rng.normal(0, 80, n), 0, 255)
-                s[:n] = e.astype(np.uint8)
-                s[2:n:6] = 127
-                if nblk > 1:
-                    s[n:2 * n] = rng.choice(np.array([0, 255, 127], np.uint8), n)
-                got = rx.conv_decode(s, nb, nblk)
-                for b in range(nblk):
-                    assert np.array_equal(got[b], po.conv_decode(s[b * n:(b + 1) * n], nb)), (nb, nblk, b)
-        for nb in (18, 8418):
-            blocks = _corner_blocks(po, nb, rng)
-            got = rx.conv_decode(np.concatenate(blocks), nb, len(blocks))
-            for b, blk in enumerate(blocks):
-                assert np.array_equal(got[b], po.conv_decode(blk, nb)), (nb, b)
-        # frames of different rates and lengths in one call: the four frames of a wave end at different steps
-        import fun_ofdm_amd as foa
-        lens = [40, 1500, 7, 300, 2000, 64, 900, 33, 1200, 5]
-        pays = [bytes(rng.integers(0, 256, n, dtype=np.uint8)) for n in lens]
-        frames = [po.build_frame(np.frombuffer(p, np.uint8), r) for p, r in zip(pays, (0, 10, 5, 8, 9, 1, 10, 3, 6, 10))]
-        parts = []
-        for f in frames:
-            parts += [np.zeros(300, complex), f]
-        iq = np.concatenate(parts + [np.zeros(2000, complex)]).astype(np.complex64)
-        descs = foa.find_alignments(iq)
-        assert descs.size == len(lens)
-        psdu, res = rx.decode_frames_host(iq, descs, foa.alignment_ends(descs, iq.size))
-        assert [bytes(psdu[i, :res["length"][i]]) for i in range(len(lens))] == pays and np.all(res["status"] == 0)
-    finally:
-        rx.set_option("forward", 3)
+    _set_viterbi(rx, VITERBI_KINDS[0])
 
 
 def _corner_blocks(po, nb, rng):
@@ -256,7 +169,7 @@ def test_conv_decode_corner_cases_against_the_compiled_reference_decoder(rx, po)
             got = rx.conv_decode(np.concatenate(blocks), nb, len(blocks))
             for b, blk in enumerate(blocks):
                 assert np.array_equal(got[b], real(blk, nb)), ("vs the compiled reference", kind, nb, b)
-    _set_viterbi(rx, VITERBI_KINDS[2])
+    _set_viterbi(rx, VITERBI_KINDS[0])
 
 
 def test_fft_forward_vs_oracle(rx, po):
@@ -351,7 +264,7 @@ def test_frame_pairs_of_extreme_length_mismatch(rx, po):
     odd frame out and a header failure: the short frame's blocks beyond its end (stored as ones), the long frame's last partial
     chunk and the late store of each chunk's third block are all in play.  Status, fields, PSDUs and every soft byte vs the oracle."""
     rx.set_option("record_soft", 1)
-    _set_viterbi(rx, VITERBI_KINDS[2])
+    _set_viterbi(rx, VITERBI_KINDS[0])
     rng = np.random.default_rng(97)
     specs = [(10, 1), (0, 4095), (0, 4095), (10, 0), (2, 3000), (10, 2), (9, 47), (0, 1300), (5, 4095), (8, 7), (3, 100)]
     iq, pays = _make_stream(po, rng, specs, snr_db=24.0, gap=(120, 300))
@@ -375,14 +288,12 @@ def test_frame_pairs_of_extreme_length_mismatch(rx, po):
     assert (res["status"] == 0).sum() >= len(specs) - 2
 
 
-@pytest.mark.parametrize("frontend", [0, 1, 2], ids=["wave-per-symbol", "lane-per-symbol", "quad-per-symbol"])
-def test_frontends_vs_oracle(rx, po, frontend):
-    """Each front-end kernel on a mixed-rate stream with CFO: status, PSDUs, every soft byte and the equalised
-    carriers (1e-4 relative, north_star) against the oracle; the three kernels share the arithmetic, not the code."""
-    rx.set_option("frontend", frontend)
+def test_frontend_vs_oracle(rx, po):
+    """The front end (k_header + k_data_symbols_q4) on a mixed-rate stream with CFO: status, PSDUs, every soft byte and the equalised
+    carriers (1e-4 relative, north_star) against the oracle."""
     rx.set_option("record_soft", 1)
     rx.set_option("record_eq", 1)
-    _set_viterbi(rx, VITERBI_KINDS[2])
+    _set_viterbi(rx, VITERBI_KINDS[0])
     try:
         rng = np.random.default_rng(29)
         specs = [(r, int(rng.integers(20, 300))) for r in range(11)] + [(10, 1024), (5, 700), (0, 61), (8, 1)]
@@ -408,7 +319,6 @@ def test_frontends_vs_oracle(rx, po, frontend):
             for k in range(eq.shape[0]):
                 assert _rel(eq[k], want[k]) < REL_TOL, (f, k)
     finally:
-        rx.set_option("frontend", -1)
         rx.set_option("record_eq", 0)
 
 
@@ -545,7 +455,7 @@ def test_config3_rate_sweep_4096_byte_psdu(rx, po, rate):
     length field cannot express more): identical status / PSDU as the oracle, frame by frame."""
     from fun_ofdm_amd import synth
     import fun_ofdm_amd as foa
-    _set_viterbi(rx, VITERBI_KINDS[2])
+    _set_viterbi(rx, VITERBI_KINDS[0])
     n = 3
     pays = synth.splitmix64_bytes(0x0FD3 + rate, n, 4092)
     frames = synth.build_frames(pays, rate)
@@ -677,16 +587,12 @@ def test_device_sync_at_the_detection_threshold(rx, po):
     cap = s.size // 300 + 64
     t_desc = torch.zeros(cap * 48, dtype=torch.uint8, device=dev)
     t_ends = torch.zeros(cap, dtype=torch.int64, device=dev)
-    for kind in (1, 0):                         # the product's flag kernel (grouped tail / head sums), then the cross-check build's direct sums
-        rx.set_option("sync_flags", kind)
-        t_desc.zero_(); t_ends.zero_()
-        n = rx.sync_dev(t_iq, t_desc, t_ends)
-        got = t_desc.cpu().numpy()[:n * 48].view(foa.frame_desc_dtype)
-        assert n == want.size, (kind, n, want.size)
-        assert np.array_equal(got["lts1_pos"], want["lts1_pos"]) and np.array_equal(got["rot_start"], want["rot_start"]), kind
-        for k in ("c", "s", "c_prev", "s_prev"):
-            assert np.abs(got[k] - want[k]).max() < 1e-12, (kind, k)
-    rx.set_option("sync_flags", 1)
+    n = rx.sync_dev(t_iq, t_desc, t_ends)
+    got = t_desc.cpu().numpy()[:n * 48].view(foa.frame_desc_dtype)
+    assert n == want.size, (n, want.size)
+    assert np.array_equal(got["lts1_pos"], want["lts1_pos"]) and np.array_equal(got["rot_start"], want["rot_start"])
+    for k in ("c", "s", "c_prev", "s_prev"):
+        assert np.abs(got[k] - want[k]).max() < 1e-12, k
     # ... and the host restatement is the oracle's (= the compiled reference's, tests/test_oracle_vs_ref.py)
     assert np.array_equal(po.find_alignments_f32(s)["lts1_pos"], want["lts1_pos"])
 
@@ -979,13 +885,12 @@ def test_device_sync_between_pipelined_decode_calls(rx, po):
             assert np.array_equal(x, y)
 
 
-@pytest.mark.parametrize("lanes", [1, 0], ids=["lanes", "three-streams"])
-def test_pipelined_calls_keep_their_results_apart(rx, po, lanes):
+def test_pipelined_calls_keep_their_results_apart(rx, po):
     """Back-to-back decode calls without a sync in between (the finish of call k runs on a second stream under the
     forward pass of call k+1, on alternating work sets): every call must produce exactly what it produces alone."""
     import torch
     dev = torch.device("cuda", 0)
-    _set_viterbi(rx, VITERBI_KINDS[2])
+    _set_viterbi(rx, VITERBI_KINDS[0])
     rng = np.random.default_rng(31)
     cases = []
     for k in range(5):
@@ -997,7 +902,6 @@ def test_pipelined_calls_keep_their_results_apart(rx, po, lanes):
     rx.set_option("pipeline", 0)
     alone = [rx.decode_frames_host(iq, d, e) for iq, d, e in cases]
     rx.set_option("pipeline", 1)
-    rx.set_option("lanes", lanes)                          # both stream arrangements of the pipelined path (fun_ofdm_amd.h)
     bufs = []
     for iq, d, e in cases:
         t_iq = torch.from_numpy(iq.view(np.float32).reshape(-1, 2)).to(dev)
@@ -1007,7 +911,7 @@ def test_pipelined_calls_keep_their_results_apart(rx, po, lanes):
         t_r = torch.zeros((d.size, 4), dtype=torch.int32, device=dev)
         bufs.append((t_iq, t_d, t_e, t_p, t_r))
     torch.cuda.synchronize()
-    for depth in ((0, 2, 3, 4) if lanes else (0,)):       # loops in flight: by grid size (these small batches: four), or fixed
+    for depth in (0, 2, 3, 4):                             # loops in flight: by grid size (these small batches: four), or fixed
         rx.set_option("depth", depth)
         for b in bufs:
             b[3].zero_(); b[4].zero_()
@@ -1033,7 +937,6 @@ def test_pipelined_calls_keep_their_results_apart(rx, po, lanes):
         rx.decode_frames_dev(t_iq, t_d[:n * 48], t_e[:n], t_p[:n], t_r[:n])
     rx.sync()
     assert np.array_equal(t_r.cpu().numpy(), alone[-1][1].view(np.int32).reshape(-1, 4)) and np.array_equal(t_p.cpu().numpy(), alone[-1][0])
-    rx.set_option("lanes", 1)
 
 
 @pytest.mark.parametrize("seed", [101, 102, 103])
@@ -1058,13 +961,13 @@ def test_random_batches_vs_oracle(rx, po, seed):
             continue
         ends = _ends(descs, iq.size)
         opsdu, ores = po.decode_batch_f32(iq, descs, ends, threads=4)
-        for kind in (VITERBI_KINDS[2], (2, 96, 96), VITERBI_KINDS[1]):
+        for kind in (VITERBI_KINDS[0], (2, 96, 96), VITERBI_KINDS[1]):
             _set_viterbi(rx, kind)
             psdu, res = rx.decode_frames_host(iq, descs, ends)
             assert np.array_equal(res.view(np.int32), ores.view(np.int32)), (seed, rep, kind, snr)
             ok = res["status"] == 0
             assert np.array_equal(psdu[ok], opsdu[ok]), (seed, rep, kind)
-    _set_viterbi(rx, VITERBI_KINDS[2])
+    _set_viterbi(rx, VITERBI_KINDS[0])
 
 
 @pytest.mark.parametrize("pipeline", [1, 0])
@@ -1072,7 +975,7 @@ def test_async_host_calls(rx, po, pipeline):
     """foa_rx_submit_host / foa_rx_collect: several calls in flight, the caller's buffers reusable at once, results
     identical to the synchronous entry point and delivered in submission order."""
     import time
-    _set_viterbi(rx, VITERBI_KINDS[2])
+    _set_viterbi(rx, VITERBI_KINDS[0])
     rng = np.random.default_rng(41)
     cases = []
     for k in range(6):

@@ -1,5 +1,12 @@
 #!/bin/bash
-# usage: tools/variant.sh <name> <hipcc -D flags...>   builds build/var_<name>.so; run with FOA_LIB=build/var_<name>.so (A/B timing on one box)
-mkdir -p build
+# usage: tools/variant.sh <name> <hipcc -D flags...>   builds build/var_<name>.so from fun_ofdm_amd/csrc with extra compiler flags;
+# run with FOA_LIB=$PWD/build/var_<name>.so (A/B timing of two builds on one box: tools/ab_libs.sh)
+set -e
 name=$1; shift
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-function "$@" -o build/var_$name.so fun_ofdm_amd/csrc/foa_rx.hip
+src=fun_ofdm_amd/csrc; obj=build/var_$name.o.d
+mkdir -p $obj
+for u in rx_handle rx_decode rx_sync rx_stage rx_tx rx_stream; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function "$@" -c -o $obj/$u.o $src/$u.hip &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/var_$name.so $obj/*.o
