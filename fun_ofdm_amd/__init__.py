@@ -7,4 +7,4 @@ no CPU implementation of the path and raises if the HIP library is missing.
 """
 from ._lib import lib, library_path, FoaError, build  # noqa: F401
 from .rx import (Receiver, Sync, Stream, Shard, find_alignments, alignment_ends, frame_desc_dtype, frame_result_dtype, ST_OK, ST_HEADER_FAIL, ST_CRC_FAIL,  # noqa: F401
-                 ST_TRUNCATED, ST_NO_SPACE, RATE_NAMES, RATE_MBPS, STANDARD_RATES)
+                 ST_TRUNCATED, ST_NO_SPACE, ST_SUPERSEDED, RATE_NAMES, RATE_MBPS, STANDARD_RATES)

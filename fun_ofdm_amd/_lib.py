@@ -37,10 +37,13 @@ _SIGS = {
     "foa_rx_reserve": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t]),
     "foa_rx_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "foa_rx_decode_frames_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "foa_rx_decode_frames_ctx_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
     "foa_rx_decode_frames_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "foa_rx_decode_frames_f64_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
     "foa_rx_sync": (C.c_int, [C.c_void_p]),
     "foa_rx_stream": (C.c_void_p, [C.c_void_p]),
     "foa_rx_submit_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_uint64)]),
+    "foa_rx_submit_host_ctx": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_uint64)]),
     "foa_rx_collect": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]),
     "foa_rx_wait_age": (C.c_int, [C.c_void_p, C.c_int]),
     "foa_rx_wait_previous": (C.c_int, [C.c_void_p]),

@@ -136,13 +136,26 @@ __device__ __forceinline__ void fft64_regs(cpx (&x)[64])
     }
 }
 
-// timing_sync.cpp:124-125 rotation + float->double widening of one window sample
-__device__ __forceinline__ cpx load_rotated(const float2 *iq, int64_t idx, const foa_frame_desc &d)
+// A stream sample as the arithmetic takes it: complex<float> widened exactly as the CPU receiver widens it; complex<double> as it is
+// (the fused stage block of blocks.hpp hands over the doubles timing_sync produced).
+__device__ __forceinline__ cpx widen(float2 v) { return cpx{ (double)v.x, (double)v.y }; }
+__device__ __forceinline__ cpx widen(double2 v) { return cpx{ v.x, v.y }; }
+
+template <typename S> struct sample_is_rotated { static constexpr bool value = false; };
+template <> struct sample_is_rotated<double2> { static constexpr bool value = true; };     // timing_sync's own output: taken as it is
+
+// timing_sync.cpp:124-125 rotation (+ widening) of one window sample
+template <typename S>
+__device__ __forceinline__ cpx rotate_sample(S raw, cpx r)
 {
-    float2 s = iq[idx];
-    cpx v = { (double)s.x, (double)s.y };
+    if constexpr (sample_is_rotated<S>::value) return widen(raw);
+    else return cmul(widen(raw), r);
+}
+template <typename S>
+__device__ __forceinline__ cpx load_rotated(const S *iq, int64_t idx, const foa_frame_desc &d)
+{
     cpx r = idx >= d.rot_start ? cpx{ d.c, d.s } : cpx{ d.c_prev, d.s_prev };
-    return cmul(v, r);
+    return rotate_sample(iq[idx], r);
 }
 
 // phase_tracker.cpp:97-98 rotates by (cos(-angle), sin(-angle)) with angle = arg(pe): that is conj(pe)/|pe|.

@@ -12,18 +12,36 @@ constexpr int kNumRates = 11;
 constexpr int kWave = 64;
 constexpr int kMaxDecodedBytes = 4128;   // num_data_bytes <= 4104 for length <= 4095 at any rate
 
-// Per-frame working record kept in HBM between the kernels of one decode call.
+// Per-alignment working record kept in HBM between the kernels of one decode call.
 struct FrameInfo {
-    int32_t status;      // FOA_ST_*; frames whose header failed keep nsym = 0
-    int32_t rate;
+    int32_t status;      // FOA_ST_*; alignments that decode nothing keep nsym = 0
+    int32_t rate;        // Rate enum the SIGNAL vector announced, -1 if it did not decode (or there was none)
     int32_t length;
     int32_t nsym;        // data symbols to process (0 if nothing to do)
     int32_t sym_off;     // first data symbol's index in the call-wide symbol numbering
     int32_t nsteps;      // trellis steps = nsym * dbps
-    int64_t soft_off;    // byte offset of this frame's depunctured soft bytes (= 2 * dec_off: two per trellis step)
     int64_t dec_off;     // offset (in per-step elements) of this frame's region in the soft-pair, decision and decoded buffers
     int32_t seg_off;     // first chain-back segment's index in the call-wide segment numbering (viterbi_tb.h)
-    int32_t reserved_;
+    int32_t hdr_nsym;    // data symbols SIGNAL announced (0 if it did not decode): what foa_frame_result::num_symbols reports
+    // what fft_symbols emits for this alignment behind its two LTS vectors (fft_symbols.cpp:41-73): the vectors of the complete symbol
+    // windows from SIGNAL on, and -- when the next alignment's LTS1 arrives past a window's cyclic prefix -- one partly filled one
+    int32_t nvec;        // vectors in all: complete windows k = 0 (SIGNAL) .. + the partial one
+    int32_t fresh;       // the partial vector's own samples (the rest still holds the window before): 0 .. 63, -1 = no partial vector
+    int32_t flags;       // kInfoLink | kInfoCross
+    int32_t spec_off;    // first entry of this frame in the table of symbols that are not plain windows of its own alignment
+    int32_t n_own;       // data symbols that ARE plain windows of its own alignment: min(hdr_nsym, complete windows - 1)
+    int32_t pad_;
+};
+constexpr int kInfoLink = 1;     // the stream goes on into the next alignment of the call (ends[f] is its LTS1): one vector sequence
+constexpr int kInfoCross = 2;    // valid SIGNAL, frame longer than the alignment's own complete windows, linked: decided by the scan kernels
+
+// A data symbol of a frame that is not window k of the frame's own alignment: the partial vector, or a vector of a later alignment
+// the frame fills on with (frame_decoder.cpp:52-88).
+struct SpecSym {
+    int32_t frame;       // the frame it belongs to (rate, output position)
+    int32_t src;         // the alignment whose window, rotation, channel estimate and symbol count it takes
+    int32_t k;           // vector k of that alignment (0 = its SIGNAL window)
+    int32_t fresh;       // 64: a complete window; < 64: samples fresh .. 63 come from the window before (fft_symbols.cpp:46-50)
 };
 
 // rates.h:52-196 as a device table

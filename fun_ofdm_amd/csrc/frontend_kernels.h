@@ -13,27 +13,41 @@ namespace foa {
 
 // =================================================================================================
 // K1: per alignment: LTS1 + LTS2 + SIGNAL.  Channel estimate -> hinv, SIGNAL decode -> FrameInfo.
-// One wave (64 threads) per block, one block per frame.
+// One wave (64 threads) per block, one block per alignment; n_total = the call's alignments, context included.
+// What the alignment's extent gives fft_symbols to emit (fft_symbols.cpp:41-73) is worked out here too: K complete symbol windows
+// from SIGNAL on, and the partly filled vector it pushes when the NEXT alignment's LTS1 arrives past a window's cyclic prefix.
 // =================================================================================================
-__global__ __launch_bounds__(64) void k_header(const float2 *__restrict__ iq, const foa_frame_desc *__restrict__ descs,
-                                               const int64_t *__restrict__ ends, int64_t n_samples, int n_frames,
+// S: float2 (the raw stream; the descriptor's phasors rotate it) or double2 (a stream timing_sync has rotated already: phasors 1).
+template <typename S>
+__global__ __launch_bounds__(64) void k_header(const S *__restrict__ iq, const foa_frame_desc *__restrict__ descs,
+                                               const int64_t *__restrict__ ends, int64_t n_samples, int n_total,
                                                FrameInfo *__restrict__ info, double2 *__restrict__ hinv, double2 *__restrict__ eq_tap)
 {
     __shared__ cpx lds[64];
     __shared__ uint8_t dem[48];
     __shared__ uint64_t decs[24];
     const int f = blockIdx.x, lane = threadIdx.x;
-    if (f >= n_frames) return;
+    if (f >= n_total) return;
     const foa_frame_desc d = descs[f];
-    const int64_t end = min(ends[f], n_samples), p = d.lts1_pos;      // nothing is read beyond the stream, whatever the caller's ends say
+    const int64_t e_raw = ends[f], end = min(e_raw, n_samples), p = d.lts1_pos;      // nothing is read beyond the stream, whatever the caller's ends say
+    // linked: the stream goes on into the next alignment of the call (its LTS1 tag is where this one's samples end)
+    const bool link = f + 1 < n_total && e_raw <= n_samples && e_raw == descs[f + 1].lts1_pos;
     FrameInfo fi;
-    fi.status = FOA_ST_HEADER_FAIL; fi.rate = -1; fi.length = 0; fi.nsym = 0; fi.sym_off = 0; fi.nsteps = 0;
-    fi.soft_off = 0; fi.dec_off = 0;
-    if (p < 0 || p + 208 > end) {                     // LTS or SIGNAL window cut off
-        fi.status = FOA_ST_TRUNCATED;
+    fi.status = FOA_ST_HEADER_FAIL; fi.rate = -1; fi.length = 0; fi.nsym = 0; fi.sym_off = 0; fi.nsteps = 0; fi.dec_off = 0; fi.seg_off = 0;
+    fi.hdr_nsym = 0; fi.nvec = 0; fi.fresh = -1; fi.flags = link ? kInfoLink : 0; fi.spec_off = 0; fi.n_own = 0; fi.pad_ = 0;
+    // complete windows [p + 144 + 80 k, + 64) that end by `end`; the window in progress when the next LTS1 arrives is pushed if it has
+    // got past its cyclic prefix (m_offset > 15, fft_symbols.cpp:46): its first mo - 16 samples are its own
+    const int64_t K = end >= p + 208 ? (end - (p + 208)) / 80 + 1 : 0;
+    const int mo = end >= p + 128 ? (int)((end - (p + 128)) % 80) : 0;
+    const bool has_part = link && mo > 15;
+    if (p < 0 || end < p + 128 || K + (has_part ? 1 : 0) == 0) {
+        // an LTS window is cut off, or not even part of a SIGNAL vector exists: no vector, no START_OF_FRAME from this alignment
+        fi.status = link ? FOA_ST_SUPERSEDED : FOA_ST_TRUNCATED;
         if (lane == 0) info[f] = fi;
         return;
     }
+    fi.nvec = (int32_t)min(K + (has_part ? 1 : 0), (int64_t)0x7FFFFFFF);
+    fi.fresh = has_part ? mo - 16 : -1;
     const int s = lane_subcarrier(lane);
     // channel_est.cpp:44-58: est = sum over the two LTS of (LTS_FREQ_DOMAIN / Y) / 2
     cpx est = { 0.0, 0.0 };
@@ -46,11 +60,14 @@ __global__ __launch_bounds__(64) void k_header(const float2 *__restrict__ iq, co
         est.y += q.y / 2.0;
     }
     hinv[(size_t)f * 64 + s] = make_double2(est.x, est.y);
-    // SIGNAL: equalise (channel_est.cpp:77-81), pilot phase with polarity[0] (phase_tracker.cpp:74-99)
-    cpx y = fft64_lane(load_rotated(iq, p + 144 + lane, d), lds, lane);
+    // SIGNAL: equalise (channel_est.cpp:77-81), pilot phase with polarity[0] (phase_tracker.cpp:74-99).  If the next LTS1 cuts the
+    // SIGNAL window itself (K = 0), the vector pushed holds its first `fresh` samples and, behind them, what the vector held before:
+    // the LTS2 window (fft_symbols.cpp:46-50)
+    const int64_t sig_idx = (K == 0 && lane >= fi.fresh) ? p + 64 + lane : p + 144 + lane;
+    cpx y = fft64_lane(load_rotated(iq, sig_idx, d), lds, lane);
     cpx z = pilot_derotate(cmul(est, y), (int)g_tab.polarity[0]);
     const int di = g_tab.data_index[s];
-    if (eq_tap && di >= 0) eq_tap[(size_t)f * 48 + di] = make_double2(z.x, z.y);   // SIGNAL tap: one row per frame
+    if (eq_tap && di >= 0) eq_tap[(size_t)f * 48 + di] = make_double2(z.x, z.y);   // SIGNAL tap: one row per alignment
     // ppdu.cpp:171-175: BPSK demap, deinterleave
     if (di >= 0) {
         uint8_t b;
@@ -62,30 +79,59 @@ __global__ __launch_bounds__(64) void k_header(const float2 *__restrict__ iq, co
     decode_signal_bits(dem, decs, lane, rate, length, nsym);
     if (lane == 0) {
         if (rate >= 0) {
-            fi.rate = rate; fi.length = length;
-            if (p + 144 + 80 * (int64_t)nsym + 64 > end) { fi.status = FOA_ST_TRUNCATED; fi.nsteps = -nsym; }   // nsym still reported
-            else { fi.status = FOA_ST_CRC_FAIL; fi.nsym = nsym; fi.nsteps = nsym * g_tab.rates[rate].dbps; }   // pending until the CRC is checked
+            fi.rate = rate; fi.length = length; fi.hdr_nsym = nsym;
+            fi.n_own = (int32_t)min((int64_t)nsym, max(K - 1, (int64_t)0));
+            if (nsym <= K - 1) { fi.status = FOA_ST_CRC_FAIL; fi.nsym = nsym; fi.nsteps = nsym * g_tab.rates[rate].dbps; }   // pending until the CRC is checked
+            else if (link) { fi.status = FOA_ST_TRUNCATED; fi.flags |= kInfoCross; }      // needs vectors beyond its own complete windows: the scan decides
+            else fi.status = FOA_ST_TRUNCATED;                                            // the samples end first
         }
         info[f] = fi;
     }
 }
 
 // =================================================================================================
-// K2: exclusive scans over frames -> sym_off / soft_off / dec_off / seg_off, and the symbol / segment maps.
+// K2: exclusive scans over frames -> sym_off / spec_off / dec_off / seg_off, and the symbol / segment maps.
 // =================================================================================================
 
 // Three small kernels instead of one block: a single CU's memory pipeline (one 64-line request per wave instruction)
 // made the one-block version the 50 us tail of a 2 ms call.  One thread per frame throughout.
 constexpr int kScanBlock = 256;
 
-struct ScanQ { int64_t v[4]; };          // data symbols, (unused), per-step words (soft pairs / decisions / decoded), chain-back segments
+struct ScanQ { int64_t v[4]; };          // data symbols, of which special (SpecSym entries), per-step words (soft pairs / decisions / decoded), chain-back segments
 
-__device__ __forceinline__ ScanQ scan_quantities(const FrameInfo *info, int f, int n_frames, int seg_steps)
+// A frame that is longer than its alignment's own complete windows and linked to what follows (kInfoCross): frame_decoder copies the
+// vectors behind its SIGNAL wherever they come from -- its alignment's partial vector, the next alignment's SIGNAL vector, that
+// alignment's symbols if its SIGNAL is invalid, and so on -- and drops the frame when a VALID SIGNAL arrives before the last of them
+// (frame_decoder.cpp:52-88).  Walks the alignments behind f: FOA_ST_CRC_FAIL = the hdr_nsym vectors are all there (decode it),
+// FOA_ST_SUPERSEDED = a valid SIGNAL intervenes, FOA_ST_TRUNCATED = the linked alignments end first.  The records of other alignments
+// are read field by field and only in fields k_header wrote and nothing rewrites (nvec, rate, flags).
+__device__ __forceinline__ int cross_walk(const FrameInfo *info, int f)
+{
+    const int nsym = info[f].hdr_nsym;
+    int64_t c = info[f].nvec - 1;                                   // vectors behind the SIGNAL vector that the frame has so far
+    int g = f;
+    while (c < nsym) {
+        if (!(info[g].flags & kInfoLink)) return FOA_ST_TRUNCATED;
+        g++;
+        const int nv = info[g].nvec;
+        if (nv == 0) continue;
+        if (info[g].rate >= 0 && c + 1 < nsym) return FOA_ST_SUPERSEDED;     // (a SIGNAL vector that is the frame's LAST vector completes it first)
+        c += nv;
+    }
+    return FOA_ST_CRC_FAIL;
+}
+
+__device__ __forceinline__ ScanQ scan_quantities(const FrameInfo *info, int f, int n_frames, int seg_steps, int *cross_status = nullptr)
 {
     ScanQ q = { { 0, 0, 0, 0 } };
     if (f < n_frames) {
-        const int nsym = info[f].nsym, nsteps = nsym > 0 ? info[f].nsteps : 0;
-        q.v[0] = nsym; q.v[1] = 0; q.v[2] = dec_words(nsteps); q.v[3] = tb_segments(nsteps, seg_steps);
+        int nsym = info[f].nsym, nsteps = nsym > 0 ? info[f].nsteps : 0, spec = 0;
+        if (info[f].flags & kInfoCross) {
+            const int st = cross_walk(info, f);
+            if (cross_status) *cross_status = st;
+            if (st == FOA_ST_CRC_FAIL) { nsym = info[f].hdr_nsym; nsteps = nsym * g_tab.rates[info[f].rate].dbps; spec = nsym - info[f].n_own; }
+        }
+        q.v[0] = nsym; q.v[1] = spec; q.v[2] = dec_words(nsteps); q.v[3] = tb_segments(nsteps, seg_steps);
     }
     return q;
 }
@@ -182,34 +228,52 @@ __global__ __launch_bounds__(64) void k_scan_blocks_w(int64_t *__restrict__ blk,
     }
 }
 
-// pass 3: offsets into the frame records (frames that do not fit are marked FOA_ST_NO_SPACE), and the symbol -> frame
-// and segment -> frame maps (so that the data-symbol and chain-back kernels find their frame without a search;
-// frames are short: <= 1368 symbols)
+// pass 3: offsets into the frame records (frames that do not fit are marked FOA_ST_NO_SPACE), the symbol -> frame and segment -> frame
+// maps (so that the data-symbol and chain-back kernels find their frame without a search; frames are short: <= 1368 symbols), and for
+// the rare frame that fills on beyond its own alignment the table of where each of those symbols comes from.
+// sym2frame[w] = f: symbol w is window k = w - sym_off + 1 of frame f's own alignment; -1: unused slot; <= -2: entry -2 - value of spec.
 __global__ __launch_bounds__(kScanBlock) void k_scan_apply(FrameInfo *__restrict__ info, int n_frames, int64_t sym_cap,
                                                            int64_t dec_cap, int seg_steps, int64_t seg_cap, const int64_t *__restrict__ blk,
-                                                           int32_t *__restrict__ sym2frame, int32_t *__restrict__ seg2frame)
+                                                           int32_t *__restrict__ sym2frame, int32_t *__restrict__ seg2frame, SpecSym *__restrict__ spec)
 {
     __shared__ int64_t part[4][kScanBlock / 64];
     const int f = blockIdx.x * kScanBlock + threadIdx.x;
-    const ScanQ q = scan_quantities(info, f, n_frames, seg_steps);
+    int cross = -1;
+    const ScanQ q = scan_quantities(info, f, n_frames, seg_steps, &cross);
     int64_t tot[4];
     const ScanQ ex = block_exclusive_scan(q, tot, part);
     if (f >= n_frames) return;
-    const int64_t a = ex.v[0] + blk[blockIdx.x],
+    const int64_t a = ex.v[0] + blk[blockIdx.x], sp0 = ex.v[1] + blk[(size_t)gridDim.x + blockIdx.x],
                   c = ex.v[2] + blk[(size_t)2 * gridDim.x + blockIdx.x], d = ex.v[3] + blk[(size_t)3 * gridDim.x + blockIdx.x];
-    const int nsym = (int)q.v[0];
+    const int nsym = (int)q.v[0], nspec = (int)q.v[1];
     info[f].seg_off = (int32_t)d;
     const int ns = (int)q.v[3];
-    if (nsym > 0 && (a + nsym > sym_cap || c + q.v[2] > dec_cap)) {
+    if (cross >= 0 && cross != FOA_ST_CRC_FAIL) { info[f].status = cross; return; }      // never completes: superseded, or the samples end first
+    if (nsym > 0 && (a + nsym > sym_cap || c + q.v[2] > dec_cap || sp0 + nspec > sym_cap)) {
         // keeps its slots in the numbering; they are marked unused (as far as the maps reach)
-        info[f].status = FOA_ST_NO_SPACE; info[f].nsteps = -nsym; info[f].nsym = 0;
+        info[f].status = FOA_ST_NO_SPACE; info[f].nsteps = 0; info[f].nsym = 0;
         for (int k = 0; k < nsym; k++) if (a + k < sym_cap) sym2frame[a + k] = -1;
         for (int k = 0; k < ns; k++) if (d + k < seg_cap) seg2frame[d + k] = -1;
         return;
     }
-    info[f].sym_off = (int32_t)a; info[f].soft_off = 2 * c; info[f].dec_off = c;    // (soft_off: byte offset of the frame's soft pairs)
-    for (int k = 0; k < nsym; k++) sym2frame[a + k] = f;
+    info[f].sym_off = (int32_t)a; info[f].dec_off = c;
+    const int n_plain = nsym - nspec;
+    for (int k = 0; k < n_plain; k++) sym2frame[a + k] = f;
     for (int k = 0; k < ns; k++) if (d + k < seg_cap) seg2frame[d + k] = f;
+    if (cross == FOA_ST_CRC_FAIL) {
+        // the frame decodes: its record becomes a plain pending one, its symbols beyond the own complete windows get their sources
+        info[f].status = FOA_ST_CRC_FAIL; info[f].nsym = nsym; info[f].nsteps = nsym * g_tab.rates[info[f].rate].dbps; info[f].spec_off = (int32_t)sp0;
+        int src = f, k = n_plain + 1;                                   // next vector of alignment src (vector 0 is its SIGNAL)
+        for (int i = 0; i < nspec; i++) {
+            while (k >= info[src].nvec) { src++; k = 0; }               // (alignments without vectors are skipped over)
+            const int fr = info[src].fresh;
+            SpecSym e;
+            e.frame = f; e.src = src; e.k = k; e.fresh = (fr >= 0 && k == info[src].nvec - 1) ? fr : 64;
+            spec[sp0 + i] = e;
+            sym2frame[a + n_plain + i] = -2 - (int32_t)(sp0 + i);
+            k++;
+        }
+    }
 }
 
 }  // namespace foa

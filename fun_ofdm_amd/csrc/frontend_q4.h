@@ -111,10 +111,11 @@ __device__ __forceinline__ void q4_emit(Q4Shared &sh, Q4Wave &ws, const cpx (&X)
     }
 }
 
+template <typename S>
 __global__ __launch_bounds__(64 * kQ4Waves)
-void k_data_symbols_q4(const float2 *__restrict__ iq, const foa_frame_desc *__restrict__ descs, const FrameInfo *__restrict__ info,
-                       const int32_t *__restrict__ sym2frame, const int64_t *__restrict__ totals, const double2 *__restrict__ hinv,
-                       uint16_t *__restrict__ sp, double2 *__restrict__ eq_tap)
+void k_data_symbols_q4(const S *__restrict__ iq, const foa_frame_desc *__restrict__ descs, const FrameInfo *__restrict__ info,
+                       const int32_t *__restrict__ sym2frame, const SpecSym *__restrict__ spec, const int64_t *__restrict__ totals,
+                       const double2 *__restrict__ hinv, uint16_t *__restrict__ sp, double2 *__restrict__ eq_tap)
 {
     __shared__ Q4Shared sh;
     // (No wave priority: what matters is that these waves do not go ahead of the forward pass's; profiles/r03_ab_fwd_prio.txt.)
@@ -131,16 +132,21 @@ void k_data_symbols_q4(const float2 *__restrict__ iq, const foa_frame_desc *__re
 
     const int64_t w0 = ((int64_t)blockIdx.x * kQ4Waves + wave) * 16, w = w0 + qd;      // this quad's symbol slot
     if (w0 >= total) return;                                       // whole wave idle (wave-uniform; no block sync below)
+    // The symbol's frame, and where its window comes from: window k of the frame's own alignment as a rule; for a frame that fills on
+    // beyond its alignment (sym2frame <= -2, k_scan_apply) the partial vector or a vector of a later alignment: that alignment's window,
+    // rotation, channel estimate and symbol count (channel_est.cpp:77-81 and phase_tracker.cpp:74-99 know nothing of frames).
     const int fq = w < total ? sym2frame[w] : -1;
-    const bool valid = fq >= 0;
-    const int f = valid ? fq : 0;
+    const bool valid = fq != -1;
+    int f = fq >= 0 ? fq : 0, src = f, ks = 0, fresh = 64;
+    if (fq <= -2) { const SpecSym e = spec[-2 - fq]; f = e.frame; src = e.src; ks = e.k; fresh = e.fresh; }
     const FrameInfo fi = info[f];
     const int rate = valid ? fi.rate : 0;
-    const int k = valid ? (int)(w - fi.sym_off) + 1 : 1;             // 1-based data symbol (SIGNAL is symbol 0)
-    const foa_frame_desc d = descs[f];
+    const int kf = valid ? (int)(w - fi.sym_off) + 1 : 1;            // 1-based data symbol of the frame (SIGNAL is symbol 0): where its soft bytes go
+    const int k = fq <= -2 ? ks : kf;                                // vector of alignment src: which window, which pilot polarity
+    const foa_frame_desc d = descs[src];
     const int64_t start = d.lts1_pos + 144 + 80 * (int64_t)k;
     const RateRow rr = g_tab.rates[rate];
-    const int64_t my_out = fi.dec_off + (int64_t)(k - 1) * rr.dbps;
+    const int64_t my_out = fi.dec_off + (int64_t)(kf - 1) * rr.dbps;
 
     // ---- samples n = m + 4u, rotated (timing_sync.cpp:124-125) ----
     cpx x[16];
@@ -149,17 +155,18 @@ void k_data_symbols_q4(const float2 *__restrict__ iq, const foa_frame_desc *__re
     // per-sample choice was a 64-bit compare and four v_cndmask_b32 on VCC per sample, sixteen times per lane: the select on VCC issues
     // at 16 clocks per wave instruction on this part, tools/probe_issue.hip -- a seventh of the kernel's issue time for a choice that
     // always comes out the same way.)
-    if (__all(!valid || start >= d.rot_start)) {
+    if (__all(!valid || (start >= d.rot_start && fresh == 64))) {
         const cpx r = { d.c, d.s };
 #pragma unroll
         for (int u = 0; u < 16; u++) {
-            const float2 sm = valid ? iq[start + m + 4 * u] : make_float2(0.0f, 0.0f);
-            x[u] = cmul(cpx{ (double)sm.x, (double)sm.y }, r);
+            x[u] = valid ? rotate_sample(iq[start + m + 4 * u], r) : cpx{ 0.0, 0.0 };
         }
     } else {
+        // (also the partly filled vector of fft_symbols.cpp:46-50: samples fresh .. 63 still hold the window before)
 #pragma unroll
         for (int u = 0; u < 16; u++) {
-            const int64_t idx = start + m + 4 * u;
+            const int n = m + 4 * u;
+            const int64_t idx = (n >= fresh ? start - 80 : start) + n;
             x[u] = valid ? load_rotated(iq, idx, d) : cpx{ 0.0, 0.0 };
         }
     }
@@ -200,7 +207,7 @@ void k_data_symbols_q4(const float2 *__restrict__ iq, const foa_frame_desc *__re
 
     __builtin_amdgcn_sched_barrier(0);                             // keep the tap loads below from crowding the FFT's registers
     // ---- channel_est.cpp:77-81 + phase_tracker.cpp:83-99 ----
-    const double2 *h = hinv + (size_t)f * 64;
+    const double2 *h = hinv + (size_t)src * 64;
     cpx pe = { 0.0, 0.0 };
     {
 #pragma clang fp contract(off)

@@ -49,6 +49,7 @@ int foa::workspace(foa_rx *rx, size_t n_samples, size_t n_frames)
     size_t dec_cap = 216 * sym_cap + 192 * (n_frames + 1);
     int rc;
     if ((rc = rx->w->info.ensure(n_frames + 1)) || (rc = rx->w->hinv.ensure((n_frames + 1) * 64)) || (rc = rx->w->sym2frame.ensure(sym_cap)) ||
+        (rc = rx->w->spec.ensure(sym_cap)) ||
         (rc = rx->w->dec.ensure(dec_cap)) || (rc = rx->w->sp.ensure(dec_cap)) || (rc = rx->w->decoded.ensure(dec_cap)) ||
         (rc = rx->w->totals.ensure(8 + 4 * ((n_frames + kScanBlock - 1) / kScanBlock + 1))))
         return rc;
@@ -57,7 +58,7 @@ int foa::workspace(foa_rx *rx, size_t n_samples, size_t n_frames)
     const size_t seg_cap = dec_cap / 96 + n_frames + 64;
     if ((rc = rx->w->seg2frame.ensure(seg_cap)) || (rc = rx->w->tb_state.ensure(seg_cap))) return rc;
     // capacities handed to the scan are those of the buffers actually allocated
-    rx->w->sym_cap = rx->w->sym2frame.n; rx->w->dec_cap = rx->w->dec.n < rx->w->sp.n ? rx->w->dec.n : rx->w->sp.n;
+    rx->w->sym_cap = std::min(rx->w->sym2frame.n, rx->w->spec.n); rx->w->dec_cap = rx->w->dec.n < rx->w->sp.n ? rx->w->dec.n : rx->w->sp.n;
     if (rx->record_eq && rx->w->eq_data.n / 48 < rx->w->sym_cap) rx->w->sym_cap = rx->w->eq_data.n / 48;
     return FOA_OK;
 }
@@ -126,15 +127,33 @@ int foa::job_ready(foa_rx *rx, uint64_t ticket, bool wait, HostJob **out)
     return 1;
 }
 
+static int decode_frames_any(foa_rx *rx, const void *d_iq, bool f64, size_t n_samples, const foa_frame_desc *d_descs, const int64_t *d_ends,
+                             size_t n_frames, size_t n_context, uint8_t *d_psdu, size_t slot_bytes, foa_frame_result *d_results);
+
 extern "C" {
 
 int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, const foa_frame_desc *d_descs, const int64_t *d_ends,
                              size_t n_frames, uint8_t *d_psdu, size_t slot_bytes, foa_frame_result *d_results)
 {
+    return foa_rx_decode_frames_ctx_dev(rx, d_iq, n_samples, d_descs, d_ends, n_frames, 0, d_psdu, slot_bytes, d_results);
+}
+
+int foa_rx_decode_frames_ctx_dev(foa_rx *rx, const float *d_iq, size_t n_samples, const foa_frame_desc *d_descs, const int64_t *d_ends,
+                                 size_t n_frames, size_t n_context, uint8_t *d_psdu, size_t slot_bytes, foa_frame_result *d_results)
+{
+    return decode_frames_any(rx, d_iq, false, n_samples, d_descs, d_ends, n_frames, n_context, d_psdu, slot_bytes, d_results);
+}
+
+}  // extern "C"
+
+// f64: d_iq holds complex<double> samples that timing_sync has rotated already (the fused stage block of blocks.hpp); else complex<float>
+static int decode_frames_any(foa_rx *rx, const void *d_iq, bool f64, size_t n_samples, const foa_frame_desc *d_descs, const int64_t *d_ends,
+                             size_t n_frames, size_t n_context, uint8_t *d_psdu, size_t slot_bytes, foa_frame_result *d_results)
+{
     if (!rx) return fail(FOA_E_INVALID, "rx is NULL");
     if (n_frames == 0) { rx->last_frames = 0; return FOA_OK; }
     if (!d_iq || !d_descs || !d_ends || !d_psdu || !d_results) return fail(FOA_E_INVALID, "NULL device pointer");
-    if (n_frames > 0x7FFFFFF0u) return fail(FOA_E_INVALID, "too many frames");
+    if (n_frames > 0x7FFFFFF0u || n_context > 0x7FFFFFF0u - n_frames) return fail(FOA_E_INVALID, "too many frames");
     HIP_TRY(enter_device(rx->device));
     // Work sets take turns when calls are pipelined: this call's front end and forward pass may then start while the previous call's
     // chain-back is still reading another set.
@@ -147,7 +166,7 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
         HIP_TRY(hipEventSynchronize(rx->w->done));
         rx->ns_wait_set += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
     }
-    int rc = workspace(rx, n_samples, n_frames);
+    int rc = workspace(rx, n_samples, n_frames + n_context);
     if (rc) return rc;
     // Pipelined calls take turns on two (or four) streams ("lanes"): a call's front end, forward pass and chain-back walk run on ONE
     // stream, the front end behind the walk of the call `depth` back (queued there when the call before this one was made).  The loop
@@ -157,13 +176,15 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
     const int depth = rx->depth > 0 ? rx->depth : (n_frames < (size_t)kDeepBelow ? std::min(4, rx->max_depth) : 2);
     hipStream_t st = piped ? lane_stream(rx, (int)(rx->n_calls++ % (unsigned)depth)) : rx->stream;
     if (!piped && rx->prev->used && rx->prev != rx->w) HIP_TRY(hipStreamWaitEvent(st, rx->prev->done, 0));
-    const int nf = (int)n_frames;
+    const int nf = (int)n_frames, n_total = (int)(n_frames + n_context);      // context alignments: header kernel only
     const float2 *iq = (const float2 *)d_iq;
+    const double2 *iq64 = (const double2 *)d_iq;
     double2 *eq_sig = rx->record_eq ? rx->w->eq_sig.p : nullptr, *eq_data = rx->record_eq ? rx->w->eq_data.p : nullptr;
 
     if (rx->in_wait) { HIP_TRY(hipStreamWaitEvent(st, rx->in_ready, 0)); rx->in_wait = false; }
     HIP_TRY(hipEventRecord(rx->w->ev[0], st));
-    hipLaunchKernelGGL(k_header, dim3(nf), dim3(64), 0, st, iq, d_descs, d_ends, (int64_t)n_samples, nf, rx->w->info.p, rx->w->hinv.p, eq_sig);
+    if (f64) hipLaunchKernelGGL(k_header<double2>, dim3(n_total), dim3(64), 0, st, iq64, d_descs, d_ends, (int64_t)n_samples, n_total, rx->w->info.p, rx->w->hinv.p, eq_sig);
+    else hipLaunchKernelGGL(k_header<float2>, dim3(n_total), dim3(64), 0, st, iq, d_descs, d_ends, (int64_t)n_samples, n_total, rx->w->info.p, rx->w->hinv.p, eq_sig);
     HIP_TRY(hipEventRecord(rx->w->ev[1], st));
     // segments of this call: at most (total data steps)/S + one per frame; lanes beyond the real total idle
     const size_t max_segs = std::min(rx->w->seg2frame.n, rx->w->dec_cap / (size_t)rx->tb_segment + n_frames + 1);
@@ -173,12 +194,15 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
     if (n_sb <= 4096) hipLaunchKernelGGL(k_scan_blocks_w, dim3(1), dim3(64), 0, st, blk, n_sb, (int64_t)rx->w->sym_cap, rx->w->totals.p);
     else hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, blk, n_sb, (int64_t)rx->w->sym_cap, rx->w->totals.p);
     hipLaunchKernelGGL(k_scan_apply, dim3(n_sb), dim3(kScanBlock), 0, st, rx->w->info.p, nf, (int64_t)rx->w->sym_cap,
-                       (int64_t)rx->w->dec_cap, rx->tb_segment, (int64_t)rx->w->seg2frame.n, blk, rx->w->sym2frame.p, rx->w->seg2frame.p);
+                       (int64_t)rx->w->dec_cap, rx->tb_segment, (int64_t)rx->w->seg2frame.n, blk, rx->w->sym2frame.p, rx->w->seg2frame.p, rx->w->spec.p);
     HIP_TRY(hipEventRecord(rx->w->ev[2], st));
     // upper bound on data symbols in n_samples samples; waves beyond the real total exit at once
     const size_t max_sym = rx->w->sym_cap;
-    hipLaunchKernelGGL(k_data_symbols_q4, dim3((unsigned)((max_sym + 16 * kQ4Waves - 1) / (16 * kQ4Waves))), dim3(64 * kQ4Waves), 0, st, iq,
-                       d_descs, rx->w->info.p, rx->w->sym2frame.p, rx->w->totals.p, rx->w->hinv.p, rx->w->sp.p, eq_data);
+    const dim3 q4_grid((unsigned)((max_sym + 16 * kQ4Waves - 1) / (16 * kQ4Waves)));
+    if (f64) hipLaunchKernelGGL(k_data_symbols_q4<double2>, q4_grid, dim3(64 * kQ4Waves), 0, st, iq64, d_descs, rx->w->info.p, rx->w->sym2frame.p, rx->w->spec.p,
+                                rx->w->totals.p, rx->w->hinv.p, rx->w->sp.p, eq_data);
+    else hipLaunchKernelGGL(k_data_symbols_q4<float2>, q4_grid, dim3(64 * kQ4Waves), 0, st, iq, d_descs, rx->w->info.p, rx->w->sym2frame.p, rx->w->spec.p,
+                            rx->w->totals.p, rx->w->hinv.p, rx->w->sp.p, eq_data);
     HIP_TRY(hipEventRecord(rx->w->ev[3], st));
     if (piped) {
         // the previous call's chain-back + finish goes under this call's forward pass
@@ -207,27 +231,28 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
     return FOA_OK;
 }
 
-int foa_rx_decode_frames_host(foa_rx *rx, const float *iq, size_t n_samples, const foa_frame_desc *descs, const int64_t *ends,
-                              size_t n_frames, uint8_t *psdu, size_t slot_bytes, foa_frame_result *results)
+static int decode_frames_host_any(foa_rx *rx, const void *iq, bool f64, size_t n_samples, const foa_frame_desc *descs, const int64_t *ends,
+                                  size_t n_frames, uint8_t *psdu, size_t slot_bytes, foa_frame_result *results)
 {
     if (!rx) return fail(FOA_E_INVALID, "rx is NULL");
     if (n_frames == 0) return FOA_OK;
     if (!iq || !descs || !ends || !psdu || !results) return fail(FOA_E_INVALID, "NULL pointer");
     HIP_TRY(enter_device(rx->device));
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    size_t o_iq = 0, o_desc = o_iq + up(n_samples * 8), o_end = o_desc + up(n_frames * sizeof(foa_frame_desc)),
+    const size_t sample_bytes = f64 ? 16 : 8;
+    size_t o_iq = 0, o_desc = o_iq + up(n_samples * sample_bytes), o_end = o_desc + up(n_frames * sizeof(foa_frame_desc)),
            o_psdu = o_end + up(n_frames * 8), o_res = o_psdu + up(n_frames * slot_bytes), total = o_res + up(n_frames * sizeof(foa_frame_result));
     int rc = rx->scratch.ensure(total);
     if (rc) return rc;
     uint8_t *b = rx->scratch.p;
     hipStream_t st = side_stream(rx);
-    HIP_TRY(hipMemcpyAsync(b + o_iq, iq, n_samples * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(b + o_iq, iq, n_samples * sample_bytes, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(b + o_desc, descs, n_frames * sizeof(foa_frame_desc), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(b + o_end, ends, n_frames * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(b + o_psdu, 0, n_frames * slot_bytes, st));
     if ((rc = inputs_queued(rx, st))) return rc;
-    rc = foa_rx_decode_frames_dev(rx, (const float *)(b + o_iq), n_samples, (const foa_frame_desc *)(b + o_desc), (const int64_t *)(b + o_end),
-                                  n_frames, b + o_psdu, slot_bytes, (foa_frame_result *)(b + o_res));
+    rc = decode_frames_any(rx, b + o_iq, f64, n_samples, (const foa_frame_desc *)(b + o_desc), (const int64_t *)(b + o_end),
+                           n_frames, 0, b + o_psdu, slot_bytes, (foa_frame_result *)(b + o_res));
     if (rc) return rc;
     if ((rc = flush_pending(rx, nullptr))) return rc;                   // the finish runs on the second stream
     HIP_TRY(hipStreamWaitEvent(st, rx->w->done, 0));
@@ -237,8 +262,28 @@ int foa_rx_decode_frames_host(foa_rx *rx, const float *iq, size_t n_samples, con
     return FOA_OK;
 }
 
+extern "C" {
+
+int foa_rx_decode_frames_host(foa_rx *rx, const float *iq, size_t n_samples, const foa_frame_desc *descs, const int64_t *ends,
+                              size_t n_frames, uint8_t *psdu, size_t slot_bytes, foa_frame_result *results)
+{
+    return decode_frames_host_any(rx, iq, false, n_samples, descs, ends, n_frames, psdu, slot_bytes, results);
+}
+
+int foa_rx_decode_frames_f64_host(foa_rx *rx, const double *iq, size_t n_samples, const foa_frame_desc *descs, const int64_t *ends,
+                                  size_t n_frames, uint8_t *psdu, size_t slot_bytes, foa_frame_result *results)
+{
+    return decode_frames_host_any(rx, iq, true, n_samples, descs, ends, n_frames, psdu, slot_bytes, results);
+}
+
 int foa_rx_submit_host(foa_rx *rx, const float *iq, size_t n_samples, const foa_frame_desc *descs, const int64_t *ends, size_t n_frames,
                        size_t slot_bytes, uint64_t *ticket)
+{
+    return foa_rx_submit_host_ctx(rx, iq, n_samples, descs, ends, n_frames, 0, slot_bytes, ticket);
+}
+
+int foa_rx_submit_host_ctx(foa_rx *rx, const float *iq, size_t n_samples, const foa_frame_desc *descs, const int64_t *ends, size_t n_frames,
+                           size_t n_context, size_t slot_bytes, uint64_t *ticket)
 {
     if (!rx || !ticket) return fail(FOA_E_INVALID, "NULL argument");
     if (n_frames == 0 || !iq || !descs || !ends) return fail(FOA_E_INVALID, "empty call or NULL pointer");
@@ -247,7 +292,8 @@ int foa_rx_submit_host(foa_rx *rx, const float *iq, size_t n_samples, const foa_
     for (auto &j : rx->jobs) if (!j.busy) { job = &j; break; }
     if (!job) return fail(FOA_E_STATE, "%d calls are in flight: collect the oldest first", kMaxJobs);
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t o_iq = 0, o_desc = o_iq + up(n_samples * 8), o_end = o_desc + up(n_frames * sizeof(foa_frame_desc)), o_psdu = o_end + up(n_frames * 8),
+    const size_t n_all = n_frames + n_context;
+    const size_t o_iq = 0, o_desc = o_iq + up(n_samples * 8), o_end = o_desc + up(n_all * sizeof(foa_frame_desc)), o_psdu = o_end + up(n_all * 8),
                  o_res = o_psdu + up(n_frames * slot_bytes), total = o_res + up(n_frames * sizeof(foa_frame_result));
     int rc = job->dev.ensure(total);
     if (rc) return rc;
@@ -261,8 +307,8 @@ int foa_rx_submit_host(foa_rx *rx, const float *iq, size_t n_samples, const foa_
     if (!job->done) HIP_TRY(hipEventCreateWithFlags(&job->done, hipEventDisableTiming));
     // the caller's buffers are ours only until we return: mirror them, then everything else is asynchronous
     memcpy(job->pin + o_iq, iq, n_samples * 8);
-    memcpy(job->pin + o_desc, descs, n_frames * sizeof(foa_frame_desc));
-    memcpy(job->pin + o_end, ends, n_frames * 8);
+    memcpy(job->pin + o_desc, descs, n_all * sizeof(foa_frame_desc));
+    memcpy(job->pin + o_end, ends, n_all * 8);
     const bool piped = rx->pipeline;
     hipStream_t st = side_stream(rx);
     uint8_t *b = job->dev.p;
@@ -271,8 +317,8 @@ int foa_rx_submit_host(foa_rx *rx, const float *iq, size_t n_samples, const foa_
     if ((rc = inputs_queued(rx, st))) return rc;
     job->total = total; job->o_psdu = o_psdu; job->o_res = o_res; job->n_frames = n_frames; job->slot_bytes = slot_bytes; job->copy_queued = false;
     rx->attach_job = piped ? job : nullptr;
-    rc = foa_rx_decode_frames_dev(rx, (const float *)(b + o_iq), n_samples, (const foa_frame_desc *)(b + o_desc), (const int64_t *)(b + o_end), n_frames,
-                                  b + o_psdu, slot_bytes, (foa_frame_result *)(b + o_res));
+    rc = foa_rx_decode_frames_ctx_dev(rx, (const float *)(b + o_iq), n_samples, (const foa_frame_desc *)(b + o_desc), (const int64_t *)(b + o_end), n_frames,
+                                      n_context, b + o_psdu, slot_bytes, (foa_frame_result *)(b + o_res));
     rx->attach_job = nullptr;
     if (rc) return rc;
     if (!piped) {

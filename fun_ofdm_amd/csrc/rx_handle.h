@@ -65,6 +65,7 @@ struct WorkSet {
     DevBuf<FrameInfo> info;
     DevBuf<double2> hinv;
     DevBuf<int32_t> sym2frame, seg2frame;
+    DevBuf<SpecSym> spec;         // symbols that are not plain windows of their frame's own alignment (k_scan_apply -> k_data_symbols_q4)
     DevBuf<uint16_t> tb_state;
     DevBuf<uint64_t> dec;
     DevBuf<uint16_t> sp;          // depunctured soft pairs, one per trellis step (front end -> forward pass, taps)
@@ -79,7 +80,7 @@ struct WorkSet {
     bool used = false, have_timing = false, piped = false;
     void release_all()
     {
-        info.release(); hinv.release(); sym2frame.release(); seg2frame.release(); tb_state.release(); dec.release(); sp.release();
+        info.release(); hinv.release(); sym2frame.release(); seg2frame.release(); spec.release(); tb_state.release(); dec.release(); sp.release();
         decoded.release(); totals.release(); eq_sig.release(); eq_data.release();
     }
 };
@@ -134,7 +135,7 @@ struct foa_rx {
         bool valid = false;
         hipStream_t lane = nullptr;  // the stream of the call's forward pass, where its walk follows
         foa::WorkSet *w = nullptr;
-        int nf = 0, S = 0, L = 0;
+        int nf = 0, S = 0, L = 0;            // (nf: the alignments that are decoded -- context alignments have no results)
         size_t max_segs = 0, slot_bytes = 0;
         uint8_t *psdu = nullptr;
         foa_frame_result *results = nullptr;

@@ -61,8 +61,9 @@ int foa_conv_decode(foa_rx *rx, const uint8_t *symbols, uint8_t *data, int data_
             const int nseg = tb_segments(T, rx->tb_segment);
             for (size_t b = 0; b < n_blocks; b++) {
                 FrameInfo &fi = info[b];
-                fi.status = FOA_ST_CRC_FAIL; fi.rate = 0; fi.length = 0; fi.nsym = 1; fi.sym_off = 0; fi.nsteps = T; fi.soft_off = 0;
-                fi.dec_off = (int64_t)b * words; fi.seg_off = (int32_t)(b * (size_t)nseg); fi.reserved_ = 0;
+                memset(&fi, 0, sizeof fi);
+                fi.status = FOA_ST_CRC_FAIL; fi.rate = 0; fi.length = 0; fi.nsym = 1; fi.hdr_nsym = 1; fi.nsteps = T; fi.fresh = -1;
+                fi.dec_off = (int64_t)b * words; fi.seg_off = (int32_t)(b * (size_t)nseg);
                 seg2frame.insert(seg2frame.end(), (size_t)nseg, (int32_t)b);
             }
             const size_t total = n_blocks * (size_t)words + 64;
@@ -187,9 +188,10 @@ int foa_decode_data_f64(foa_rx *rx, const double *carriers, const uint64_t *carr
         const int dbps = tab.rates[rate].dbps, nsym = (16 + 8 * (len + 4) + 6 + dbps - 1) / dbps;
         if (carrier_off[f + 1] - carrier_off[f] != (uint64_t)nsym * 48) return fail(FOA_E_INVALID, "frame %zu: needs %d carriers", f, nsym * 48);
         FrameInfo &fi = info[f];
-        fi.status = FOA_ST_CRC_FAIL; fi.rate = rate; fi.length = len; fi.nsym = nsym; fi.sym_off = (int32_t)sym2frame.size();
-        fi.nsteps = nsym * dbps; fi.soft_off = 2 * dec_off; fi.dec_off = dec_off;
-        fi.seg_off = (int32_t)seg2frame.size(); fi.reserved_ = 0;
+        memset(&fi, 0, sizeof fi);
+        fi.status = FOA_ST_CRC_FAIL; fi.rate = rate; fi.length = len; fi.nsym = nsym; fi.hdr_nsym = nsym; fi.n_own = nsym; fi.fresh = -1;
+        fi.sym_off = (int32_t)sym2frame.size(); fi.nsteps = nsym * dbps; fi.dec_off = dec_off;
+        fi.seg_off = (int32_t)seg2frame.size();
         seg2frame.insert(seg2frame.end(), (size_t)tb_segments(fi.nsteps, rx->tb_segment), (int32_t)f);
         dec_off += dec_words(fi.nsteps);
         coff[f] = (int64_t)carrier_off[f];

@@ -137,7 +137,8 @@ struct ShardDev {
         Fl fl;
         fl.handle = next_handle++; fl.n_frames = m; fl.ticket = 0;
         if (m) {
-            int rc = stream_decode_batch(rx, dev[k].p, (size_t)n_buf[k], (const foa_frame_desc *)d_desc[k].p + i0, d_ends[k].p + i0, m, slot_bytes, &fl.ticket, nullptr);
+            const size_t n_ctx = std::min((size_t)q[1], desc_cap) - (i0 + m);          // (context for the batch's cut frames, as in stream_engine.h)
+            int rc = stream_decode_batch(rx, dev[k].p, (size_t)n_buf[k], (const foa_frame_desc *)d_desc[k].p + i0, d_ends[k].p + i0, m, n_ctx, slot_bytes, &fl.ticket, nullptr);
             if (rc) return rc;
             alignments.fetch_add(m);
         }

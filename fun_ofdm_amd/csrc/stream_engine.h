@@ -48,7 +48,8 @@ constexpr int kStreamBufs = 6;                      // device sample buffers / p
 // Queue the decode of m alignments of a batch buffer through a job slot of the asynchronous host entry (page-locked mirror, D2H behind the
 // finish kernel); *ticket identifies the job for stream_collect_job.  Shared by the single-device engine below and the multi-device one
 // (shard_engine.h).  t_prep (may be null): ns spent finding and sizing the job slot.
-static int stream_decode_batch(foa_rx *rx, const float *d, size_t n_buf, const foa_frame_desc *descs, const int64_t *ends, size_t m, size_t slot_bytes,
+// n_ctx: alignments behind the m decoded ones that serve them as context (foa_rx_decode_frames_ctx_dev): the rest of the buffer's.
+static int stream_decode_batch(foa_rx *rx, const float *d, size_t n_buf, const foa_frame_desc *descs, const int64_t *ends, size_t m, size_t n_ctx, size_t slot_bytes,
                                uint64_t *ticket, int64_t *t_prep)
 {
     const auto t0 = std::chrono::steady_clock::now();
@@ -74,7 +75,7 @@ static int stream_decode_batch(foa_rx *rx, const float *d, size_t n_buf, const f
     job->total = total; job->o_psdu = 0; job->o_res = o_res; job->n_frames = m; job->slot_bytes = slot_bytes; job->copy_queued = false;
     rx->attach_job = piped ? job : nullptr;
     if (t_prep) *t_prep += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
-    rc = foa_rx_decode_frames_dev(rx, d, n_buf, descs, ends, m, job->dev.p, slot_bytes, (foa_frame_result *)(job->dev.p + o_res));
+    rc = foa_rx_decode_frames_ctx_dev(rx, d, n_buf, descs, ends, m, n_ctx, job->dev.p, slot_bytes, (foa_frame_result *)(job->dev.p + o_res));
     rx->attach_job = nullptr;
     if (rc) return rc;
     if (!piped) {
@@ -102,6 +103,7 @@ static int stream_collect_job(foa_rx *rx, uint64_t ticket, size_t n_frames, bool
     for (size_t i = 0; i < n_frames; i++) {
         const int st = res[i].status;
         if (st >= 0 && st < 5) by_status[st]++;
+        else if (st == FOA_ST_SUPERSEDED) by_status[FOA_ST_TRUNCATED]++;          // (counted together: foa_stream_stats)
         if (st == FOA_ST_OK) { bytes += (size_t)res[i].length; n_ok++; }
     }
     const size_t at = out->bytes.size(), at_len = out->len.size();
@@ -224,7 +226,10 @@ struct StreamGpu {
         InFlight fl;
         fl.handle = next_handle++; fl.n_frames = m; fl.ticket = 0;
         if (m) {
-            rc = stream_decode_batch(rx, d, (size_t)n_buf, (const foa_frame_desc *)d_desc[k].p + i0, d_ends[k].p + i0, m, slot_bytes, &fl.ticket, &t_prep);
+            // (the buffer's alignments behind the batch's own go along as context: a frame cut short by a later LTS1 may fill on with their
+            // vectors, fft_symbols.cpp:41-50 / frame_decoder.cpp:52-88 -- they are decoded by the next batch)
+            const size_t n_ctx = std::min((size_t)q[1], desc_cap) - (i0 + m);
+            rc = stream_decode_batch(rx, d, (size_t)n_buf, (const foa_frame_desc *)d_desc[k].p + i0, d_ends[k].p + i0, m, n_ctx, slot_bytes, &fl.ticket, &t_prep);
             if (rc) return rc;
             alignments.fetch_add(m);
         }

@@ -31,8 +31,6 @@ struct SyncCand {
     int32_t found, pad;
 };
 
-__device__ __forceinline__ cpx widen(float2 v) { return cpx{ (double)v.x, (double)v.y }; }
-
 constexpr int kFlagSamples = 1024;   // samples per block of k_sync_flags
 constexpr int kFlagGroupBytes = 144; // LDS bytes per group of 16 samples (128 + 16 of padding): a lane stride of 144 B serves ds_read_b128 without bank conflicts
 

@@ -25,7 +25,7 @@ __device__ __forceinline__ void write_result(foa_frame_result *res, const FrameI
 {
     foa_frame_result r;
     r.status = status; r.rate = fi.rate; r.length = fi.length;
-    r.num_symbols = fi.nsym > 0 ? fi.nsym : (fi.nsteps < 0 ? -fi.nsteps : 0);
+    r.num_symbols = fi.hdr_nsym;
     *res = r;
 }
 
@@ -329,8 +329,8 @@ __global__ __launch_bounds__(64) void k_tb_finish(const FrameInfo *__restrict__ 
     finish_tables_init(tabs, lane, 64);
     __syncthreads();
     FrameInfo fi;
-    fi.status = FOA_ST_HEADER_FAIL; fi.rate = -1; fi.length = 0; fi.nsym = 0; fi.sym_off = 0; fi.nsteps = 0; fi.soft_off = 0; fi.dec_off = 0;
-    fi.seg_off = 0;
+    fi.status = FOA_ST_HEADER_FAIL; fi.rate = -1; fi.length = 0; fi.nsym = 0; fi.sym_off = 0; fi.nsteps = 0; fi.dec_off = 0;
+    fi.seg_off = 0; fi.hdr_nsym = 0;
     if (f < n_frames) fi = info[f];
     const bool live = f < n_frames && fi.nsym > 0;
     const int N = live ? fi.nsteps - 6 : 0, nseg = live ? tb_segments(fi.nsteps, S) : 0;

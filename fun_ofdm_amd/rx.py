@@ -10,7 +10,7 @@ frame_desc_dtype = np.dtype([("lts1_pos", np.int64), ("rot_start", np.int64), ("
                              ("c_prev", np.float64), ("s_prev", np.float64)])
 frame_result_dtype = np.dtype([("status", np.int32), ("rate", np.int32), ("length", np.int32), ("num_symbols", np.int32)])
 
-ST_OK, ST_HEADER_FAIL, ST_CRC_FAIL, ST_TRUNCATED, ST_NO_SPACE = range(5)
+ST_OK, ST_HEADER_FAIL, ST_CRC_FAIL, ST_TRUNCATED, ST_NO_SPACE, ST_SUPERSEDED = range(6)
 
 # fun::Rate (src/rates.h:31-44)
 RATE_NAMES = ("1/2 BPSK", "2/3 BPSK", "3/4 BPSK", "1/2 QPSK", "2/3 QPSK", "3/4 QPSK", "1/2 QAM16", "2/3 QAM16", "3/4 QAM16",
@@ -72,14 +72,17 @@ class Receiver:
         self._check(self._lib.foa_rx_decode_frames_host(self._h, _vp(iq), iq.size, _vp(descs), _vp(ends), m, _vp(psdu), slot_bytes, _vp(res)))
         return psdu, res
 
-    def submit_host(self, iq, descs, ends, slot_bytes=4096):
-        """Asynchronous decode_frames_host: returns a ticket (foa_rx_submit_host)."""
+    def submit_host(self, iq, descs, ends, slot_bytes=4096, n_context=0):
+        """Asynchronous decode_frames_host: returns a ticket (foa_rx_submit_host_ctx).  n_context: the last n_context alignments of
+        descs / ends are context only (looked at, not decoded; no results)."""
         iq = np.ascontiguousarray(iq, np.complex64)
         descs = np.ascontiguousarray(descs, frame_desc_dtype)
         ends = np.ascontiguousarray(ends, np.int64)
+        assert ends.size == descs.size and 0 <= n_context < max(descs.size, 1)
         t = C.c_uint64(0)
-        self._check(self._lib.foa_rx_submit_host(self._h, _vp(iq), iq.size, _vp(descs), _vp(ends), descs.size, slot_bytes, C.byref(t)))
-        return (int(t.value), descs.size, slot_bytes)
+        m = descs.size - n_context
+        self._check(self._lib.foa_rx_submit_host_ctx(self._h, _vp(iq), iq.size, _vp(descs), _vp(ends), m, n_context, slot_bytes, C.byref(t)))
+        return (int(t.value), m, slot_bytes)
 
     def collect(self, ticket, wait=True):
         """-> (psdu, results) of a submit_host ticket, or None if wait=False and it is not complete yet."""
@@ -92,18 +95,18 @@ class Receiver:
         return (psdu, res) if rc == 1 else None
 
     # ---- batch decode, device buffers (torch tensors on this device) ------------------------------
-    def decode_frames_dev(self, iq, descs, ends, psdu, results):
+    def decode_frames_dev(self, iq, descs, ends, psdu, results, n_context=0):
         """All arguments are CUDA(HIP) torch tensors already resident in HBM:
         iq complex64[n] (or float32[n,2]); descs uint8[m*48] (frame_desc_dtype bytes); ends int64[m];
         psdu uint8[m, slot]; results int32[m, 4].  Asynchronous on the handle's streams, which are NOT ordered against
         torch's: whatever torch still has queued on these tensors must be through before the call (a host-side
         synchronize of torch's stream here would cost the pipelined loop 3-8 %, so it is left to the caller)."""
         n = iq.numel() if iq.is_complex() else iq.numel() // 2
-        m = ends.numel()
-        assert descs.numel() * descs.element_size() == m * frame_desc_dtype.itemsize
+        m = ends.numel() - n_context                         # (n_context: the last alignments of descs / ends are context only, foa_rx_decode_frames_ctx_dev)
+        assert descs.numel() * descs.element_size() == ends.numel() * frame_desc_dtype.itemsize
         assert psdu.shape[0] == m and results.numel() == 4 * m
-        self._check(self._lib.foa_rx_decode_frames_dev(self._h, iq.data_ptr(), n, descs.data_ptr(), ends.data_ptr(), m, psdu.data_ptr(),
-                                             psdu.shape[1], results.data_ptr()))
+        self._check(self._lib.foa_rx_decode_frames_ctx_dev(self._h, iq.data_ptr(), n, descs.data_ptr(), ends.data_ptr(), m, n_context, psdu.data_ptr(),
+                                                 psdu.shape[1], results.data_ptr()))
 
     def sync_dev(self, iq, descs, ends):
         """Device-side frame_detector + timing_sync: iq complex64[n] (CUDA tensor), descs uint8[cap*48], ends int64[cap]
@@ -270,7 +273,7 @@ class Stream:
         a = np.zeros(8, np.uint64)
         self._check(self._lib.foa_stream_stats(self._h, _vp(a)))
         return dict(ok=int(a[0]), header_fail=int(a[1]), crc_fail=int(a[2]), truncated=int(a[3]), no_space=int(a[4]), alignments=int(a[5]),
-                    batches=int(a[6]), samples=int(a[7]))
+                    batches=int(a[6]), samples=int(a[7]))       # (truncated: FOA_ST_TRUNCATED + FOA_ST_SUPERSEDED)
 
 
 class Shard(Stream):

@@ -45,9 +45,14 @@ enum {
     FOA_ST_OK = 0,           /* CRC-32 matched: psdu slot holds `length` payload bytes */
     FOA_ST_HEADER_FAIL = 1,  /* SIGNAL parity or rate check failed (ppdu.cpp:187-203) */
     FOA_ST_CRC_FAIL = 2,     /* ppdu.cpp:272-279 */
-    FOA_ST_TRUNCATED = 3,    /* not enough samples before `end` for the symbols SIGNAL announces */
-    FOA_ST_NO_SPACE = 4      /* workspace exhausted (overlapping frame ranges), or the CRC matched but the payload is longer
+    FOA_ST_TRUNCATED = 3,    /* the samples handed over END before the alignment's LTS windows, its SIGNAL symbol or the last symbol its
+                              * SIGNAL announces: with more of the stream the outcome would be another (a caller that cuts a stream into
+                              * pieces decodes the alignment again when it has them) */
+    FOA_ST_NO_SPACE = 4,     /* workspace exhausted (overlapping frame ranges), or the CRC matched but the payload is longer
                               * than slot_bytes (nothing is copied) */
+    FOA_ST_SUPERSEDED = 5    /* a later alignment took the stream over before this one's frame was complete: its LTS or SIGNAL window is
+                              * cut by the next LTS1 tag, or a valid SIGNAL arrived before the frame's last symbol (frame_decoder.cpp:52-76
+                              * abandons the frame being collected).  Final: the reference never delivers such a frame. */
 };
 
 /* One alignment = one LTS1/LTS2 tag pair produced by timing_sync (src/timing_sync.cpp:98-113).
@@ -131,20 +136,42 @@ int foa_rx_set_option(foa_rx *rx, const char *name, int64_t value);
  * phase_tracker and frame_decoder (files and lines above) for n_frames alignments.
  *   d_iq       n_samples interleaved (re,im) float pairs: the raw stream handed to process_samples,
  *              before timing_sync's rotation (the kernel applies it from the descriptor)
- *   d_descs    n_frames descriptors
- *   d_ends     per frame: exclusive end index of the samples that belong to it (next alignment's
- *              lts1_pos, or n_samples)
+ *   d_descs    n_frames descriptors, in stream order
+ *   d_ends     per alignment: exclusive end index of the samples that belong to it: the next alignment's lts1_pos where the stream
+ *              goes on into it, anything else (n_samples, the end of a capture's slot) where it does not
  *   d_psdu     n_frames slots of slot_bytes bytes (slot_bytes >= longest payload, <= 4095 needed)
  *   d_results  n_frames results
+ * What an alignment's end means.  fft_symbols emits a vector every 80 samples behind an LTS2 tag until the next LTS1 tag re-aligns it,
+ * pushing the partly filled vector it holds at that moment (fft_symbols.cpp:41-50); channel_est equalises each with the estimate in
+ * force and frame_decoder copies the vectors behind a valid SIGNAL into its frame wherever they come from, dropping the frame when
+ * another valid SIGNAL arrives first (frame_decoder.cpp:52-88).  An alignment whose end IS the next descriptor's lts1_pos is therefore
+ * LINKED to it: a frame cut short by the next LTS1 takes the partial vector, the next alignment's SIGNAL vector and -- if that SIGNAL is
+ * invalid -- its symbols, exactly as the reference's blocks do (FOA_ST_SUPERSEDED if a valid SIGNAL intervenes).  Any other end is where
+ * the stream ends for that alignment and everything linked in front of it (FOA_ST_TRUNCATED if a frame needs more).  Frames that fit in
+ * front of their alignment's end -- every frame of an undisturbed stream -- do not depend on any of this.
  */
 int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, const foa_frame_desc *d_descs,
                              const int64_t *d_ends, size_t n_frames, uint8_t *d_psdu, size_t slot_bytes,
                              foa_frame_result *d_results);
+/* The same for a caller that decodes ONE stream in pieces: d_descs / d_ends hold n_frames + n_context alignments; the last n_context
+ * are CONTEXT -- their LTS and SIGNAL are looked at, and their vectors serve the frames in front of them (as sources, as superseding
+ * SIGNALs), but they are not decoded and get no result or PSDU slot (the caller decodes them with its next piece). */
+int foa_rx_decode_frames_ctx_dev(foa_rx *rx, const float *d_iq, size_t n_samples, const foa_frame_desc *d_descs,
+                                 const int64_t *d_ends, size_t n_frames, size_t n_context, uint8_t *d_psdu, size_t slot_bytes,
+                                 foa_frame_result *d_results);
 
 /* Same with HOST pointers: copies in, decodes, copies out, synchronises. */
 int foa_rx_decode_frames_host(foa_rx *rx, const float *iq, size_t n_samples, const foa_frame_desc *descs,
                               const int64_t *ends, size_t n_frames, uint8_t *psdu, size_t slot_bytes,
                               foa_frame_result *results);
+
+/* The same for a stream timing_sync has ALREADY rotated: iq holds n_samples complex<double> samples (interleaved re, im) exactly as
+ * fun::timing_sync::work leaves them in its output_buffer (src/timing_sync.cpp:114-125), and the descriptors' phasors are not applied
+ * (lts1_pos and the ends are what counts).  This is what the fused stage block fun_amd::rx_backend
+ * (fun::block<fun::tagged_sample, std::vector<unsigned char>>, include/fun_ofdm_amd/blocks.hpp) calls once per work(): the reference's
+ * own frame_detector and timing_sync threads in front, everything behind them in one device call. */
+int foa_rx_decode_frames_f64_host(foa_rx *rx, const double *iq, size_t n_samples, const foa_frame_desc *descs, const int64_t *ends,
+                                  size_t n_frames, uint8_t *psdu, size_t slot_bytes, foa_frame_result *results);
 
 /* Block until everything queued on the handle's stream has finished. */
 int foa_rx_sync(foa_rx *rx);
@@ -166,6 +193,9 @@ void *foa_rx_stream(foa_rx *rx);
  * H2D of batch k+1, compute of batch k and D2H of batch k-1 overlap on the library's streams. */
 int foa_rx_submit_host(foa_rx *rx, const float *iq, size_t n_samples, const foa_frame_desc *descs, const int64_t *ends, size_t n_frames,
                        size_t slot_bytes, uint64_t *ticket);
+/* ... with n_context context alignments behind the n_frames decoded ones (foa_rx_decode_frames_ctx_dev) */
+int foa_rx_submit_host_ctx(foa_rx *rx, const float *iq, size_t n_samples, const foa_frame_desc *descs, const int64_t *ends, size_t n_frames,
+                           size_t n_context, size_t slot_bytes, uint64_t *ticket);
 int foa_rx_collect(foa_rx *rx, uint64_t ticket, int wait, uint8_t *psdu, foa_frame_result *results);
 
 /* HIP-event durations (ms) of the kernels of the most recent decode call, measured on the handle's
@@ -290,7 +320,8 @@ int foa_stream_flush(foa_stream *s);
 int foa_stream_ready(foa_stream *s, int wait, size_t *n_payloads, size_t *n_bytes);
 /* The payloads of the batch foa_stream_ready reported, back to back in stream order, and their lengths; releases it. */
 int foa_stream_take(foa_stream *s, uint8_t *payloads, uint32_t *lengths);
-/* out[0..4]: alignments per FOA_ST_* status so far (taken batches), [5] alignments submitted, [6] batches, [7] samples pushed */
+/* out[0..4]: alignments per FOA_ST_* status so far (taken batches; FOA_ST_SUPERSEDED is counted with FOA_ST_TRUNCATED in [3]), [5] alignments
+ * submitted, [6] batches, [7] samples pushed */
 int foa_stream_stats(const foa_stream *s, uint64_t out[8]);
 
 /* ---- the same stream engine over SEVERAL devices (BASELINE config 4's frame sharding, behind the C ABI) -----------------------------

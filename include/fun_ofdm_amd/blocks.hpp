@@ -5,6 +5,7 @@
 //   fun_amd::channel_est         fun::block<tagged_vector<64>, tagged_vector<64>>  (src/channel_est.h)
 //   fun_amd::phase_tracker       fun::block<tagged_vector<64>, tagged_vector<48>>  (src/phase_tracker.h)
 //   fun_amd::frame_decoder       fun::block<tagged_vector<48>, std::vector<unsigned char>> (src/frame_decoder.h)
+//   fun_amd::rx_backend          fun::block<tagged_sample, std::vector<unsigned char>>: the four above fused into one device call
 //
 // Each adaptor keeps the block's control state (tags, counters, partially collected frames) on the host exactly as
 // the reference block does and sends the arithmetic of one work() call to the GPU in as few calls as possible.
@@ -297,6 +298,72 @@ private:
 };
 
 // ---------------------------------------------------------------------------------------------------------------
+// rx_backend: fft_symbols + channel_est + phase_tracker + frame_decoder as ONE block for a chain that keeps the reference's
+// own frame_detector and timing_sync threads: add_block(new fun_amd::rx_backend()) behind them instead of the four blocks
+// (src/receiver_chain.cpp:29-51).  It consumes the tagged, rotated samples timing_sync hands on (src/timing_sync.cpp:98-125: LTS1 /
+// LTS2 tags, every sample multiplied by the phasor in force) and makes ONE device call per work(): the fused kernels on those very
+// doubles (foa_rx_decode_frames_f64_host).  Payloads come out in stream order, each by the call that brings its frame's last sample.
+// ---------------------------------------------------------------------------------------------------------------
+class rx_backend : public fun::block<fun::tagged_sample, std::vector<unsigned char> > {
+public:
+    explicit rx_backend(int device = 0) : block("rx_backend"), dev_(device), base_(0), need_end_(0) {}
+    virtual void work()
+    {
+        if (input_buffer.size() == 0) return;
+        output_buffer.resize(0);
+        const size_t n = input_buffer.size(), o = buf_.size();
+        const int64_t pos0 = base_ + (int64_t)(o / 2);
+        buf_.resize(o + 2 * n);
+        for (size_t x = 0; x < n; x++) {
+            buf_[o + 2 * x] = input_buffer[x].sample.real(); buf_[o + 2 * x + 1] = input_buffer[x].sample.imag();
+            if (input_buffer[x].tag == fun::LTS1) pending_.push_back(pos0 + (int64_t)x);       // (LTS2 follows 64 samples on: timing_sync.cpp:105-106)
+        }
+        const int64_t avail = pos0 + (int64_t)n;
+        // Every pending alignment goes to the device with the stream as far as it has come: an alignment ends where the next one's LTS1
+        // re-aligns fft_symbols (it is linked to it: a frame cut short there fills on with what follows, fft_symbols.cpp:41-50 /
+        // frame_decoder.cpp:52-88) or where the samples end for now.  FOA_ST_TRUNCATED = ran into that end: it and what is behind it
+        // wait for the next call; everything else is final.  (The newest alignment alone, known to need more: no device call.)
+        if (!pending_.empty() && !(pending_.size() == 1 && need_end_ > avail)) {
+            const size_t m = pending_.size();
+            std::vector<foa_frame_desc> d(m);
+            std::vector<int64_t> e(m);
+            for (size_t i = 0; i < m; i++) {
+                d[i].lts1_pos = pending_[i] - base_; d[i].rot_start = d[i].lts1_pos;
+                d[i].c = 1.0; d[i].s = 0.0; d[i].c_prev = 1.0; d[i].s_prev = 0.0;      // (not applied: the samples are rotated already)
+                e[i] = (i + 1 < m ? pending_[i + 1] : avail) - base_;
+            }
+            std::vector<unsigned char> psdu(m * 4096);
+            std::vector<foa_frame_result> res(m);
+            check(foa_rx_decode_frames_f64_host(dev_.get(), buf_.data(), buf_.size() / 2, d.data(), e.data(), m, psdu.data(), 4096, res.data()),
+                  "foa_rx_decode_frames_f64_host");
+            size_t done = 0;
+            for (size_t i = 0; i < m; i++) {
+                if (res[i].status == FOA_ST_TRUNCATED) {
+                    need_end_ = i + 1 == m ? pending_[i] + (res[i].rate >= 0 ? 144 + 80 * (int64_t)res[i].num_symbols + 64 : 208) : 0;
+                    break;
+                }
+                if (res[i].status == FOA_ST_OK) output_buffer.push_back(std::vector<unsigned char>(psdu.begin() + i * 4096, psdu.begin() + i * 4096 + res[i].length));
+                done++;
+            }
+            if (done == m) need_end_ = 0;
+            pending_.erase(pending_.begin(), pending_.begin() + done);
+        }
+        // samples in front of the oldest pending alignment are never looked at again
+        const int64_t keep_from = pending_.empty() ? avail : pending_.front();
+        if (keep_from > base_) {
+            buf_.erase(buf_.begin(), buf_.begin() + 2 * (size_t)(keep_from - base_));
+            base_ = keep_from;
+        }
+    }
+private:
+    device_handle dev_;
+    std::vector<double> buf_;          // the rotated stream from stream index base_ on, interleaved re, im
+    int64_t base_;
+    std::deque<int64_t> pending_;      // LTS1 positions (stream index) not decided yet
+    int64_t need_end_;                 // the newest alignment, alone: the stream index its frame needs (0: unknown)
+};
+
+// ---------------------------------------------------------------------------------------------------------------
 // receiver_chain: process_samples() with everything after the host-side pre-sync on the device (fused kernels)
 // ---------------------------------------------------------------------------------------------------------------
 class receiver_chain {
@@ -366,41 +433,33 @@ public:
         std::vector<std::vector<unsigned char> > out;
         if (samples.empty()) return out;
         append(samples);
-        const int64_t avail = base_ + (int64_t)(buf_.size() / 2);    // stream index one past the newest sample
-        const int64_t settled = foa_sync_settled(sync_);             // timing_sync has looked at everything before this
-        // which pending alignments can be finished now?  An alignment's extent ends at the next alignment's LTS1
-        // (fft_symbols re-aligns there) or, if there is none yet, wherever the stream has got to.
-        std::vector<foa_frame_desc> descs;
-        std::vector<int64_t> ends;
+        // Every pending alignment is handed to the device with the stream as far as its tags are FINAL (timing_sync may still place an
+        // LTS1 up to 8 samples before the point it has settled): an alignment ends at the next one's LTS1 -- it is linked to it, and a
+        // frame cut short there fills on with what follows, as in the reference (fun_ofdm_amd.h) -- or at that horizon.  Whatever comes
+        // back FOA_ST_TRUNCATED ran into the horizon: it and everything behind it wait for more of the stream; everything else is final.
+        const int64_t hz = horizon(false);
+        // (the newest alignment alone, known to need more: no GPU call per chunk while a long frame comes in)
+        if (pending_.size() == 1 && pending_[0].need_end > hz) { trim(); return out; }
         size_t take = 0;
-        for (; take < pending_.size(); take++) {
-            entry &e = pending_[take];
-            const bool has_next = take + 1 < pending_.size();
-            const int64_t end = has_next ? pending_[take + 1].d.lts1_pos : avail;
-            if (!has_next) {
-                // nothing may re-align before `settled`; wait until the frame is complete (or at least its SIGNAL)
-                const int64_t need = e.need_end > 0 ? e.need_end : e.d.lts1_pos + 208;
-                if (avail < need || settled - 8 < need) break;     // a later alignment could still start up to 8 samples before `settled`
-            }
-            descs.push_back(e.d);
-            ends.push_back(end);
+        while (take < pending_.size() && pending_[take].d.lts1_pos < hz) take++;
+        if (take == 0) { trim(); return out; }
+        std::vector<foa_frame_desc> rel(take);
+        std::vector<int64_t> rel_end(take);
+        for (size_t i = 0; i < take; i++) {
+            rel[i] = pending_[i].d;
+            rel[i].lts1_pos -= base_; rel[i].rot_start -= base_;
+            rel_end[i] = (i + 1 < pending_.size() ? pending_[i + 1].d.lts1_pos : hz) - base_;
         }
-        if (descs.empty()) { trim(); return out; }
-        // decode [0, take) on the device; samples are addressed relative to base_
-        std::vector<foa_frame_desc> rel(descs);
-        std::vector<int64_t> rel_end(ends);
-        for (size_t i = 0; i < rel.size(); i++) { rel[i].lts1_pos -= base_; rel[i].rot_start -= base_; rel_end[i] -= base_; }
-        std::vector<unsigned char> psdu(rel.size() * 4096);
-        std::vector<foa_frame_result> res(rel.size());
-        check(foa_rx_decode_frames_host(dev_.get(), buf_.data(), buf_.size() / 2, rel.data(), rel_end.data(), rel.size(), psdu.data(), 4096, res.data()),
+        std::vector<unsigned char> psdu(take * 4096);
+        std::vector<foa_frame_result> res(take);
+        check(foa_rx_decode_frames_host(dev_.get(), buf_.data(), (size_t)(hz - base_), rel.data(), rel_end.data(), take, psdu.data(), 4096, res.data()),
               "foa_rx_decode_frames_host");
         size_t done = 0;
-        for (size_t i = 0; i < rel.size(); i++) {
-            const bool last = i + 1 == pending_.size();
-            if (res[i].status == FOA_ST_TRUNCATED && last) {
-                // the newest alignment is not complete yet: remember how far it reaches and try again later
-                if (res[i].rate >= 0) pending_[i].need_end = pending_[i].d.lts1_pos + 144 + 80 * (int64_t)res[i].num_symbols + 64;
-                else pending_[i].need_end = pending_[i].d.lts1_pos + 208;
+        for (size_t i = 0; i < take; i++) {
+            if (res[i].status == FOA_ST_TRUNCATED) {
+                // not complete yet: if it is the newest alignment, remember how far its frame reaches and try again then
+                if (i + 1 == pending_.size())
+                    pending_[i].need_end = pending_[i].d.lts1_pos + (res[i].rate >= 0 ? 144 + 80 * (int64_t)res[i].num_symbols + 64 : 208);
                 break;
             }
             if (res[i].status == FOA_ST_OK) out.push_back(std::vector<unsigned char>(psdu.begin() + i * 4096, psdu.begin() + i * 4096 + res[i].length));
@@ -425,7 +484,7 @@ private:
         int64_t need_end;     // stream index the frame needs before it can be decoded (0: SIGNAL not decoded yet)
         explicit entry(const foa_frame_desc &x) : d(x), need_end(0) {}
     };
-    struct job { uint64_t ticket; size_t n_frames; };
+    struct job { uint64_t ticket; size_t n_frames; bool final; std::vector<entry> sent; };     // sent: the alignments it decodes, stream-absolute
     static const int64_t kLongestFrame = 320 + 80 * 1369 + 160;       // samples: 4095 bytes at 6 Mbps, plus timing_sync's look-ahead
 
     // the device consumes complex<float> (BASELINE north_star); the pre-sync decides on the doubles it was given
@@ -444,19 +503,46 @@ private:
             check(foa_sync_push_f64(sync_, nullptr, 0, found.data(), found.size(), &got), "foa_sync_push_f64");
         }
     }
-    // oldest batch in flight -> payloads (returns false if it is not finished and wait is false)
+    // Stream index up to which the tags are final: timing_sync has looked at everything before `settled` and may still place an LTS1 up
+    // to 8 samples before it (at the end of a capture: everything there is).
+    int64_t horizon(bool final) const
+    {
+        const int64_t avail = base_ + (int64_t)(buf_.size() / 2);
+        return final ? avail : std::min(avail, foa_sync_settled(sync_) - 8);
+    }
+    // oldest batch in flight -> payloads (returns false if it is not finished and wait is false).  A frame that ran into the end of what
+    // was known when its batch went out (FOA_ST_TRUNCATED; only a frame cut short by a later LTS1 and filling on beyond the horizon can)
+    // is decoded again with more of the stream: it and everything sent behind it go back to the head of the pending list, in order.
     bool collect_front(bool wait, std::vector<std::vector<unsigned char> > *out)
     {
-        const job j = jobs_.front();
+        job &j = jobs_.front();
         std::vector<unsigned char> psdu(j.n_frames * 4096);
         std::vector<foa_frame_result> res(j.n_frames);
         const int rc = foa_rx_collect(dev_.get(), j.ticket, wait ? 1 : 0, psdu.data(), res.data());
         if (rc < 0) check(rc, "foa_rx_collect");
         if (rc == 0) return false;
-        jobs_.pop_front();
+        size_t good = j.n_frames;
+        if (!j.final)
+            for (size_t i = 0; i < j.n_frames; i++) if (res[i].status == FOA_ST_TRUNCATED) { good = i; break; }
         if (out)
-            for (size_t i = 0; i < j.n_frames; i++)
+            for (size_t i = 0; i < good; i++)
                 if (res[i].status == FOA_ST_OK) out->push_back(std::vector<unsigned char>(psdu.begin() + i * 4096, psdu.begin() + i * 4096 + res[i].length));
+        if (good < j.n_frames && out) {
+            std::vector<entry> back(j.sent.begin() + good, j.sent.end());
+            jobs_.pop_front();
+            while (!jobs_.empty()) {                                   // what is in flight behind it was decided without it: decode it again too
+                job &k = jobs_.front();
+                std::vector<unsigned char> p2(k.n_frames * 4096);
+                std::vector<foa_frame_result> r2(k.n_frames);
+                const int rc2 = foa_rx_collect(dev_.get(), k.ticket, 1, p2.data(), r2.data());
+                if (rc2 < 0) check(rc2, "foa_rx_collect");
+                back.insert(back.end(), k.sent.begin(), k.sent.end());
+                jobs_.pop_front();
+            }
+            pending_.insert(pending_.begin(), back.begin(), back.end());
+            return true;
+        }
+        jobs_.pop_front();
         return true;
     }
     std::vector<std::vector<unsigned char> > process_async(const std::vector<std::complex<double> > &samples, bool final)
@@ -466,34 +552,46 @@ private:
         while (!jobs_.empty() && collect_front(false, &out)) {}
         calls_++;
         if (final || calls_ % batch_calls_ == 0) {
-            const int64_t avail = base_ + (int64_t)(buf_.size() / 2), settled = foa_sync_settled(sync_);
-            // An alignment goes out once its extent is final: the next alignment is known (fft_symbols re-aligns there), or
-            // so much stream has passed that neither its frame nor a later tag can reach back into it.  (Its length is not
-            // known here -- SIGNAL is decoded on the device -- so the newest alignment of a burst waits for that.)
-            std::vector<foa_frame_desc> rel;
-            std::vector<int64_t> rel_end;
-            size_t take = 0;
-            for (; take < pending_.size(); take++) {
+            const int64_t hz = horizon(final);
+            // An alignment goes out once its extent is final: the next alignment is known (fft_symbols re-aligns there), or so much
+            // stream has passed that neither its frame nor a later tag can reach back into it.  (Its length is not known here -- SIGNAL
+            // is decoded on the device -- so the newest alignment of a burst waits for that.)  The alignments behind those go along as
+            // CONTEXT (foa_rx_submit_host_ctx): a frame cut short by the next LTS1 may fill on with their vectors.
+            size_t take = 0, known = 0;
+            while (known < pending_.size() && pending_[known].d.lts1_pos < hz) known++;
+            for (; take < known; take++) {
                 const bool has_next = take + 1 < pending_.size();
-                const int64_t lts1 = pending_[take].d.lts1_pos;
-                if (!has_next && !final && (avail - lts1 < kLongestFrame || settled - 8 < lts1 + kLongestFrame)) break;
-                rel.push_back(pending_[take].d);
-                rel_end.push_back(has_next ? pending_[take + 1].d.lts1_pos : avail);
+                if (!has_next && !final && hz - pending_[take].d.lts1_pos < kLongestFrame) break;
             }
-            if (!rel.empty()) {
-                // the batch only needs the samples from just before its first alignment to its last end
-                const int64_t lo = std::max(base_, std::min(rel.front().lts1_pos, rel.front().rot_start) - 16), hi = rel_end.back();
-                for (size_t i = 0; i < rel.size(); i++) { rel[i].lts1_pos -= lo; rel[i].rot_start -= lo; rel_end[i] -= lo; }
+            if (take > 0) {
+                // the batch only needs the samples from just before its first alignment to the horizon
+                const int64_t lo = std::max(base_, std::min(pending_[0].d.lts1_pos, pending_[0].d.rot_start) - 16);
+                std::vector<foa_frame_desc> rel(known);
+                std::vector<int64_t> rel_end(known);
+                for (size_t i = 0; i < known; i++) {
+                    rel[i] = pending_[i].d;
+                    rel[i].lts1_pos -= lo; rel[i].rot_start -= lo;
+                    rel_end[i] = (i + 1 < pending_.size() ? pending_[i + 1].d.lts1_pos : hz) - lo;
+                }
                 while (jobs_.size() >= 6) collect_front(true, &out);
-                job j;
-                j.n_frames = rel.size();
-                check(foa_rx_submit_host(dev_.get(), buf_.data() + 2 * (lo - base_), (size_t)(hi - lo), rel.data(), rel_end.data(), rel.size(), 4096, &j.ticket),
-                      "foa_rx_submit_host");
-                jobs_.push_back(j);
-                pending_.erase(pending_.begin(), pending_.begin() + take);
+                if (pending_.size() >= take && !pending_.empty() && pending_[0].d.lts1_pos - lo == rel[0].lts1_pos) {     // (a collect above may have put alignments back: next round then)
+                    job j;
+                    j.n_frames = take; j.final = final;
+                    j.sent.assign(pending_.begin(), pending_.begin() + take);
+                    check(foa_rx_submit_host_ctx(dev_.get(), buf_.data() + 2 * (lo - base_), (size_t)(hz - lo), rel.data(), rel_end.data(), take, known - take, 4096, &j.ticket),
+                          "foa_rx_submit_host_ctx");
+                    jobs_.push_back(j);
+                    pending_.erase(pending_.begin(), pending_.begin() + take);
+                }
             }
         }
-        if (final) while (!jobs_.empty()) collect_front(true, &out);
+        if (final) {
+            while (!jobs_.empty()) collect_front(true, &out);
+            if (!pending_.empty()) {                                     // put back by the last collects: one more, final round
+                std::vector<std::vector<unsigned char> > rest = process_async(std::vector<std::complex<double> >(), true);
+                out.insert(out.end(), rest.begin(), rest.end());
+            }
+        }
         trim();
         return out;
     }
@@ -544,7 +642,9 @@ private:
         if (!sync_) return;
         const int64_t settled = foa_sync_settled(sync_);
         int64_t keep_from = settled - 400;
-        if (!pending_.empty()) keep_from = std::min(keep_from, pending_.front().d.lts1_pos - 16);
+        if (!pending_.empty()) keep_from = std::min(keep_from, std::min(pending_.front().d.lts1_pos, pending_.front().d.rot_start) - 16);
+        if (!jobs_.empty() && !jobs_.front().sent.empty())               // (a batch in flight may have to be decoded again: collect_front)
+            keep_from = std::min(keep_from, std::min(jobs_.front().sent.front().d.lts1_pos, jobs_.front().sent.front().d.rot_start) - 16);
         if (keep_from > base_) {
             const size_t drop = (size_t)(keep_from - base_);
             if (drop * 2 >= buf_.size()) { base_ += (int64_t)(buf_.size() / 2); buf_.clear(); }

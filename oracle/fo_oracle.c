@@ -1101,16 +1101,21 @@ static void *batch_worker(void *arg)
     return NULL;
 }
 
+static void v2_fixup(const float *iq, int64_t n, const fo_frame_desc *descs, const int64_t *ends, size_t n_frames, uint8_t *psdu, size_t slot_bytes,
+                     fo_frame_result *res);
+
 void fo_decode_batch_f32(const float *iq, int64_t n, const fo_frame_desc *descs, const int64_t *ends,
                          size_t n_frames, uint8_t *psdu, size_t slot_bytes, fo_frame_result *res, int threads)
 {
-    (void)n;
     struct batch_job j = { iq, descs, ends, n_frames, psdu, slot_bytes, res, 0, PTHREAD_MUTEX_INITIALIZER };
-    if (threads <= 1) { batch_worker(&j); return; }
-    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
-    for (int t = 0; t < threads; t++) pthread_create(&th[t], NULL, batch_worker, &j);
-    for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
-    free(th);
+    if (threads <= 1) batch_worker(&j);
+    else {
+        pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
+        for (int t = 0; t < threads; t++) pthread_create(&th[t], NULL, batch_worker, &j);
+        for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+        free(th);
+    }
+    v2_fixup(iq, n, descs, ends, n_frames, psdu, slot_bytes, res);      /* alignments cut short by the next one: decided with what follows them */
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -1280,6 +1285,9 @@ void fo_pool_decode(fo_pool *p, const float *iq, const fo_frame_desc *descs, con
     pthread_mutex_lock(&p->mu);
     while (p->running > 0) pthread_cond_wait(&p->done, &p->mu);
     pthread_mutex_unlock(&p->mu);
+    int64_t n = 0;                                        /* (the stream is at least as long as the furthest end handed over) */
+    for (size_t f = 0; f < n_frames; f++) if (ends[f] > n) n = ends[f];
+    v2_fixup(iq, n, descs, ends, n_frames, psdu, slot_bytes, res);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -1321,28 +1329,42 @@ void fo_chain_from_tags_f32(const float *iq, int64_t n, const fo_frame_desc *des
     fo_fft_symbols_free(fs); fo_channel_est_free(ce); fo_phase_tracker_free(pt); fo_frame_decoder_free(dec);
 }
 
-/* What those blocks do, restated per alignment (the shape a batch decoder has).  Alignment j, LTS1 at p, ends at e = the next
- * alignment's LTS1 (or the end of the stream).  fft_symbols emits for it: the two LTS vectors, then the vectors of the complete
- * symbol windows [p + 144 + 80 k, + 64), k = 0 (SIGNAL) .. K - 1, that end by e, and -- when another LTS1 follows and the window in
- * progress has got past its cyclic prefix (m_offset > 15, fft_symbols.cpp:46) -- ONE MORE: the first (e - p - 128) mod 80 - 16
- * samples of window K, the rest of the vector still holding window K - 1 (the LTS2 window for K = 0).  channel_est equalises all of
- * them with alignment j's estimate and phase_tracker counts them on (k = 0 is START_OF_FRAME).  These vectors of all alignments,
- * in stream order, are ONE sequence: frame_decoder copies the nsym vectors that follow a valid SIGNAL into its frame wherever they
- * come from -- the partial vector, the next alignment's SIGNAL, its data symbols if that SIGNAL is invalid -- and drops the frame
- * when a VALID SIGNAL arrives before the last of them (frame_decoder.cpp:52-88).
- * Alignments whose LTS windows are cut (e < p + 128) take no part (residual: pile-ups closer than 128 samples). */
-typedef struct { int32_t K, has_part, fresh, nvec, valid, rate, length, nsym; int64_t voff; fo_c64 est[64]; } v2_al;
+/* What those blocks do, restated per alignment (the shape a batch decoder has).  Alignment j, LTS1 at p, ends at e = ends[j] (clamped
+ * to the stream) and is LINKED to alignment j+1 iff e is that alignment's LTS1 -- i.e. iff the stream goes on into it; an alignment
+ * whose samples end anywhere else is where the stream ends as far as it and its predecessors are concerned.  fft_symbols emits for it:
+ * the two LTS vectors, then the vectors of the complete symbol windows [p + 144 + 80 k, + 64), k = 0 (SIGNAL) .. K - 1, that end by e,
+ * and -- when it is linked and the window in progress has got past its cyclic prefix (m_offset > 15, fft_symbols.cpp:46) -- ONE MORE:
+ * the first (e - p - 128) mod 80 - 16 samples of window K, the rest of the vector still holding window K - 1 (the LTS2 window for
+ * K = 0).  channel_est equalises all of them with alignment j's estimate and phase_tracker counts them on (k = 0 is START_OF_FRAME).
+ * These vectors of all linked alignments, in stream order, are ONE sequence: frame_decoder copies the nsym vectors that follow a valid
+ * SIGNAL into its frame wherever they come from -- the partial vector, the next alignment's SIGNAL, its data symbols if that SIGNAL is
+ * invalid -- and drops the frame when a VALID SIGNAL arrives before the last of them (frame_decoder.cpp:52-88).
+ * Status of alignment j: HEADER_FAIL / OK / CRC_FAIL as the blocks decide; TRUNCATED = the samples ran out (an unlinked end) before its
+ * LTS windows, its SIGNAL vector or its frame's last vector; SUPERSEDED = the stream went on into a later alignment that took it over:
+ * its LTS or SIGNAL window was cut by the next LTS1 (no vector at all), or a valid SIGNAL arrived before its frame's last vector.
+ * Alignments whose LTS windows are cut take no part as sources (pile-ups closer than 128 samples: the residual this restatement
+ * leaves; fo_chain_from_tags_f32 is the ground truth there). */
+typedef struct { int32_t K, has_part, fresh, nvec, valid, rate, length, nsym, link, dead, done; fo_c64 est[64]; } v2_al;
 
-static void v2_vector(const float *iq, const fo_frame_desc *d, const v2_al *a, int k, fo_tagged_vec48 *out)
+/* The stream: complex<float> samples that the descriptor's phasors rotate (timing_sync.cpp:124-125), or (f64) complex<double> samples
+ * that timing_sync has rotated already -- its own output_buffer, as the fused stage block of blocks.hpp receives it. */
+typedef struct { const void *iq; int f64; } v2_stream;
+static inline cplx v2_sample(const v2_stream *st, int64_t idx, const fo_frame_desc *d)
+{
+    if (st->f64) { const double *q = (const double *)st->iq; return CMPLX(q[2 * idx], q[2 * idx + 1]); }
+    const float *q = (const float *)st->iq;
+    const cplx smp = CMPLX((double)q[2 * idx], (double)q[2 * idx + 1]);
+    return smp * (idx >= d->rot_start ? CMPLX(d->c, d->s) : CMPLX(d->c_prev, d->s_prev));
+}
+
+static void v2_vector(const v2_stream *iq, const fo_frame_desc *d, const v2_al *a, int k, fo_tagged_vec48 *out)
 {
     const int64_t w0 = d->lts1_pos + 144 + 80 * (int64_t)k;
     const int partial = a->has_part && k == a->K;
-    const cplx rot = CMPLX(d->c, d->s), rot_prev = CMPLX(d->c_prev, d->s_prev);
     fo_tagged_vec64 v, eq;
     for (int i = 0; i < 64; i++) {
         const int64_t idx = (partial && i >= a->fresh) ? w0 - 80 + i : w0 + i;
-        const cplx smp = CMPLX((double)iq[2 * idx], (double)iq[2 * idx + 1]);
-        v.samples[i] = from_c(smp * (idx >= d->rot_start ? rot : rot_prev));
+        v.samples[i] = from_c(v2_sample(iq, idx, d));
     }
     v.tag = FO_NONE; v._pad = 0;
     fo_fft64(v.samples);
@@ -1354,69 +1376,111 @@ static void v2_vector(const float *iq, const fo_frame_desc *d, const v2_al *a, i
     fo_phase_tracker_work(&pt, &eq, 1, out);
 }
 
-void fo_decode_batch_v2_f32(const float *iq, int64_t n, const fo_frame_desc *descs, size_t n_al, uint8_t *psdu, size_t slot_bytes, fo_frame_result *res)
+/* what alignment j contributes: extent, vectors, channel estimate, SIGNAL outcome (n_tot = alignments in descs, context included) */
+static void v2_al_compute(const v2_stream *iq, int64_t n, const fo_frame_desc *descs, const int64_t *ends, size_t n_tot, size_t j, v2_al *a)
+{
+    if (a->done) return;
+    memset(a, 0, sizeof *a);
+    a->done = 1;
+    const fo_frame_desc *d = &descs[j];
+    const int64_t p = d->lts1_pos;
+    const int64_t e_raw = ends ? ends[j] : (j + 1 < n_tot ? descs[j + 1].lts1_pos : n);
+    const int64_t e = e_raw < n ? e_raw : n;
+    a->link = j + 1 < n_tot && e_raw == descs[j + 1].lts1_pos && e_raw <= n;
+    if (p < 0 || e < p + 128) { a->dead = 1; return; }             /* LTS cut off: no estimate, no vectors */
+    a->K = e >= p + 208 ? (int32_t)((e - (p + 208)) / 80 + 1) : 0;
+    const int mo = (int)((e - (p + 128)) % 80);
+    a->has_part = a->link && mo > 15;
+    a->fresh = a->has_part ? mo - 16 : 0;
+    a->nvec = a->K + a->has_part;
+    /* channel_est.cpp:44-58 on the two LTS vectors */
+    fo_channel_est ce;
+    memset(&ce, 0, sizeof ce);
+    for (int w = 0; w < 2; w++) {
+        fo_tagged_vec64 v, dummy;
+        for (int i = 0; i < 64; i++) v.samples[i] = from_c(v2_sample(iq, p + 64 * w + i, d));
+        v.tag = w == 0 ? FO_LTS_START : FO_NONE; v._pad = 0;
+        fo_fft64(v.samples);
+        fo_channel_est_work(&ce, &v, 1, &dummy);
+    }
+    memcpy(a->est, ce.est, sizeof a->est);
+    if (a->nvec == 0) return;                                         /* not even part of a SIGNAL vector: no START_OF_FRAME from this alignment */
+    fo_tagged_vec48 sig;
+    v2_vector(iq, d, a, 0, &sig);
+    a->valid = fo_decode_header(sig.samples, &a->rate, &a->length, &a->nsym);
+}
+
+/* the outcome of alignment j (al: one record per alignment of descs, zeroed before the first call: filled as the walk needs them) */
+static void v2_resolve(const v2_stream *iq, int64_t n, const fo_frame_desc *descs, const int64_t *ends, size_t n_tot, v2_al *al, size_t j, uint8_t *psdu,
+                       fo_frame_result *res)
+{
+    v2_al_compute(iq, n, descs, ends, n_tot, j, &al[j]);
+    const v2_al *a = &al[j];
+    res->status = FO_ST_TRUNCATED; res->rate = -1; res->length = 0; res->num_symbols = 0;
+    if (a->dead || a->nvec == 0) { if (a->link) res->status = FO_ST_SUPERSEDED; return; }
+    if (!a->valid) { res->status = FO_ST_HEADER_FAIL; return; }
+    res->rate = a->rate; res->length = a->length; res->num_symbols = a->nsym;
+    /* the frame's vectors 1 .. nsym of the sequence behind its SIGNAL: its own (k = 1 .. nvec - 1), then those of the alignments it is linked to */
+    int64_t c = a->nvec - 1;
+    size_t g = j;
+    while (c < a->nsym) {
+        if (!al[g].link) return;                                      /* the samples end first: TRUNCATED */
+        g++;
+        v2_al_compute(iq, n, descs, ends, n_tot, g, &al[g]);
+        if (al[g].nvec == 0) continue;
+        if (al[g].valid && c + 1 < a->nsym) { res->status = FO_ST_SUPERSEDED; return; }     /* a valid SIGNAL before the frame's last vector */
+        c += al[g].nvec;
+    }
+    fo_c64 *car = (fo_c64 *)malloc(sizeof(fo_c64) * 48 * (size_t)a->nsym);
+    size_t src = j;
+    int64_t k = 1;                                                    /* next vector of alignment src */
+    for (int64_t v = 1; v <= a->nsym; v++) {
+        while (k >= al[src].nvec) { src++; k = 0; }                   /* (alignments without vectors are skipped over) */
+        fo_tagged_vec48 dv;
+        v2_vector(iq, &descs[src], &al[src], (int)k, &dv);
+        memcpy(car + (size_t)(v - 1) * 48, dv.samples, sizeof dv.samples);
+        k++;
+    }
+    const int ok = fo_decode_data(car, a->rate, a->length, psdu, NULL, NULL);
+    res->status = ok ? FO_ST_OK : FO_ST_CRC_FAIL;
+    free(car);
+}
+
+void fo_decode_batch_v2_f32(const float *iq, int64_t n, const fo_frame_desc *descs, const int64_t *ends, size_t n_al, size_t n_ctx, uint8_t *psdu,
+                            size_t slot_bytes, fo_frame_result *res)
 {
     ensure_tables();
-    v2_al *al = (v2_al *)calloc(n_al ? n_al : 1, sizeof(v2_al));
-    int64_t voff = 0;
-    for (size_t j = 0; j < n_al; j++) {
-        v2_al *a = &al[j];
-        const fo_frame_desc *d = &descs[j];
-        const int64_t p = d->lts1_pos, e = j + 1 < n_al ? descs[j + 1].lts1_pos : n;
-        res[j].status = FO_ST_TRUNCATED; res[j].rate = -1; res[j].length = 0; res[j].num_symbols = 0;
-        a->voff = voff;
-        if (p < 0 || e < p + 128 || e > n) continue;                 /* LTS cut off: no estimate, no vectors */
-        a->K = e >= p + 208 ? (int32_t)((e - (p + 208)) / 80 + 1) : 0;
-        const int mo = (int)((e - (p + 128)) % 80);
-        a->has_part = (j + 1 < n_al) && mo > 15;
-        a->fresh = a->has_part ? mo - 16 : 0;
-        a->nvec = a->K + a->has_part;
-        voff += a->nvec;
-        /* channel_est.cpp:44-58 on the two LTS vectors */
-        fo_channel_est ce;
-        memset(&ce, 0, sizeof ce);
-        for (int w = 0; w < 2; w++) {
-            fo_tagged_vec64 v, dummy;
-            const cplx rot = CMPLX(d->c, d->s), rot_prev = CMPLX(d->c_prev, d->s_prev);
-            for (int i = 0; i < 64; i++) {
-                const int64_t idx = p + 64 * w + i;
-                v.samples[i] = from_c(CMPLX((double)iq[2 * idx], (double)iq[2 * idx + 1]) * (idx >= d->rot_start ? rot : rot_prev));
-            }
-            v.tag = w == 0 ? FO_LTS_START : FO_NONE; v._pad = 0;
-            fo_fft64(v.samples);
-            fo_channel_est_work(&ce, &v, 1, &dummy);
-        }
-        memcpy(a->est, ce.est, sizeof a->est);
-        if (a->nvec == 0) continue;                                   /* not even part of a SIGNAL vector: no START_OF_FRAME from this alignment */
-        fo_tagged_vec48 sig;
-        v2_vector(iq, d, a, 0, &sig);
-        res[j].status = FO_ST_HEADER_FAIL;
-        a->valid = fo_decode_header(sig.samples, &a->rate, &a->length, &a->nsym);
-        if (a->valid) { res[j].rate = a->rate; res[j].length = a->length; res[j].num_symbols = a->nsym; res[j].status = FO_ST_TRUNCATED; }
-    }
-    const int64_t total = voff;
-    for (size_t j = 0; j < n_al; j++) {
-        const v2_al *a = &al[j];
-        if (!a->valid) continue;
-        const int64_t first = a->voff + 1, last = a->voff + a->nsym;       /* the frame's vectors in the global sequence */
-        if (last >= total) continue;                                       /* the stream ends first: never decoded (TRUNCATED) */
-        int dropped = 0;
-        for (size_t g = j + 1; g < n_al && al[g].voff < last; g++)
-            if (al[g].nvec > 0 && al[g].valid && al[g].voff > a->voff) { dropped = 1; break; }     /* a valid SIGNAL before the frame's last vector */
-        if (dropped) continue;
-        fo_c64 *car = (fo_c64 *)malloc(sizeof(fo_c64) * 48 * (size_t)a->nsym);
-        size_t g = j;
-        for (int64_t v = first; v <= last; v++) {
-            while (g + 1 < n_al && (al[g + 1].voff <= v)) g++;             /* the alignment whose vectors include v (alignments without vectors are skipped over) */
-            size_t src = g;
-            while (al[src].nvec == 0 || al[src].voff > v) src--;           /* (an alignment with no vectors shares its voff with the next one) */
-            fo_tagged_vec48 dv;
-            v2_vector(iq, &descs[src], &al[src], (int)(v - al[src].voff), &dv);
-            memcpy(car + (size_t)(v - first) * 48, dv.samples, sizeof dv.samples);
-        }
-        const int ok = fo_decode_data(car, a->rate, a->length, psdu + j * slot_bytes, NULL, NULL);
-        res[j].status = ok ? FO_ST_OK : FO_ST_CRC_FAIL;
-        free(car);
+    const size_t n_tot = n_al + n_ctx;
+    v2_al *al = (v2_al *)calloc(n_tot ? n_tot : 1, sizeof(v2_al));
+    const v2_stream st = { iq, 0 };
+    for (size_t j = 0; j < n_al; j++) v2_resolve(&st, n, descs, ends, n_tot, al, j, psdu + j * slot_bytes, &res[j]);
+    free(al);
+}
+
+void fo_decode_batch_v2_f64(const double *iq, int64_t n, const fo_frame_desc *descs, const int64_t *ends, size_t n_al, size_t n_ctx, uint8_t *psdu,
+                            size_t slot_bytes, fo_frame_result *res)
+{
+    ensure_tables();
+    const size_t n_tot = n_al + n_ctx;
+    v2_al *al = (v2_al *)calloc(n_tot ? n_tot : 1, sizeof(v2_al));
+    const v2_stream st = { iq, 1 };
+    for (size_t j = 0; j < n_al; j++) v2_resolve(&st, n, descs, ends, n_tot, al, j, psdu + j * slot_bytes, &res[j]);
+    free(al);
+}
+
+/* After a pass that decoded every alignment on its own (fo_decode_batch_f32, fo_pool_decode): the alignments whose outcome depends
+ * on the alignments behind them -- linked, and cut short by the next LTS1 -- are decided again by the rules above.  Everything else
+ * (a complete SIGNAL window with an invalid header, a frame that fits in front of the next LTS1, an unlinked end) comes out the same
+ * either way. */
+static void v2_fixup(const float *iq, int64_t n, const fo_frame_desc *descs, const int64_t *ends, size_t n_frames, uint8_t *psdu, size_t slot_bytes,
+                     fo_frame_result *res)
+{
+    v2_al *al = NULL;
+    for (size_t j = 0; j + 1 < n_frames; j++) {
+        if (res[j].status != FO_ST_TRUNCATED || ends[j] != descs[j + 1].lts1_pos || ends[j] > n) continue;
+        if (!al) al = (v2_al *)calloc(n_frames, sizeof(v2_al));
+        const v2_stream st = { iq, 0 };
+        v2_resolve(&st, n, descs, ends, n_frames, al, j, psdu + j * slot_bytes, &res[j]);
     }
     free(al);
 }

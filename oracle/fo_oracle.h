@@ -184,7 +184,7 @@ typedef struct {
     int32_t rate, length, num_symbols;
 } fo_frame_result;
 
-enum { FO_ST_OK = 0, FO_ST_HEADER_FAIL = 1, FO_ST_CRC_FAIL = 2, FO_ST_TRUNCATED = 3 };
+enum { FO_ST_OK = 0, FO_ST_HEADER_FAIL = 1, FO_ST_CRC_FAIL = 2, FO_ST_TRUNCATED = 3, FO_ST_SUPERSEDED = 5 };     /* (4 is the device's NO_SPACE) */
 
 /* Decode one alignment: fft_symbols -> channel_est -> phase_tracker -> frame_decoder on the float
  * samples iq[2*n] (interleaved re,im; widened to double exactly like the CPU receiver would), where
@@ -199,7 +199,9 @@ void fo_decode_alignment_f32(const float *iq, int64_t end, const fo_frame_desc *
  * receiver.h:16) and returns up to cap alignment descriptors in stream order. */
 size_t fo_find_alignments_f32(const float *iq, int64_t n, fo_frame_desc *out, size_t cap);
 
-/* Frame-parallel CPU baseline: decode n_frames alignments with `threads` worker threads. */
+/* The batch path's checker: decode n_frames alignments of one stream (`threads` worker threads, each alignment on its own as above),
+ * then decide the alignments that are cut short by the next one with what follows them (fo_decode_batch_v2_f32's rules) -- the same
+ * results as fo_decode_batch_v2_f32 with n_ctx = 0. */
 void fo_decode_batch_f32(const float *iq, int64_t n, const fo_frame_desc *descs, const int64_t *ends,
                          size_t n_frames, uint8_t *psdu, size_t slot_bytes, fo_frame_result *res, int threads);
 
@@ -207,11 +209,21 @@ void fo_decode_batch_f32(const float *iq, int64_t n, const fo_frame_desc *descs,
  * given list of alignments: the ground truth for a batch decoder handed the same descriptors -- the partial-vector flush of
  * fft_symbols.cpp:41-50 and frame_decoder's frame-in-progress logic (frame_decoder.cpp:52-88) included. */
 void fo_chain_from_tags_f32(const float *iq, int64_t n, const fo_frame_desc *descs, size_t n_al, fo_payloads *out);
-/* ... and those blocks restated per alignment, the way the device's batch path is organised (every alignment's vectors, the partial
- * one included, form one sequence; a frame takes the nsym vectors behind its SIGNAL from wherever they come and is dropped by a valid
- * SIGNAL among them).  ends are implied: alignment j ends at alignment j+1's lts1_pos, the last one at n.  status TRUNCATED = the frame
- * is never delivered by the reference (stream over, or dropped), with rate / length / num_symbols as SIGNAL announced them. */
-void fo_decode_batch_v2_f32(const float *iq, int64_t n, const fo_frame_desc *descs, size_t n_al, uint8_t *psdu, size_t slot_bytes, fo_frame_result *res);
+/* ... and those blocks restated per alignment, the way the device's batch path is organised: every alignment's vectors, the partial
+ * one included, form one sequence with those of the alignments it is LINKED to (ends[j] == descs[j+1].lts1_pos: the stream goes on into
+ * the next alignment); a frame takes the nsym vectors behind its SIGNAL from wherever they come and is dropped by a valid SIGNAL among
+ * them.  ends may be NULL (alignment j ends at alignment j+1's lts1_pos, the last one at n).  descs holds n_al + n_ctx alignments: the
+ * last n_ctx are CONTEXT -- sources of vectors and of superseding SIGNALs for the frames before them, not decoded themselves (what a
+ * caller that cuts a stream into batches hands over behind a batch).  Status: FO_ST_TRUNCATED = the samples ended (an unlinked end)
+ * before the LTS windows, the SIGNAL vector or the frame's last vector; FO_ST_SUPERSEDED = a later alignment took the stream over (LTS
+ * or SIGNAL window cut by the next LTS1, or a valid SIGNAL before the frame's last vector); rate / length / num_symbols as SIGNAL
+ * announced them wherever it decoded. */
+void fo_decode_batch_v2_f32(const float *iq, int64_t n, const fo_frame_desc *descs, const int64_t *ends, size_t n_al, size_t n_ctx, uint8_t *psdu,
+                            size_t slot_bytes, fo_frame_result *res);
+/* The same on complex<double> samples that timing_sync has rotated already (its output_buffer: timing_sync.cpp:114-125); the
+ * descriptors' phasors are not applied. */
+void fo_decode_batch_v2_f64(const double *iq, int64_t n, const fo_frame_desc *descs, const int64_t *ends, size_t n_al, size_t n_ctx, uint8_t *psdu,
+                            size_t slot_bytes, fo_frame_result *res);
 
 /* ---- the TIMED CPU baseline of bench.py (never the checker: the functions above are) ----
  * fo_viterbi_forward_simd: fo_viterbi_forward on sixteen butterflies per SSE instruction, the way the reference's own decoder

@@ -23,6 +23,7 @@ frame_result = np.dtype([("status", np.int32), ("rate", np.int32), ("length", np
 
 NONE, STS_START, STS_END, LTS_START, LTS1, LTS2, START_OF_FRAME = range(7)
 ST_OK, ST_HEADER_FAIL, ST_CRC_FAIL, ST_TRUNCATED = range(4)
+ST_SUPERSEDED = 5
 NUM_RATES = 11
 STANDARD_RATES = (0, 2, 3, 5, 6, 8, 9, 10)   # the eight 802.11a rates in the reference's enum
 
@@ -77,7 +78,8 @@ def lib():
             "fo_frame_decoder_stats": (vp, [vp]),
             "fo_receiver_chain_new": (vp, []), "fo_receiver_chain_new_threaded": (vp, []), "fo_receiver_chain_free": (None, [vp]),
             "fo_receiver_chain_process_samples": (vp, [vp, vp, sz]), "fo_receiver_chain_decoder_stats": (vp, [vp]),
-            "fo_chain_from_tags_f32": (None, [vp, i64, vp, sz, vp]), "fo_decode_batch_v2_f32": (None, [vp, i64, vp, sz, vp, sz, vp]),
+            "fo_chain_from_tags_f32": (None, [vp, i64, vp, sz, vp]), "fo_decode_batch_v2_f32": (None, [vp, i64, vp, vp, sz, sz, vp, sz, vp]),
+            "fo_decode_batch_v2_f64": (None, [vp, i64, vp, vp, sz, sz, vp, sz, vp]),
             "fo_viterbi_forward_simd": (None, [vp, i32, vp, vp]), "fo_viterbi_simd_kind": (C.c_char_p, []), "fo_set_timed_simd_viterbi": (None, [i32]),
             "fo_pool_new": (vp, [i32]), "fo_pool_free": (None, [vp]), "fo_pool_threads": (i32, [vp]),
             "fo_pool_decode": (None, [vp, vp, vp, vp, sz, vp, sz, vp]),
@@ -508,14 +510,30 @@ def chain_from_tags_f32(iq, descs):
         lib().fo_payloads_free(h)
 
 
-def decode_batch_v2_f32(iq, descs, slot_bytes=4096):
-    """The batch restatement with the partial-vector flush and frame_decoder's frame-in-progress logic (fo_decode_batch_v2_f32)."""
+def decode_batch_v2_f32(iq, descs, ends=None, slot_bytes=4096, n_ctx=0):
+    """The batch restatement with the partial-vector flush and frame_decoder's frame-in-progress logic (fo_decode_batch_v2_f32).
+    ends: per alignment (None: the next alignment's lts1_pos, the stream's end for the last); n_ctx: the last n_ctx alignments of
+    descs are context only.  -> (psdu, results) of the first descs.size - n_ctx alignments."""
     iq = np.ascontiguousarray(iq, np.complex64)
     descs = np.ascontiguousarray(descs, frame_desc)
-    n = descs.size
+    n = descs.size - n_ctx
     psdu = np.zeros((n, slot_bytes), np.uint8)
     res = np.zeros(n, frame_result)
-    lib().fo_decode_batch_v2_f32(_ptr(iq), iq.size, _ptr(descs), n, _ptr(psdu), slot_bytes, _ptr(res))
+    e = None if ends is None else np.ascontiguousarray(ends, np.int64)
+    assert e is None or e.size == descs.size
+    lib().fo_decode_batch_v2_f32(_ptr(iq), iq.size, _ptr(descs), None if e is None else _ptr(e), n, n_ctx, _ptr(psdu), slot_bytes, _ptr(res))
+    return psdu, res
+
+
+def decode_batch_v2_f64(iq_rotated, descs, ends=None, slot_bytes=4096, n_ctx=0):
+    """fo_decode_batch_v2_f64: the same on complex128 samples timing_sync has rotated already (phasors of descs not applied)."""
+    iq = np.ascontiguousarray(iq_rotated, np.complex128)
+    descs = np.ascontiguousarray(descs, frame_desc)
+    n = descs.size - n_ctx
+    psdu = np.zeros((n, slot_bytes), np.uint8)
+    res = np.zeros(n, frame_result)
+    e = None if ends is None else np.ascontiguousarray(ends, np.int64)
+    lib().fo_decode_batch_v2_f64(_ptr(iq), iq.size, _ptr(descs), None if e is None else _ptr(e), n, n_ctx, _ptr(psdu), slot_bytes, _ptr(res))
     return psdu, res
 
 

@@ -3,6 +3,8 @@
 // fun_ofdm_amd/csrc/sync_host.h (the streaming pre-sync behind foa_sync_*).
 // TEST INFRASTRUCTURE: the decode entry points are answered by the oracle (oracle/fo_oracle.c); nothing in the product
 // links this file.  The foa_sync_* functions are the real host code (SyncHost), wrapped exactly as csrc/rx_sync.hip wraps it.
+#include <cmath>
+#include <complex>
 #include <cstring>
 #include <map>
 #include <string>
@@ -52,17 +54,23 @@ int foa_rx_decode_frames_host(foa_rx *, const float *iq, size_t n_samples, const
     return FOA_OK;
 }
 
-int foa_rx_submit_host(foa_rx *rx, const float *iq, size_t n_samples, const foa_frame_desc *descs, const int64_t *ends, size_t n_frames,
-                       size_t slot_bytes, uint64_t *ticket)
+int foa_rx_submit_host_ctx(foa_rx *rx, const float *iq, size_t n_samples, const foa_frame_desc *descs, const int64_t *ends, size_t n_frames,
+                           size_t n_context, size_t slot_bytes, uint64_t *ticket)
 {
     if (rx->jobs.size() >= 8) return FOA_E_STATE;
     foa_rx::job j;
     j.psdu.assign(n_frames * slot_bytes, 0);
     j.res.resize(n_frames);
-    foa_rx_decode_frames_host(rx, iq, n_samples, descs, ends, n_frames, j.psdu.data(), slot_bytes, j.res.data());
+    if (n_frames)
+        fo_decode_batch_v2_f32(iq, (int64_t)n_samples, (const fo_frame_desc *)descs, ends, n_frames, n_context, j.psdu.data(), slot_bytes, (fo_frame_result *)j.res.data());
     *ticket = rx->next_ticket++;
     rx->jobs[*ticket] = std::move(j);
     return FOA_OK;
+}
+int foa_rx_submit_host(foa_rx *rx, const float *iq, size_t n_samples, const foa_frame_desc *descs, const int64_t *ends, size_t n_frames,
+                       size_t slot_bytes, uint64_t *ticket)
+{
+    return foa_rx_submit_host_ctx(rx, iq, n_samples, descs, ends, n_frames, 0, slot_bytes, ticket);
 }
 
 int foa_rx_collect(foa_rx *rx, uint64_t ticket, int, uint8_t *psdu, foa_frame_result *results)
@@ -154,12 +162,80 @@ int foa_shard_stats(const foa_shard *, uint64_t out[8], uint64_t *, int) { memse
 int foa_recommended_hw_queues(void) { return 8; }
 const char *foa_rx_notes(foa_rx *) { return ""; }
 
-// the per-block adaptors are not part of this run; their entry points only have to link
-int foa_fft_forward_f64(foa_rx *, double *, size_t) { return FOA_E_NO_DEVICE; }
-int foa_channel_estimate_f64(foa_rx *, const double *, double *, size_t) { return FOA_E_NO_DEVICE; }
-int foa_equalize_f64(foa_rx *, double *, size_t, const double *, size_t, const int32_t *) { return FOA_E_NO_DEVICE; }
-int foa_phase_track_f64(foa_rx *, const double *, const int32_t *, size_t, double *) { return FOA_E_NO_DEVICE; }
-int foa_decode_header_f64(foa_rx *, const double *, size_t, foa_frame_result *) { return FOA_E_NO_DEVICE; }
-int foa_decode_data_f64(foa_rx *, const double *, const uint64_t *, size_t, foa_frame_result *, uint8_t *, size_t) { return FOA_E_NO_DEVICE; }
+// the per-stage entry points, answered by the oracle's functions of the same stage (the adaptors' HOST logic -- tags, counters, frames in
+// progress -- is what a CPU run of them exercises)
+typedef std::complex<double> cd;
+int foa_fft_forward_f64(foa_rx *, double *v, size_t n)
+{
+    for (size_t i = 0; i < n; i++) fo_fft64((fo_c64 *)(v + 128 * i));
+    return FOA_OK;
+}
+int foa_channel_estimate_f64(foa_rx *, const double *pairs, double *hinv, size_t n)
+{
+    for (size_t i = 0; i < n; i++) {
+        fo_channel_est *ce = fo_channel_est_new();
+        fo_tagged_vec64 v[2], out[2];
+        for (int w = 0; w < 2; w++) { memcpy(v[w].samples, pairs + (2 * i + w) * 128, sizeof v[w].samples); v[w].tag = w == 0 ? FO_LTS_START : FO_NONE; v[w]._pad = 0; }
+        fo_channel_est_work(ce, v, 2, out);
+        memcpy(hinv + i * 128, fo_channel_est_state(ce), 64 * sizeof(fo_c64));
+        fo_channel_est_free(ce);
+    }
+    return FOA_OK;
+}
+int foa_equalize_f64(foa_rx *, double *v, size_t n, const double *hinv, size_t n_hinv, const int32_t *idx)
+{
+    for (size_t i = 0; i < n; i++) {
+        if (idx[i] < 0 || (size_t)idx[i] >= n_hinv) return FOA_E_INVALID;
+        cd *x = (cd *)(v + 128 * i);
+        const cd *h = (const cd *)(hinv + 128 * (size_t)idx[i]);
+        for (int j = 0; j < 64; j++) x[j] = h[j] * x[j];                     // channel_est.cpp:77-81
+    }
+    return FOA_OK;
+}
+int foa_phase_track_f64(foa_rx *, const double *v, const int32_t *count, size_t n, double *out48)
+{
+    const double *pol = fo_polarity();
+    const int *didx = fo_data_subcarriers(), *pidx = fo_pilot_subcarriers();
+    static const double sgn[4] = { 1.0, 1.0, 1.0, -1.0 };
+    for (size_t i = 0; i < n; i++) {                                         // phase_tracker.cpp:83-99
+        const cd *x = (const cd *)(v + 128 * i);
+        cd pe(0, 0);
+        for (int p = 0; p < 4; p++) {
+            const int pilot = (int)(sgn[p] * pol[count[i] % 127]);
+            pe += (x[pidx[p]] * std::conj(cd((double)pilot, 0.0))) / 4.0;
+        }
+        const double angle = std::atan2(pe.imag(), pe.real());
+        const cd rot(std::cos(-angle), std::sin(-angle));
+        cd *o = (cd *)(out48 + 96 * i);
+        for (int s2 = 0; s2 < 48; s2++) o[s2] = x[didx[s2]] * rot;
+    }
+    return FOA_OK;
+}
+int foa_decode_header_f64(foa_rx *, const double *c48, size_t n, foa_frame_result *res)
+{
+    for (size_t i = 0; i < n; i++) {
+        int rate = -1, length = 0, nsym = 0;
+        const int ok = fo_decode_header((const fo_c64 *)(c48 + 96 * i), &rate, &length, &nsym);
+        res[i].status = ok ? FOA_ST_OK : FOA_ST_HEADER_FAIL; res[i].rate = ok ? rate : -1; res[i].length = ok ? length : 0; res[i].num_symbols = ok ? nsym : 0;
+    }
+    return FOA_OK;
+}
+int foa_decode_data_f64(foa_rx *, const double *car, const uint64_t *off, size_t n, foa_frame_result *res, uint8_t *psdu, size_t slot)
+{
+    for (size_t i = 0; i < n; i++) {
+        std::vector<uint8_t> pay(4096);
+        const int ok = fo_decode_data((const fo_c64 *)(car + 2 * off[i]), res[i].rate, res[i].length, pay.data(), nullptr, nullptr);
+        res[i].status = ok ? FOA_ST_OK : FOA_ST_CRC_FAIL;
+        if (ok && (size_t)res[i].length <= slot) memcpy(psdu + i * slot, pay.data(), (size_t)res[i].length);
+    }
+    return FOA_OK;
+}
+int foa_rx_decode_frames_f64_host(foa_rx *, const double *iq, size_t n_samples, const foa_frame_desc *descs, const int64_t *ends, size_t n_frames,
+                                  uint8_t *psdu, size_t slot_bytes, foa_frame_result *results)
+{
+    if (n_frames == 0) return FOA_OK;
+    fo_decode_batch_v2_f64(iq, (int64_t)n_samples, (const fo_frame_desc *)descs, ends, n_frames, 0, psdu, slot_bytes, (fo_frame_result *)results);
+    return FOA_OK;
+}
 
 }  // extern "C"

@@ -71,6 +71,15 @@ def payloads(psdu, res):
     return [psdu[f, :res[f]["length"]].tobytes() for f in range(res.size) if res[f]["status"] == 0]
 
 
+def alone_misses(s, d, ends, res):
+    """frames only the flush-aware restatement delivers: CRC-passing there, not decodable from their own alignment's samples alone"""
+    n = 0
+    for j in np.nonzero(res["status"] == 0)[0]:
+        r1, _ = po.decode_alignment_f32(s, d[j], end=int(ends[j]))
+        n += int(r1["status"] != 0)
+    return n
+
+
 def run_cpu(lo, hi):
     bad = tot = n_al = flush_hits = 0
     for seed in range(lo, hi):
@@ -79,8 +88,11 @@ def run_cpu(lo, hi):
         psdu, res = po.decode_batch_v2_f32(s, d)
         got = payloads(psdu, res)
         ends = np.append(d["lts1_pos"][1:], s.size).astype(np.int64)
-        _, old = po.decode_batch_f32(s, d, ends)
-        flush_hits += int(np.count_nonzero((res["status"] == 0) & (old["status"] != 0)))      # frames only the flush-aware restatement delivers
+        psdu2, res2 = po.decode_batch_f32(s, d, ends)            # every alignment on its own + the fix-up pass: must be the same thing
+        if not (np.array_equal(res.view(np.int32), res2.view(np.int32)) and np.array_equal(psdu, psdu2)):
+            bad += 1
+            print("DIFF seed", seed, "decode_batch_f32 and decode_batch_v2_f32 disagree", res["status"].tolist(), res2["status"].tolist())
+        flush_hits += alone_misses(s, d, ends, res)
         tot += len(want)
         n_al += d.size
         if got != want:
@@ -99,8 +111,7 @@ def run_gpu(lo, hi):
         opsdu, ores = po.decode_batch_v2_f32(s, d)
         ends = np.append(d["lts1_pos"][1:], s.size).astype(np.int64)
         psdu, res = rx.decode_frames_host(s, d, ends)
-        _, old = po.decode_batch_f32(s, d, ends)
-        flush_hits += int(np.count_nonzero((ores["status"] == 0) & (old["status"] != 0)))
+        flush_hits += alone_misses(s, d, ends, ores)
         tot += len(want)
         n_al += d.size
         ok = np.array_equal(res.view(np.int32), ores.view(np.int32)) and payloads(psdu, res) == want

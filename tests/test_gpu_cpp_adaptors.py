@@ -78,8 +78,8 @@ def test_second_preamble_inside_a_frame(tmp_path, po):
     """frame_decoder.cpp:52-76: a preamble that arrives before the current frame ends.  With a valid SIGNAL the reference
     abandons the frame it was collecting and starts the new one; with an invalid SIGNAL it keeps filling the old frame (from
     the re-aligned symbol windows, fft_symbols.cpp:41-50), which then fails its CRC.  Either way the old frame is never
-    delivered.  The batch path reports it as FOA_ST_TRUNCATED (its extent ends at the next alignment) -- a status the
-    reference has no word for -- and must deliver exactly the reference chain's ordered payload list; so must
+    delivered.  The batch path does the same with the linked alignments (FOA_ST_SUPERSEDED / FOA_ST_CRC_FAIL, result for result the
+    oracle's restatement of those rules) and must deliver exactly the reference chain's ordered payload list; so must
     fun_amd::receiver_chain::process_samples in both of its modes."""
     import numpy as np
     import fun_ofdm_amd as foa
@@ -106,7 +106,9 @@ def test_second_preamble_inside_a_frame(tmp_path, po):
                 got = [psdu[f, :res[f]["length"]].tobytes() for f in range(descs.size) if res[f]["status"] == foa.ST_OK]
                 assert got == want, (seed, case)
                 if case != "none":
-                    assert descs.size == 3 and res[0]["status"] == foa.ST_TRUNCATED and res[0]["rate"] == 0 and res[0]["length"] == 300
+                    # frame A: abandoned when B's valid SIGNAL arrives; with B's SIGNAL garbled it fills on with the re-aligned symbols and fails its CRC
+                    assert descs.size == 3 and res[0]["status"] == (foa.ST_SUPERSEDED if case == "valid" else foa.ST_CRC_FAIL)
+                    assert res[0]["rate"] == 0 and res[0]["length"] == 300
                     assert res[1]["status"] == (foa.ST_OK if case == "valid" else foa.ST_HEADER_FAIL)
                 seen.add((case, tuple(int(x) for x in res["status"])))
                 # fun_amd::receiver_chain (synchronous and in asynchronous batches) over the same capture

@@ -52,3 +52,14 @@ def test_colliding_frames_and_false_alarms_inside_frames_equal_the_block_chain(p
     assert not bad and n_al > 100 and tot > 15, (tot, n_al, bad)
     tot, n_al, bad = stress_collide.run_gpu(2000, 2200)
     assert not bad and n_al > 350, (tot, n_al, bad)
+
+
+def test_placed_tags_partial_vector_flush_and_frames_in_progress_equal_the_blocks(po):
+    """fft_symbols.cpp:41-50 (the partly filled vector pushed when LTS1 arrives mid-symbol), channel_est.cpp:77-81, frame_decoder.cpp:52-88 (a frame
+    fills on with whatever vectors follow its SIGNAL; a valid SIGNAL abandons it) with tags PLACED where they decide a frame's fate (late in its
+    last symbol, a symbol earlier, anywhere, on noise): the device's batch path handed those descriptors against the oracle's BLOCKS fed with
+    the same tag stream (ordered payload list) and against the per-alignment restatement (status, fields, PSDUs of every alignment).  A third
+    of the delivered payloads of these cases exist only because of those rules."""
+    import stress_tags
+    tot, n_al, bad, hits = stress_tags.run_gpu(0, 400)
+    assert bad == 0 and n_al > 2000 and tot > 250 and hits > 80, (tot, n_al, bad, hits)

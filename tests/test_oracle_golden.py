@@ -224,8 +224,8 @@ def test_chain_with_the_timed_simd_viterbi_delivers_the_same_payloads(po):
 def test_batch_restatement_with_the_partial_vector_flush_equals_the_blocks(po):
     """fft_symbols.cpp:41-50 / frame_decoder.cpp:52-88 on GIVEN tag streams: the oracle's blocks fed with made-up alignments (an LTS1 late in a
     frame's last symbol, a symbol earlier, anywhere, on noise) against the per-alignment restatement of the same rules
-    (fo_decode_batch_v2_f32: the specification of the one place where the device's batch path reports FOA_ST_TRUNCATED although the
-    reference may still deliver -- DESIGN.md 2).  On streams without cut frames it is the plain per-alignment decoder."""
+    (fo_decode_batch_v2_f32: what the device's batch path implements for linked alignments).  On streams without cut frames it is the
+    plain per-alignment decoder.  More of this in tests/test_oracle_batch.py."""
     import sys, os
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "manual"))
     import stress_tags
