@@ -227,9 +227,10 @@ def cpu_baseline(iq, descs, ends, pays, wall_s=2.0):
         r = in_frame(n) / d1 / 1e6
         probe_rows.append({"threads": c, "Msamples_per_s": round(r, 1)})
         best = max(best, (r, c))
-    # the smallest count within 10 % of the fastest: threads beyond the container's share of the host add a few per cent at most and halve
-    # the efficiency figure (16 -> 32 threads on a 16-CPU quota: +6 %)
-    cores = min(row["threads"] for row in probe_rows if row["Msamples_per_s"] >= 0.9 * best[0])
+    # the count the probe found FASTEST is the one timed (the headline CPU figure must not sit below what the host achieves); the smallest
+    # count within 10 % of it -- threads beyond the container's share of the host add a few per cent at most -- is reported beside it
+    cores = best[1]
+    frugal = min(row["threads"] for row in probe_rows if row["Msamples_per_s"] >= 0.9 * best[0])
     pool = po.Pool(cores)
     psdu, res = pool.decode(iq, descs, ends, slot_bytes=PAYLOAD)              # warm-up pass = the results the GPU is checked against
     t0 = time.perf_counter()
@@ -253,7 +254,7 @@ def cpu_baseline(iq, descs, ends, pays, wall_s=2.0):
     cp, cr = po.decode_batch_f32(iq[:int(ends[n_chk - 1])], descs[:n_chk], ends[:n_chk], slot_bytes=PAYLOAD, threads=cores)
     equal = bool(np.array_equal(cr.view(np.int32), res[:n_chk].view(np.int32)) and np.array_equal(cp, psdu[:n_chk]))
     out = dict(value=round(value, 1), unit="Msamples/s", cores=cores, threads=cores, cpu_model=cpu_model(), kind="port",
-               affinity_cpus=affinity, cgroup_cpu_quota=quota, thread_count_probe=probe_rows,
+               affinity_cpus=affinity, cgroup_cpu_quota=quota, thread_count_probe=probe_rows, smallest_thread_count_within_10pct=frugal,
                per_thread_single={"value": round(rate1, 2), "unit": "Msamples/s", "alignments": n1, "runs_s": [round(v, 3) for v in runs1]},
                parallel_efficiency=round(value / (cores * rate1), 3),
                protocol="median of 3 repetitions of %d whole passes over the workload's alignments (one warm-up pass before)" % passes,
@@ -475,6 +476,7 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
             dist.barrier()
         kern = {k: 0.0 for k in ("header", "scan", "symbols", "viterbi_fwd", "viterbi_finish", "total")}
         kern_n = 0
+        space = [0.0, 0.0, 0.0, 0]                       # forward passes of consecutive calls: start to start, overlap, own duration (ms, summed), count
         n_gathers[0] = 0
         age = min(4, max(2, args.timing_age))
         t_start = time.perf_counter()
@@ -487,6 +489,9 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
                 for k, v in rx.kernel_ms(age=age).items():
                     kern[k] += v
                 kern_n += 1
+                if i > age and hasattr(rx, "forward_spacing"):
+                    a, b, c = rx.forward_spacing(min(age, 3))
+                    space[0] += a; space[1] += b; space[2] += c; space[3] += 1
             if args.host_jitter_us and i % 5 == 4:
                 time.sleep(args.host_jitter_us * 1e-6)
         d_psdu, d_res = finish_steps()
@@ -506,14 +511,14 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
             t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        return elapsed, kern, kern_n, d_psdu, d_res, n_gathers[0]
+        return elapsed, kern, kern_n, d_psdu, d_res, n_gathers[0], space
 
     # The timed region is repeated (--reps) inside the one run and `value` is the MEDIAN region: a single 20-step region is
     # ~25 ms, and one unlucky arrangement of the overlapping kernels would be the whole measurement.
     regions = [timed_region() for _ in range(max(1, args.reps))]
     order = sorted(range(len(regions)), key=lambda j: regions[j][0])
     med = order[len(order) // 2] if len(order) % 2 else order[len(order) // 2 - 1]      # (even count: the lower middle, a region that was really run)
-    elapsed, kern, kern_n, _, _, _ = regions[med]
+    elapsed, kern, kern_n, _, _, _, space = regions[med]
     d_psdu, d_res = regions[-1][3], regions[-1][4]
     gathers_ok = all(r[5] == args.steps for r in regions)
     rep_ms = [r[0] / args.steps * 1e3 for r in regions]
@@ -654,7 +659,7 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
                 out["repeats"]["step_over_sum_alone"] = round(ms_per_step / alone["total"], 3)
         if args.steps <= 50 and kern_n and not on_cpu:
             kms = {k: v / kern_n for k, v in kern.items()}
-            out["roofline"] = roofline(args, kms, real.size, ms_per_step, piped, probe)
+            out["roofline"] = roofline(args, kms, real.size, ms_per_step, piped, probe, space)
             out["kernel_ms"] = {k: round(v, 4) for k, v in kms.items()}
     wall = {}
     if rank == 0 and not args.no_extra_legs and world == 1 and not on_cpu:
@@ -679,7 +684,7 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
     return out
 
 
-def roofline(args, kms, n_real, ms_per_step, piped, probe):
+def roofline(args, kms, n_real, ms_per_step, piped, probe, space=None):
     """The dominant kernel is the Viterbi forward pass and what binds it is VALU issue, not HBM:
     `bound`/`achieved`/`peak`/`frac` describe that roof; the HBM figures the contract also asks for are the `hbm` object.
 
@@ -709,6 +714,13 @@ def roofline(args, kms, n_real, ms_per_step, piped, probe):
          "frac_at_step_rate": {"achieved": round(alg_ops / t_step / 1e12, 3), "frac": round(alg_ops / t_step / peak, 4),
                                "what": "the same ops / ms_per_step: a throughput figure -- two launches overlap on two hardware queues, so a launch lasts "
                                        "longer than a step (rounds 2-3 reported this one as `frac`)" if piped else "calls in line: equal to frac"}}
+    if space and space[3]:
+        k = space[3]
+        r["launch_overlap"] = {"start_to_start_ms": round(space[0] / k, 4), "overlap_with_the_pass_before_ms": round(space[1] / k, 4), "launch_ms": round(space[2] / k, 4),
+                               "launches_read": k,
+                               "what": "consecutive forward passes run on two streams and overlap: a launch starts every start_to_start_ms (= the step) and lasts launch_ms, "
+                                       "sharing the SIMDs with the tail of the pass before for overlap ms -- `frac` is measured under that self-contention (a launch alone: "
+                                       "kernel_ms_alone), `frac_at_step_rate` is what the machine sustains"}
     if probe:
         live_peak = probe["pk_u16"]["wave_instr_per_s"] * 64 * 2
         r["peak_measured_live"] = {"value": round(live_peak / 1e12, 2), "unit": "T ops/s", "frac": round(alg_ops / t_k / live_peak, 4),
@@ -730,6 +742,17 @@ def roofline(args, kms, n_real, ms_per_step, piped, probe):
         "hbm_bytes_per_launch": {"value": int(tr[0]), "file": tr[1]} if tr else None,
         "l2_hit_frac": {"value": l2[0], "file": l2[1]} if l2 else None,
         "lds_bank_conflict_frac": {"value": bc[0], "file": bc[1]} if bc else None}
+    if nv:
+        # how the fraction decomposes (counts from profiles/, durations live): instructions per two-frame trellis step against the 4.5 the
+        # counted ops need (288 ops per step and frame / 128 ops per packed wave instruction), and how busy the vector pipes are
+        wave_steps = (n_real / 2.0) * 39 * 216
+        av = _profile_json("_pmc_sq.json", "per_launch", fwd_kernel, args.frames, "SQ_ACTIVE_INST_VALU")
+        r["decomposition"] = {"valu_instr_per_two_frame_step": round(nv[0] / wave_steps, 2), "needed_by_the_counted_ops": round(2 * ALG_LANE_OPS_PER_STEP / 128.0, 2),
+                              "clk_per_valu_instr": round(4.0 * av[0] / nv[0], 3) if av else None,
+                              "valu_busy_over_the_step": round(4.0 * av[0] / (N_SIMD * t_step * probe["pk_u16"]["ghz"] * 1e9), 3) if (av and probe) else None,
+                              "valu_busy_saturated_simds": {"value": 0.906, "file": "r04_pmc_forward_saturated.txt"},
+                              "what": "frac ~ (needed / issued instructions) x (4 / clocks per instruction) x pipe occupancy; counts per launch from profiles/ "
+                                      "(same seeded workload, same kernel), the step and the clock live"}
     if nv and probe:
         ach = nv[0] / t_step
         r["valu_issue"] = {"achieved": round(ach / 1e9, 1), "peak": round(probe["pk_u16"]["wave_instr_per_s"] / 1e9, 1), "unit": "G wave-instr/s",
@@ -1073,10 +1096,26 @@ def extra_legs(args, rx, dev, iq, descs, ends, real, psdu_dev_path, res_dev_path
         pk = re.search(r"(\d+) packets", r.stdout)
         if not mm:
             raise RuntimeError((r.stdout + r.stderr)[-300:])
+        # what bounds this leg: every sample crosses PCIe once as complex<float> (8 B) after the host has narrowed it from complex<double> (16 B read)
+        try:
+            hb = torch.empty(1 << 28, dtype=torch.uint8).pin_memory()
+            db = torch.empty(1 << 28, dtype=torch.uint8, device=dev)
+            db.copy_(hb, non_blocking=True); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(4):
+                db.copy_(hb, non_blocking=True)
+            torch.cuda.synchronize()
+            h2d = 4 * hb.numel() / (time.perf_counter() - t0) / 1e9
+            del hb, db
+        except Exception:
+            h2d = None
         legs["process_samples_api"] = {"Msamples_per_s": float(mm.group(1)), "x_realtime_20MSps": round(float(mm.group(1)) / 20.0, 1), "samples": int(mm.group(2)),
                                        "seconds": float(mm.group(3)), "calls": int(mm.group(4)), "chunk": int(mm.group(5)),
                                        "packets": int(pk.group(1)) if pk else None, "frames_sent": n, "runs_Msamples_per_s": [t[0] for t in runs_ps], "protocol": "median of 3 runs",
                                        "same_list_as_batch_path": bool(same_list), "batch_path_payloads": len(batch_list),
+                                       "pcie_ceiling": {"h2d_GBps_pinned_measured": round(h2d, 1) if h2d else None, "Gsamples_per_s": round(h2d / 8.0, 2) if h2d else None,
+                                                        "what": "8 bytes per sample host to device: the leg cannot exceed this whatever the GPU does (the device-resident "
+                                                                "rate is `value`); the host also reads 16 bytes and writes 8 per sample to narrow complex<double>"},
                                        "what": "fun_amd::receiver_chain::process_samples(std::vector<std::complex<double>>) in device mode: 4 Mi-sample "
                                                "batches, 8 helper threads (two core complexes), pre-sync and decode on the GPU, payloads through the callback; capture preloaded, the engine "
                                                "warmed with a copy of the capture's first batches before the clock starts (foa_sim --warm-batches)"}

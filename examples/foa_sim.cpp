@@ -19,8 +19,9 @@
 // radio's pace: 20; the engine's latency under a given load); --latency PITCH LEAD SAMPLES reports how long after the call that
 // delivered a frame's last sample its payload came back (frame k of the capture occupies samples [k*PITCH + LEAD, k*PITCH + LEAD +
 // SAMPLES) and carries k in its first four payload bytes, little-endian: tools/bench_latency.py builds such captures).  --longest N (device
-// mode, --preload): the longest frame the stream will hold, in samples + 192 (option "stream_longest"): the engine then waits N samples
-// instead of 110 592 before it decodes a frame -- 5.5 ms less latency at the air's own pace for a receiver that knows its traffic.
+// mode, --preload): the longest frame the stream will hold, in samples + 192 (option "stream_longest"): every batch then re-synchronises
+// N + 2048 samples of carry instead of 112 640 -- most of a small batch's cost (a frame's latency no longer depends on it: a frame is
+// decoded by the first batch that holds its last sample).
 //
 // build:  g++ -O2 -std=c++17 examples/foa_sim.cpp -Iinclude -Lfun_ofdm_amd/csrc -lfun_ofdm_amd -lpthread -o foa_sim
 #include <algorithm>
@@ -144,7 +145,7 @@ int main(int argc, char **argv)
                 for (; fed_q < quiet; fed_q += (size_t)chunk) chain.process_samples(std::vector<std::complex<double> >((size_t)chunk));
                 // the capture proper must start on a multiple of the reference's call size: timing_sync.cpp:99 is decided by absolute stream
                 // index (include/fun_ofdm_amd.h), and the payload list is compared with a decode of the capture from index 0
-                const size_t pad = (4096 - (fed_w + fed_q) % 4096) % 4096;
+                const size_t pad = (4096 - (512 + fed_w + fed_q) % 4096) % 4096;      // (512: the priming call above)
                 if (pad) chain.process_samples(std::vector<std::complex<double> >(pad));
                 for (int idle = 0; idle < 200;) {                    // until nothing has come back for a while (empty calls only poll)
                     std::this_thread::sleep_for(std::chrono::microseconds(200));

@@ -44,6 +44,12 @@ struct SpecSym {
     int32_t fresh;       // 64: a complete window; < 64: samples fresh .. 63 come from the window before (fft_symbols.cpp:46-50)
 };
 
+// The stream engines' state between batches (stream_engine.h), carried on the device: the stream index of the STS_END sample of the first
+// alignment not decided yet, and the phasor timing_sync had in force before it (timing_sync.cpp:113-125: m_phase_acc).
+struct StreamState { int64_t lo_abs; double c, s; };
+constexpr int64_t kStreamSettle = 192;     // an STS_END within this many samples of a buffer's end is left to the next batch: timing_sync looks
+                                           // 160 samples ahead of it (timing_sync.cpp:69-113), frame_detector's windows 32 behind
+
 // rates.h:52-196 as a device table
 struct RateRow {
     int32_t rate_field, cbps, dbps, bpsc, punct, numbits;

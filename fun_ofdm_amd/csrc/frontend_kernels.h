@@ -18,16 +18,13 @@ namespace foa {
 // from SIGNAL on, and the partly filled vector it pushes when the NEXT alignment's LTS1 arrives past a window's cyclic prefix.
 // =================================================================================================
 // S: float2 (the raw stream; the descriptor's phasors rotate it) or double2 (a stream timing_sync has rotated already: phasors 1).
+// Alignment f of [0, n_total) by one wave; lds / dem / decs: the block's LDS.
 template <typename S>
-__global__ __launch_bounds__(64) void k_header(const S *__restrict__ iq, const foa_frame_desc *__restrict__ descs,
-                                               const int64_t *__restrict__ ends, int64_t n_samples, int n_total,
-                                               FrameInfo *__restrict__ info, double2 *__restrict__ hinv, double2 *__restrict__ eq_tap)
+__device__ __forceinline__ void header_alignment(const S *__restrict__ iq, const foa_frame_desc *__restrict__ descs, const int64_t *__restrict__ ends,
+                                                 int64_t n_samples, int f, int n_total, FrameInfo *__restrict__ info, double2 *__restrict__ hinv,
+                                                 double2 *__restrict__ eq_tap, cpx *lds, uint8_t *dem, uint64_t *decs)
 {
-    __shared__ cpx lds[64];
-    __shared__ uint8_t dem[48];
-    __shared__ uint64_t decs[24];
-    const int f = blockIdx.x, lane = threadIdx.x;
-    if (f >= n_total) return;
+    const int lane = threadIdx.x;
     const foa_frame_desc d = descs[f];
     const int64_t e_raw = ends[f], end = min(e_raw, n_samples), p = d.lts1_pos;      // nothing is read beyond the stream, whatever the caller's ends say
     // linked: the stream goes on into the next alignment of the call (its LTS1 tag is where this one's samples end)
@@ -87,6 +84,34 @@ __global__ __launch_bounds__(64) void k_header(const S *__restrict__ iq, const f
         }
         info[f] = fi;
     }
+}
+
+template <typename S>
+__global__ __launch_bounds__(64) void k_header(const S *__restrict__ iq, const foa_frame_desc *__restrict__ descs,
+                                               const int64_t *__restrict__ ends, int64_t n_samples, int n_total,
+                                               FrameInfo *__restrict__ info, double2 *__restrict__ hinv, double2 *__restrict__ eq_tap)
+{
+    __shared__ cpx lds[64];
+    __shared__ uint8_t dem[48];
+    __shared__ uint64_t decs[24];
+    const int f = blockIdx.x;
+    if (f >= n_total) return;
+    header_alignment(iq, descs, ends, n_samples, f, n_total, info, hinv, eq_tap, lds, dem, decs);
+}
+
+// ---- the stream engines' look-ahead (stream_engine.h): which alignments of a batch buffer can be decided with the samples there are? ----
+// The same header work over alignments range[0] .. range[1] - 1 of a buffer whose alignment structure is final up to sample n_samples
+// (device-side range: the grid is an upper bound), into the engine's own records ...
+__global__ __launch_bounds__(64) void k_header_range(const float2 *__restrict__ iq, const foa_frame_desc *__restrict__ descs, const int64_t *__restrict__ ends,
+                                                     int64_t n_samples, const int32_t *__restrict__ range, FrameInfo *__restrict__ info,
+                                                     double2 *__restrict__ hinv)
+{
+    __shared__ cpx lds[64];
+    __shared__ uint8_t dem[48];
+    __shared__ uint64_t decs[24];
+    const int f = range[0] + (int)blockIdx.x;
+    if (f >= range[1]) return;
+    header_alignment(iq, descs, ends, n_samples, f, range[1], info, hinv, (double2 *)nullptr, lds, dem, decs);
 }
 
 // =================================================================================================
@@ -273,6 +298,31 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_apply(FrameInfo *__restrict
             sym2frame[a + n_plain + i] = -2 - (int32_t)(sp0 + i);
             k++;
         }
+    }
+}
+
+// ... and the first of them that cannot: FOA_ST_TRUNCATED is "the samples ended before this alignment's frame was complete", i.e. it and
+// everything behind it wait for the next batch (unless the stream is over: final).  One wave.
+// state: { stream index of the STS_END sample of the first alignment not decided yet, phasor in force before it } -- carried from batch to
+// batch on the device.  sel: { STS_END candidates, alignments found, first alignment of the batch, how many it decides, context behind them }.
+__global__ __launch_bounds__(64) void k_stream_resolve(const FrameInfo *__restrict__ info, const foa_frame_desc *__restrict__ descs, const int32_t *__restrict__ range,
+                                                       const int32_t *__restrict__ sy_n, int64_t start_abs, int64_t hz_abs, int final, StreamState *__restrict__ state,
+                                                       int32_t *__restrict__ sel)
+{
+    const int lane = threadIdx.x, i0 = range[0], i1 = range[1];
+    int first = i1;
+    if (!final)
+        for (int a = i0 + lane; a < i1; a += 64) {
+            int st = info[a].status;
+            if (info[a].flags & kInfoCross) st = cross_walk(info, a);
+            if (st == FOA_ST_TRUNCATED) { first = a; break; }
+        }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) first = min(first, __shfl_xor(first, o));
+    if (lane == 0) {
+        sel[0] = sy_n[0]; sel[1] = sy_n[3]; sel[2] = i0; sel[3] = first - i0; sel[4] = i1 - first;
+        state->lo_abs = first < i1 ? start_abs + descs[first].rot_start : hz_abs;
+        if (first > i0) { state->c = descs[first - 1].c; state->s = descs[first - 1].s; }
     }
 }
 

@@ -30,6 +30,14 @@ void foa::launch_finish3(hipStream_t st, hipStream_t st_fin, const FrameInfo *in
     hipLaunchKernelGGL(k_tb_finish, dim3((nf + 63) / 64), dim3(64), 0, st_fin, info, nf, dec, decoded, tb_state, S, psdu, slot_bytes, results);
 }
 
+void foa::launch_stream_resolve(hipStream_t st, const float *d_iq, int64_t n_eff, const foa_frame_desc *descs, const int64_t *ends, const int32_t *range,
+                                const int32_t *sy_n, int64_t start_abs, int64_t hz_abs, bool final, StreamState *state, FrameInfo *info, double2 *hinv, int32_t *sel,
+                                unsigned grid)
+{
+    hipLaunchKernelGGL(k_header_range, dim3(grid), dim3(64), 0, st, (const float2 *)d_iq, descs, ends, n_eff, range, info, hinv);
+    hipLaunchKernelGGL(k_stream_resolve, dim3(1), dim3(64), 0, st, info, descs, range, sy_n, start_abs, hz_abs, final ? 1 : 0, state, sel);
+}
+
 static hipStream_t lane_stream(foa_rx *rx, int lane) { return lane == 0 ? rx->stream : lane == 1 ? rx->stream4 : lane == 2 ? rx->stream5 : rx->stream6; }
 
 int foa::inputs_queued(foa_rx *rx, hipStream_t cs)

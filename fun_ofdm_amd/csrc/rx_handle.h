@@ -185,14 +185,24 @@ void launch_finish3(hipStream_t st, hipStream_t st_fin, const FrameInfo *info, i
                     const int64_t *totals, uint16_t *tb_state, size_t max_segs, int S, int L, uint8_t *psdu, size_t slot_bytes,
                     foa_frame_result *results, hipEvent_t walk_done = nullptr);
 
+// ... (rx_decode.hip) and how many of them, in order, can be DECIDED with the samples up to n_eff: LTS + SIGNAL of each (k_header_range into
+// the engine's own records info / hinv, `grid` >= the range's length) and the first whose frame would run into the end (k_stream_resolve).
+// sel (device, 5 ints): { STS_END candidates, alignments found, first of the batch, how many it decides, context alignments behind them };
+// *state moves on to the first undecided alignment.
+void launch_stream_resolve(hipStream_t st, const float *d_iq, int64_t n_eff, const foa_frame_desc *descs, const int64_t *ends, const int32_t *range,
+                           const int32_t *sy_n, int64_t start_abs, int64_t hz_abs, bool final, StreamState *state, FrameInfo *info, double2 *hinv, int32_t *sel,
+                           unsigned grid);
+
 // ---- rx_sync.hip ----
 int upload_tables_sync(const DeviceTables &t);
 // The launching half of foa_rx_sync_dev: every kernel of the pre-sync stage queued on the side stream, nothing waited for.  The counts
 // stay on the device in rx->sy_n ([0] STS_END candidates, [3] alignments found); *ccap_out = the candidate capacity they are checked
 // against.  origin: stream index of d_iq[0].
 int sync_dev_issue(foa_rx *rx, const float *d_iq, size_t n_samples, foa_frame_desc *d_descs, int64_t *d_ends, size_t cap, int32_t *ccap_out, int64_t origin);
-// k_stream_select (sync_kernels.h) for the stream engines: which alignments of a batch buffer are this batch's
-void launch_stream_select(hipStream_t st, foa_frame_desc *descs, const int32_t *sy_n, int32_t cap, int64_t lo, int64_t hi, double *prev_cs, int32_t *sel);
+// The stream engines' look-ahead for one batch buffer, queued on st behind the buffer's pre-sync: which alignments are still to be
+// decided and final in their tags (k_stream_range: STS_END in [state->lo_abs, hz_abs), first one's c_prev patched from the state) ...
+void launch_stream_range(hipStream_t st, foa_frame_desc *descs, const int32_t *sy_n, int32_t cap, int64_t start_abs, int64_t hz_abs, const StreamState *state,
+                         int32_t *range);
 
 // ---- rx_stage.hip / rx_tx.hip ----
 int upload_tables_stage(const DeviceTables &t);

@@ -332,6 +332,21 @@ int foa_rx_kernel_ms_age(foa_rx *rx, int age, float out_ms[6])
     return kernel_ms_of(rx, w, out_ms);
 }
 
+int foa_rx_forward_spacing_ms(foa_rx *rx, int age, float out[3])
+{
+    if (!rx || !out) return fail(FOA_E_INVALID, "NULL argument");
+    if (age < 1 || age > 3) return fail(FOA_E_INVALID, "age must lie in 1 .. 3");
+    WorkSet *w = rx->w;
+    for (int i = 0; i < age && w; i++) w = w->before;
+    WorkSet *b = w ? w->before : nullptr;
+    if (!w || !b || !w->piped || !b->piped || w == rx->w) return fail(FOA_E_STATE, "no two pipelined decode calls of that age");
+    HIP_TRY(hipEventSynchronize(w->ev[5]));
+    HIP_TRY(hipEventElapsedTime(&out[0], b->ev[7], w->ev[7]));          // start to start
+    HIP_TRY(hipEventElapsedTime(&out[1], w->ev[7], b->ev[5]));          // > 0: the earlier pass was still running when this one started
+    HIP_TRY(hipEventElapsedTime(&out[2], w->ev[7], w->ev[5]));          // this pass's own duration
+    return FOA_OK;
+}
+
 int foa_rx_probe_issue(foa_rx *rx, double out[6])
 {
     if (!rx || !out) return fail(FOA_E_INVALID, "NULL argument");

@@ -13,9 +13,10 @@ int foa::upload_tables_sync(const DeviceTables &t)
     return FOA_OK;
 }
 
-void foa::launch_stream_select(hipStream_t st, foa_frame_desc *descs, const int32_t *sy_n, int32_t cap, int64_t lo, int64_t hi, double *prev_cs, int32_t *sel)
+void foa::launch_stream_range(hipStream_t st, foa_frame_desc *descs, const int32_t *sy_n, int32_t cap, int64_t start_abs, int64_t hz_abs, const StreamState *state,
+                              int32_t *range)
 {
-    hipLaunchKernelGGL(k_stream_select, dim3(1), dim3(64), 0, st, descs, sy_n, cap, lo, hi, prev_cs, sel);
+    hipLaunchKernelGGL(k_stream_range, dim3(1), dim3(64), 0, st, descs, sy_n, cap, start_abs, hz_abs, state, range);
 }
 
 int foa::sync_dev_issue(foa_rx *rx, const float *d_iq, size_t n_samples, foa_frame_desc *d_descs, int64_t *d_ends, size_t cap, int32_t *ccap_out, int64_t origin)

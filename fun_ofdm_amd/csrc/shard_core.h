@@ -11,18 +11,19 @@
 //   * the CARRY: buffer k = the last C samples before batch k + the batch (stream_engine.h).  Here the host keeps those C samples in
 //     page-locked memory (one carry per staging slot, built when the batch before is staged) and every buffer is two host-to-device
 //     copies -- no device ever reads another device's memory;
-//   * the PHASOR timing_sync left in force (the (c, s) of the last alignment decoded so far, patched into the first descriptor of the next
-//     batch: timing_sync.cpp:113-125).  It is a chain through the batches in stream order, hence through the devices in turn: batch k's
-//     selection kernel is queued only once batch k-1's has finished and handed its phasor to the host (sixteen bytes), which passes it
-//     on.  Everything before the selection (upload, the frame_detector / timing_sync kernels over the whole buffer) and everything after it
-//     (the decode call) runs without waiting for any other device.
+//   * the CHAIN STATE: where the first alignment not decided yet begins, and the phasor timing_sync left in force before it
+//     (timing_sync.cpp:113-125) -- 24 bytes.  It is a chain through the batches in stream order, hence through the devices in turn: batch
+//     k's look-ahead (which of the buffer's alignments can be decided with the samples there are: stream_engine.h) is queued as soon as
+//     batch k-1's has finished and handed its state to the host, which passes it on -- on a stream of its own on the device, behind
+//     nothing but the buffer's own pre-sync.  Everything before it (upload, the frame_detector / timing_sync kernels over the whole
+//     buffer) and everything after it (the decode call) runs without waiting for any other device.
 // Dev (one device) provides, all non-blocking unless said otherwise:
 //   int  upload(int slot, const float *carry, const float *batch, int64_t n_new, int64_t start)   H2D of carry (C samples) + batch into the
 //                                                     device buffer of `slot`, then the pre-sync kernels over it; start = stream index of the buffer's first sample
-//   int  select(int slot, int64_t lo, int64_t hi, const double prev[2])   after the pre-sync: pick the alignments whose STS_END lies in [lo, hi)
-//                                                     (buffer-relative), patch `prev` into the first, report the last one's phasor
-//   int  selected(int slot, double last[2])           1: through (last = phasor in force after this batch: prev if it selected nothing), 0: not yet, < 0 error
-//   int  decode(int slot, int64_t n_new, uint64_t *handle)    queue the decode of the selected alignments (may block on the device's own pipeline)
+//   int  select(int slot, int64_t n_eff, bool final, const ChainState &in)   behind the pre-sync: decide, from in.lo_abs on, the alignments that can be
+//                                                     decided with the buffer's first n_eff samples (final: all of them)
+//   int  selected(int slot, ChainState *out)          1: through (*out = the state after this batch), 0: not yet, < 0 error
+//   int  decode(int slot, int64_t n_new, uint64_t *handle)    queue the decode of the alignments selected (may block on the device's own pipeline)
 //   int  collect(uint64_t handle, bool wait, StreamReady *out)    1 done, 0 not yet, < 0 error
 #pragma once
 
@@ -33,6 +34,9 @@
 #include "stream_core.h"
 
 namespace foa {
+
+struct ChainState { int64_t lo_abs; double c, s; };         // (= StreamState of the device code, foa_common.h)
+constexpr int64_t kShardSettle = 192;                       // (= kStreamSettle: tags this close to a buffer's end are not final)
 
 template <typename Dev>
 class ShardBackend {
@@ -56,11 +60,11 @@ public:
     {
         const int64_t k = n_staged_;
         Info &in = info_[slot];
-        in.batch = k; in.dev = device_of_batch(k); in.n_new = n_new; in.sel_queued = false; in.sel_done = false;
+        in = Info();
+        in.batch = k; in.dev = device_of_batch(k); in.n_new = n_new; in.final = final;
         const int64_t pushed = staged_samples_ + n_new;
         const int64_t start = pushed - n_new - C_;                      // stream index of the buffer's first sample
-        const int64_t cut = final ? pushed + 1 : pushed - L_;           // this batch decodes the alignments whose STS_END lies in [cut_prev, cut)
-        in.lo = cut_prev_ - start; in.hi = cut - start;
+        in.n_eff = final ? C_ + n_new : C_ + n_new - kShardSettle;      // the buffer's tags are final up to here
         // the carry of the NEXT batch, while this batch's samples are still in their staging slot (the slot is the caller's again once
         // this batch has been submitted): the last C samples of (this carry ++ this batch)
         float *next = carry_[(slot + 1) % kSlots];
@@ -71,29 +75,42 @@ public:
             memcpy(next + 2 * (C_ - n_new), stage_[slot], (size_t)n_new * 8);
         }
         const int rc = devs_[in.dev]->upload(slot, carry_[slot], stage_[slot], n_new, start);
-        cut_prev_ = cut; staged_samples_ = pushed; n_staged_++;
+        in.staged = rc == 0;
+        staged_samples_ = pushed; n_staged_++;
+        if (rc == 0) advance_chain();
         return rc;
     }
 
-    // the core asks this for the OLDEST staged batch only, so the phasor chain advances in stream order
+    // The chain: the look-ahead of batch chain_next_ is queued the moment that batch is staged and the batch before has handed its state on
+    // -- not when the core gets round to asking about it (the core asks about the OLDEST staged batch only, i.e. after the batch before has
+    // been submitted: with a decode call's worth of host work in between, every batch paid that on the chain).
+    void advance_chain()
+    {
+        for (;;) {
+            int slot = -1;
+            for (int i = 0; i < kSlots; i++) if (info_[i].batch == chain_next_ && info_[i].staged) { slot = i; break; }
+            if (slot < 0) return;
+            Info &in = info_[slot];
+            if (in.sel_done) return;                                    // (cannot happen: chain_next_ moves on when a selection is through)
+            if (!in.sel_queued) {
+                if (devs_[in.dev]->select(slot, in.n_eff, in.final, state_) != 0) { in.sel_done = true; in.failed = true; chain_next_ = in.batch + 1; continue; }   // (submit reports it)
+                in.sel_queued = true;
+                return;
+            }
+            ChainState out;
+            const int r = devs_[in.dev]->selected(slot, &out);
+            if (r == 0) return;
+            if (r < 0) in.failed = true;
+            else state_ = out;
+            in.sel_done = true;
+            chain_next_ = in.batch + 1;
+        }
+    }
+
     bool uploaded(int slot)
     {
-        Info &in = info_[slot];
-        if (in.sel_done) return true;
-        if (!in.sel_queued) {
-            if (in.batch != chain_next_) return false;                  // (cannot happen: batches are staged and asked about in order)
-            if (devs_[in.dev]->select(slot, in.lo, in.hi, phasor_) != 0) { in.sel_done = true; in.failed = true; return true; }   // (submit reports it)
-            in.sel_queued = true;
-            return false;
-        }
-        double last[2];
-        const int r = devs_[in.dev]->selected(slot, last);
-        if (r == 0) return false;
-        if (r < 0) in.failed = true;
-        else { phasor_[0] = last[0]; phasor_[1] = last[1]; }
-        in.sel_done = true;
-        chain_next_ = in.batch + 1;
-        return true;
+        advance_chain();
+        return info_[slot].sel_done;
     }
 
     int submit(int slot, int64_t n_new, bool final, uint64_t *handle)
@@ -121,14 +138,14 @@ public:
     }
 
 private:
-    struct Info { int64_t batch = -1, n_new = 0, lo = 0, hi = 0; int dev = 0; bool sel_queued = false, sel_done = false, failed = false; };
+    struct Info { int64_t batch = -1, n_new = 0, n_eff = 0; int dev = 0; bool staged = false, final = false, sel_queued = false, sel_done = false, failed = false; };
     struct Flight { uint64_t handle; int dev; uint64_t dev_handle; };
     std::vector<Dev *> devs_;
     const int64_t B_, C_, L_;
     float *stage_[kSlots], *carry_[kSlots];
     Info info_[kSlots];
-    int64_t n_staged_ = 0, n_submitted_ = 0, staged_samples_ = 0, cut_prev_ = 0, chain_next_ = 0;
-    double phasor_[2] = { 1.0, 0.0 };              // timing_sync's m_phase_acc before the first frame: 0
+    int64_t n_staged_ = 0, n_submitted_ = 0, staged_samples_ = 0, chain_next_ = 0;
+    ChainState state_ = { 0, 1.0, 0.0 };           // nothing decided yet; timing_sync's m_phase_acc before the first frame: 0
     std::deque<Flight> flight_;
     uint64_t next_handle_ = 1;
 };

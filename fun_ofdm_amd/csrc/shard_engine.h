@@ -17,16 +17,21 @@ struct ShardDev {
     DevBuf<float> dev[foa::kStreamBufs];
     DevBuf<uint8_t> d_desc[foa::kStreamBufs];
     DevBuf<int64_t> d_ends[foa::kStreamBufs];
-    hipEvent_t in_done[foa::kStreamBufs] = {}, sel_done[foa::kStreamBufs] = {};
+    hipEvent_t in_done[foa::kStreamBufs] = {}, sel_done[foa::kStreamBufs] = {}, sync_done[foa::kStreamBufs] = {};
     hipStream_t st_in = nullptr;
-    DevBuf<double> d_prev;
+    hipStream_t st_sel = nullptr;                    // the chain's own stream: a batch's look-ahead waits for that batch's pre-sync and nothing else -- on the
+                                                     // side stream it would sit behind the pre-syncs of the device's NEXT batches, which are staged ahead
+    DevBuf<StreamState> state;                       // the chain state as handed in, moved on by the look-ahead
+    DevBuf<FrameInfo> la_info;                       // the look-ahead's own alignment records / channel estimates (the chain is serial: one batch at a time)
+    DevBuf<double2> la_hinv;
+    DevBuf<int32_t> la_range;
     DevBuf<int32_t> sel_dev;
     DevBuf<int32_t> syn_dev;                         // per buffer: the pre-sync's counts (rx->sy_n) as they stood when ITS kernels finished -- the
-                                                     // selection is queued later, possibly behind the pre-sync of the handle's next batch, which reuses the scratch
-    int32_t *sel = nullptr;                          // page-locked: per buffer { STS_END candidates, alignments found, first of the batch, count }
-    double *ph = nullptr;                            // page-locked: per buffer { phasor handed in (2), phasor in force after the batch (2) }
+                                                     // look-ahead is queued later, possibly after the pre-sync of the handle's next batch, which reuses the scratch
+    int32_t *sel = nullptr;                          // page-locked: per buffer { STS_END candidates, alignments found, first of the batch, how many it decides, context behind them }
+    StreamState *st_pin = nullptr;                   // page-locked: per buffer { state handed in, state after the batch }
     int32_t ccap[foa::kStreamBufs] = {};
-    int64_t n_buf[foa::kStreamBufs] = {};
+    int64_t n_buf[foa::kStreamBufs] = {}, n_eff[foa::kStreamBufs] = {}, start_abs[foa::kStreamBufs] = {};
     struct Fl { uint64_t handle, ticket; size_t n_frames; };
     std::deque<Fl> flight;
     uint64_t next_handle = 1;
@@ -52,13 +57,18 @@ struct ShardDev {
             if (!rc) rc = d_ends[i].ensure(desc_cap);
             if (!rc && hipEventCreateWithFlags(&in_done[i], hipEventDisableTiming) != hipSuccess) rc = fail(FOA_E_HIP, "hipEventCreate failed");
             if (!rc && hipEventCreateWithFlags(&sel_done[i], hipEventDisableTiming) != hipSuccess) rc = fail(FOA_E_HIP, "hipEventCreate failed");
+            if (!rc && hipEventCreateWithFlags(&sync_done[i], hipEventDisableTiming) != hipSuccess) rc = fail(FOA_E_HIP, "hipEventCreate failed");
         }
         if (!rc && hipStreamCreateWithFlags(&st_in, hipStreamNonBlocking) != hipSuccess) rc = fail(FOA_E_HIP, "hipStreamCreate failed");
-        if (!rc && hipHostMalloc((void **)&sel, (size_t)foa::kStreamBufs * 4 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) rc = fail(FOA_E_NOMEM, "hipHostMalloc failed");
-        if (!rc && hipHostMalloc((void **)&ph, (size_t)foa::kStreamBufs * 4 * sizeof(double), hipHostMallocDefault) != hipSuccess) rc = fail(FOA_E_NOMEM, "hipHostMalloc failed");
-        if (!rc) rc = sel_dev.ensure((size_t)foa::kStreamBufs * 4);
+        if (!rc && hipStreamCreateWithFlags(&st_sel, hipStreamNonBlocking) != hipSuccess) rc = fail(FOA_E_HIP, "hipStreamCreate failed");
+        if (!rc && hipHostMalloc((void **)&sel, (size_t)foa::kStreamBufs * 8 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) rc = fail(FOA_E_NOMEM, "hipHostMalloc failed");
+        if (!rc && hipHostMalloc((void **)&st_pin, (size_t)foa::kStreamBufs * 2 * sizeof(StreamState), hipHostMallocDefault) != hipSuccess) rc = fail(FOA_E_NOMEM, "hipHostMalloc failed");
+        if (!rc) rc = sel_dev.ensure((size_t)foa::kStreamBufs * 8);
         if (!rc) rc = syn_dev.ensure((size_t)foa::kStreamBufs * 8);
-        if (!rc) rc = d_prev.ensure(2);
+        if (!rc) rc = la_range.ensure((size_t)foa::kStreamBufs * 2);
+        if (!rc) rc = la_info.ensure(desc_cap + 1);
+        if (!rc) rc = la_hinv.ensure((desc_cap + 1) * 64);
+        if (!rc) rc = state.ensure(1);
         // everything a batch will need is allocated here, not by the first batches that need it (stream_engine.h)
         if (!rc) rc = foa_rx_reserve(rx, (size_t)(foa::kStreamCarry + B), (size_t)((foa::kStreamCarry + B) / 1200 + 64));
         if (!rc) { rx->depth_saved = rx->depth; rx->depth = (B <= ((int64_t)1 << 20) && rx->max_depth >= 4) ? 4 : 2; }      // (as the single-device engine: small batches want four loops in flight)
@@ -74,14 +84,16 @@ struct ShardDev {
             dev[i].release(); d_desc[i].release(); d_ends[i].release();
             if (in_done[i]) (void)hipEventDestroy(in_done[i]);
             if (sel_done[i]) (void)hipEventDestroy(sel_done[i]);
-            in_done[i] = sel_done[i] = nullptr;
+            if (sync_done[i]) (void)hipEventDestroy(sync_done[i]);
+            in_done[i] = sel_done[i] = sync_done[i] = nullptr;
         }
         if (st_in) (void)hipStreamDestroy(st_in);
-        st_in = nullptr;
+        if (st_sel) (void)hipStreamDestroy(st_sel);
+        st_in = st_sel = nullptr;
         if (sel) (void)hipHostFree(sel);
-        if (ph) (void)hipHostFree(ph);
-        sel = nullptr; ph = nullptr;
-        sel_dev.release(); d_prev.release(); syn_dev.release();
+        if (st_pin) (void)hipHostFree(st_pin);
+        sel = nullptr; st_pin = nullptr;
+        sel_dev.release(); state.release(); syn_dev.release(); la_info.release(); la_hinv.release(); la_range.release();
     }
 
     // ---- the Dev interface of shard_core.h (submitter thread only) ----
@@ -96,49 +108,56 @@ struct ShardDev {
         HIP_TRY(hipEventRecord(in_done[k], st_in));
         hipStream_t st = side_stream(rx);
         HIP_TRY(hipStreamWaitEvent(st, in_done[k], 0));
-        n_buf[k] = C + n_new;
+        n_buf[k] = C + n_new; start_abs[k] = start;
         int rc = sync_dev_issue(rx, d, (size_t)n_buf[k], (foa_frame_desc *)d_desc[k].p, d_ends[k].p, desc_cap, &ccap[k], start);
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(syn_dev.p + 8 * k, rx->sy_n.p, 8 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipEventRecord(sync_done[k], st));
         HIP_TRY(hipGetLastError());
         return FOA_OK;
     }
-    int select(int k, int64_t lo, int64_t hi, const double prev[2]) { return keep(select_impl(k, lo, hi, prev)); }
-    int select_impl(int k, int64_t lo, int64_t hi, const double prev[2])
+    int select(int k, int64_t n_eff_k, bool final, const foa::ChainState &in) { return keep(select_impl(k, n_eff_k, final, in)); }
+    int select_impl(int k, int64_t n_eff_k, bool final, const foa::ChainState &in)
     {
         HIP_TRY(enter_device(rx->device));
-        hipStream_t st = side_stream(rx);
-        ph[4 * k] = prev[0]; ph[4 * k + 1] = prev[1];
-        HIP_TRY(hipMemcpyAsync(d_prev.p, ph + 4 * k, 2 * sizeof(double), hipMemcpyHostToDevice, st));
-        launch_stream_select(st, (foa_frame_desc *)d_desc[k].p, syn_dev.p + 8 * k, (int32_t)desc_cap, lo, hi, d_prev.p, sel_dev.p + 4 * k);
-        HIP_TRY(hipMemcpyAsync(sel + 4 * k, sel_dev.p + 4 * k, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(ph + 4 * k + 2, d_prev.p, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+        hipStream_t st = st_sel;
+        HIP_TRY(hipStreamWaitEvent(st, sync_done[k], 0));            // this buffer's pre-sync (and its counts in syn_dev): nothing else
+        n_eff[k] = n_eff_k;
+        st_pin[2 * k].lo_abs = in.lo_abs; st_pin[2 * k].c = in.c; st_pin[2 * k].s = in.s;
+        HIP_TRY(hipMemcpyAsync(state.p, st_pin + 2 * k, sizeof(StreamState), hipMemcpyHostToDevice, st));
+        const int64_t hz_abs = start_abs[k] + n_eff_k;
+        launch_stream_range(st, (foa_frame_desc *)d_desc[k].p, syn_dev.p + 8 * k, (int32_t)desc_cap, start_abs[k], hz_abs, state.p, la_range.p + 2 * k);
+        launch_stream_resolve(st, dev[k].p, n_eff_k, (const foa_frame_desc *)d_desc[k].p, d_ends[k].p, la_range.p + 2 * k, syn_dev.p + 8 * k, start_abs[k], hz_abs, final,
+                              state.p, la_info.p, la_hinv.p, sel_dev.p + 8 * k, (unsigned)desc_cap);
+        HIP_TRY(hipMemcpyAsync(sel + 8 * k, sel_dev.p + 8 * k, 5 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(st_pin + 2 * k + 1, state.p, sizeof(StreamState), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipEventRecord(sel_done[k], st));
         HIP_TRY(hipGetLastError());
         return FOA_OK;
     }
-    int selected(int k, double last[2])
+    int selected(int k, foa::ChainState *out)
     {
         (void)hipSetDevice(rx->device);                  // (the submitter thread's current device is whichever handle it served last)
         const hipError_t e = hipEventQuery(sel_done[k]);
         if (e == hipErrorNotReady) return 0;
         if (e != hipSuccess) return keep(fail(FOA_E_HIP, "hipEventQuery: %s", hipGetErrorString(e)));
-        last[0] = ph[4 * k + 2]; last[1] = ph[4 * k + 3];
+        out->lo_abs = st_pin[2 * k + 1].lo_abs; out->c = st_pin[2 * k + 1].c; out->s = st_pin[2 * k + 1].s;
         return 1;
     }
     int decode(int k, int64_t n_new, uint64_t *handle) { (void)n_new; return keep(decode_impl(k, handle)); }
     int decode_impl(int k, uint64_t *handle)
     {
         HIP_TRY(enter_device(rx->device));
-        const int32_t *q = sel + 4 * k;
+        const int32_t *q = sel + 8 * k;
         if (q[0] > ccap[k]) return fail(FOA_E_NOMEM, "too many STS_END candidates (%d)", q[0]);
         if ((size_t)q[1] > desc_cap) return fail(FOA_E_INVALID, "internal: %d alignments in one batch buffer", q[1]);
-        const size_t i0 = (size_t)q[2], m = (size_t)q[3];
+        const size_t i0 = (size_t)q[2], m = (size_t)q[3], n_ctx = (size_t)q[4];
         Fl fl;
         fl.handle = next_handle++; fl.n_frames = m; fl.ticket = 0;
         if (m) {
-            const size_t n_ctx = std::min((size_t)q[1], desc_cap) - (i0 + m);          // (context for the batch's cut frames, as in stream_engine.h)
-            int rc = stream_decode_batch(rx, dev[k].p, (size_t)n_buf[k], (const foa_frame_desc *)d_desc[k].p + i0, d_ends[k].p + i0, m, n_ctx, slot_bytes, &fl.ticket, nullptr);
+            // (context for the batch's cut frames, and the stream's end for its decisions, as in stream_engine.h.  The host has SEEN the
+            // look-ahead's event -- selected() -- so the descriptor it patched is in place)
+            int rc = stream_decode_batch(rx, dev[k].p, (size_t)n_eff[k], (const foa_frame_desc *)d_desc[k].p + i0, d_ends[k].p + i0, m, n_ctx, slot_bytes, &fl.ticket, nullptr);
             if (rc) return rc;
             alignments.fetch_add(m);
         }
@@ -165,6 +184,7 @@ struct ShardDev {
 
 typedef foa::ShardBackend<ShardDev> ShardBe;
 static_assert(ShardBe::kSlots == foa::StreamCore<ShardBe>::kSlots && ShardBe::kSlots == foa::kStreamBufs, "one staging slot, one carry and one device buffer per slot of the core");
+static_assert(sizeof(foa::ChainState) == sizeof(StreamState) && foa::kShardSettle == foa::kStreamSettle, "shard_core.h mirrors the device code's chain state");
 
 struct foa_shard {
     std::vector<foa_rx *> rx;                        // one handle per entry of the device list (the same device may appear more than once)

@@ -8,17 +8,21 @@
 //
 //   stream      ....|<------------- batch k-1 ------------->|<-------------- batch k --------------->|....
 //   device buf k              |<-- carry C -->|<------------- batch k (H2D) -------------------------->|
-//                             ^ start_k = pos_k - C                          cut_k = pos_k + B - L    ^ pos_k + B
+//                             ^ start_k = pos_k - C                      decisions up to pos_k + B - 192 ^ pos_k + B
 //
 //   * device buffer k = the last C samples before the batch (a device-to-device copy out of buffer k-1) + the batch;
-//   * foa_rx_sync_dev runs over the whole buffer; of the alignments it finds, batch k DECODES those whose STS_END
-//     sample x lies in [cut_(k-1), cut_k): L = longest possible frame + slack, so every such frame is complete inside the
-//     buffer, and C = L + 2048, so everything within 2048 samples before cut_(k-1) is inside buffer k as well -- the
-//     detector's 16-sample windows, the plateau that ends in an STS_END, the earlier hit that can overwrite a tag
-//     (timing_sync.cpp:105-106) all see the same samples as they would in one pass over the whole stream;
-//   * the one piece of state that does cross batches, the phasor timing_sync left in force (m_phase_acc,
-//     timing_sync.cpp:113-125), is the phasor of the last alignment decoded so far: the host patches it into the first
-//     descriptor of the batch.
+//   * the pre-sync kernels run over the whole buffer.  Of the alignments they find, batch k DECIDES, in stream order from the first one
+//     not decided yet, those that can be decided with the samples there are: a look-ahead (LTS + SIGNAL of the candidates, k_header_range,
+//     then k_stream_resolve) finds the first alignment whose frame would run into the end of the buffer -- FOA_ST_TRUNCATED -- and it and
+//     everything behind it wait for batch k+1.  A frame is therefore handed out by the first batch that holds its last sample (the
+//     reference: five 4096-sample calls after it, receiver_chain.cpp:118-125), whatever the longest frame the format allows;
+//   * tags within kStreamSettle samples of the buffer's end are not final (timing_sync looks 160 samples ahead): the batch's decisions
+//     are made as if the stream ended there, and alignments whose STS_END lies beyond are left to the next batch;
+//   * C = L + 2048 with L = the longest frame (+ look-ahead), so the first undecided alignment and everything within 2048 samples before
+//     it are inside buffer k+1 as well -- the detector's 16-sample windows, the plateau that ends in an STS_END, the earlier hit that can
+//     overwrite a tag (timing_sync.cpp:105-106) all see the same samples as they would in one pass over the whole stream;
+//   * the state that crosses batches stays on the device (StreamState): where the first undecided alignment's STS_END lies, and the phasor
+//     timing_sync left in force before it (m_phase_acc, timing_sync.cpp:113-125), patched into the batch's first descriptor.
 // Batches are queued through the same asynchronous job slots as foa_rx_submit_host (pinned mirrors, D2H behind the
 // finish kernel), so H2D of batch k+1, the kernels of batch k and the D2H of batch k-1 overlap, and results come out in
 // stream order.  The double -> float narrowing of process_samples' complex<double> input is the only per-sample work the
@@ -138,11 +142,14 @@ struct StreamGpu {
     int64_t submitted_samples = 0;                   // samples in the batches submitted so far
     int64_t n_batches = 0;
     int64_t n_staged = 0;                            // batches whose upload has been queued
-    int64_t cut_prev = 0;                            // STS_END positions below this have been dealt with (batches staged so far)
     int64_t staged_samples = 0;                      // samples in the batches staged so far
-    DevBuf<double> d_prev;                           // phasor of the last alignment decoded (timing_sync's m_phase_acc), kept on the device
-    DevBuf<int32_t> sel_dev;                         // the same on the device, copied out behind the selection kernel
-    int32_t *sel = nullptr;                          // page-locked: per buffer { STS_END candidates, alignments found, first of the batch, count }
+    DevBuf<StreamState> state;                       // first undecided alignment + phasor in force before it, kept on the device from batch to batch
+    DevBuf<FrameInfo> la_info;                       // the look-ahead's own alignment records and channel estimates (one batch at a time: the side stream is in order)
+    DevBuf<double2> la_hinv;
+    DevBuf<int32_t> la_range;                        // per buffer: the candidates' index range
+    DevBuf<int32_t> sel_dev;                         // per buffer, 8 ints: the look-ahead's verdict, copied out behind it
+    int32_t *sel = nullptr;                          // page-locked: per buffer { STS_END candidates, alignments found, first of the batch, how many it decides, context behind them }
+    int64_t n_eff[foa::kStreamBufs] = {};            // per buffer: samples up to which its tags are final (the "end of the stream" for its decisions)
     hipEvent_t sel_done[foa::kStreamBufs] = {};      // pre-sync + selection of the buffer's batch are through and `sel` is written
     int32_t ccap[foa::kStreamBufs] = {};
     struct InFlight { uint64_t handle, ticket; size_t n_frames; };
@@ -188,14 +195,16 @@ struct StreamGpu {
         HIP_TRY(hipStreamWaitEvent(st, in_done[k], 0));
         const int64_t n_buf = C + n_new, pushed = staged_samples + n_new;
         const int64_t start = pushed - n_new - C;                    // stream index of the buffer's first sample
-        const int64_t cut = final ? pushed + 1 : pushed - L;        // this batch decodes the alignments whose STS_END sample lies in [cut_prev, cut)
+        n_eff[k] = final ? n_buf : n_buf - foa::kStreamSettle;       // tags are final up to here: the batch decides as if the stream ended there
+        const int64_t hz_abs = start + n_eff[k];
         int rc = sync_dev_issue(rx, d, (size_t)n_buf, (foa_frame_desc *)d_desc[k].p, d_ends[k].p, desc_cap, &ccap[k], start);
         if (rc) return rc;
-        launch_stream_select(st, (foa_frame_desc *)d_desc[k].p, rx->sy_n.p, (int32_t)desc_cap, cut_prev - start, cut - start, d_prev.p, sel_dev.p + 4 * k);
-        HIP_TRY(hipMemcpyAsync(sel + 4 * k, sel_dev.p + 4 * k, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        launch_stream_range(st, (foa_frame_desc *)d_desc[k].p, rx->sy_n.p, (int32_t)desc_cap, start, hz_abs, state.p, la_range.p + 2 * k);
+        launch_stream_resolve(st, d, n_eff[k], (const foa_frame_desc *)d_desc[k].p, d_ends[k].p, la_range.p + 2 * k, rx->sy_n.p, start, hz_abs, final, state.p,
+                              la_info.p, la_hinv.p, sel_dev.p + 8 * k, (unsigned)desc_cap);
+        HIP_TRY(hipMemcpyAsync(sel + 8 * k, sel_dev.p + 8 * k, 5 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipEventRecord(sel_done[k], st));
         HIP_TRY(hipGetLastError());
-        cut_prev = cut;
         staged_samples = pushed;
         n_staged++;
         return FOA_OK;
@@ -211,25 +220,25 @@ struct StreamGpu {
     }
     int submit_impl(int k, int64_t n_new, bool final, uint64_t *handle)
     {
-        const int64_t n_buf = C + n_new, pushed = submitted_samples + n_new;
+        const int64_t pushed = submitted_samples + n_new;
+        (void)final;
         HIP_TRY(enter_device(rx->device));
         float *d = dev[k].p;
         int64_t t0 = now_ns();
         HIP_TRY(hipEventSynchronize(sel_done[k]));                   // (through already when the core asked uploaded(); the staging slot is free again)
         t_sync += now_ns() - t0;
-        const int32_t *q = sel + 4 * k;
+        const int32_t *q = sel + 8 * k;
         if (q[0] > ccap[k]) return fail(FOA_E_NOMEM, "too many STS_END candidates (%d)", q[0]);
         if ((size_t)q[1] > desc_cap) return fail(FOA_E_INVALID, "internal: %d alignments in one batch buffer", q[1]);
-        const size_t i0 = (size_t)q[2], m = (size_t)q[3];
+        const size_t i0 = (size_t)q[2], m = (size_t)q[3], n_ctx = (size_t)q[4];
         int rc;
         t0 = now_ns();
         InFlight fl;
         fl.handle = next_handle++; fl.n_frames = m; fl.ticket = 0;
         if (m) {
-            // (the buffer's alignments behind the batch's own go along as context: a frame cut short by a later LTS1 may fill on with their
-            // vectors, fft_symbols.cpp:41-50 / frame_decoder.cpp:52-88 -- they are decoded by the next batch)
-            const size_t n_ctx = std::min((size_t)q[1], desc_cap) - (i0 + m);
-            rc = stream_decode_batch(rx, d, (size_t)n_buf, (const foa_frame_desc *)d_desc[k].p + i0, d_ends[k].p + i0, m, n_ctx, slot_bytes, &fl.ticket, &t_prep);
+            // (the candidates behind the batch's own go along as context: a frame cut short by a later LTS1 may fill on with their vectors,
+            // fft_symbols.cpp:41-50 / frame_decoder.cpp:52-88 -- the look-ahead decided with them, and they are decided by the next batch)
+            rc = stream_decode_batch(rx, d, (size_t)n_eff[k], (const foa_frame_desc *)d_desc[k].p + i0, d_ends[k].p + i0, m, n_ctx, slot_bytes, &fl.ticket, &t_prep);
             if (rc) return rc;
             alignments.fetch_add(m);
         }
@@ -309,12 +318,15 @@ int foa_stream_create(foa_rx *rx, size_t batch_samples, int narrow_threads, foa_
         if (!rc && hipEventCreateWithFlags(&g.sel_done[i], hipEventDisableTiming) != hipSuccess) rc = fail(FOA_E_HIP, "hipEventCreate failed");
     }
     if (!rc && hipStreamCreateWithFlags(&g.st_in, hipStreamNonBlocking) != hipSuccess) rc = fail(FOA_E_HIP, "hipStreamCreate failed");
-    if (!rc && hipHostMalloc((void **)&g.sel, (size_t)foa::kStreamBufs * 4 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) rc = fail(FOA_E_NOMEM, "hipHostMalloc failed");
-    if (!rc) rc = g.sel_dev.ensure((size_t)foa::kStreamBufs * 4);
-    if (!rc) rc = g.d_prev.ensure(2);
+    if (!rc && hipHostMalloc((void **)&g.sel, (size_t)foa::kStreamBufs * 8 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) rc = fail(FOA_E_NOMEM, "hipHostMalloc failed");
+    if (!rc) rc = g.sel_dev.ensure((size_t)foa::kStreamBufs * 8);
+    if (!rc) rc = g.la_range.ensure((size_t)foa::kStreamBufs * 2);
+    if (!rc) rc = g.la_info.ensure(g.desc_cap + 1);
+    if (!rc) rc = g.la_hinv.ensure((g.desc_cap + 1) * 64);
+    if (!rc) rc = g.state.ensure(1);
     if (!rc) {
-        const double one[2] = { 1.0, 0.0 };                         // timing_sync's m_phase_acc before the first frame: 0
-        if (hipMemcpy(g.d_prev.p, one, sizeof one, hipMemcpyHostToDevice) != hipSuccess) rc = fail(FOA_E_HIP, "hipMemcpy failed");
+        const StreamState first = { 0, 1.0, 0.0 };                  // nothing decided yet; timing_sync's m_phase_acc before the first frame: 0
+        if (hipMemcpy(g.state.p, &first, sizeof first, hipMemcpyHostToDevice) != hipSuccess) rc = fail(FOA_E_HIP, "hipMemcpy failed");
     }
     if (rc) { foa_stream_destroy(s); return rc; }
     // Everything a batch will need is allocated HERE, not by the first batches that need it: a first-use hipMalloc (and every growth, whose
@@ -370,7 +382,7 @@ static void stream_free_buffers(StreamGpu &g)
     g.st_in = nullptr;
     if (g.sel) (void)hipHostFree(g.sel);
     g.sel = nullptr;
-    g.sel_dev.release(); g.d_prev.release();
+    g.sel_dev.release(); g.state.release(); g.la_info.release(); g.la_hinv.release(); g.la_range.release();
 }
 
 // Stops the engine and gives everything it holds on the device back; the handle is the caller's again.  Idempotent: foa_rx_destroy

@@ -352,30 +352,28 @@ __global__ __launch_bounds__(256) void k_sync_emit(const SyncCand *__restrict__ 
     ends[pos] = e;
 }
 
-// Stream engine (stream_engine.h): which of the alignments the pre-sync found over a batch's buffer are THIS batch's -- STS_END sample
-// (rot_start) in [lo, hi), buffer-relative -- and the phasor timing_sync had in force before the first of them (the phasor of the last
-// alignment decoded so far, kept on the device from batch to batch).  One wave; the descriptors are in stream order, so the range is
-// [#{rot_start < lo}, #{rot_start < hi}).  sel = { STS_END candidates, alignments found, first, count }.
-__global__ __launch_bounds__(64) void k_stream_select(foa_frame_desc *__restrict__ descs, const int32_t *__restrict__ sy_n, int32_t cap, int64_t lo, int64_t hi,
-                                                      double *__restrict__ prev_cs, int32_t *__restrict__ sel)
+// Stream engines (stream_engine.h): the alignments the pre-sync found over a batch's buffer that are still to be decided and whose tags
+// are final -- STS_END sample (rot_start) in [lo, hz), buffer-relative, lo from the state the batch before left on the device -- and the
+// phasor timing_sync had in force before the first of them (the phasor of the last alignment decided so far).  One wave; the descriptors
+// are in stream order, so the range is [#{rot_start < lo}, #{rot_start < hz}).
+__global__ __launch_bounds__(64) void k_stream_range(foa_frame_desc *__restrict__ descs, const int32_t *__restrict__ sy_n, int32_t cap, int64_t start_abs, int64_t hz_abs,
+                                                     const StreamState *__restrict__ state, int32_t *__restrict__ range)
 {
     const int lane = threadIdx.x;
     const int found = min(sy_n[3], cap);
-    int below_lo = 0, below_hi = 0;
+    const int64_t lo = state->lo_abs - start_abs, hz = hz_abs - start_abs;
+    int below_lo = 0, below_hz = 0;
     for (int i = lane; i < found; i += 64) {
         const int64_t x = descs[i].rot_start;
         below_lo += x < lo;
-        below_hi += x < hi;
+        below_hz += x < hz;
     }
 #pragma unroll
-    for (int o = 32; o; o >>= 1) { below_lo += __shfl_xor(below_lo, o); below_hi += __shfl_xor(below_hi, o); }
+    for (int o = 32; o; o >>= 1) { below_lo += __shfl_xor(below_lo, o); below_hz += __shfl_xor(below_hz, o); }
     if (lane == 0) {
-        const int m = below_hi - below_lo;
-        if (m > 0) {
-            descs[below_lo].c_prev = prev_cs[0]; descs[below_lo].s_prev = prev_cs[1];
-            prev_cs[0] = descs[below_hi - 1].c; prev_cs[1] = descs[below_hi - 1].s;
-        }
-        sel[0] = sy_n[0]; sel[1] = sy_n[3]; sel[2] = below_lo; sel[3] = m;
+        below_hz = max(below_hz, below_lo);
+        if (below_hz > below_lo) { descs[below_lo].c_prev = state->c; descs[below_lo].s_prev = state->s; }
+        range[0] = below_lo; range[1] = below_hz;
     }
 }
 

@@ -72,6 +72,17 @@ class Receiver:
         self._check(self._lib.foa_rx_decode_frames_host(self._h, _vp(iq), iq.size, _vp(descs), _vp(ends), m, _vp(psdu), slot_bytes, _vp(res)))
         return psdu, res
 
+    def decode_frames_f64_host(self, iq_rotated, descs, ends, slot_bytes=4096):
+        """foa_rx_decode_frames_f64_host: complex128 samples that timing_sync has rotated already (the descriptors' phasors are not applied)."""
+        iq = np.ascontiguousarray(iq_rotated, np.complex128)
+        descs = np.ascontiguousarray(descs, frame_desc_dtype)
+        ends = np.ascontiguousarray(ends, np.int64)
+        m = descs.size
+        psdu = np.zeros((m, slot_bytes), np.uint8)
+        res = np.zeros(m, frame_result_dtype)
+        self._check(self._lib.foa_rx_decode_frames_f64_host(self._h, _vp(iq), iq.size, _vp(descs), _vp(ends), m, _vp(psdu), slot_bytes, _vp(res)))
+        return psdu, res
+
     def submit_host(self, iq, descs, ends, slot_bytes=4096, n_context=0):
         """Asynchronous decode_frames_host: returns a ticket (foa_rx_submit_host_ctx).  n_context: the last n_context alignments of
         descs / ends are context only (looked at, not decoded; no results)."""
@@ -165,6 +176,12 @@ class Receiver:
     def wait_age(self, age):
         """Block until the decode call `age` calls back is complete (see foa_rx_wait_age)."""
         self._check(self._lib.foa_rx_wait_age(self._h, int(age)))
+
+    def forward_spacing(self, age=2):
+        """foa_rx_forward_spacing_ms: (start-to-start, overlap with the pass before, own duration) in ms of the forward pass `age` calls back."""
+        out = (C.c_float * 3)()
+        self._check(self._lib.foa_rx_forward_spacing_ms(self._h, int(age), out))
+        return float(out[0]), float(out[1]), float(out[2])
 
     def probe_issue(self):
         """Live issue-rate probe (foa_rx_probe_issue): {"pk_u16": {clk_per_wave_instr, ghz, wave_instr_per_s}, "vop2_u32": {...}}."""

@@ -210,6 +210,12 @@ int foa_rx_prev_kernel_ms(foa_rx *rx, float out_ms[6]);
  * forward pass that is on the GPU now). */
 int foa_rx_kernel_ms_age(foa_rx *rx, int age, float out_ms[6]);
 
+/* Pipelined calls: how the forward pass of the call `age` calls back (1 .. 3) lies against the one of the call before it, from the same HIP
+ * events: out[0] = start to start, out[1] = how long the earlier pass was still running after this one had started (> 0: they overlapped;
+ * consecutive passes run on different streams by design), out[2] = this pass's own duration (ms).  A launch that shares the machine with its
+ * neighbour lasts longer than the step: bench.py reports both next to its roofline fraction. */
+int foa_rx_forward_spacing_ms(foa_rx *rx, int age, float out[3]);
+
 /* Issue-rate probe of the device the handle lives on (measurement aid for bench.py's roofline; nothing in the receive path
  * uses it): out[0..2] = SIMD clocks per wave64 `v_pk_add_u16 ... clamp`, shader clock (GHz) sustained meanwhile, wave-instructions
  * per second over the whole chip; out[3..5] the same for the plain 32-bit VOP2 `v_add_u32`.  Eight waves per SIMD issue from

@@ -1,6 +1,7 @@
 // shard_core_test.cpp -- one stream dealt over N devices (fun_ofdm_amd/csrc/shard_core.h) against device doubles: batch k must go to
-// device k mod N with exactly the C samples before it as its carry, the selection of batch k must be queued only after batch k-1's has
-// finished and with the phasor that one reported, payloads must come back in stream order whatever the devices' speeds.  CPU only; run
+// device k mod N with exactly the C samples before it as its carry, the look-ahead of batch k must be queued only after batch k-1's has
+// finished and with the chain state that one reported (and as soon as it has: not behind the decode call of the batch before), payloads
+// must come back in stream order whatever the devices' speeds.  CPU only; run
 // under ThreadSanitizer and AddressSanitizer + UBSan by tools/run_sanitizers.sh.
 #include <algorithm>
 #include <cstdio>
@@ -19,14 +20,15 @@ struct World {
     std::mutex m;
     int64_t uploads = 0, selects_queued = 0, selects_done = 0, decodes = 0;
     int64_t next_select_batch = 0;                  // the chain: selections must be queued in batch order, each after the previous finished
-    double last_phasor[2] = { 1.0, 0.0 };
+    foa::ChainState last = { 0, 1.0, 0.0 };
+    int64_t eager = 0;                              // look-aheads queued before the batch before them had been decoded (the chain runs ahead of the decode calls)
     std::vector<int> device_of_batch;
     int bad = 0;
 };
 
 struct FakeDev {
     World *w; int id; int n_dev;
-    struct Buf { int64_t batch = -1, n_new = 0, start = 0, lo = 0, hi = 0; int polls = 0; bool selected = false; double prev[2] = { 0, 0 }; };
+    struct Buf { int64_t batch = -1, n_new = 0, start = 0, n_eff = 0; int polls = 0; bool selected = false; foa::ChainState in = { 0, 0, 0 }; };
     Buf buf[6];
     std::deque<std::pair<uint64_t, int64_t> > flight;      // (handle, batch)
     uint64_t next = 1;
@@ -52,28 +54,31 @@ struct FakeDev {
         buf[slot].batch = k; buf[slot].n_new = n_new; buf[slot].start = start;
         return 0;
     }
-    int select(int slot, int64_t lo, int64_t hi, const double prev[2])
+    int select(int slot, int64_t n_eff, bool final, const foa::ChainState &in)
     {
         std::lock_guard<std::mutex> lk(w->m);
         Buf &b = buf[slot];
-        if (b.batch != w->next_select_batch || w->selects_done != b.batch) { w->bad++; printf("selection of batch %lld queued out of turn (%lld done)\n", (long long)b.batch, (long long)w->selects_done); }
-        if (prev[0] != w->last_phasor[0] || prev[1] != w->last_phasor[1]) { w->bad++; printf("batch %lld got the wrong phasor\n", (long long)b.batch); }
-        // the selection window in stream coordinates must tile the stream: [cut(k-1), cut(k))
-        b.lo = lo + b.start; b.hi = hi + b.start;
-        b.prev[0] = prev[0]; b.prev[1] = prev[1];
+        if (b.batch != w->next_select_batch || w->selects_done != b.batch) { w->bad++; printf("look-ahead of batch %lld queued out of turn (%lld done)\n", (long long)b.batch, (long long)w->selects_done); }
+        if (in.lo_abs != w->last.lo_abs || in.c != w->last.c || in.s != w->last.s) { w->bad++; printf("batch %lld got the wrong chain state\n", (long long)b.batch); }
+        // tags are final up to kShardSettle before the buffer's end (all of it when the stream is over)
+        if (n_eff != w->C + b.n_new - (final ? 0 : foa::kShardSettle)) { w->bad++; printf("batch %lld: n_eff %lld\n", (long long)b.batch, (long long)n_eff); }
+        if (in.lo_abs < b.start) { w->bad++; printf("batch %lld: the first undecided alignment lies before its buffer\n", (long long)b.batch); }
+        if (w->decodes < b.batch) w->eager++;
+        b.n_eff = n_eff; b.in = in;
         w->selects_queued++;
         w->next_select_batch++;
         return 0;
     }
-    int selected(int slot, double last[2])
+    int selected(int slot, foa::ChainState *out)
     {
         Buf &b = buf[slot];
         if (++b.polls < slow) return 0;
         std::lock_guard<std::mutex> lk(w->m);
-        // every third batch "finds no alignment": the phasor passes through unchanged
-        if (b.batch % 3 == 2) { last[0] = b.prev[0]; last[1] = b.prev[1]; }
-        else { last[0] = 0.001 * (double)(b.batch + 1); last[1] = (double)id; }
-        w->last_phasor[0] = last[0]; w->last_phasor[1] = last[1];
+        // every third batch decides no frame (the phasor passes through unchanged); the others move on to somewhere in the last L samples
+        // they could decide (an undecided frame is at most L long)
+        if (b.batch % 3 == 2) { *out = b.in; out->lo_abs = std::max(b.in.lo_abs, b.start + b.n_eff - w->L); }      // (a frame stays undecided for L samples at most)
+        else { out->lo_abs = std::max(b.in.lo_abs, b.start + b.n_eff - (int64_t)((b.batch * 7919) % (w->L + 1))); out->c = 0.001 * (double)(b.batch + 1); out->s = (double)id; }
+        w->last = *out;
         w->selects_done++;
         b.selected = true;
         return 1;
@@ -139,7 +144,8 @@ static void run(int n_dev, int64_t B, int64_t C, int64_t L, size_t total, unsign
     CHECK(w.uploads == (int64_t)want && w.selects_done == (int64_t)want && w.decodes == (int64_t)want, "uploads %lld, selections %lld, decodes %lld of %zu",
           (long long)w.uploads, (long long)w.selects_done, (long long)w.decodes, want);
     for (auto *d : devs) delete d;
-    printf("%d devices, B %lld, C %lld, %zu samples, pushes up to %zu, %d helpers: %zu batches in order\n", n_dev, (long long)B, (long long)C, total, max_push, helpers, order.size());
+    printf("%d devices, B %lld, C %lld, %zu samples, pushes up to %zu, %d helpers: %zu batches in order, %lld look-aheads queued ahead of the decode call before them\n", n_dev,
+           (long long)B, (long long)C, total, max_push, helpers, order.size(), (long long)w.eager);
 }
 
 int main()

@@ -122,6 +122,36 @@ def run_gpu(lo, hi):
     return tot, n_al, bad, flush_hits
 
 
+def rotated(s, d):
+    """the stream as timing_sync hands it on for these alignments: every sample times the phasor in force at its index (timing_sync.cpp:121-125)"""
+    out = s.astype(np.complex128)
+    rot = np.full(s.size, complex(d[0]["c_prev"], d[0]["s_prev"]) if d.size else 1.0 + 0j)
+    for j in range(d.size):
+        rot[max(int(d[j]["rot_start"]), 0):] = complex(d[j]["c"], d[j]["s"])
+    return out * rot
+
+
+def run_gpu_f64(lo, hi):
+    """the same cases as complex<double> samples rotated already (what the fused stage block fun_amd::rx_backend hands the device)"""
+    import fun_ofdm_amd as foa
+    rx = foa.Receiver(0)
+    bad = tot = n_al = 0
+    for seed in range(lo, hi):
+        s, d = make_case(seed)
+        r = rotated(s, d)
+        want = po.chain_from_tags_f32(s, d)
+        ends = np.append(d["lts1_pos"][1:], s.size).astype(np.int64)
+        opsdu, ores = po.decode_batch_v2_f64(r, d, ends)
+        psdu, res = rx.decode_frames_f64_host(r, d, ends)
+        tot += len(want)
+        n_al += d.size
+        if not (np.array_equal(res.view(np.int32), ores.view(np.int32)) and np.array_equal(psdu, opsdu) and payloads(psdu, res) == want):
+            bad += 1
+            print("DIFF (f64) seed", seed, "blocks", len(want), "device", res["status"].tolist(), "restatement", ores["status"].tolist())
+    rx.close()
+    return tot, n_al, bad
+
+
 if __name__ == "__main__":
     mode = sys.argv[1] if len(sys.argv) > 1 else "cpu"
     lo = int(sys.argv[2]) if len(sys.argv) > 2 else 0

@@ -32,6 +32,26 @@ def test_bench_two_ranks_decode_and_gather():
     assert abs(out["value"] - expect) <= 0.051 + expect * (0.5e-4 / out["ms_per_step"] + 1e-6)
 
 
+def test_bench_over_every_device_count_of_this_box():
+    """`bench.py --gpus N` for N = 1 .. the devices there are (one rank per device over RCCL, as the driver starts it on a node): N ranks in the
+    collective, N x the frames decoded bit-exactly, RCCL reporting N ranks.  On a one-GPU box this is the N = 1 line; on an 8-GPU node it is
+    BASELINE config 4's code path at reduced size, with nothing to edit."""
+    import torch
+    n_dev = torch.cuda.device_count()
+    assert n_dev >= 1
+    for n in range(1, n_dev + 1):
+        e = dict(os.environ)
+        e.pop("WORLD_SIZE", None)
+        e["FOA_BENCH_FORCE_DIST"] = "1"                    # (N = 1 too goes through the process group and the gather)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--frames", "500", "--steps", "3", "--warmup", "2", "--no-extra-legs",
+                            "--no-sync-leg", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=e)
+        assert r.returncode == 0, r.stderr[-3000:]
+        out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+        assert out["n_gpus"] == n and out["scaling"] == "weak" and out["config"]["psdu_bit_exact"] is True
+        assert out["config"]["collective"]["ranks"] == n and out["config"]["collective"]["backend"] == "nccl" and out["config"]["collective"]["gathers_per_region"] == 3
+        assert out["config"]["frames_ok"] >= n * 500 - n and ("RCCL saw %d rank" % n) in r.stderr
+
+
 def test_bench_single_rank_line_has_the_contract_fields():
     out = _bench("--frames", "600", "--steps", "4", "--warmup", "2", "--legs-frames", "40", "--fill-frames", "96")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",

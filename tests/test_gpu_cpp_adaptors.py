@@ -22,6 +22,26 @@ def test_cpp_adaptors(tmp_path, po):
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def test_mixed_chain_reference_presync_blocks_in_front_of_the_gpu_blocks(tmp_path, po):
+    """tests/cpp/mixed_chain.cpp against the real library: the reference's compiled frame_detector and timing_sync (oracle/_ref, built
+    from /root/reference in the dev container; the library travels) -> fun_amd::fft_symbols .. frame_decoder, and -> the fused
+    fun_amd::rx_backend, wired as fun::receiver_chain wires its blocks (src/receiver_chain.cpp:29-51, :106-126): the oracle chain's
+    ordered payload list on a mixed-rate stream with CFO.  (The same file is compiled against the reference's own headers in
+    tests/test_boundary_reference.py.)"""
+    import fun_ofdm_amd as foa
+    ref_dir = os.path.join(ROOT, "oracle", "_ref")
+    if not os.path.exists(os.path.join(ref_dir, "libfun_ofdm_ref.so")):
+        pytest.skip("oracle/_ref/libfun_ofdm_ref.so is not on this box (built from /root/reference in the dev container, git-ignored)")
+    exe = str(tmp_path / "mixed_chain")
+    libdir, ora = os.path.dirname(foa.library_path()), os.path.join(ROOT, "oracle")
+    subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "cpp", "mixed_chain.cpp"), "-I", os.path.join(ROOT, "include"), "-I", ora,
+                    "-L", libdir, "-lfun_ofdm_amd", "-L", ora, "-loracle", "-L", ref_dir, "-lfun_ofdm_ref", "-Wl,-rpath," + libdir, "-Wl,-rpath," + ora,
+                    "-Wl,-rpath," + ref_dir, "-Wl,-rpath,/opt/rocm/lib", "-lm", "-lpthread", "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0 and "chain B" in r.stdout, r.stdout + r.stderr
+
+
 def test_sim_cli_over_iq_file(tmp_path):
     """examples/foa_sim.cpp: a raw fc32 capture in, length-prefixed PSDU records out, through
     fun_amd::file_source -> fun_amd::receiver -> receiver_chain::process_samples."""

@@ -63,3 +63,6 @@ def test_placed_tags_partial_vector_flush_and_frames_in_progress_equal_the_block
     import stress_tags
     tot, n_al, bad, hits = stress_tags.run_gpu(0, 400)
     assert bad == 0 and n_al > 2000 and tot > 250 and hits > 80, (tot, n_al, bad, hits)
+    # ... and as the pre-rotated complex<double> stream the fused stage block hands over (foa_rx_decode_frames_f64_host)
+    tot, n_al, bad = stress_tags.run_gpu_f64(400, 520)
+    assert bad == 0 and n_al > 600 and tot > 70, (tot, n_al, bad)

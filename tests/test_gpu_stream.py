@@ -178,10 +178,32 @@ def test_one_stream_per_handle_and_handle_destroyed_first(po):
     st2.close()
 
 
-# ---- the same engine over several devices (foa_shard_*): one test box has one GPU, so the device list names it once, twice, three times
-# (handles sharing it); what is tested is the dealing of batches, the host-side carries and the phasor chain through the handles ----
-@pytest.mark.parametrize("devices,batch,chunk", [([0], 4096, 4096), ([0, 0], 4096, 1000), ([0, 0], 20000, 4096), ([0, 0, 0], 65536, 7777),
-                                                 ([0, 0], 1 << 18, 4096), ([0, 0], 1 << 22, 100000)])
+# ---- the same engine over several devices (foa_shard_*).  A test box with one GPU names it once, twice, three times (handles sharing it):
+# what is tested then is the dealing of batches, the host-side carries and the chain state through the handles.  On a node with more GPUs the
+# lists below widen by themselves: every prefix [0 .. n-1] of the devices there are (torch.cuda.device_count() does not start the runtime).
+def _device_prefixes():
+    try:
+        import torch
+        n = torch.cuda.device_count()
+    except Exception:
+        n = 0
+    return [list(range(k)) for k in range(2, n + 1)]
+
+
+_SHARD_CASES = [([0], 4096, 4096), ([0, 0], 4096, 1000), ([0, 0], 20000, 4096), ([0, 0, 0], 65536, 7777), ([0, 0], 1 << 18, 4096), ([0, 0], 1 << 22, 100000)] + \
+               [(d, 16384, 4096) for d in _device_prefixes()] + [(d, 1 << 18, 65536) for d in _device_prefixes()]
+
+
+def test_multi_device_cases_cover_the_devices_of_this_box():
+    """The multi-device tests enumerate the box: with N >= 2 devices every list [0 .. n-1], n = 2 .. N, is among the cases."""
+    import fun_ofdm_amd as foa
+    n = foa.lib().foa_device_count()
+    assert n >= 1
+    real = [d for d, _, _ in _SHARD_CASES if len(set(d)) == len(d) and len(d) > 1]
+    assert sorted(set(len(d) for d in real)) == list(range(2, n + 1))
+
+
+@pytest.mark.parametrize("devices,batch,chunk", _SHARD_CASES)
 def test_shard_engine_equals_reference_chain(mixed, devices, batch, chunk):
     import fun_ofdm_amd as foa
     iq, pays, want = mixed
@@ -214,7 +236,7 @@ def test_shard_engine_phasor_chain_across_devices(po):
     iq = np.concatenate(parts)
     want = po.ReceiverChain().run_stream(iq.astype(np.complex128))
     assert len(want) >= 10
-    for devices, batch in (([0, 0], 32768), ([0, 0, 0], 16384)):
+    for devices, batch in [([0, 0], 32768), ([0, 0, 0], 16384)] + [(d, 16384) for d in _device_prefixes()]:
         sh = foa.Shard(devices, batch)
         try:
             got = sh.push(iq) + sh.flush()
