@@ -124,10 +124,12 @@ int foa_rx_reserve(foa_rx *rx, size_t n_samples, size_t n_frames);
  *                 to each batch's offset in the stream (or starts every batch on a multiple of sync_call, or sets sync_call 0);
  *                 otherwise frames are dropped at batch-relative positions the reference never drops them at
  *   "stream_longest"  read by foa_stream_create: the longest frame the stream will hold, in samples from the first preamble sample to the last data
- *                 sample, plus 192 (timing_sync's look-ahead and the window offset).  A batch decodes the frames whose STS_END lies at least this far
- *                 before its end, so that every frame is whole inside the batch that decodes it; the default 0 = 110 592 covers the longest frame the
- *                 format allows (4095 bytes at 6 Mbps).  Also shortens the carry every batch re-synchronises (stream_longest + 2048 samples),
- *                 which is most of a small batch's cost. */
+ *                 sample, plus 192 (timing_sync's look-ahead and the window offset).  Every batch buffer starts this far (+ 2048) before its batch, so
+ *                 that a frame still undecided when a batch ends is whole inside the next buffer; the default 0 = 110 592 covers the longest frame the
+ *                 format allows (4095 bytes at 6 Mbps).  What it buys is a shorter carry (stream_longest + 2048 samples re-synchronised with every
+ *                 batch: most of a small batch's cost), not latency: a frame is decoded by the first batch that holds its last sample whatever
+ *                 this value.  A frame LONGER than it is delivered only if some batch buffer (carry + batch) happens to hold all of it -- a
+ *                 deviation from the reference the caller has asked for, and one that depends on where the batch boundaries fall. */
 int foa_rx_set_option(foa_rx *rx, const char *name, int64_t value);
 
 /*
@@ -286,12 +288,13 @@ int foa_rx_sync_dev_end(foa_rx *rx, size_t *n_found);
  * What fun::receiver_chain::process_samples() does call by call (src/receiver_chain.cpp:106-126: frame_detector ->
  * timing_sync -> fft_symbols -> channel_est -> phase_tracker -> frame_decoder on a 4096-sample chunk, state carried from
  * call to call), done batch by batch on the GPU: pushed samples collect in page-locked memory; every `batch_samples`
- * samples one batch goes out -- H2D, foa_rx_sync_dev over the batch plus the 112 640 samples before it, foa_rx_decode_frames_dev
- * for the alignments whose STS_END lies in the batch's share of the stream, D2H of the PSDUs -- asynchronously, several
- * batches in flight; finished batches hand out their CRC-passing payloads in stream order.  Consecutive batches overlap by
- * more than the longest frame, so a frame is decoded exactly once, by the batch that holds all of it, and the pre-sync
- * sees the same samples around every decision as a single pass over the whole stream would (fun_ofdm_amd/csrc/
- * stream_engine.h).  The payload list equals the reference chain's (tests/test_gpu_stream.py); latency is one batch.
+ * samples one batch goes out -- H2D, the pre-sync kernels over the batch plus the 112 640 samples before it, a look-ahead that finds
+ * the alignments that can be DECIDED with the samples there are (everything in front of the first frame that would run into the
+ * buffer's end), foa_rx_decode_frames_ctx_dev for those, D2H of the PSDUs -- asynchronously, several batches in flight; finished
+ * batches hand out their CRC-passing payloads in stream order.  Consecutive buffers overlap by more than the longest frame, so a
+ * frame is decoded exactly once, by the first batch that holds its last sample, and the pre-sync sees the same samples around every
+ * decision as a single pass over the whole stream would (fun_ofdm_amd/csrc/stream_engine.h).  The payload list equals the reference
+ * chain's (tests/test_gpu_stream.py); a payload comes back one batch period + the device's ~1 ms after its frame's last sample.
  * One engine per handle at a time; the handle's other entry points must not be used while a stream is open (the engine's
  * submitter thread makes the GPU calls; push / flush / ready / take / stats belong to ONE caller thread). */
 typedef struct foa_stream foa_stream;
@@ -336,11 +339,11 @@ int foa_stream_stats(const foa_stream *s, uint64_t out[8]);
  * decode and copy back on that device, through a receiver handle the shard creates for it -- so n_devices consecutive batches are in
  * work at once, and the CRC-passing payloads still come out in stream order (foa_shard_ready / _take, batch by batch).  Every batch
  * buffer is filled from the host (the carry of 112 640 samples before the batch included), so no device reads another device's memory and
- * there is no collective: what crosses from one batch to the next is the phasor timing_sync left in force (timing_sync.cpp:113-125),
- * sixteen bytes the host hands from device to device in stream order (fun_ofdm_amd/csrc/shard_core.h; its ordering logic runs against
+ * there is no collective: what crosses from one batch to the next is where the first undecided alignment begins and the phasor timing_sync
+ * left in force (timing_sync.cpp:113-125), 24 bytes the host hands from device to device in stream order (fun_ofdm_amd/csrc/shard_core.h; its ordering logic runs against
  * device doubles at 1, 2, 3 and 8 devices in tests/cpp/shard_core_test.cpp).  The payload list equals foa_stream_*'s and the reference
  * chain's (tests/test_gpu_stream.py runs it with the one device a test box has, listed once and twice).  A device may be listed more
- * than once (two handles on one device share it).  NOT measured on a multi-GPU node: none was available to the builder (DESIGN.md 5).
+ * than once (two handles on one device share it).  NOT measured on a multi-GPU node: none was available to the builder (DESIGN.md 7).
  * Threads, ownership of handed-over buffers and the meaning of every call are those of the foa_stream_* functions of the same name. */
 typedef struct foa_shard foa_shard;
 int foa_shard_create(const int *devices, int n_devices, size_t batch_samples, int narrow_threads, foa_shard **out);

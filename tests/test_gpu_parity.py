@@ -1011,3 +1011,52 @@ def test_async_host_calls(rx, po, pipeline):
             assert np.array_equal(psdu, want[0][0])
     finally:
         rx.set_option("pipeline", 1)
+
+
+def test_context_alignments_and_explicit_ends_follow_the_restatement(rx, po):
+    """foa_rx_submit_host_ctx / foa_rx_decode_frames_ctx_dev: a stream decoded in two pieces, the rest handed over as CONTEXT, gives the
+    results of the one-piece decode (a frame cut short by a later LTS1 fills on with the context's vectors); without context such a frame is
+    FOA_ST_TRUNCATED; ends that are not the next alignment's LTS1 make alignments independent.  Against fo_decode_batch_v2_f32."""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "manual"))
+    import stress_tags
+    import fun_ofdm_amd as foa
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(8)
+    n_split = n_trunc = 0
+    for seed in range(60):
+        s, d = stress_tags.make_case(seed)
+        if d.size < 3:
+            continue
+        ends = np.append(d["lts1_pos"][1:], s.size).astype(np.int64)
+        k = int(rng.integers(1, d.size))
+        # (a) host entry with context
+        want_p, want_r = po.decode_batch_v2_f32(s, d, ends, n_ctx=d.size - k)
+        got_p, got_r = rx.collect(rx.submit_host(s, d, ends, n_context=d.size - k))
+        assert np.array_equal(got_r.view(np.int32), want_r.view(np.int32)) and np.array_equal(got_p, want_p), (seed, k)
+        # (b) device entry with context
+        t_iq = torch.from_numpy(s.view(np.float32).reshape(-1, 2)).to(dev)
+        t_d = torch.from_numpy(d.view(np.uint8).copy()).to(dev)
+        t_e = torch.from_numpy(ends).to(dev)
+        t_p = torch.zeros((k, 4096), dtype=torch.uint8, device=dev)
+        t_r = torch.zeros((k, 4), dtype=torch.int32, device=dev)
+        rx.decode_frames_dev(t_iq, t_d, t_e, t_p, t_r, n_context=d.size - k)
+        rx.sync()
+        assert np.array_equal(t_r.cpu().numpy(), want_r.view(np.int32).reshape(-1, 4)) and np.array_equal(t_p.cpu().numpy(), want_p), (seed, k)
+        # (c) the first piece alone: what needed the rest is TRUNCATED, nothing else changes
+        p0, r0 = rx.decode_frames_host(s, d[:k], ends[:k])
+        o0p, o0r = po.decode_batch_v2_f32(s, d[:k], ends[:k])
+        assert np.array_equal(r0.view(np.int32), o0r.view(np.int32)) and np.array_equal(p0, o0p), (seed, k)
+        differ = r0["status"] != want_r["status"]
+        assert np.all(r0["status"][differ] == foa.ST_TRUNCATED)
+        n_split += 1
+        n_trunc += int(np.count_nonzero(differ))
+        # (d) unlinked ends
+        e2 = ends - rng.integers(1, 40, d.size)
+        p2, r2 = rx.decode_frames_host(s, d, e2)
+        o2p, o2r = po.decode_batch_v2_f32(s, d, e2)
+        assert np.array_equal(r2.view(np.int32), o2r.view(np.int32)) and np.array_equal(p2, o2p), (seed, "unlinked")
+        assert not np.any(r2["status"] == foa.ST_SUPERSEDED)
+    assert n_split > 40 and n_trunc > 5

@@ -289,8 +289,8 @@ def test_process_samples_over_a_device_list_through_the_cpp_chain(tmp_path, po, 
 
 
 def test_stream_longest_option_keeps_the_payload_list_and_cuts_what_is_longer(rx, po):
-    """Option "stream_longest" (the latency knob): a stream whose frames all fit gives the reference chain's payload list for any batch size; a
-    frame longer than the value is reported truncated, i.e. missing from the list, and nothing else changes."""
+    """Option "stream_longest" (sizes the carry every batch re-synchronises): a stream whose frames all fit gives the reference chain's payload list
+    for any batch size; a frame longer than the value that no buffer ever holds whole is missing from the list, and nothing else changes."""
     import fun_ofdm_amd as foa
     rng = np.random.default_rng(64)
     specs = [(int(rng.choice((5, 6, 8, 9, 10))), int(rng.integers(1, 700))) for _ in range(40)]       # <= 700 bytes at >= 18 Mbps: <= 320 + 80 * 80 samples
@@ -326,6 +326,14 @@ def test_stream_longest_option_keeps_the_payload_list_and_cuts_what_is_longer(rx
         finally:
             st.close()
         assert len(got2) == len(want) and [p for p in want2 if len(p) != 3000] == got2
+        # ... with THESE batches: the value only sizes the carry, so whether a longer frame is delivered depends on whether a buffer ever
+        # holds all of it (include/fun_ofdm_amd.h).  One 256 Ki-sample batch does: then the frame comes out like any other
+        st = foa.Stream(rx, 1 << 18)
+        try:
+            got3 = st.push(iq2) + st.flush()
+        finally:
+            st.close()
+        assert got3 == want2
         with pytest.raises(foa.FoaError):
             rx.set_option("stream_longest", 100)
     finally:
