@@ -22,7 +22,7 @@ def per_kernel(sub, counter):
                 low = {k.lower(): v for k, v in row.items()}
                 if low.get("counter_name") != counter:
                     continue
-                name = low["kernel_name"].split("(")[0].split("::")[-1]
+                name = low["kernel_name"].split("(")[0].split("<")[0].split("::")[-1].strip()       # (template arguments dropped: k_header<float2> -> k_header)
                 acc[name][0] += float(low["counter_value"])
                 acc[name][1].add(low.get("dispatch_id"))
     return {k: v[0] / max(1, len(v[1])) for k, v in acc.items()}
@@ -74,7 +74,7 @@ for path in glob.glob(os.path.join(out, "pg", "**", "*counter_collection.csv"), 
             low = {k.lower(): v for k, v in row.items()}
             if low.get("counter_name") != "GRBM_GUI_ACTIVE" or "start_timestamp" not in low:
                 continue
-            name = low["kernel_name"].split("(")[0].split("::")[-1]
+            name = low["kernel_name"].split("(")[0].split("<")[0].split("::")[-1].strip()       # (template arguments dropped: k_header<float2> -> k_header)
             if not name.startswith("k_"):
                 continue
             dur = float(low["end_timestamp"]) - float(low["start_timestamp"])

@@ -13,7 +13,7 @@ rows = []
 with open(src, newline="") as fh:
     for r in csv.DictReader(fh):
         low = {k.lower(): v for k, v in r.items()}
-        name = low["kernel_name"].split("(")[0].split("::")[-1]
+        name = low["kernel_name"].split("(")[0].split("<")[0].split("::")[-1].strip()
         if name.startswith("k_"):
             rows.append((int(low["start_timestamp"]), int(low["end_timestamp"]), name, low.get("queue_id", "?")))
 rows.sort()
