@@ -27,12 +27,13 @@ struct FrameInfo {
     // windows from SIGNAL on, and -- when the next alignment's LTS1 arrives past a window's cyclic prefix -- one partly filled one
     int32_t nvec;        // vectors in all: complete windows k = 0 (SIGNAL) .. + the partial one
     int32_t fresh;       // the partial vector's own samples (the rest still holds the window before): 0 .. 63, -1 = no partial vector
-    int32_t flags;       // kInfoLink | kInfoCross
+    int32_t flags;       // kInfoLink | kInfoCross | kInfoLate
     int32_t spec_off;    // first entry of this frame in the table of symbols that are not plain windows of its own alignment
     int32_t n_own;       // data symbols that ARE plain windows of its own alignment: min(hdr_nsym, complete windows - 1)
     int32_t pad_;
 };
 constexpr int kInfoLink = 1;     // the stream goes on into the next alignment of the call (ends[f] is its LTS1): one vector sequence
+constexpr int kInfoLate = 4;     // an earlier alignment's LTS2 tag sits inside this one's first LTS window: its vectors come one symbol later (frontend_kernels.h)
 constexpr int kInfoCross = 2;    // valid SIGNAL, frame longer than the alignment's own complete windows, linked: decided by the scan kernels
 
 // A data symbol of a frame that is not window k of the frame's own alignment: the partial vector, or a vector of a later alignment
@@ -41,7 +42,7 @@ struct SpecSym {
     int32_t frame;       // the frame it belongs to (rate, output position)
     int32_t src;         // the alignment whose window, rotation, channel estimate and symbol count it takes
     int32_t k;           // vector k of that alignment (0 = its SIGNAL window)
-    int32_t fresh;       // 64: a complete window; < 64: samples fresh .. 63 come from the window before (fft_symbols.cpp:46-50)
+    int32_t fresh;       // low byte 64: a complete window; < 64: samples fresh .. 63 come from the window before (fft_symbols.cpp:46-50); bit 8: src is a late alignment (kInfoLate)
 };
 
 // The stream engines' state between batches (stream_engine.h), carried on the device: the stream index of the STS_END sample of the first

@@ -21,7 +21,7 @@ namespace foa {
 // Alignment f of [0, n_total) by one wave; lds / dem / decs: the block's LDS.
 template <typename S>
 __device__ __forceinline__ void header_alignment(const S *__restrict__ iq, const foa_frame_desc *__restrict__ descs, const int64_t *__restrict__ ends,
-                                                 int64_t n_samples, int f, int n_total, FrameInfo *__restrict__ info, double2 *__restrict__ hinv,
+                                                 int64_t n_samples, int f, int n_lead, int n_total, FrameInfo *__restrict__ info, double2 *__restrict__ hinv,
                                                  double2 *__restrict__ eq_tap, cpx *lds, uint8_t *dem, uint64_t *decs)
 {
     const int lane = threadIdx.x;
@@ -29,15 +29,27 @@ __device__ __forceinline__ void header_alignment(const S *__restrict__ iq, const
     const int64_t e_raw = ends[f], end = min(e_raw, n_samples), p = d.lts1_pos;      // nothing is read beyond the stream, whatever the caller's ends say
     // linked: the stream goes on into the next alignment of the call (its LTS1 tag is where this one's samples end)
     const bool link = f + 1 < n_total && e_raw <= n_samples && e_raw == descs[f + 1].lts1_pos;
+    // late: an LTS1 less than 64 samples behind an earlier one of the same stream.  That alignment's LTS2 tag (timing_sync.cpp:105-106) falls
+    // inside this one's first LTS window and restarts the vector there (fft_symbols.cpp:53-56), this alignment's own LTS2 tag restarts it
+    // again, so the first complete vector -- still tagged LTS_START -- is the window at p + 64; the one 80 samples on is taken as the second
+    // LTS vector (channel_est.cpp:44-58) and START_OF_FRAME goes to the window behind that: the grid of an alignment at q = p + 80 whose first
+    // LTS window sits 16 samples early.  (descs / ends may be looked at down to index -n_lead: the stream engines' earlier tags.)
+    bool late = false;
+    for (int i = f - 1; i >= -n_lead; i--) {
+        const int64_t ei = ends[i], dp = p - descs[i].lts1_pos;
+        if (ei != descs[i + 1].lts1_pos || ei > n_samples || dp < 0 || dp >= 64) break;
+        if (dp > 0) { late = true; break; }
+    }
+    const int64_t q = late ? p + 80 : p;
     FrameInfo fi;
     fi.status = FOA_ST_HEADER_FAIL; fi.rate = -1; fi.length = 0; fi.nsym = 0; fi.sym_off = 0; fi.nsteps = 0; fi.dec_off = 0; fi.seg_off = 0;
-    fi.hdr_nsym = 0; fi.nvec = 0; fi.fresh = -1; fi.flags = link ? kInfoLink : 0; fi.spec_off = 0; fi.n_own = 0; fi.pad_ = 0;
-    // complete windows [p + 144 + 80 k, + 64) that end by `end`; the window in progress when the next LTS1 arrives is pushed if it has
+    fi.hdr_nsym = 0; fi.nvec = 0; fi.fresh = -1; fi.flags = (link ? kInfoLink : 0) | (late ? kInfoLate : 0); fi.spec_off = 0; fi.n_own = 0; fi.pad_ = 0;
+    // complete windows [q + 144 + 80 k, + 64) that end by `end`; the window in progress when the next LTS1 arrives is pushed if it has
     // got past its cyclic prefix (m_offset > 15, fft_symbols.cpp:46): its first mo - 16 samples are its own
-    const int64_t K = end >= p + 208 ? (end - (p + 208)) / 80 + 1 : 0;
-    const int mo = end >= p + 128 ? (int)((end - (p + 128)) % 80) : 0;
+    const int64_t K = end >= q + 208 ? (end - (q + 208)) / 80 + 1 : 0;
+    const int mo = end >= q + 128 ? (int)((end - (q + 128)) % 80) : 0;
     const bool has_part = link && mo > 15;
-    if (p < 0 || end < p + 128 || K + (has_part ? 1 : 0) == 0) {
+    if (p < 0 || end < q + 128 || K + (has_part ? 1 : 0) == 0) {
         // an LTS window is cut off, or not even part of a SIGNAL vector exists: no vector, no START_OF_FRAME from this alignment
         fi.status = link ? FOA_ST_SUPERSEDED : FOA_ST_TRUNCATED;
         if (lane == 0) info[f] = fi;
@@ -51,16 +63,17 @@ __device__ __forceinline__ void header_alignment(const S *__restrict__ iq, const
     const cpx ref = { (double)g_tab.lts_freq[s], 0.0 };
 #pragma unroll
     for (int w = 0; w < 2; w++) {
-        cpx y = fft64_lane(load_rotated(iq, p + 64 * w + lane, d), lds, lane);
-        cpx q = cdiv(ref, y);
-        est.x += q.x / 2.0;
-        est.y += q.y / 2.0;
+        const int64_t w0 = w == 0 ? (late ? p + 64 : p) : q + 64;
+        cpx y = fft64_lane(load_rotated(iq, w0 + lane, d), lds, lane);
+        cpx r = cdiv(ref, y);
+        est.x += r.x / 2.0;
+        est.y += r.y / 2.0;
     }
     hinv[(size_t)f * 64 + s] = make_double2(est.x, est.y);
     // SIGNAL: equalise (channel_est.cpp:77-81), pilot phase with polarity[0] (phase_tracker.cpp:74-99).  If the next LTS1 cuts the
     // SIGNAL window itself (K = 0), the vector pushed holds its first `fresh` samples and, behind them, what the vector held before:
-    // the LTS2 window (fft_symbols.cpp:46-50)
-    const int64_t sig_idx = (K == 0 && lane >= fi.fresh) ? p + 64 + lane : p + 144 + lane;
+    // the second LTS window (fft_symbols.cpp:46-50)
+    const int64_t sig_idx = (K == 0 && lane >= fi.fresh) ? q + 64 + lane : q + 144 + lane;
     cpx y = fft64_lane(load_rotated(iq, sig_idx, d), lds, lane);
     cpx z = pilot_derotate(cmul(est, y), (int)g_tab.polarity[0]);
     const int di = g_tab.data_index[s];
@@ -88,7 +101,7 @@ __device__ __forceinline__ void header_alignment(const S *__restrict__ iq, const
 
 template <typename S>
 __global__ __launch_bounds__(64) void k_header(const S *__restrict__ iq, const foa_frame_desc *__restrict__ descs,
-                                               const int64_t *__restrict__ ends, int64_t n_samples, int n_total,
+                                               const int64_t *__restrict__ ends, int64_t n_samples, int n_lead, int n_total,
                                                FrameInfo *__restrict__ info, double2 *__restrict__ hinv, double2 *__restrict__ eq_tap)
 {
     __shared__ cpx lds[64];
@@ -96,7 +109,7 @@ __global__ __launch_bounds__(64) void k_header(const S *__restrict__ iq, const f
     __shared__ uint64_t decs[24];
     const int f = blockIdx.x;
     if (f >= n_total) return;
-    header_alignment(iq, descs, ends, n_samples, f, n_total, info, hinv, eq_tap, lds, dem, decs);
+    header_alignment(iq, descs, ends, n_samples, f, n_lead, n_total, info, hinv, eq_tap, lds, dem, decs);
 }
 
 // ---- the stream engines' look-ahead (stream_engine.h): which alignments of a batch buffer can be decided with the samples there are? ----
@@ -111,7 +124,7 @@ __global__ __launch_bounds__(64) void k_header_range(const float2 *__restrict__ 
     __shared__ uint64_t decs[24];
     const int f = range[0] + (int)blockIdx.x;
     if (f >= range[1]) return;
-    header_alignment(iq, descs, ends, n_samples, f, range[1], info, hinv, (double2 *)nullptr, lds, dem, decs);
+    header_alignment(iq, descs, ends, n_samples, f, 0, range[1], info, hinv, (double2 *)nullptr, lds, dem, decs);      // (descs[0] is the buffer's first tag)
 }
 
 // =================================================================================================
@@ -293,7 +306,7 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_apply(FrameInfo *__restrict
             while (k >= info[src].nvec) { src++; k = 0; }               // (alignments without vectors are skipped over)
             const int fr = info[src].fresh;
             SpecSym e;
-            e.frame = f; e.src = src; e.k = k; e.fresh = (fr >= 0 && k == info[src].nvec - 1) ? fr : 64;
+            e.frame = f; e.src = src; e.k = k; e.fresh = ((fr >= 0 && k == info[src].nvec - 1) ? fr : 64) | ((info[src].flags & kInfoLate) ? 256 : 0);
             spec[sp0 + i] = e;
             sym2frame[a + n_plain + i] = -2 - (int32_t)(sp0 + i);
             k++;

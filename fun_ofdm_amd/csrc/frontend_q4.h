@@ -137,14 +137,15 @@ void k_data_symbols_q4(const S *__restrict__ iq, const foa_frame_desc *__restric
     // rotation, channel estimate and symbol count (channel_est.cpp:77-81 and phase_tracker.cpp:74-99 know nothing of frames).
     const int fq = w < total ? sym2frame[w] : -1;
     const bool valid = fq != -1;
-    int f = fq >= 0 ? fq : 0, src = f, ks = 0, fresh = 64;
-    if (fq <= -2) { const SpecSym e = spec[-2 - fq]; f = e.frame; src = e.src; ks = e.k; fresh = e.fresh; }
+    int f = fq >= 0 ? fq : 0, src = f, ks = 0, fresh = 64, late = -1;
+    if (fq <= -2) { const SpecSym e = spec[-2 - fq]; f = e.frame; src = e.src; ks = e.k; fresh = e.fresh & 255; late = e.fresh >> 8; }
     const FrameInfo fi = info[f];
+    if (late < 0) late = (fi.flags & kInfoLate) ? 1 : 0;                // (a late alignment's windows sit one symbol further on: frontend_kernels.h)
     const int rate = valid ? fi.rate : 0;
     const int kf = valid ? (int)(w - fi.sym_off) + 1 : 1;            // 1-based data symbol of the frame (SIGNAL is symbol 0): where its soft bytes go
     const int k = fq <= -2 ? ks : kf;                                // vector of alignment src: which window, which pilot polarity
     const foa_frame_desc d = descs[src];
-    const int64_t start = d.lts1_pos + 144 + 80 * (int64_t)k;
+    const int64_t start = d.lts1_pos + 144 + 80 * (int64_t)(k + late);
     const RateRow rr = g_tab.rates[rate];
     const int64_t my_out = fi.dec_off + (int64_t)(kf - 1) * rr.dbps;
 

@@ -136,7 +136,15 @@ int foa::job_ready(foa_rx *rx, uint64_t ticket, bool wait, HostJob **out)
 }
 
 static int decode_frames_any(foa_rx *rx, const void *d_iq, bool f64, size_t n_samples, const foa_frame_desc *d_descs, const int64_t *d_ends,
-                             size_t n_frames, size_t n_context, uint8_t *d_psdu, size_t slot_bytes, foa_frame_result *d_results);
+                             size_t n_frames, size_t n_context, size_t n_lead, uint8_t *d_psdu, size_t slot_bytes, foa_frame_result *d_results);
+
+// (stream engines: the n_lead tags in front of d_descs[0] in the same arrays are the stream's earlier alignments -- decided already, looked at
+// only to see whether one of them sits less than 64 samples in front of the first alignment of this call: frontend_kernels.h, "late")
+int foa::decode_frames_lead_dev(foa_rx *rx, const float *d_iq, size_t n_samples, const foa_frame_desc *d_descs, const int64_t *d_ends, size_t n_frames,
+                                size_t n_context, size_t n_lead, uint8_t *d_psdu, size_t slot_bytes, foa_frame_result *d_results)
+{
+    return decode_frames_any(rx, d_iq, false, n_samples, d_descs, d_ends, n_frames, n_context, n_lead, d_psdu, slot_bytes, d_results);
+}
 
 extern "C" {
 
@@ -149,14 +157,14 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
 int foa_rx_decode_frames_ctx_dev(foa_rx *rx, const float *d_iq, size_t n_samples, const foa_frame_desc *d_descs, const int64_t *d_ends,
                                  size_t n_frames, size_t n_context, uint8_t *d_psdu, size_t slot_bytes, foa_frame_result *d_results)
 {
-    return decode_frames_any(rx, d_iq, false, n_samples, d_descs, d_ends, n_frames, n_context, d_psdu, slot_bytes, d_results);
+    return decode_frames_any(rx, d_iq, false, n_samples, d_descs, d_ends, n_frames, n_context, 0, d_psdu, slot_bytes, d_results);
 }
 
 }  // extern "C"
 
 // f64: d_iq holds complex<double> samples that timing_sync has rotated already (the fused stage block of blocks.hpp); else complex<float>
 static int decode_frames_any(foa_rx *rx, const void *d_iq, bool f64, size_t n_samples, const foa_frame_desc *d_descs, const int64_t *d_ends,
-                             size_t n_frames, size_t n_context, uint8_t *d_psdu, size_t slot_bytes, foa_frame_result *d_results)
+                             size_t n_frames, size_t n_context, size_t n_lead, uint8_t *d_psdu, size_t slot_bytes, foa_frame_result *d_results)
 {
     if (!rx) return fail(FOA_E_INVALID, "rx is NULL");
     if (n_frames == 0) { rx->last_frames = 0; return FOA_OK; }
@@ -191,8 +199,8 @@ static int decode_frames_any(foa_rx *rx, const void *d_iq, bool f64, size_t n_sa
 
     if (rx->in_wait) { HIP_TRY(hipStreamWaitEvent(st, rx->in_ready, 0)); rx->in_wait = false; }
     HIP_TRY(hipEventRecord(rx->w->ev[0], st));
-    if (f64) hipLaunchKernelGGL(k_header<double2>, dim3(n_total), dim3(64), 0, st, iq64, d_descs, d_ends, (int64_t)n_samples, n_total, rx->w->info.p, rx->w->hinv.p, eq_sig);
-    else hipLaunchKernelGGL(k_header<float2>, dim3(n_total), dim3(64), 0, st, iq, d_descs, d_ends, (int64_t)n_samples, n_total, rx->w->info.p, rx->w->hinv.p, eq_sig);
+    if (f64) hipLaunchKernelGGL(k_header<double2>, dim3(n_total), dim3(64), 0, st, iq64, d_descs, d_ends, (int64_t)n_samples, (int)n_lead, n_total, rx->w->info.p, rx->w->hinv.p, eq_sig);
+    else hipLaunchKernelGGL(k_header<float2>, dim3(n_total), dim3(64), 0, st, iq, d_descs, d_ends, (int64_t)n_samples, (int)n_lead, n_total, rx->w->info.p, rx->w->hinv.p, eq_sig);
     HIP_TRY(hipEventRecord(rx->w->ev[1], st));
     // segments of this call: at most (total data steps)/S + one per frame; lanes beyond the real total idle
     const size_t max_segs = std::min(rx->w->seg2frame.n, rx->w->dec_cap / (size_t)rx->tb_segment + n_frames + 1);
@@ -260,7 +268,7 @@ static int decode_frames_host_any(foa_rx *rx, const void *iq, bool f64, size_t n
     HIP_TRY(hipMemsetAsync(b + o_psdu, 0, n_frames * slot_bytes, st));
     if ((rc = inputs_queued(rx, st))) return rc;
     rc = decode_frames_any(rx, b + o_iq, f64, n_samples, (const foa_frame_desc *)(b + o_desc), (const int64_t *)(b + o_end),
-                           n_frames, 0, b + o_psdu, slot_bytes, (foa_frame_result *)(b + o_res));
+                           n_frames, 0, 0, b + o_psdu, slot_bytes, (foa_frame_result *)(b + o_res));
     if (rc) return rc;
     if ((rc = flush_pending(rx, nullptr))) return rc;                   // the finish runs on the second stream
     HIP_TRY(hipStreamWaitEvent(st, rx->w->done, 0));

@@ -155,12 +155,28 @@ int foa_rx_create(foa_rx **out, int device)
             rx->notes += buf;
         }
     }
+    if (getenv("FOA_EXP_PRIO")) {
+        // EXPERIMENT: the runtime keeps a pool of hardware queues PER stream priority (profiles/r05_probe_queues.txt), so streams spread over
+        // the three levels get queues of their own whatever GPU_MAX_HW_QUEUES says
+        int lo = 0, hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        const int mode = atoi(getenv("FOA_EXP_PRIO"));
+        const int p_fin = hi, p_side = hi, p_l01 = (lo + hi) / 2, p_l23 = mode == 2 ? (lo + hi) / 2 : lo;
+        HIP_TRY(hipStreamCreateWithPriority(&rx->stream, hipStreamNonBlocking, p_l01));
+        HIP_TRY(hipStreamCreateWithPriority(&rx->stream2, hipStreamNonBlocking, p_fin));
+        HIP_TRY(hipStreamCreateWithPriority(&rx->stream3, hipStreamNonBlocking, p_side));
+        HIP_TRY(hipStreamCreateWithPriority(&rx->stream4, hipStreamNonBlocking, p_l01));
+        HIP_TRY(hipStreamCreateWithPriority(&rx->stream5, hipStreamNonBlocking, p_l23));
+        HIP_TRY(hipStreamCreateWithPriority(&rx->stream6, hipStreamNonBlocking, p_l23));
+        rx->max_depth = 4;
+    } else {
     HIP_TRY(hipStreamCreateWithFlags(&rx->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&rx->stream2, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&rx->stream3, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&rx->stream4, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&rx->stream5, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&rx->stream6, hipStreamNonBlocking));
+    }
     HIP_TRY(hipEventCreateWithFlags(&rx->in_ready, hipEventDisableTiming));
     for (auto &ws : rx->sets) {
         for (auto &e : ws.ev) HIP_TRY(hipEventCreate(&e));

@@ -151,6 +151,15 @@ int foa_rx_set_option(foa_rx *rx, const char *name, int64_t value);
  * invalid -- its symbols, exactly as the reference's blocks do (FOA_ST_SUPERSEDED if a valid SIGNAL intervenes).  Any other end is where
  * the stream ends for that alignment and everything linked in front of it (FOA_ST_TRUNCATED if a frame needs more).  Frames that fit in
  * front of their alignment's end -- every frame of an undisturbed stream -- do not depend on any of this.
+ * Pile-ups.  An alignment whose end comes before its second LTS window is complete (less than 128 samples on) gives no vector at all
+ * (FOA_ST_SUPERSEDED).  An alignment less than 64 samples behind another one it is linked to has that one's LTS2 tag inside its own first
+ * LTS window: fft_symbols restarts the vector there and again at the alignment's own LTS2 tag, so the first vector it completes -- still
+ * tagged LTS_START -- is the window at lts1_pos + 64, channel_est takes the window 80 samples on as the second LTS vector, and SIGNAL and
+ * every symbol are read one symbol (80 samples) later than in an undisturbed alignment (fft_symbols.cpp:53-56, channel_est.cpp:44-58).
+ * The call reproduces that from the descriptors it is given, so a caller that decodes a stream in pieces hands the alignments of such a
+ * pile-up over TOGETHER (the adaptors of blocks.hpp keep them together; the timing_sync restated here does not produce such tags on
+ * anything but pathological input).  With these rules a call returns, for any list of descriptors in stream order, what the reference's
+ * blocks return when fed the tags those descriptors stand for.
  */
 int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, const foa_frame_desc *d_descs,
                              const int64_t *d_ends, size_t n_frames, uint8_t *d_psdu, size_t slot_bytes,

@@ -297,6 +297,18 @@ private:
     std::vector<double> frame_;       // carriers of the frame being collected
 };
 
+// An alignment less than 64 samples behind another takes its vectors one symbol late (the earlier one's LTS2 tag falls into its first LTS
+// window: fun_ofdm_amd.h), so the device has to see the two together: an alignment that waits for more of the stream keeps the (dead)
+// alignments of its pile-up waiting with it.  pos(i): LTS1 stream index of pending alignment i; done: leading alignments decided.
+template <typename Pending, typename Pos>
+inline size_t keep_pile_together(const Pending &pending, size_t done, Pos pos)
+{
+    while (done > 0 && done < pending.size() && pos(pending[done]) - pos(pending[done - 1]) < 64) done--;
+    return done;
+}
+inline int64_t pile_pos_(int64_t p) { return p; }
+inline size_t keep_pile_together(const std::deque<int64_t> &pending, size_t done) { return keep_pile_together(pending, done, pile_pos_); }
+
 // ---------------------------------------------------------------------------------------------------------------
 // rx_backend: fft_symbols + channel_est + phase_tracker + frame_decoder as ONE block for a chain that keeps the reference's
 // own frame_detector and timing_sync threads: add_block(new fun_amd::rx_backend()) behind them instead of the four blocks
@@ -337,15 +349,15 @@ public:
             check(foa_rx_decode_frames_f64_host(dev_.get(), buf_.data(), buf_.size() / 2, d.data(), e.data(), m, psdu.data(), 4096, res.data()),
                   "foa_rx_decode_frames_f64_host");
             size_t done = 0;
-            for (size_t i = 0; i < m; i++) {
-                if (res[i].status == FOA_ST_TRUNCATED) {
-                    need_end_ = i + 1 == m ? pending_[i] + (res[i].rate >= 0 ? 144 + 80 * (int64_t)res[i].num_symbols + 64 : 208) : 0;
-                    break;
-                }
-                if (res[i].status == FOA_ST_OK) output_buffer.push_back(std::vector<unsigned char>(psdu.begin() + i * 4096, psdu.begin() + i * 4096 + res[i].length));
-                done++;
+            for (; done < m; done++) {
+                if (res[done].status != FOA_ST_TRUNCATED) continue;
+                need_end_ = done + 1 == m ? pending_[done] + (res[done].rate >= 0 ? 144 + 80 * (int64_t)res[done].num_symbols + 64 : 208) : 0;
+                break;
             }
             if (done == m) need_end_ = 0;
+            done = keep_pile_together(pending_, done);
+            for (size_t i = 0; i < done; i++)
+                if (res[i].status == FOA_ST_OK) output_buffer.push_back(std::vector<unsigned char>(psdu.begin() + i * 4096, psdu.begin() + i * 4096 + res[i].length));
             pending_.erase(pending_.begin(), pending_.begin() + done);
         }
         // samples in front of the oldest pending alignment are never looked at again
@@ -455,16 +467,16 @@ public:
         check(foa_rx_decode_frames_host(dev_.get(), buf_.data(), (size_t)(hz - base_), rel.data(), rel_end.data(), take, psdu.data(), 4096, res.data()),
               "foa_rx_decode_frames_host");
         size_t done = 0;
-        for (size_t i = 0; i < take; i++) {
-            if (res[i].status == FOA_ST_TRUNCATED) {
-                // not complete yet: if it is the newest alignment, remember how far its frame reaches and try again then
-                if (i + 1 == pending_.size())
-                    pending_[i].need_end = pending_[i].d.lts1_pos + (res[i].rate >= 0 ? 144 + 80 * (int64_t)res[i].num_symbols + 64 : 208);
-                break;
-            }
-            if (res[i].status == FOA_ST_OK) out.push_back(std::vector<unsigned char>(psdu.begin() + i * 4096, psdu.begin() + i * 4096 + res[i].length));
-            done++;
+        for (; done < take; done++) {
+            if (res[done].status != FOA_ST_TRUNCATED) continue;
+            // not complete yet: if it is the newest alignment, remember how far its frame reaches and try again then
+            if (done + 1 == pending_.size())
+                pending_[done].need_end = pending_[done].d.lts1_pos + (res[done].rate >= 0 ? 144 + 80 * (int64_t)res[done].num_symbols + 64 : 208);
+            break;
         }
+        done = keep_pile_together(pending_, done, entry_pos);
+        for (size_t i = 0; i < done; i++)
+            if (res[i].status == FOA_ST_OK) out.push_back(std::vector<unsigned char>(psdu.begin() + i * 4096, psdu.begin() + i * 4096 + res[i].length));
         pending_.erase(pending_.begin(), pending_.begin() + done);
         trim();
         return out;
@@ -484,6 +496,7 @@ private:
         int64_t need_end;     // stream index the frame needs before it can be decoded (0: SIGNAL not decoded yet)
         explicit entry(const foa_frame_desc &x) : d(x), need_end(0) {}
     };
+    static int64_t entry_pos(const entry &e) { return e.d.lts1_pos; }
     struct job { uint64_t ticket; size_t n_frames; bool final; std::vector<entry> sent; };     // sent: the alignments it decodes, stream-absolute
     static const int64_t kLongestFrame = 320 + 80 * 1369 + 160;       // samples: 4095 bytes at 6 Mbps, plus timing_sync's look-ahead
 
@@ -522,8 +535,10 @@ private:
         if (rc < 0) check(rc, "foa_rx_collect");
         if (rc == 0) return false;
         size_t good = j.n_frames;
-        if (!j.final)
+        if (!j.final) {
             for (size_t i = 0; i < j.n_frames; i++) if (res[i].status == FOA_ST_TRUNCATED) { good = i; break; }
+            good = keep_pile_together(j.sent, good, entry_pos);
+        }
         if (out)
             for (size_t i = 0; i < good; i++)
                 if (res[i].status == FOA_ST_OK) out->push_back(std::vector<unsigned char>(psdu.begin() + i * 4096, psdu.begin() + i * 4096 + res[i].length));
@@ -563,6 +578,7 @@ private:
                 const bool has_next = take + 1 < pending_.size();
                 if (!has_next && !final && hz - pending_[take].d.lts1_pos < kLongestFrame) break;
             }
+            if (!final) take = keep_pile_together(pending_, take, entry_pos);      // (a pile-up goes out in one batch)
             if (take > 0) {
                 // the batch only needs the samples from just before its first alignment to the horizon
                 const int64_t lo = std::max(base_, std::min(pending_[0].d.lts1_pos, pending_[0].d.rot_start) - 16);

@@ -1342,9 +1342,11 @@ void fo_chain_from_tags_f32(const float *iq, int64_t n, const fo_frame_desc *des
  * Status of alignment j: HEADER_FAIL / OK / CRC_FAIL as the blocks decide; TRUNCATED = the samples ran out (an unlinked end) before its
  * LTS windows, its SIGNAL vector or its frame's last vector; SUPERSEDED = the stream went on into a later alignment that took it over:
  * its LTS or SIGNAL window was cut by the next LTS1 (no vector at all), or a valid SIGNAL arrived before its frame's last vector.
- * Alignments whose LTS windows are cut take no part as sources (pile-ups closer than 128 samples: the residual this restatement
- * leaves; fo_chain_from_tags_f32 is the ground truth there). */
-typedef struct { int32_t K, has_part, fresh, nvec, valid, rate, length, nsym, link, dead, done; fo_c64 est[64]; } v2_al;
+ * Pile-ups: an alignment whose second LTS window is cut (e < p + 128) gives no vector -- what fft_symbols pushes of it is swallowed by
+ * channel_est as an LTS vector of an estimate the next LTS_START zeroes (channel_est.cpp:44-50); an alignment less than 64 samples behind
+ * another is LATE: see v2_al_compute.  With that the restatement equals the blocks for every tag layout (tests/manual/stress_tags.py places
+ * tags down to one sample apart). */
+typedef struct { int32_t K, has_part, fresh, nvec, valid, rate, length, nsym, link, dead, done, late; fo_c64 est[64]; } v2_al;
 
 /* The stream: complex<float> samples that the descriptor's phasors rotate (timing_sync.cpp:124-125), or (f64) complex<double> samples
  * that timing_sync has rotated already -- its own output_buffer, as the fused stage block of blocks.hpp receives it. */
@@ -1359,7 +1361,7 @@ static inline cplx v2_sample(const v2_stream *st, int64_t idx, const fo_frame_de
 
 static void v2_vector(const v2_stream *iq, const fo_frame_desc *d, const v2_al *a, int k, fo_tagged_vec48 *out)
 {
-    const int64_t w0 = d->lts1_pos + 144 + 80 * (int64_t)k;
+    const int64_t w0 = d->lts1_pos + 80 * a->late + 144 + 80 * (int64_t)k;
     const int partial = a->has_part && k == a->K;
     fo_tagged_vec64 v, eq;
     for (int i = 0; i < 64; i++) {
@@ -1376,6 +1378,19 @@ static void v2_vector(const v2_stream *iq, const fo_frame_desc *d, const v2_al *
     fo_phase_tracker_work(&pt, &eq, 1, out);
 }
 
+/* An LTS1 less than 64 samples behind an earlier one of the same stream (linked all the way): see v2_al_compute */
+static int v2_is_late(const fo_frame_desc *descs, const int64_t *ends, int64_t n, size_t j)
+{
+    const int64_t p = descs[j].lts1_pos;
+    for (size_t i = j; i-- > 0;) {
+        const int64_t ei = ends ? ends[i] : descs[i + 1].lts1_pos;
+        const int64_t dp = p - descs[i].lts1_pos;
+        if (ei != descs[i + 1].lts1_pos || ei > n || dp < 0 || dp >= 64) return 0;
+        if (dp > 0) return 1;
+    }
+    return 0;
+}
+
 /* what alignment j contributes: extent, vectors, channel estimate, SIGNAL outcome (n_tot = alignments in descs, context included) */
 static void v2_al_compute(const v2_stream *iq, int64_t n, const fo_frame_desc *descs, const int64_t *ends, size_t n_tot, size_t j, v2_al *a)
 {
@@ -1387,9 +1402,15 @@ static void v2_al_compute(const v2_stream *iq, int64_t n, const fo_frame_desc *d
     const int64_t e_raw = ends ? ends[j] : (j + 1 < n_tot ? descs[j + 1].lts1_pos : n);
     const int64_t e = e_raw < n ? e_raw : n;
     a->link = j + 1 < n_tot && e_raw == descs[j + 1].lts1_pos && e_raw <= n;
-    if (p < 0 || e < p + 128) { a->dead = 1; return; }             /* LTS cut off: no estimate, no vectors */
-    a->K = e >= p + 208 ? (int32_t)((e - (p + 208)) / 80 + 1) : 0;
-    const int mo = (int)((e - (p + 128)) % 80);
+    /* An LTS1 less than 64 samples behind an earlier one: that alignment's LTS2 tag (timing_sync.cpp:105-106) falls inside this one's first
+     * LTS window and restarts the vector there (fft_symbols.cpp:53-56), this alignment's own LTS2 tag restarts it again, and the first
+     * complete vector -- still tagged LTS_START -- is the window at p + 64; the next one, 80 samples on, is taken as the second LTS vector
+     * (channel_est.cpp:44-58), and START_OF_FRAME goes to the window behind that: everything sits one symbol LATE. */
+    a->late = v2_is_late(descs, ends, n, j);
+    const int64_t q = p + 80 * a->late;                               /* where an undisturbed alignment with the same vector grid would sit */
+    if (p < 0 || e < q + 128) { a->dead = 1; return; }                /* LTS cut off: no estimate, no vectors */
+    a->K = e >= q + 208 ? (int32_t)((e - (q + 208)) / 80 + 1) : 0;
+    const int mo = (int)((e - (q + 128)) % 80);
     a->has_part = a->link && mo > 15;
     a->fresh = a->has_part ? mo - 16 : 0;
     a->nvec = a->K + a->has_part;
@@ -1398,7 +1419,8 @@ static void v2_al_compute(const v2_stream *iq, int64_t n, const fo_frame_desc *d
     memset(&ce, 0, sizeof ce);
     for (int w = 0; w < 2; w++) {
         fo_tagged_vec64 v, dummy;
-        for (int i = 0; i < 64; i++) v.samples[i] = from_c(v2_sample(iq, p + 64 * w + i, d));
+        const int64_t w0 = w == 0 ? (a->late ? p + 64 : p) : q + 64;
+        for (int i = 0; i < 64; i++) v.samples[i] = from_c(v2_sample(iq, w0 + i, d));
         v.tag = w == 0 ? FO_LTS_START : FO_NONE; v._pad = 0;
         fo_fft64(v.samples);
         fo_channel_est_work(&ce, &v, 1, &dummy);
@@ -1469,17 +1491,20 @@ void fo_decode_batch_v2_f64(const double *iq, int64_t n, const fo_frame_desc *de
 }
 
 /* After a pass that decoded every alignment on its own (fo_decode_batch_f32, fo_pool_decode): the alignments whose outcome depends
- * on the alignments behind them -- linked, and cut short by the next LTS1 -- are decided again by the rules above.  Everything else
+ * on the alignments around them -- linked and cut short by the next LTS1, or one symbol late behind a pile-up -- are decided again by the
+ * rules above.  Everything else
  * (a complete SIGNAL window with an invalid header, a frame that fits in front of the next LTS1, an unlinked end) comes out the same
  * either way. */
 static void v2_fixup(const float *iq, int64_t n, const fo_frame_desc *descs, const int64_t *ends, size_t n_frames, uint8_t *psdu, size_t slot_bytes,
                      fo_frame_result *res)
 {
     v2_al *al = NULL;
-    for (size_t j = 0; j + 1 < n_frames; j++) {
-        if (res[j].status != FO_ST_TRUNCATED || ends[j] != descs[j + 1].lts1_pos || ends[j] > n) continue;
+    for (size_t j = 0; j < n_frames; j++) {
+        const int cut = j + 1 < n_frames && res[j].status == FO_ST_TRUNCATED && ends[j] == descs[j + 1].lts1_pos && ends[j] <= n;
+        if (!cut && !v2_is_late(descs, ends, n, j)) continue;
         if (!al) al = (v2_al *)calloc(n_frames, sizeof(v2_al));
         const v2_stream st = { iq, 0 };
+        memset(psdu + j * slot_bytes, 0, slot_bytes);                     /* (what the alignment gave on its own does not count) */
         v2_resolve(&st, n, descs, ends, n_frames, al, j, psdu + j * slot_bytes, &res[j]);
     }
     free(al);

@@ -5,8 +5,9 @@ The physical streams of stress_collide.py hardly ever put an LTS1 tag where the 
 frame's fate (the detector needs the second preamble ~10 dB above the first frame, which ruins the symbols under it).  Here the tags are
 PLACED: on a clean multi-frame stream, extra alignments are inserted at chosen sample offsets -- late in a frame's last symbol (the partial
 vector completes the frame), one symbol earlier (the partial vector and the next alignment's SIGNAL complete it), anywhere (the frame is
-dropped or fails), on noise -- with phasors chained as timing_sync would chain them.  Alignments are kept >= 208 samples apart (closer
-pile-ups cut LTS windows: the documented residual).
+dropped or fails), on noise, and in PILE-UPS (one to three more tags within 1 .. 207 samples of an alignment, a true one included: cut
+LTS windows, a SIGNAL window that is only part fresh, an LTS2 tag inside the next alignment's first LTS window -- which moves that
+alignment's vectors one symbol later) -- with phasors chained as timing_sync would chain them.
 Usage: python3 tests/manual/stress_tags.py cpu|gpu [first seed] [last seed]"""
 import os
 import sys
@@ -46,12 +47,15 @@ def make_case(seed):
             lts.append((int(rng.integers(a + 400, max(a + 401, end + 100))), False))
     if rng.random() < 0.3:
         lts.append((int(rng.integers(0, s.size - 300)), False))
+    for p, real in list(lts):                            # pile-ups: more tags close to one that is there
+        if rng.random() < 0.12:
+            for _ in range(int(rng.integers(1, 4))):
+                lts.append((p + int(rng.choice((-1, 1))) * int(rng.choice((rng.integers(1, 64), rng.integers(64, 128), rng.integers(128, 208)))), False))
     lts.sort()
     keep = []
-    for p, real in lts:                                  # >= 208 apart; a real alignment wins over a made-up one next to it
-        if keep and p - keep[-1][0] < 208:
-            if real and not keep[-1][1]:
-                keep[-1] = (p, real)
+    for p, real in lts:                                  # one tag per sample (a true alignment wins)
+        if keep and p == keep[-1][0]:
+            keep[-1] = (p, real or keep[-1][1])
             continue
         if 0 <= p < s.size - 130:
             keep.append((p, real))

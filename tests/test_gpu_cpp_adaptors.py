@@ -2,11 +2,14 @@
 of include/fun_ofdm_amd/blocks.hpp against the oracle, through the C ABI.  GPU only."""
 import os
 import subprocess
+import sys
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def test_cpp_adaptors(tmp_path, po):
@@ -40,6 +43,27 @@ def test_mixed_chain_reference_presync_blocks_in_front_of_the_gpu_blocks(tmp_pat
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     print(r.stdout, r.stderr)
     assert r.returncode == 0 and "chain B" in r.stdout, r.stdout + r.stderr
+
+
+def test_rx_backend_over_placed_tags_in_calls_of_any_size(tmp_path, po):
+    """tests/cpp/backend_tags.cpp against the real library: fun_amd::rx_backend over the placed-tag cases of tests/manual/stress_tags.py
+    (second preambles inside frames, pile-ups of LTS1 tags down to one sample apart), cut into work() calls of several sizes, against the
+    oracle's block chain over the same tags (the CPU twin over the stub ABI: tests/test_backend_tags.py)."""
+    import fun_ofdm_amd as foa
+    import test_backend_tags as t
+    exe = str(tmp_path / "backend_tags")
+    libdir = os.path.dirname(foa.library_path())
+    subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "cpp", "backend_tags.cpp"), "-I", os.path.join(ROOT, "include"),
+                    "-L", libdir, "-lfun_ofdm_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lm", "-lpthread", "-o", exe], check=True)
+    piles = n = 0
+    for seed in range(1000, 1040):
+        s, d, f_s, f_t = t.write_case(tmp_path, seed)
+        piles += int(np.sum(np.diff(d["lts1_pos"]) < 64))
+        want = po.chain_from_tags_f32(s, d)
+        n += len(want)
+        for chunk in (4096, 997):
+            assert t.run_program(exe, f_s, f_t, chunk) == want, (seed, chunk)
+    assert piles >= 8 and n >= 15, (piles, n)
 
 
 def test_sim_cli_over_iq_file(tmp_path):

@@ -57,12 +57,12 @@ def test_colliding_frames_and_false_alarms_inside_frames_equal_the_block_chain(p
 def test_placed_tags_partial_vector_flush_and_frames_in_progress_equal_the_blocks(po):
     """fft_symbols.cpp:41-50 (the partly filled vector pushed when LTS1 arrives mid-symbol), channel_est.cpp:77-81, frame_decoder.cpp:52-88 (a frame
     fills on with whatever vectors follow its SIGNAL; a valid SIGNAL abandons it) with tags PLACED where they decide a frame's fate (late in its
-    last symbol, a symbol earlier, anywhere, on noise): the device's batch path handed those descriptors against the oracle's BLOCKS fed with
+    last symbol, a symbol earlier, anywhere, on noise, in pile-ups down to one sample apart): the device's batch path handed those descriptors against the oracle's BLOCKS fed with
     the same tag stream (ordered payload list) and against the per-alignment restatement (status, fields, PSDUs of every alignment).  A third
     of the delivered payloads of these cases exist only because of those rules."""
     import stress_tags
     tot, n_al, bad, hits = stress_tags.run_gpu(0, 400)
-    assert bad == 0 and n_al > 2000 and tot > 250 and hits > 80, (tot, n_al, bad, hits)
+    assert bad == 0 and n_al > 2000 and tot > 180 and hits > 60, (tot, n_al, bad, hits)
     # ... and as the pre-rotated complex<double> stream the fused stage block hands over (foa_rx_decode_frames_f64_host)
     tot, n_al, bad = stress_tags.run_gpu_f64(400, 520)
-    assert bad == 0 and n_al > 600 and tot > 70, (tot, n_al, bad)
+    assert bad == 0 and n_al > 600 and tot > 40, (tot, n_al, bad)
