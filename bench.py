@@ -25,11 +25,6 @@ import time
 
 import numpy as np
 
-# The library keeps up to six HIP streams busy (four lanes of pipelined calls, the finish stream, the copy / pre-sync stream); the
-# runtime's default of four hardware queues per process makes streams share queues, i.e. run one after the other.  Must be set
-# before the runtime starts (before torch is imported).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

@@ -73,9 +73,6 @@ static void on_packets(std::vector<std::vector<unsigned char> > packets)
 
 int main(int argc, char **argv)
 {
-    // the host process's part of the set-up (include/fun_ofdm_amd.h, foa_recommended_hw_queues): the HIP runtime fixes its hardware queues
-    // when it starts, i.e. before the library is first called
-    ::setenv("GPU_MAX_HW_QUEUES", std::to_string(foa_recommended_hw_queues()).c_str(), 0);
 #if defined(__GLIBC__)
     // A caller that hands process_samples() megabyte-sized vectors at gigabytes per second must not have its allocator give every one of
     // them back to the kernel: glibc serves requests above its mmap threshold (128 KB until the first such block is freed, then whatever

@@ -30,7 +30,6 @@ _SIGS = {
     "foa_version": (C.c_int, []),
     "foa_last_error": (C.c_char_p, []),
     "foa_device_count": (C.c_int, []),
-    "foa_recommended_hw_queues": (C.c_int, []),
     "foa_rx_notes": (C.c_char_p, [C.c_void_p]),
     "foa_rx_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "foa_rx_destroy": (None, [C.c_void_p]),
@@ -106,14 +105,6 @@ def lib():
         if not os.path.exists(path):
             raise FoaError("%s not found: build it with fun_ofdm_amd.build() / `make -C fun_ofdm_amd/csrc` "
                            "(this package has no CPU implementation)" % path)
-        # The library keeps up to six HIP streams busy and the runtime fixes its number of hardware queues when it STARTS (default 4:
-        # lanes would share queues and small batches lose 20-30 %, include/fun_ofdm_amd.h foa_recommended_hw_queues).  This process is
-        # the library's host: say so before anything starts the runtime.  A host that has set the variable keeps its choice; one that
-        # started the runtime before importing this package is told so by Receiver (foa_rx_notes).
-        import sys
-        tc = getattr(sys.modules.get("torch"), "cuda", None)
-        if not (tc is not None and tc.is_initialized()):                # (too late otherwise: the library then sees the variable unset and says so)
-            os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
         # PyTorch-ROCm wheels bundle their own libamdhip64; two HIP runtimes in one process do not
         # coexist (the second sees no GPU).  Importing torch first makes this library bind to the
         # runtime torch already loaded, so device buffers and streams can be shared with it.

@@ -111,7 +111,7 @@ struct foa_rx {
     hipStream_t stream3 = nullptr;     // pipelined path: copies of the host-pointer entry points and the pre-sync stage
     hipStream_t stream4 = nullptr;     // the second lane of pipelined calls (the first is `stream`)
     hipStream_t stream5 = nullptr, stream6 = nullptr;      // third and fourth lane, used for small grids (option "depth")
-    int hw_queues = 4, max_depth = 4;  // hardware queues the runtime was started with, as far as the environment tells (foa_rx_create), and the depth they allow
+    int max_depth = 4;                 // lanes that can run side by side (2 if the host cut the runtime down to one hardware queue per priority: foa_rx_create)
     std::string notes;                 // non-fatal remarks about how the handle is set up (foa_rx_notes)
     int64_t sync_origin = 0;           // one-shot device pre-sync: stream index of d_iq[0] (option "sync_origin")
     int64_t stream_longest = 0;        // foa_stream_create: longest frame (samples, preamble to last symbol + 192) the stream will hold; 0 = any frame the format allows
@@ -164,12 +164,14 @@ namespace foa {
 // A machine that a call fills (config 2: five forward-pass waves per SIMD) is best served by two calls' loops in flight; a call of a few
 // thousand frames leaves most SIMDs one wave or none, its forward pass lasts as long as ONE wave needs for its frames' trellis steps
 // whatever the batch, and more loops in flight are what raises the throughput then (1 000 frames x 4 092 bytes at 54 Mbps: 1.43 ms per
-// batch with two, 0.94 with four).  Needs as many hardware queues as streams in use: GPU_MAX_HW_QUEUES >= 6.
+// batch with two, 0.94 with four).  The lanes sit on hardware queues of their own (stream priorities: foa_rx_create).
 constexpr int kDeepBelow = 2049;                 // frames: up to one forward-pass wave per SIMD
 
 inline bool piped(const foa_rx *rx) { return rx->pipeline; }
 // Host-pointer entry points copy their inputs (and the pre-sync stage runs) on the third stream when calls are pipelined, off the
 // lanes, so that a copy never sits behind a forward pass; the decode call that follows waits for the event.
+// the priority level of copy / pre-sync / look-ahead streams (foa_rx_create: hardware queues come in a pool per priority)
+inline int high_priority() { int least = 0, greatest = 0; (void)hipDeviceGetStreamPriorityRange(&least, &greatest); return greatest; }
 inline hipStream_t side_stream(foa_rx *rx) { return rx->pipeline ? rx->stream3 : rx->stream; }
 
 // ---- rx_decode.hip ----

@@ -122,8 +122,6 @@ int foa_device_count(void)
     return n;
 }
 
-int foa_recommended_hw_queues(void) { return 8; }
-
 const char *foa_rx_notes(foa_rx *rx) { return rx ? rx->notes.c_str() : ""; }
 
 int foa_rx_create(foa_rx **out, int device)
@@ -139,43 +137,29 @@ int foa_rx_create(foa_rx **out, int device)
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(FOA_E_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
     foa_rx *rx = new foa_rx();
     rx->device = device;
-    // Six streams want six hardware queues.  The runtime reads GPU_MAX_HW_QUEUES once, when it starts, so it is the HOST PROCESS that
-    // sets it (foa_recommended_hw_queues(); bench.py, examples/foa_sim.cpp and the Python package do) -- a library does not edit its
-    // host's environment.  What the variable says now is all that can be known here: with fewer than six queues four lanes would
-    // share queues and run one after the other, so small grids then keep two loops in flight and the handle says so (foa_rx_notes).
+    // Six streams want six hardware queues, and the runtime's default is four (GPU_MAX_HW_QUEUES, read once when it starts: a library
+    // cannot change it, and does not edit its host's environment).  But the runtime keeps a pool of that many queues PER STREAM PRIORITY
+    // (tools/probe_queues.hip, profiles/r05_probe_queues.txt: six streams spread over the three levels run side by side at the default,
+    // six at one level take two turns), so the streams are spread: lanes 1-2 at the normal level, lanes 3-4 (small grids only) at the
+    // low one, the stitch / CRC stream and the copy / pre-sync stream at the high one -- short kernels that gate the next call.  No pool
+    // holds more than two streams of a handle (four with a stream engine's), whatever the host set: small batches run at the same speed
+    // with 4 and with 8 queues (profiles/r05_ab_stream_priorities.txt: 1 000 frames per call 9.3 -> 11.3 Gsample/s at the default).
     {
+        int least = 0, greatest = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));         // (numerically greatest <= least)
+        const int normal = (least + greatest) / 2;
+        HIP_TRY(hipStreamCreateWithPriority(&rx->stream, hipStreamNonBlocking, normal));
+        HIP_TRY(hipStreamCreateWithPriority(&rx->stream4, hipStreamNonBlocking, normal));
+        HIP_TRY(hipStreamCreateWithPriority(&rx->stream5, hipStreamNonBlocking, least));
+        HIP_TRY(hipStreamCreateWithPriority(&rx->stream6, hipStreamNonBlocking, least));
+        HIP_TRY(hipStreamCreateWithPriority(&rx->stream2, hipStreamNonBlocking, greatest));
+        HIP_TRY(hipStreamCreateWithPriority(&rx->stream3, hipStreamNonBlocking, greatest));
         const char *q = getenv("GPU_MAX_HW_QUEUES");
-        rx->hw_queues = (q && atoi(q) > 0) ? atoi(q) : 4;             // (the runtime's default)
-        if (rx->hw_queues < 6) {
+        if (q && atoi(q) < 2) {                                          // (also set but empty) one queue per pool: two streams of a level take turns
             rx->max_depth = 2;
-            char buf[320];
-            snprintf(buf, sizeof buf, "GPU_MAX_HW_QUEUES is %s (%d hardware queues): decode calls of fewer than %d frames keep 2 loops in flight instead of 4 "
-                     "(20-30 %% slower for such batches); set GPU_MAX_HW_QUEUES=%d in the environment before the HIP runtime starts. ",
-                     q ? "set low" : "unset", rx->hw_queues, kDeepBelow, foa_recommended_hw_queues());
-            rx->notes += buf;
+            rx->notes += "GPU_MAX_HW_QUEUES is set below 2: streams of one priority share a hardware queue, so decode calls keep 2 loops in flight instead of 4 and "
+                         "the stitch kernels wait for copies; leave the variable unset (the runtime's default of 4 is enough). ";
         }
-    }
-    if (getenv("FOA_EXP_PRIO")) {
-        // EXPERIMENT: the runtime keeps a pool of hardware queues PER stream priority (profiles/r05_probe_queues.txt), so streams spread over
-        // the three levels get queues of their own whatever GPU_MAX_HW_QUEUES says
-        int lo = 0, hi = 0;
-        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        const int mode = atoi(getenv("FOA_EXP_PRIO"));
-        const int p_fin = hi, p_side = hi, p_l01 = (lo + hi) / 2, p_l23 = mode == 2 ? (lo + hi) / 2 : lo;
-        HIP_TRY(hipStreamCreateWithPriority(&rx->stream, hipStreamNonBlocking, p_l01));
-        HIP_TRY(hipStreamCreateWithPriority(&rx->stream2, hipStreamNonBlocking, p_fin));
-        HIP_TRY(hipStreamCreateWithPriority(&rx->stream3, hipStreamNonBlocking, p_side));
-        HIP_TRY(hipStreamCreateWithPriority(&rx->stream4, hipStreamNonBlocking, p_l01));
-        HIP_TRY(hipStreamCreateWithPriority(&rx->stream5, hipStreamNonBlocking, p_l23));
-        HIP_TRY(hipStreamCreateWithPriority(&rx->stream6, hipStreamNonBlocking, p_l23));
-        rx->max_depth = 4;
-    } else {
-    HIP_TRY(hipStreamCreateWithFlags(&rx->stream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&rx->stream2, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&rx->stream3, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&rx->stream4, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&rx->stream5, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&rx->stream6, hipStreamNonBlocking));
     }
     HIP_TRY(hipEventCreateWithFlags(&rx->in_ready, hipEventDisableTiming));
     for (auto &ws : rx->sets) {

@@ -318,7 +318,7 @@ int foa_stream_create(foa_rx *rx, size_t batch_samples, int narrow_threads, foa_
         if (!rc && hipEventCreateWithFlags(&g.in_done[i], hipEventDisableTiming) != hipSuccess) rc = fail(FOA_E_HIP, "hipEventCreate failed");
         if (!rc && hipEventCreateWithFlags(&g.sel_done[i], hipEventDisableTiming) != hipSuccess) rc = fail(FOA_E_HIP, "hipEventCreate failed");
     }
-    if (!rc && hipStreamCreateWithFlags(&g.st_in, hipStreamNonBlocking) != hipSuccess) rc = fail(FOA_E_HIP, "hipStreamCreate failed");
+    if (!rc && hipStreamCreateWithPriority(&g.st_in, hipStreamNonBlocking, high_priority()) != hipSuccess) rc = fail(FOA_E_HIP, "hipStreamCreate failed");
     if (!rc && hipHostMalloc((void **)&g.sel, (size_t)foa::kStreamBufs * 8 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) rc = fail(FOA_E_NOMEM, "hipHostMalloc failed");
     if (!rc) rc = g.sel_dev.ensure((size_t)foa::kStreamBufs * 8);
     if (!rc) rc = g.la_range.ensure((size_t)foa::kStreamBufs * 2);
@@ -355,7 +355,7 @@ int foa_stream_create(foa_rx *rx, size_t batch_samples, int narrow_threads, foa_
     // against 2.0 Gsample/s through process_samples with four).  A SMALL batch is a handful of forward-pass waves, and one wave walks its
     // frames' trellis at the lone-wave rate (0.65 ms for a 1024-byte frame at 54 Mbps) whatever the batch: what sets the rate of 64 Ki-sample
     // batches is loops in flight over that latency -- 0.36 ms per batch with two -- so batches below a million samples get four where the
-    // runtime has the hardware queues for them (foa_recommended_hw_queues).  FOA_STREAM_DEPTH overrides (A/B).
+    // runtime has the hardware queues for them (foa_rx_create).  FOA_STREAM_DEPTH overrides (A/B).
     rx->depth_saved = rx->depth;
     rx->depth = (batch_samples <= ((size_t)1 << 20) && rx->max_depth >= 4) ? 4 : 2;
     if (const char *e = getenv("FOA_STREAM_DEPTH")) { const int v = atoi(e); if (v >= 2 && v <= 4) rx->depth = v; }

@@ -83,16 +83,14 @@ const char *foa_last_error(void);
 int foa_device_count(void);
 
 /* The library runs a call's stages on up to six HIP streams (two to four lanes of pipelined decode calls, one for the stitch / CRC
- * kernels, one for copies and the pre-sync).  Streams only overlap when they sit on different hardware queues, and the HIP runtime
- * fixes their number when it STARTS: GPU_MAX_HW_QUEUES, default 4.  The library does not touch its host's environment; a host that
- * wants small batches (< 2049 frames per call) at full speed sets GPU_MAX_HW_QUEUES to this value (8) before its first HIP call --
- * bench.py and examples/foa_sim.cpp do.  With fewer than six queues such calls keep two loops in flight instead of four (20-30 %
- * slower for those batches; config 2-sized calls are not affected) and foa_rx_notes() says so. */
-int foa_recommended_hw_queues(void);
+ * kernels, one for copies and the pre-sync).  Streams only overlap when they sit on different hardware queues; the HIP runtime keeps a
+ * pool of GPU_MAX_HW_QUEUES queues (default 4, fixed when it starts) per stream PRIORITY, and the library spreads its streams over the
+ * three priority levels, so it runs at full speed with the runtime's defaults: the host sets nothing (rounds 3-4 asked for
+ * GPU_MAX_HW_QUEUES=8).  Only a host that cuts the runtime down to ONE queue per priority is told so by foa_rx_notes(). */
 
 /* Create a receiver on HIP device `device` (its own non-blocking streams). */
 int foa_rx_create(foa_rx **out, int device);
-/* Non-fatal remarks about how the handle is set up ("" if none), e.g. too few hardware queues for four lanes.  Valid until the handle
+/* Non-fatal remarks about how the handle is set up ("" if none), e.g. a runtime cut down to one hardware queue per priority.  Valid until the handle
  * is destroyed. */
 const char *foa_rx_notes(foa_rx *rx);
 void foa_rx_destroy(foa_rx *rx);
@@ -113,7 +111,7 @@ int foa_rx_reserve(foa_rx *rx, size_t n_samples, size_t n_frames);
  *                 stream.  (Waits for everything in flight before it switches.)
  *   "depth"       pipelined calls: how many calls' loops are in flight -- 0 (default) = by grid size: 2, or 4 for calls of up to 2048 frames,
  *                 whose forward pass leaves most SIMDs a single wave (1 000-frame batches decode 40-50 % faster in steady state); 2, 3, 4 =
- *                 fixed.  More than two need more hardware queues than the runtime's default of four (foa_recommended_hw_queues)
+ *                 fixed.  (the lanes sit on hardware queues of their own: stream priorities, see above)
  *   "record_soft" keep the depunctured soft bytes for foa_rx_get_taps (default 1; 0 saves their HBM writes)
  *   "record_eq"   keep the equalised carriers for foa_rx_get_taps (default 0)
  *

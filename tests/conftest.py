@@ -9,10 +9,6 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
-# The test process is the library's HOST: it gives the HIP runtime the hardware queues the library's streams want, before anything starts
-# the runtime (include/fun_ofdm_amd.h, foa_recommended_hw_queues; the library itself no longer edits the environment).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

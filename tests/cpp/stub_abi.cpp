@@ -159,7 +159,6 @@ int foa_shard_flush(foa_shard *s) { return foa_stream_flush(&s->st); }
 int foa_shard_ready(foa_shard *s, int w, size_t *np, size_t *nb) { return foa_stream_ready(&s->st, w, np, nb); }
 int foa_shard_take(foa_shard *s, uint8_t *p, uint32_t *l) { return foa_stream_take(&s->st, p, l); }
 int foa_shard_stats(const foa_shard *, uint64_t out[8], uint64_t *, int) { memset(out, 0, 8 * sizeof(uint64_t)); return FOA_OK; }
-int foa_recommended_hw_queues(void) { return 8; }
 const char *foa_rx_notes(foa_rx *) { return ""; }
 
 // the per-stage entry points, answered by the oracle's functions of the same stage (the adaptors' HOST logic -- tags, counters, frames in

@@ -18,7 +18,6 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import fun_ofdm_amd as foa                      # noqa: E402
 from fun_ofdm_amd import synth                  # noqa: E402
 

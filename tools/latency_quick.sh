@@ -6,7 +6,6 @@ python3 - "$n" <<'PY'
 import json, os, re, subprocess, sys
 import numpy as np, torch
 ROOT = os.getcwd(); sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import fun_ofdm_amd as foa
 from fun_ofdm_amd import synth
 n = int(sys.argv[1])
