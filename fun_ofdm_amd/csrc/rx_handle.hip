@@ -137,28 +137,33 @@ int foa_rx_create(foa_rx **out, int device)
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(FOA_E_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
     foa_rx *rx = new foa_rx();
     rx->device = device;
-    // Six streams want six hardware queues, and the runtime's default is four (GPU_MAX_HW_QUEUES, read once when it starts: a library
-    // cannot change it, and does not edit its host's environment).  But the runtime keeps a pool of that many queues PER STREAM PRIORITY
-    // (tools/probe_queues.hip, profiles/r05_probe_queues.txt: six streams spread over the three levels run side by side at the default,
-    // six at one level take two turns), so the streams are spread: lanes 1-2 at the normal level, lanes 3-4 (small grids only) at the
-    // low one, the stitch / CRC stream and the copy / pre-sync stream at the high one -- short kernels that gate the next call.  No pool
-    // holds more than two streams of a handle (four with a stream engine's), whatever the host set: small batches run at the same speed
-    // with 4 and with 8 queues (profiles/r05_ab_stream_priorities.txt: 1 000 frames per call 9.3 -> 11.3 Gsample/s at the default).
+    // Six streams want six hardware queues that do not get in each other's way.  Two things decide that, both measured (tools/probe_queues.hip,
+    // tools/probe_pipes.hip, profiles/r05_ab_stream_layout_host_queues.txt):
+    //  * the runtime keeps a pool of GPU_MAX_HW_QUEUES hardware queues (default 4, read when it starts) PER STREAM PRIORITY and hands a new
+    //    stream the least used one once the pool is full.  Streams of the normal priority share the pool with whatever the host made;
+    //  * a process's hardware queues go round the GPU's four dispatch pipes in the order they were made (queue k on pipe k mod 4), and a grid
+    //    that does not fit on the machine at once -- the forward pass -- keeps its pipe busy until its last workgroup has started: another
+    //    queue on that pipe waits.  Two lanes, the stitch stream and the copy stream on two pipes run at 24-29 Gsample/s instead of 37,
+    //    which is what round 4's layout (six normal streams) did in a host that had made two or three streams of its own.
+    // So: no stream at the normal level.  The four lanes sit at the LOW level (the decode yields to the host's own normal-priority work), the
+    // stitch / CRC stream and the copy / pre-sync stream at the HIGH one (short kernels that gate the next call), and they are made in the
+    // order lane 1, stitch, copy, lane 2, lane 3, lane 4: four queues in a row are on four different pipes wherever the row starts.  Same
+    // speed with 0 .. 3 queues made by the host before, with the runtime's default of 4 queues and with 8; small batches no longer need
+    // GPU_MAX_HW_QUEUES=8 (1 000 frames per call: 9.2 -> 11.0 Gsample/s at the default).
     {
         int least = 0, greatest = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));         // (numerically greatest <= least)
-        const int normal = (least + greatest) / 2;
-        HIP_TRY(hipStreamCreateWithPriority(&rx->stream, hipStreamNonBlocking, normal));
-        HIP_TRY(hipStreamCreateWithPriority(&rx->stream4, hipStreamNonBlocking, normal));
-        HIP_TRY(hipStreamCreateWithPriority(&rx->stream5, hipStreamNonBlocking, least));
-        HIP_TRY(hipStreamCreateWithPriority(&rx->stream6, hipStreamNonBlocking, least));
+        HIP_TRY(hipStreamCreateWithPriority(&rx->stream, hipStreamNonBlocking, least));
         HIP_TRY(hipStreamCreateWithPriority(&rx->stream2, hipStreamNonBlocking, greatest));
         HIP_TRY(hipStreamCreateWithPriority(&rx->stream3, hipStreamNonBlocking, greatest));
+        HIP_TRY(hipStreamCreateWithPriority(&rx->stream4, hipStreamNonBlocking, least));
+        HIP_TRY(hipStreamCreateWithPriority(&rx->stream5, hipStreamNonBlocking, least));
+        HIP_TRY(hipStreamCreateWithPriority(&rx->stream6, hipStreamNonBlocking, least));
         const char *q = getenv("GPU_MAX_HW_QUEUES");
-        if (q && atoi(q) < 2) {                                          // (also set but empty) one queue per pool: two streams of a level take turns
+        if (q && atoi(q) < 4) {                                          // (also set but empty = 1) fewer queues per pool than lanes
             rx->max_depth = 2;
-            rx->notes += "GPU_MAX_HW_QUEUES is set below 2: streams of one priority share a hardware queue, so decode calls keep 2 loops in flight instead of 4 and "
-                         "the stitch kernels wait for copies; leave the variable unset (the runtime's default of 4 is enough). ";
+            rx->notes += "GPU_MAX_HW_QUEUES is set below 4: the four lanes of small decode calls would share hardware queues, so such calls keep 2 loops in "
+                         "flight instead of 4; leave the variable unset (the runtime's default of 4 per priority level is enough). ";
         }
     }
     HIP_TRY(hipEventCreateWithFlags(&rx->in_ready, hipEventDisableTiming));
