@@ -83,14 +83,18 @@ const char *foa_last_error(void);
 int foa_device_count(void);
 
 /* The library runs a call's stages on up to six HIP streams (two to four lanes of pipelined decode calls, one for the stitch / CRC
- * kernels, one for copies and the pre-sync).  Streams only overlap when they sit on different hardware queues; the HIP runtime keeps a
- * pool of GPU_MAX_HW_QUEUES queues (default 4, fixed when it starts) per stream PRIORITY, and the library spreads its streams over the
- * three priority levels, so it runs at full speed with the runtime's defaults: the host sets nothing (rounds 3-4 asked for
- * GPU_MAX_HW_QUEUES=8).  Only a host that cuts the runtime down to ONE queue per priority is told so by foa_rx_notes(). */
+ * kernels, one for copies and the pre-sync).  Streams overlap when they sit on different hardware queues, and big grids only when those
+ * queues sit on different dispatch pipes.  The HIP runtime keeps a pool of GPU_MAX_HW_QUEUES queues (default 4, fixed when it starts) per
+ * stream PRIORITY, and a process's queues go round the four pipes in the order they were made; so the library makes its lanes at the LOW
+ * priority level and its stitch and copy streams at the HIGH one, in an order that puts any four in a row on four pipes -- none at the
+ * normal level, where the host's own streams live.  It runs at full speed with the runtime's defaults and whatever streams the host has
+ * made (profiles/r05_ab_stream_layout_host_queues.txt); the host sets nothing (rounds 3-4 asked for GPU_MAX_HW_QUEUES=8, and lost a
+ * third of their speed behind two host streams).  The decode therefore yields to normal-priority work of the host on the same GPU.
+ * Only a host that sets GPU_MAX_HW_QUEUES below 4 is told so by foa_rx_notes(). */
 
 /* Create a receiver on HIP device `device` (its own non-blocking streams). */
 int foa_rx_create(foa_rx **out, int device);
-/* Non-fatal remarks about how the handle is set up ("" if none), e.g. a runtime cut down to one hardware queue per priority.  Valid until the handle
+/* Non-fatal remarks about how the handle is set up ("" if none), e.g. a runtime cut down to fewer hardware queues per priority than the library has lanes.  Valid until the handle
  * is destroyed. */
 const char *foa_rx_notes(foa_rx *rx);
 void foa_rx_destroy(foa_rx *rx);
