@@ -19,6 +19,16 @@ RATE_MBPS = (6, 8, 9, 12, 16, 18, 24, 32, 36, 48, 54)
 STANDARD_RATES = (0, 2, 3, 5, 6, 8, 9, 10)
 
 
+def _settle(t):
+    """The library's streams know nothing of torch's: before a call that reads or writes torch tensors, whatever torch's current stream still
+    has queued (a fill of an output tensor, the copy that made an input) must be through.  A query when the stream is idle -- the steady
+    state of a pipelined loop -- costs a microsecond; only a busy stream is waited for."""
+    import torch
+    s = torch.cuda.current_stream(t.device)
+    if not s.query():
+        s.synchronize()
+
+
 def _vp(a):
     return a.ctypes.data_as(C.c_void_p)
 
@@ -110,8 +120,9 @@ class Receiver:
         """All arguments are CUDA(HIP) torch tensors already resident in HBM:
         iq complex64[n] (or float32[n,2]); descs uint8[m*48] (frame_desc_dtype bytes); ends int64[m];
         psdu uint8[m, slot]; results int32[m, 4].  Asynchronous on the handle's streams, which are NOT ordered against
-        torch's: whatever torch still has queued on these tensors must be through before the call (a host-side
-        synchronize of torch's stream here would cost the pipelined loop 3-8 %, so it is left to the caller)."""
+        torch's (and run at other priorities: a fill torch has queued for an output tensor may land after the kernels
+        that write it), so the wrapper waits for torch's current stream if it still has work queued (_settle)."""
+        _settle(iq)
         n = iq.numel() if iq.is_complex() else iq.numel() // 2
         m = ends.numel() - n_context                         # (n_context: the last alignments of descs / ends are context only, foa_rx_decode_frames_ctx_dev)
         assert descs.numel() * descs.element_size() == ends.numel() * frame_desc_dtype.itemsize
@@ -125,6 +136,7 @@ class Receiver:
         n = iq.numel() if iq.is_complex() else iq.numel() // 2
         cap = ends.numel()
         assert descs.numel() * descs.element_size() >= cap * frame_desc_dtype.itemsize
+        _settle(iq)
         got = C.c_size_t(0)
         self._check(self._lib.foa_rx_sync_dev(self._h, iq.data_ptr(), n, descs.data_ptr(), ends.data_ptr(), cap, C.byref(got)))
         return int(got.value)
@@ -134,6 +146,7 @@ class Receiver:
         n = iq.numel() if iq.is_complex() else iq.numel() // 2
         cap = ends.numel()
         assert descs.numel() * descs.element_size() >= cap * frame_desc_dtype.itemsize
+        _settle(iq)
         self._check(self._lib.foa_rx_sync_dev_begin(self._h, iq.data_ptr(), n, descs.data_ptr(), ends.data_ptr(), cap))
 
     def sync_dev_end(self):
