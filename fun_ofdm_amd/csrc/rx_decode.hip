@@ -138,14 +138,6 @@ int foa::job_ready(foa_rx *rx, uint64_t ticket, bool wait, HostJob **out)
 static int decode_frames_any(foa_rx *rx, const void *d_iq, bool f64, size_t n_samples, const foa_frame_desc *d_descs, const int64_t *d_ends,
                              size_t n_frames, size_t n_context, size_t n_lead, uint8_t *d_psdu, size_t slot_bytes, foa_frame_result *d_results);
 
-// (stream engines: the n_lead tags in front of d_descs[0] in the same arrays are the stream's earlier alignments -- decided already, looked at
-// only to see whether one of them sits less than 64 samples in front of the first alignment of this call: frontend_kernels.h, "late")
-int foa::decode_frames_lead_dev(foa_rx *rx, const float *d_iq, size_t n_samples, const foa_frame_desc *d_descs, const int64_t *d_ends, size_t n_frames,
-                                size_t n_context, size_t n_lead, uint8_t *d_psdu, size_t slot_bytes, foa_frame_result *d_results)
-{
-    return decode_frames_any(rx, d_iq, false, n_samples, d_descs, d_ends, n_frames, n_context, n_lead, d_psdu, slot_bytes, d_results);
-}
-
 extern "C" {
 
 int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, const foa_frame_desc *d_descs, const int64_t *d_ends,
@@ -158,6 +150,14 @@ int foa_rx_decode_frames_ctx_dev(foa_rx *rx, const float *d_iq, size_t n_samples
                                  size_t n_frames, size_t n_context, uint8_t *d_psdu, size_t slot_bytes, foa_frame_result *d_results)
 {
     return decode_frames_any(rx, d_iq, false, n_samples, d_descs, d_ends, n_frames, n_context, 0, d_psdu, slot_bytes, d_results);
+}
+
+int foa_rx_decode_frames_lead_ctx_dev(foa_rx *rx, const float *d_iq, size_t n_samples, const foa_frame_desc *d_descs, const int64_t *d_ends,
+                                      size_t n_lead, size_t n_frames, size_t n_context, uint8_t *d_psdu, size_t slot_bytes, foa_frame_result *d_results)
+{
+    if (n_lead > 0x7FFFFFF0u) return fail(FOA_E_INVALID, "too many frames");
+    if ((n_lead || n_frames) && (!d_descs || !d_ends)) return fail(FOA_E_INVALID, "NULL device pointer");
+    return decode_frames_any(rx, d_iq, false, n_samples, d_descs + n_lead, d_ends + n_lead, n_frames, n_context, n_lead, d_psdu, slot_bytes, d_results);
 }
 
 }  // extern "C"

@@ -181,9 +181,6 @@ int flush_pending(foa_rx *rx, hipEvent_t after_front_end);              // queue
 int drain(foa_rx *rx);                                                  // ... and wait for everything on the handle's streams
 int inputs_queued(foa_rx *rx, hipStream_t cs);
 int job_ready(foa_rx *rx, uint64_t ticket, bool wait, HostJob **out);
-// foa_rx_decode_frames_ctx_dev with n_lead earlier tags of the stream in front of d_descs[0] (looked at, not decoded: stream engines)
-int decode_frames_lead_dev(foa_rx *rx, const float *d_iq, size_t n_samples, const foa_frame_desc *d_descs, const int64_t *d_ends, size_t n_frames,
-                           size_t n_context, size_t n_lead, uint8_t *d_psdu, size_t slot_bytes, foa_frame_result *d_results);
 void launch_fwd3(hipStream_t st, const FrameInfo *info, int nf, const uint16_t *sp, uint64_t *dec);
 // chain-back walk on st, stitch + descramble + CRC on st_fin (the same stream, or another one that then waits for walk_done)
 void launch_finish3(hipStream_t st, hipStream_t st_fin, const FrameInfo *info, int nf, const uint64_t *dec, uint32_t *decoded, const int32_t *seg2frame,

@@ -157,7 +157,7 @@ struct ShardDev {
         if (m) {
             // (context for the batch's cut frames, and the stream's end for its decisions, as in stream_engine.h.  The host has SEEN the
             // look-ahead's event -- selected() -- so the descriptor it patched is in place)
-            int rc = stream_decode_batch(rx, dev[k].p, (size_t)n_eff[k], (const foa_frame_desc *)d_desc[k].p + i0, d_ends[k].p + i0, m, n_ctx, i0, slot_bytes, &fl.ticket, nullptr);
+            int rc = stream_decode_batch(rx, dev[k].p, (size_t)n_eff[k], (const foa_frame_desc *)d_desc[k].p, d_ends[k].p, i0, m, n_ctx, slot_bytes, &fl.ticket, nullptr);
             if (rc) return rc;
             alignments.fetch_add(m);
         }

@@ -53,8 +53,8 @@ constexpr int kStreamBufs = 6;                      // device sample buffers / p
 // finish kernel); *ticket identifies the job for stream_collect_job.  Shared by the single-device engine below and the multi-device one
 // (shard_engine.h).  t_prep (may be null): ns spent finding and sizing the job slot.
 // n_ctx: alignments behind the m decoded ones that serve them as context (foa_rx_decode_frames_ctx_dev): the rest of the buffer's.
-// n_lead: the buffer's tags in front of descs[0] (decided by earlier batches; an alignment less than 64 samples behind one of them is "late").
-static int stream_decode_batch(foa_rx *rx, const float *d, size_t n_buf, const foa_frame_desc *descs, const int64_t *ends, size_t m, size_t n_ctx, size_t n_lead, size_t slot_bytes,
+// descs / ends: ALL tags of the buffer; the first n_lead were decided by earlier batches (foa_rx_decode_frames_lead_ctx_dev: looked at only for where they sit).
+static int stream_decode_batch(foa_rx *rx, const float *d, size_t n_buf, const foa_frame_desc *descs, const int64_t *ends, size_t n_lead, size_t m, size_t n_ctx, size_t slot_bytes,
                                uint64_t *ticket, int64_t *t_prep)
 {
     const auto t0 = std::chrono::steady_clock::now();
@@ -80,7 +80,7 @@ static int stream_decode_batch(foa_rx *rx, const float *d, size_t n_buf, const f
     job->total = total; job->o_psdu = 0; job->o_res = o_res; job->n_frames = m; job->slot_bytes = slot_bytes; job->copy_queued = false;
     rx->attach_job = piped ? job : nullptr;
     if (t_prep) *t_prep += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
-    rc = decode_frames_lead_dev(rx, d, n_buf, descs, ends, m, n_ctx, n_lead, job->dev.p, slot_bytes, (foa_frame_result *)(job->dev.p + o_res));
+    rc = foa_rx_decode_frames_lead_ctx_dev(rx, d, n_buf, descs, ends, n_lead, m, n_ctx, job->dev.p, slot_bytes, (foa_frame_result *)(job->dev.p + o_res));
     rx->attach_job = nullptr;
     if (rc) return rc;
     if (!piped) {
@@ -239,7 +239,7 @@ struct StreamGpu {
         if (m) {
             // (the candidates behind the batch's own go along as context: a frame cut short by a later LTS1 may fill on with their vectors,
             // fft_symbols.cpp:41-50 / frame_decoder.cpp:52-88 -- the look-ahead decided with them, and they are decided by the next batch)
-            rc = stream_decode_batch(rx, d, (size_t)n_eff[k], (const foa_frame_desc *)d_desc[k].p + i0, d_ends[k].p + i0, m, n_ctx, i0, slot_bytes, &fl.ticket, &t_prep);
+            rc = stream_decode_batch(rx, d, (size_t)n_eff[k], (const foa_frame_desc *)d_desc[k].p, d_ends[k].p, i0, m, n_ctx, slot_bytes, &fl.ticket, &t_prep);
             if (rc) return rc;
             alignments.fetch_add(m);
         }

@@ -116,19 +116,21 @@ class Receiver:
         return (psdu, res) if rc == 1 else None
 
     # ---- batch decode, device buffers (torch tensors on this device) ------------------------------
-    def decode_frames_dev(self, iq, descs, ends, psdu, results, n_context=0):
+    def decode_frames_dev(self, iq, descs, ends, psdu, results, n_context=0, n_lead=0):
         """All arguments are CUDA(HIP) torch tensors already resident in HBM:
-        iq complex64[n] (or float32[n,2]); descs uint8[m*48] (frame_desc_dtype bytes); ends int64[m];
-        psdu uint8[m, slot]; results int32[m, 4].  Asynchronous on the handle's streams, which are NOT ordered against
+        iq complex64[n] (or float32[n,2]); descs uint8[(n_lead+m+n_context)*48] (frame_desc_dtype bytes); ends int64[n_lead+m+n_context];
+        psdu uint8[m, slot]; results int32[m, 4].  n_lead: the first alignments of descs / ends were decided by an earlier piece
+        (looked at only for where they sit); n_context: the last ones are context only (foa_rx_decode_frames_lead_ctx_dev).
+        Asynchronous on the handle's streams, which are NOT ordered against
         torch's (and run at other priorities: a fill torch has queued for an output tensor may land after the kernels
         that write it), so the wrapper waits for torch's current stream if it still has work queued (_settle)."""
         _settle(iq)
         n = iq.numel() if iq.is_complex() else iq.numel() // 2
-        m = ends.numel() - n_context                         # (n_context: the last alignments of descs / ends are context only, foa_rx_decode_frames_ctx_dev)
+        m = ends.numel() - n_context - n_lead
         assert descs.numel() * descs.element_size() == ends.numel() * frame_desc_dtype.itemsize
         assert psdu.shape[0] == m and results.numel() == 4 * m
-        self._check(self._lib.foa_rx_decode_frames_ctx_dev(self._h, iq.data_ptr(), n, descs.data_ptr(), ends.data_ptr(), m, n_context, psdu.data_ptr(),
-                                                 psdu.shape[1], results.data_ptr()))
+        self._check(self._lib.foa_rx_decode_frames_lead_ctx_dev(self._h, iq.data_ptr(), n, descs.data_ptr(), ends.data_ptr(), n_lead, m, n_context, psdu.data_ptr(),
+                                                      psdu.shape[1], results.data_ptr()))
 
     def sync_dev(self, iq, descs, ends):
         """Device-side frame_detector + timing_sync: iq complex64[n] (CUDA tensor), descs uint8[cap*48], ends int64[cap]

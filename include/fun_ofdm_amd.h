@@ -159,7 +159,7 @@ int foa_rx_set_option(foa_rx *rx, const char *name, int64_t value);
  * tagged LTS_START -- is the window at lts1_pos + 64, channel_est takes the window 80 samples on as the second LTS vector, and SIGNAL and
  * every symbol are read one symbol (80 samples) later than in an undisturbed alignment (fft_symbols.cpp:53-56, channel_est.cpp:44-58).
  * The call reproduces that from the descriptors it is given, so a caller that decodes a stream in pieces hands the alignments of such a
- * pile-up over TOGETHER (the adaptors of blocks.hpp keep them together; the timing_sync restated here does not produce such tags on
+ * pile-up over TOGETHER (the adaptors of blocks.hpp keep them together; foa_rx_decode_frames_lead_ctx_dev takes decided ones along; the timing_sync restated here does not produce such tags on
  * anything but pathological input).  With these rules a call returns, for any list of descriptors in stream order, what the reference's
  * blocks return when fed the tags those descriptors stand for.
  */
@@ -172,6 +172,13 @@ int foa_rx_decode_frames_dev(foa_rx *rx, const float *d_iq, size_t n_samples, co
 int foa_rx_decode_frames_ctx_dev(foa_rx *rx, const float *d_iq, size_t n_samples, const foa_frame_desc *d_descs,
                                  const int64_t *d_ends, size_t n_frames, size_t n_context, uint8_t *d_psdu, size_t slot_bytes,
                                  foa_frame_result *d_results);
+
+/* ... and with n_lead alignments IN FRONT of the n_frames decoded ones: d_descs / d_ends hold n_lead + n_frames + n_context alignments in
+ * stream order; the first n_lead were decided by an earlier piece and are looked at only for where they sit (an alignment less than 64
+ * samples behind one of them is read one symbol late: "Pile-ups" above).  Results and PSDU slots: the n_frames in the middle. */
+int foa_rx_decode_frames_lead_ctx_dev(foa_rx *rx, const float *d_iq, size_t n_samples, const foa_frame_desc *d_descs, const int64_t *d_ends,
+                                      size_t n_lead, size_t n_frames, size_t n_context, uint8_t *d_psdu, size_t slot_bytes,
+                                      foa_frame_result *d_results);
 
 /* Same with HOST pointers: copies in, decodes, copies out, synchronises. */
 int foa_rx_decode_frames_host(foa_rx *rx, const float *iq, size_t n_samples, const foa_frame_desc *descs,

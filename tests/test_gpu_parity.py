@@ -1025,13 +1025,16 @@ def test_context_alignments_and_explicit_ends_follow_the_restatement(rx, po):
     import fun_ofdm_amd as foa
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(8)
-    n_split = n_trunc = 0
+    n_split = n_trunc = n_late = 0
     for seed in range(60):
         s, d = stress_tags.make_case(seed)
         if d.size < 3:
             continue
         ends = np.append(d["lts1_pos"][1:], s.size).astype(np.int64)
         k = int(rng.integers(1, d.size))
+        close = np.nonzero(np.diff(d["lts1_pos"]) < 64)[0]
+        if close.size and seed % 2:                                    # every other case with a pile-up: cut it in the middle
+            k = int(close[0]) + 1
         # (a) host entry with context
         want_p, want_r = po.decode_batch_v2_f32(s, d, ends, n_ctx=d.size - k)
         got_p, got_r = rx.collect(rx.submit_host(s, d, ends, n_context=d.size - k))
@@ -1059,4 +1062,19 @@ def test_context_alignments_and_explicit_ends_follow_the_restatement(rx, po):
         o2p, o2r = po.decode_batch_v2_f32(s, d, e2)
         assert np.array_equal(r2.view(np.int32), o2r.view(np.int32)) and np.array_equal(p2, o2p), (seed, "unlinked")
         assert not np.any(r2["status"] == foa.ST_SUPERSEDED)
-    assert n_split > 40 and n_trunc > 5
+        # (e) the second piece with the first handed over as LEAD (foa_rx_decode_frames_lead_ctx_dev): the results of the one-piece decode --
+        # an alignment less than 64 samples behind the last alignment of the first piece is read one symbol late, as there; without the lead it
+        # is decoded as if nothing were in front of it
+        full_p, full_r = po.decode_batch_v2_f32(s, d, ends)
+        m2 = d.size - k
+        t_p2 = torch.zeros((m2, 4096), dtype=torch.uint8, device=dev)
+        t_r2 = torch.zeros((m2, 4), dtype=torch.int32, device=dev)
+        rx.decode_frames_dev(t_iq, t_d, t_e, t_p2, t_r2, n_lead=k)
+        rx.sync()
+        assert np.array_equal(t_r2.cpu().numpy(), full_r[k:].view(np.int32).reshape(-1, 4)) and np.array_equal(t_p2.cpu().numpy(), full_p[k:]), (seed, k, "lead")
+        if d["lts1_pos"][k] - d["lts1_pos"][k - 1] < 64:
+            n_late += 1
+            alone_p, alone_r = rx.decode_frames_host(s, d[k:], ends[k:])
+            o_p, o_r = po.decode_batch_v2_f32(s, d[k:], ends[k:])
+            assert np.array_equal(alone_r.view(np.int32), o_r.view(np.int32)) and np.array_equal(alone_p, o_p), (seed, k, "no lead")
+    assert n_split > 40 and n_trunc > 5 and n_late >= 3, (n_split, n_trunc, n_late)
