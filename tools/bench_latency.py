@@ -67,7 +67,7 @@ for chunk in (4096, 65536, 1 << 20):
     run("device 4M, calls of %d, 8 helpers, as fast as taken" % chunk, ["--chunk", str(chunk), "--device-batch", str(1 << 22), "--narrow-threads", "8"], reps=3)
 run("device 4M, calls of 4096, 8 helpers, no warm-up batches (round 3's protocol)", ["--chunk", "4096", "--device-batch", str(1 << 22), "--narrow-threads", "8", "--warm-batches", "0"], reps=3)
 # (c) small batches with DEFAULT options (round 5: a frame is decoded by the first batch that holds its last sample), at the air's own pace and faster
-for B, pace in ((1 << 14, 20), (1 << 14, 40), (1 << 15, 20), (1 << 16, 20), (1 << 16, 100)):
+for B, pace in ((1 << 12, 20), (1 << 13, 20), (1 << 14, 20), (1 << 14, 40), (1 << 15, 20), (1 << 16, 20), (1 << 16, 100)):
     extra = ["--chunk", "4096", "--device-batch", str(B), "--narrow-threads", "8", "--pace", str(pace)]
     run("device %dK, default options, calls of 4096, paced at %d Msample/s (%d x real time)" % (B >> 10, pace, pace // 20), extra)
 # (c2) the same with a short carry: a receiver that knows its longest frame (here 1024 bytes at 54 Mbps: 3 520 samples + 192) re-synchronises 6 K instead of 112 K samples per batch
