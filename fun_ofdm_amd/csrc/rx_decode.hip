@@ -17,7 +17,10 @@ int foa::upload_tables_decode(const DeviceTables &t)
 
 void foa::launch_fwd3(hipStream_t st, const FrameInfo *info, int nf, const uint16_t *sp, uint64_t *dec)
 {
-    hipLaunchKernelGGL(k_viterbi_fwd3, dim3(((nf + 1) / 2 + kFwdWaves - 1) / kFwdWaves), dim3(64 * kFwdWaves), 0, st, info, nf, sp, dec);
+    // (a call of up to a wave per SIMD: one frame per wave -- half the renormalisation events per wave, 7-8 % more frames per second,
+    // profiles/r05_ab_forward_one_frame_per_wave.txt; above ~1 400 frames two frames per wave win, from 2 000 on by 10 % and more)
+    if (nf < kSingleBelow) hipLaunchKernelGGL(k_viterbi_fwd3<1>, dim3((nf + kFwdWaves - 1) / kFwdWaves), dim3(64 * kFwdWaves), 0, st, info, nf, sp, dec);
+    else hipLaunchKernelGGL(k_viterbi_fwd3<2>, dim3(((nf + 1) / 2 + kFwdWaves - 1) / kFwdWaves), dim3(64 * kFwdWaves), 0, st, info, nf, sp, dec);
 }
 
 void foa::launch_finish3(hipStream_t st, hipStream_t st_fin, const FrameInfo *info, int nf, const uint64_t *dec, uint32_t *decoded, const int32_t *seg2frame,

@@ -276,14 +276,18 @@ __device__ __forceinline__ uint32_t fwd3_step_dyn(uint32_t M, int j, const uint4
     }
 }
 
-// five resident waves per SIMD (10 000 frames = 4.9 waves per SIMD on 256 CUs): cap the register budget accordingly
+// five resident waves per SIMD (10 000 frames = 4.9 waves per SIMD on 256 CUs): cap the register budget accordingly.
+// kPair = 2: two frames per wave (the packed halves).  kPair = 1: one frame per wave, the high halves idle -- for calls so small that the
+// SIMDs have a wave or two each: a wave's own step is then what takes the time, a renormalisation event costs a lone wave ~430 clocks,
+// and a wave with one frame has half as many of them (launch_fwd3 chooses).
+template <int kPair>
 __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd3(const FrameInfo *__restrict__ info, int n_frames,
                                                                  const uint16_t *__restrict__ sp, uint64_t *__restrict__ dec)
 {
     __shared__ uint4 bml_all[kFwdWaves][4 * kChunk3];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint4 *bml = bml_all[wave];
-    const int fA = 2 * (blockIdx.x * kFwdWaves + wave), fB = fA + 1;
+    const int fA = kPair * (blockIdx.x * kFwdWaves + wave), fB = kPair == 2 ? fA + 1 : n_frames;
     if (fA >= n_frames) return;
     const FrameInfo ia = info[fA];
     FrameInfo ib = ia;
