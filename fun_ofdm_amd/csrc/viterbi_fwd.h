@@ -142,23 +142,25 @@ __device__ __forceinline__ Fwd3Lane fwd3_lane_init(int lane)
 // carries out of a half iff its metric exceeds 210 (bit 15 / bit 31 of the sum then reads 0).  A carry out of the low half
 // can push a high half of exactly 210 over, so the cold path looks at both halves again; the common path only needs
 // "nothing is due" (two scalar instructions in front of the branch).
+template <int kPair>
 __device__ __forceinline__ bool fwd3_due(uint32_t s0)
 {
-    return (~(s0 + 0x002D002Du) & 0x80008000u) != 0u;
+    return (~(s0 + 0x002D002Du) & (kPair == 2 ? 0x80008000u : 0x00008000u)) != 0u;      // (one frame per wave: the high half is nobody's)
 }
+template <int kPair>
 __device__ __forceinline__ uint32_t fwd3_renorm(uint32_t Mn, uint32_t &s0)
 {
     __builtin_amdgcn_s_setprio(1);                    // the wave's recursion stands still until this is through (profiles/r03_ab_renorm_prio.txt)
     // which halves: the low one iff bit 15 of s0 + 0x002D002D reads 0 (nothing carries into it), the high one by comparing it
     // alone; the amount is wave-uniform, so the bias comes off on the scalar side and the vector side is one v_sub per half
     // (the scalar subtractions are asm so that they stay scalar: the compiler reassociates Mn - (mn - bias) into two vector ops)
-    if (!((s0 + 0x002D002Du) & 0x8000u)) {
+    if (kPair == 1 || !((s0 + 0x002D002Du) & 0x8000u)) {               // (one frame per wave: the low half is the one that was due)
         uint32_t adj;
         asm("s_sub_u32 %0, %1, %2" : "=s"(adj) : "s"(wave_min_lo16(Mn)), "s"(kBias) : "scc");
         Mn -= adj;
         s0 -= adj;
     }
-    if (s0 >= ((kRenormThr + 1u) << 16)) {
+    if (kPair == 2 && s0 >= ((kRenormThr + 1u) << 16)) {
         uint32_t adj;
         asm("s_and_b32 %0, %1, 0xffff0000\n\ts_sub_u32 %0, %0, %2" : "=s"(adj) : "s"(wave_min_hi16_word(Mn)), "s"(kBias << 16) : "scc");
         Mn -= adj;
@@ -204,7 +206,7 @@ constexpr int fwd3_acc_index(int j) { return (j >> 3) & 1; }
 // the branch).  J >= 0: data step J of the chunk (compile time), its decision filed BEHIND the test's v_readfirstlane, in the
 // shadow of its way to the scalar unit (the two instructions do not depend on it; a wave issues in order); J == -1: no decision
 // is recorded (trellis steps 0..5); J == -2: data step jdyn (run time: a frame's last, partial chunk).
-template <int PH, int J>
+template <int kPair, int PH, int J>
 __device__ __forceinline__ uint32_t fwd3_step(uint32_t M, const uint2 w, uint32_t (&acc)[2], int jdyn)
 {
     uint32_t x, y;
@@ -217,7 +219,7 @@ __device__ __forceinline__ uint32_t fwd3_step(uint32_t M, const uint2 w, uint32_
         // chunk and keeps every step's x and y alive until then (148 VGPRs, 3 waves per SIMD).  (s0 is named as an input only to
         // keep the block behind the v_readfirstlane.)
         asm volatile("v_pk_sub_u16 %1, %2, %3\n\tv_bfi_b32 %0, %4, %1, %0" : "+v"(acc[fwd3_acc_index(J)]), "=&v"(tmp) : "v"(x), "v"(y), "s"(m), "s"(s0));
-        if (__builtin_expect(fwd3_due(s0), 0)) Mn = fwd3_renorm(Mn, s0);
+        if (__builtin_expect(fwd3_due<kPair>(s0), 0)) Mn = fwd3_renorm<kPair>(Mn, s0);
         return Mn;
     }
     if constexpr (J == -2) {
@@ -228,7 +230,7 @@ __device__ __forceinline__ uint32_t fwd3_step(uint32_t M, const uint2 w, uint32_
         for (int b = 0; b < 2; b++) acc[b] = a == b ? ((acc[b] & ~m) | (tmp & m)) : acc[b];
     }
     uint32_t s0 = __builtin_amdgcn_readfirstlane(Mn);
-    if (__builtin_expect(fwd3_due(s0), 0)) Mn = fwd3_renorm(Mn, s0);      // cold: keeps the common path free of taken branches
+    if (__builtin_expect(fwd3_due<kPair>(s0), 0)) Mn = fwd3_renorm<kPair>(Mn, s0);      // cold: keeps the common path free of taken branches
     return Mn;
 }
 
@@ -243,36 +245,37 @@ struct Fwd3NoFlush { __device__ __forceinline__ void operator()(int) const {} };
 
 // six steps (one of each phase) on staging entries E0 .. E0+5; flush(blk): called right behind the step that completes the
 // 16-step block blk of the chunk
-template <int E0, int J0, typename Flush = Fwd3NoFlush>
+template <int kPair, int E0, int J0, typename Flush = Fwd3NoFlush>
 __device__ __forceinline__ uint32_t fwd3_group(uint32_t M, const uint4 *bml, const Fwd3Lane &c, uint32_t (&acc)[2], const Flush &flush = Flush())
 {
     const uint2 w0 = fwd3_inc(bml, E0 + 0, c.ofs[0]), w1 = fwd3_inc(bml, E0 + 1, c.ofs[1]), w2 = fwd3_inc(bml, E0 + 2, c.ofs[2]),
                 w3 = fwd3_inc(bml, E0 + 3, c.ofs[3]), w4 = fwd3_inc(bml, E0 + 4, c.ofs[4]), w5 = fwd3_inc(bml, E0 + 5, c.ofs[5]);
-    M = fwd3_step<0, (J0 < 0 ? J0 : J0 + 0)>(M, w0, acc, 0);
+    M = fwd3_step<kPair, 0, (J0 < 0 ? J0 : J0 + 0)>(M, w0, acc, 0);
     if constexpr (J0 >= 0 && ((J0 + 0) & 15) == 15) flush((J0 + 0) >> 4);
-    M = fwd3_step<1, (J0 < 0 ? J0 : J0 + 1)>(M, w1, acc, 0);
+    M = fwd3_step<kPair, 1, (J0 < 0 ? J0 : J0 + 1)>(M, w1, acc, 0);
     if constexpr (J0 >= 0 && ((J0 + 1) & 15) == 15) flush((J0 + 1) >> 4);
-    M = fwd3_step<2, (J0 < 0 ? J0 : J0 + 2)>(M, w2, acc, 0);
+    M = fwd3_step<kPair, 2, (J0 < 0 ? J0 : J0 + 2)>(M, w2, acc, 0);
     if constexpr (J0 >= 0 && ((J0 + 2) & 15) == 15) flush((J0 + 2) >> 4);
-    M = fwd3_step<3, (J0 < 0 ? J0 : J0 + 3)>(M, w3, acc, 0);
+    M = fwd3_step<kPair, 3, (J0 < 0 ? J0 : J0 + 3)>(M, w3, acc, 0);
     if constexpr (J0 >= 0 && ((J0 + 3) & 15) == 15) flush((J0 + 3) >> 4);
-    M = fwd3_step<4, (J0 < 0 ? J0 : J0 + 4)>(M, w4, acc, 0);
+    M = fwd3_step<kPair, 4, (J0 < 0 ? J0 : J0 + 4)>(M, w4, acc, 0);
     if constexpr (J0 >= 0 && ((J0 + 4) & 15) == 15) flush((J0 + 4) >> 4);
-    M = fwd3_step<5, (J0 < 0 ? J0 : J0 + 5)>(M, w5, acc, 0);
+    M = fwd3_step<kPair, 5, (J0 < 0 ? J0 : J0 + 5)>(M, w5, acc, 0);
     if constexpr (J0 >= 0 && ((J0 + 5) & 15) == 15) flush((J0 + 5) >> 4);
     __builtin_amdgcn_sched_barrier(0);          // keep the next groups' LDS reads from being hoisted (registers)
     return M;
 }
 
+template <int kPair>
 __device__ __forceinline__ uint32_t fwd3_step_dyn(uint32_t M, int j, const uint4 *bml, const Fwd3Lane &c, uint32_t (&acc)[2])
 {
     switch (j % 6) {
-    case 0: return fwd3_step<0, -2>(M, fwd3_inc(bml, j, c.ofs[0]), acc, j);
-    case 1: return fwd3_step<1, -2>(M, fwd3_inc(bml, j, c.ofs[1]), acc, j);
-    case 2: return fwd3_step<2, -2>(M, fwd3_inc(bml, j, c.ofs[2]), acc, j);
-    case 3: return fwd3_step<3, -2>(M, fwd3_inc(bml, j, c.ofs[3]), acc, j);
-    case 4: return fwd3_step<4, -2>(M, fwd3_inc(bml, j, c.ofs[4]), acc, j);
-    default: return fwd3_step<5, -2>(M, fwd3_inc(bml, j, c.ofs[5]), acc, j);
+    case 0: return fwd3_step<kPair, 0, -2>(M, fwd3_inc(bml, j, c.ofs[0]), acc, j);
+    case 1: return fwd3_step<kPair, 1, -2>(M, fwd3_inc(bml, j, c.ofs[1]), acc, j);
+    case 2: return fwd3_step<kPair, 2, -2>(M, fwd3_inc(bml, j, c.ofs[2]), acc, j);
+    case 3: return fwd3_step<kPair, 3, -2>(M, fwd3_inc(bml, j, c.ofs[3]), acc, j);
+    case 4: return fwd3_step<kPair, 4, -2>(M, fwd3_inc(bml, j, c.ofs[4]), acc, j);
+    default: return fwd3_step<kPair, 5, -2>(M, fwd3_inc(bml, j, c.ofs[5]), acc, j);
     }
 }
 
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd3(const FrameInfo
     get(0);
     put(6);
     get(6);
-    M = fwd3_group<0, -1>(M, bml, c, acc);
+    M = fwd3_group<kPair, 0, -1>(M, bml, c, acc);
     // A 16-step block's word -- bytes 1 and 3 of its two accumulators: (A steps 0-7, A steps 8-15, B steps 0-7, B steps 8-15) -- is formed
     // the moment the block is complete.  The first two blocks of a chunk are stored at once (thirty-two and sixteen steps before the
     // next wait for loads: old enough), the third one chunk LATE, right behind the loads that fetch the soft pairs of the chunk after:
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd3(const FrameInfo
             const uint32_t word = w | (v >= 16 ? 0u : v <= 0 ? 0xFFFFu : 0xFFFFu << v);
             __builtin_amdgcn_raw_buffer_store_b16((uint16_t)word, rdA, slot2, 128 * (b0 >> 4), 0);
         }
-        if (__builtin_expect(b0 < NBtop, 1)) {
+        if (kPair == 2 && __builtin_expect(b0 < NBtop, 1)) {
             const int v = NB - b0;
             __builtin_amdgcn_raw_buffer_store_b16((uint16_t)((w >> 16) | (v >= 16 ? 0u : v <= 0 ? 0xFFFFu : 0xFFFFu << v)), rdB, slot2, 128 * (b0 >> 4), 0);
         }
@@ -389,13 +392,13 @@ __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd3(const FrameInfo
         if (n0 > 0) store_block(n0 - 16, late);
         n_chunk = n0;
         if (nn == kChunk3) {
-            M = fwd3_group<0, 0>(M, bml, c, acc, flush);   M = fwd3_group<6, 6>(M, bml, c, acc, flush);   M = fwd3_group<12, 12>(M, bml, c, acc, flush);
-            M = fwd3_group<18, 18>(M, bml, c, acc, flush); M = fwd3_group<24, 24>(M, bml, c, acc, flush); M = fwd3_group<30, 30>(M, bml, c, acc, flush);
-            M = fwd3_group<36, 36>(M, bml, c, acc, flush); M = fwd3_group<42, 42>(M, bml, c, acc, flush);
+            M = fwd3_group<kPair, 0, 0>(M, bml, c, acc, flush);   M = fwd3_group<kPair, 6, 6>(M, bml, c, acc, flush);   M = fwd3_group<kPair, 12, 12>(M, bml, c, acc, flush);
+            M = fwd3_group<kPair, 18, 18>(M, bml, c, acc, flush); M = fwd3_group<kPair, 24, 24>(M, bml, c, acc, flush); M = fwd3_group<kPair, 30, 30>(M, bml, c, acc, flush);
+            M = fwd3_group<kPair, 36, 36>(M, bml, c, acc, flush); M = fwd3_group<kPair, 42, 42>(M, bml, c, acc, flush);
         } else {
             // the last, partial chunk: blocks the steps do not reach are still stored (all ones: the store's mask)
             for (int j = 0; j < nn; j++) {
-                M = fwd3_step_dyn(M, j, bml, c, acc);
+                M = fwd3_step_dyn<kPair>(M, j, bml, c, acc);
                 if ((j & 15) == 15) flush(j >> 4);
             }
             for (int blk = nn >> 4; blk < 3; blk++) flush(blk);
