@@ -442,7 +442,7 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
             # would do too, but on this runtime it waits for the library's streams as well and costs the loop 3-8 %
             read_done[k % n_out].synchronize()
             read_done[k % n_out] = None
-        rx.decode_frames_dev(d_iq, d_desc, d_ends, out_psdu[k % n_out], out_res[k % n_out])
+        rx.decode_frames_dev(d_iq, d_desc, d_ends, out_psdu[k % n_out], out_res[k % n_out], settle=False)      # (ordered against torch by read_done, above)
         issued[0] = k + 1
         if multi and k - done[0] >= LAG:
             rx.wait_age(LAG)

@@ -116,15 +116,17 @@ class Receiver:
         return (psdu, res) if rc == 1 else None
 
     # ---- batch decode, device buffers (torch tensors on this device) ------------------------------
-    def decode_frames_dev(self, iq, descs, ends, psdu, results, n_context=0, n_lead=0):
+    def decode_frames_dev(self, iq, descs, ends, psdu, results, n_context=0, n_lead=0, settle=True):
         """All arguments are CUDA(HIP) torch tensors already resident in HBM:
         iq complex64[n] (or float32[n,2]); descs uint8[(n_lead+m+n_context)*48] (frame_desc_dtype bytes); ends int64[n_lead+m+n_context];
         psdu uint8[m, slot]; results int32[m, 4].  n_lead: the first alignments of descs / ends were decided by an earlier piece
         (looked at only for where they sit); n_context: the last ones are context only (foa_rx_decode_frames_lead_ctx_dev).
         Asynchronous on the handle's streams, which are NOT ordered against
         torch's (and run at other priorities: a fill torch has queued for an output tensor may land after the kernels
-        that write it), so the wrapper waits for torch's current stream if it still has work queued (_settle)."""
-        _settle(iq)
+        that write it), so the wrapper waits for torch's current stream if it still has work queued (_settle).  settle=False: the
+        caller orders torch's work on these tensors against the call itself (bench.py's loop does, with one event per output set)."""
+        if settle:
+            _settle(iq)
         n = iq.numel() if iq.is_complex() else iq.numel() // 2
         m = ends.numel() - n_context - n_lead
         assert descs.numel() * descs.element_size() == ends.numel() * frame_desc_dtype.itemsize
