@@ -59,8 +59,10 @@ struct ShardDev {
             if (!rc && hipEventCreateWithFlags(&sel_done[i], hipEventDisableTiming) != hipSuccess) rc = fail(FOA_E_HIP, "hipEventCreate failed");
             if (!rc && hipEventCreateWithFlags(&sync_done[i], hipEventDisableTiming) != hipSuccess) rc = fail(FOA_E_HIP, "hipEventCreate failed");
         }
-        if (!rc && hipStreamCreateWithPriority(&st_in, hipStreamNonBlocking, foa::high_priority()) != hipSuccess) rc = fail(FOA_E_HIP, "hipStreamCreate failed");
+        // (the look-ahead stream first: made right behind the handle's six it lands on the pipe of the handle's copy / pre-sync stream, the
+        // staging stream on that of lane 2, whose forward pass holds its pipe for a millisecond at a time -- rx_handle.hip, foa_rx_create)
         if (!rc && hipStreamCreateWithPriority(&st_sel, hipStreamNonBlocking, foa::high_priority()) != hipSuccess) rc = fail(FOA_E_HIP, "hipStreamCreate failed");
+        if (!rc && hipStreamCreateWithPriority(&st_in, hipStreamNonBlocking, foa::high_priority()) != hipSuccess) rc = fail(FOA_E_HIP, "hipStreamCreate failed");
         if (!rc && hipHostMalloc((void **)&sel, (size_t)foa::kStreamBufs * 8 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) rc = fail(FOA_E_NOMEM, "hipHostMalloc failed");
         if (!rc && hipHostMalloc((void **)&st_pin, (size_t)foa::kStreamBufs * 2 * sizeof(StreamState), hipHostMallocDefault) != hipSuccess) rc = fail(FOA_E_NOMEM, "hipHostMalloc failed");
         if (!rc) rc = sel_dev.ensure((size_t)foa::kStreamBufs * 8);

@@ -57,7 +57,7 @@ class StubReceiver:
         psdu.copy_(torch.from_numpy(p))
         res.copy_(torch.from_numpy(r))
 
-    def decode_frames_dev(self, iq, descs, ends, psdu, results):
+    def decode_frames_dev(self, iq, descs, ends, psdu, results, n_context=0, n_lead=0, settle=True):
         psdu.fill_(0xEE)                                   # in flight: whoever reads this set now reads garbage
         self.queue.append((descs, psdu, results))
         self.calls += 1
