@@ -5,12 +5,12 @@ s=${1:-1}
 out=gpurun_out/soak_r05.txt
 mkdir -p gpurun_out/soak
 run() { name=$1; shift; ( "$@" 2>&1 | grep -v "amdgpu.ids" | tail -4 > gpurun_out/soak/$name.txt ) & }
-run collide   python3 tests/manual/stress_collide.py gpu 500000 $((500000 + 12000 * s))
-run decode    python3 tests/manual/stress_decode.py 400000 $((400000 + 6000 * s))
-run stream    python3 tests/manual/stress_stream.py 40000 $((40000 + 4000 * s))
-run sync      python3 tests/manual/stress_sync.py 200000 $((200000 + 10000 * s))
-run viterbi   python3 tests/manual/stress_viterbi.py 300000 $((300000 + 8000 * s))
-run tags      python3 tests/manual/stress_tags.py gpu 10000 $((10000 + 6000 * s))
+run collide   python3 tests/manual/stress_collide.py gpu 700000 $((700000 + 12000 * s))
+run decode    python3 tests/manual/stress_decode.py 600000 $((600000 + 6000 * s))
+run stream    python3 tests/manual/stress_stream.py 70000 $((70000 + 4000 * s))
+run sync      python3 tests/manual/stress_sync.py 400000 $((400000 + 10000 * s))
+run viterbi   python3 tests/manual/stress_viterbi.py 500000 $((500000 + 8000 * s))
+run tags      python3 tests/manual/stress_tags.py gpu 40000 $((40000 + 6000 * s))
 wait
 run chain_cpp python3 tests/manual/stress_chain_cpp.py 3000 $((3000 + 150 * s))
 run stages    python3 tests/manual/stress_stages.py 5000 $((5000 + 1500 * s))
