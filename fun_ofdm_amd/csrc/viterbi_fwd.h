@@ -24,6 +24,8 @@
 //   * Branch-metric increments cost no VALU in the step: when a chunk's soft pairs are staged in LDS, each step gets all eight
 //     (Branchtab class, side of the butterfly) variants of the packed increment pair, and a lane reads the 8 bytes of its variant.
 //   * The renormalisation test reads state 0 with one v_readfirstlane and decides on the scalar unit.
+//   * The same code with ONE frame per wave (template argument kPair = 1, the high halves idle and left alone) serves calls so small
+//     that every wave has a SIMD nearly to itself: a wave's own step latency and its renormalisation events are what such a call waits for.
 // What was measured on the way here and dropped is in HISTORY.md (patches and numbers under profiles/).
 #pragma once
 
