@@ -1,4 +1,5 @@
-"""BASELINE.json configs 2 and 3 at their FULL sizes as property tests (the oracle cannot decode 10 000 frames in seconds, so the size-independent
+"""BASELINE.json configs: 1 (the loopback frame) and 5 (continuous mixed-rate stream with CFO, at a size the oracle walks) against the oracle's
+receiver_chain, and 2 and 3 at their FULL sizes as property tests (the oracle cannot decode 10 000 frames in seconds, so the size-independent
 property is asserted on every frame and the oracle on a sample): every frame whose CRC passed carries exactly the payload that was sent,
 (nearly) every frame passes at 25 dB, and on the first 256 alignments status, header fields, PSDUs -- the CRC failures included -- equal
 the oracle's.  Workloads are built on the device (foa_tx_build_frames_dev + foa_tx_channel_dev).  GPU only."""
@@ -67,3 +68,85 @@ def test_config3_thousand_frames_per_rate(po, rate):
     found, ok, gpu_fail, cpu_fail = _run(po, rate, 4092, 1000, seed=300 + rate, sample=96 if rate < 5 else 256)
     assert found >= 995 and gpu_fail == cpu_fail, (rate, found, ok, gpu_fail, cpu_fail)
     assert ok >= (found - 8 if rate != 2 else int(0.7 * found)), (rate, found, ok)
+
+
+def test_config1_loopback_one_bpsk_frame(po):
+    """BASELINE configs[0] (examples/test_sim.cpp's loopback shape): ONE frame, BPSK rate 1/2, a 1500-byte text payload, no noise,
+    fed in 4096-sample calls with zeros behind it -- the case the reference's own CPU receiver_chain runs.  The oracle's receiver_chain returns
+    exactly that payload; the batch path (host pre-sync + foa_rx_decode_frames_host), the stream engine (process_samples on the device) in
+    4096-sample pushes and the same through a 4096-sample batch must return the same list."""
+    import fun_ofdm_amd as foa
+    text = (b"This is the payload of the single frame of the loopback test: 1500 bytes of text, as examples/test_sim.cpp sends them. " * 14)[:1500]
+    pay = np.frombuffer(text, np.uint8)
+    fr = po.build_frame(pay, 0)
+    iq = np.concatenate([np.zeros(700, complex), fr, np.zeros(6 * 4096 + 300, complex)]).astype(np.complex64)
+    want = po.ReceiverChain().run_stream(iq.astype(np.complex128))
+    assert want == [text]
+    rx = foa.Receiver(0)
+    try:
+        descs = foa.find_alignments(iq)
+        assert descs.size == 1
+        psdu, res = rx.decode_frames_host(iq, descs, foa.alignment_ends(descs, iq.size))
+        assert res["status"][0] == foa.ST_OK and res["rate"][0] == 0 and res["length"][0] == 1500 and psdu[0, :1500].tobytes() == text
+        opsdu, ores = po.decode_batch_f32(iq, descs, foa.alignment_ends(descs, iq.size))
+        assert np.array_equal(res.view(np.int32), ores.view(np.int32)) and np.array_equal(psdu, opsdu)
+        for batch in (4096, 1 << 16):
+            st = foa.Stream(rx, batch)
+            try:
+                got = []
+                for a in range(0, iq.size, 4096):
+                    got += st.push(iq[a:a + 4096])
+                got += st.flush()
+            finally:
+                st.close()
+            assert got == want, batch
+    finally:
+        rx.close()
+
+
+def test_config5_continuous_mixed_rate_stream_with_cfo(po):
+    """BASELINE configs[4] at a size the oracle's chain walks in seconds: frames cycling the eight standard rates back to back (no gap at all),
+    1024-byte payloads, a carrier frequency offset per frame within +-4 kHz, 25 dB; device pre-sync + decode (the bench's config-5 leg does
+    this on 45 M samples) and the stream engine against the oracle's receiver_chain in 4096-sample calls: the same ordered payload list."""
+    import torch
+    import fun_ofdm_amd as foa
+    rng = np.random.default_rng(505)
+    parts, pays = [np.zeros(500, complex)], []
+    for i in range(48):
+        rate = foa.STANDARD_RATES[i % 8]
+        pay = rng.integers(0, 256, 1024, dtype=np.uint8)
+        f = po.build_frame(pay, rate)
+        f = f * np.exp(2j * np.pi * rng.uniform(-4000, 4000) * np.arange(f.size) / 20e6 + 1j * rng.uniform(0, 6.28))
+        parts.append(f)
+        pays.append(pay.tobytes())
+    parts.append(np.zeros(900, complex))
+    s = np.concatenate(parts)
+    iq = (s + (rng.normal(size=s.size) + 1j * rng.normal(size=s.size)) * np.sqrt(0.0124 / 2 / 10 ** 2.5)).astype(np.complex64)
+    want = po.ReceiverChain().run_stream(iq.astype(np.complex128))
+    assert len(want) >= 40 and all(w in pays for w in want)
+    dev = torch.device("cuda", 0)
+    rx = foa.Receiver(0)
+    try:
+        t_iq = torch.from_numpy(iq.view(np.float32).reshape(-1, 2)).to(dev)
+        cap = iq.size // 300 + 64
+        d_desc = torch.zeros(cap * 48, dtype=torch.uint8, device=dev)
+        d_end = torch.zeros(cap, dtype=torch.int64, device=dev)
+        m = rx.sync_dev(t_iq, d_desc, d_end)
+        d_psdu = torch.zeros((m, 1024), dtype=torch.uint8, device=dev)
+        d_res = torch.zeros((m, 4), dtype=torch.int32, device=dev)
+        rx.decode_frames_dev(t_iq, d_desc[:m * 48], d_end[:m], d_psdu, d_res)
+        rx.sync()
+        res, psdu = d_res.cpu().numpy(), d_psdu.cpu().numpy()
+        got = [psdu[i, :res[i, 2]].tobytes() for i in range(m) if res[i, 0] == foa.ST_OK]
+        assert got == want
+        st = foa.Stream(rx, 1 << 16)
+        try:
+            got2 = []
+            for a in range(0, iq.size, 4096):
+                got2 += st.push(iq[a:a + 4096])
+            got2 += st.flush()
+        finally:
+            st.close()
+        assert got2 == want
+    finally:
+        rx.close()
