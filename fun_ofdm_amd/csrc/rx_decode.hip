@@ -17,8 +17,9 @@ int foa::upload_tables_decode(const DeviceTables &t)
 
 void foa::launch_fwd3(hipStream_t st, const FrameInfo *info, int nf, const uint16_t *sp, uint64_t *dec)
 {
-    // (a call of up to a wave per SIMD: one frame per wave -- half the renormalisation events per wave, 7-8 % more frames per second,
-    // profiles/r05_ab_forward_one_frame_per_wave.txt; above ~1 400 frames two frames per wave win, from 2 000 on by 10 % and more)
+    // (a call of up to 1 024 frames -- one four-wave workgroup per CU at most: one frame per wave -- half the renormalisation events per wave,
+    // 7-8 % more frames per second; with 1 100 frames some CUs get a second workgroup and two frames per wave win again by 6 %, from 2 000 on
+    // by 10 % and more: profiles/r05_ab_forward_one_frame_per_wave.txt)
     if (nf < kSingleBelow) hipLaunchKernelGGL(k_viterbi_fwd3<1>, dim3((nf + kFwdWaves - 1) / kFwdWaves), dim3(64 * kFwdWaves), 0, st, info, nf, sp, dec);
     else hipLaunchKernelGGL(k_viterbi_fwd3<2>, dim3(((nf + 1) / 2 + kFwdWaves - 1) / kFwdWaves), dim3(64 * kFwdWaves), 0, st, info, nf, sp, dec);
 }

@@ -166,7 +166,7 @@ namespace foa {
 // whatever the batch, and more loops in flight are what raises the throughput then (1 000 frames x 4 092 bytes at 54 Mbps: 1.43 ms per
 // batch with two, 0.94 with four).  The lanes sit on hardware queues of their own (stream priorities: foa_rx_create).
 constexpr int kDeepBelow = 2049;                 // frames: up to one forward-pass wave per SIMD
-constexpr int kSingleBelow = 1280;               // frames: below this the forward pass takes one frame per wave (launch_fwd3)
+constexpr int kSingleBelow = 1025;               // frames: below this -- up to one four-wave workgroup per CU -- the forward pass takes one frame per wave (launch_fwd3)
 
 inline bool piped(const foa_rx *rx) { return rx->pipeline; }
 // Host-pointer entry points copy their inputs (and the pre-sync stage runs) on the third stream when calls are pipelined, off the

@@ -971,7 +971,7 @@ def test_random_batches_vs_oracle(rx, po, seed):
 
 
 def test_large_mixed_batch_vs_oracle(rx, po):
-    """More than kSingleBelow (1 280) alignments in ONE call, so that the forward pass takes two frames per wave (smaller calls take one): random
+    """More than kSingleBelow - 1 (1 024) alignments in ONE call, so that the forward pass takes two frames per wave (smaller calls take one): random
     rates and lengths side by side in a wave's two halves (different step counts, a dead alignment next to a live one, an odd count), some
     frames in noise.  Every alignment exactly as the oracle has it; the same stream cut into small calls (one frame per wave) must agree too."""
     rng = np.random.default_rng(77)
