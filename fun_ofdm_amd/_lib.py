@@ -46,6 +46,11 @@ _SIGS = {
     "foa_rx_submit_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_uint64)]),
     "foa_rx_submit_host_ctx": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_uint64)]),
     "foa_rx_collect": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]),
+    "foa_rx_after": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "foa_rx_record_consumed": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "foa_rx_record_done": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "foa_rx_decode_frames_dev_after": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "foa_rx_sync_dev_begin_after": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]),
     "foa_rx_wait_age": (C.c_int, [C.c_void_p, C.c_int]),
     "foa_rx_wait_previous": (C.c_int, [C.c_void_p]),
     "foa_rx_kernel_ms_age": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),

@@ -235,6 +235,12 @@ __device__ __forceinline__ int depunct_pos(int D, int punct)
 
 // words reserved per frame in the per-step buffers (soft pairs / decisions / decoded): the chain-back reads whole 48-step chunks
 __host__ __device__ constexpr int64_t dec_words(int64_t nsteps) { return nsteps > 0 ? (nsteps + 48 + 63) & ~(int64_t)63 : 0; }
+// The decoded bits of a frame (one per data step, 32 to a word) live at word dec_off / 16 of the `decoded` buffer: half a bit of room per
+// step -- the frame's words, the tail of the last 96-step unit the walk writes whole, and the 16-byte pieces the finish moves --
+// where one word per step (rounds 1-5) was 4 of the 14 bytes of work-set capacity a trellis step cost.  dec_off is a multiple of 64:
+// 16-byte aligned.
+__host__ __device__ constexpr int64_t decoded_word_off(int64_t dec_off) { return dec_off >> 4; }
+__host__ __device__ constexpr size_t decoded_words_for(size_t dec_cap) { return dec_cap / 16 + 64; }
 // chain-back segments of a frame (viterbi_tb.h): its nsteps - 6 data steps in pieces of seg_steps
 __host__ __device__ constexpr int tb_segments(int nsteps, int seg_steps) { return nsteps > 6 ? (nsteps - 6 + seg_steps - 1) / seg_steps : 0; }
 

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "../../include/fun_ofdm_amd.h"
+#include "../../include/fun_ofdm_amd_diag.h"
 
 namespace foa {
 

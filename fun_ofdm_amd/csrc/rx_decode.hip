@@ -58,11 +58,14 @@ int foa::workspace(foa_rx *rx, size_t n_samples, size_t n_frames)
     // grows by one element costs a hipFree, which waits for the whole device)
     n_frames = ((n_frames + (n_frames >> 3) + 1024) & ~(size_t)1023);
     size_t sym_cap = n_samples / 80 + 4;
-    size_t dec_cap = 216 * sym_cap + 192 * (n_frames + 1);
+    // Per-step buffers (soft pairs 2 B, decisions 8 B, decoded bits 1/4 B per step of capacity): a stream of n_samples samples holds at most
+    // n_samples / 80 data symbols of at most max_dbps trellis steps each -- 216 (54 Mbps) unless the caller has promised less (option
+    // "max_dbps": a 6 Mbps capture needs a ninth of it, and the room decides how many frames one call can take)
+    size_t dec_cap = (size_t)rx->max_dbps * sym_cap + 192 * (n_frames + 1);
     int rc;
     if ((rc = rx->w->info.ensure(n_frames + 1)) || (rc = rx->w->hinv.ensure((n_frames + 1) * 64)) || (rc = rx->w->sym2frame.ensure(sym_cap)) ||
         (rc = rx->w->spec.ensure(sym_cap)) ||
-        (rc = rx->w->dec.ensure(dec_cap)) || (rc = rx->w->sp.ensure(dec_cap)) || (rc = rx->w->decoded.ensure(dec_cap)) ||
+        (rc = rx->w->dec.ensure(dec_cap)) || (rc = rx->w->sp.ensure(dec_cap)) || (rc = rx->w->decoded.ensure(decoded_words_for(dec_cap))) ||
         (rc = rx->w->totals.ensure(8 + 4 * ((n_frames + kScanBlock - 1) / kScanBlock + 1))))
         return rc;
     if (rx->record_eq && ((rc = rx->w->eq_sig.ensure((n_frames + 1) * 48)) || (rc = rx->w->eq_data.ensure(sym_cap * 48)))) return rc;
@@ -171,7 +174,7 @@ static int decode_frames_any(foa_rx *rx, const void *d_iq, bool f64, size_t n_sa
                              size_t n_frames, size_t n_context, size_t n_lead, uint8_t *d_psdu, size_t slot_bytes, foa_frame_result *d_results)
 {
     if (!rx) return fail(FOA_E_INVALID, "rx is NULL");
-    if (n_frames == 0) { rx->last_frames = 0; return FOA_OK; }
+    if (n_frames == 0) { rx->last_frames = 0; rx->after.clear(); return FOA_OK; }      // (nothing is queued: nothing waits)
     if (!d_iq || !d_descs || !d_ends || !d_psdu || !d_results) return fail(FOA_E_INVALID, "NULL device pointer");
     if (n_frames > 0x7FFFFFF0u || n_context > 0x7FFFFFF0u - n_frames) return fail(FOA_E_INVALID, "too many frames");
     HIP_TRY(enter_device(rx->device));
@@ -202,6 +205,7 @@ static int decode_frames_any(foa_rx *rx, const void *d_iq, bool f64, size_t n_sa
     double2 *eq_sig = rx->record_eq ? rx->w->eq_sig.p : nullptr, *eq_data = rx->record_eq ? rx->w->eq_data.p : nullptr;
 
     if (rx->in_wait) { HIP_TRY(hipStreamWaitEvent(st, rx->in_ready, 0)); rx->in_wait = false; }
+    if ((rc = wait_after(rx, st))) return rc;                          // foa_rx_after: the caller's producers, on the device
     HIP_TRY(hipEventRecord(rx->w->ev[0], st));
     if (f64) hipLaunchKernelGGL(k_header<double2>, dim3(n_total), dim3(64), 0, st, iq64, d_descs, d_ends, (int64_t)n_samples, (int)n_lead, n_total, rx->w->info.p, rx->w->hinv.p, eq_sig);
     else hipLaunchKernelGGL(k_header<float2>, dim3(n_total), dim3(64), 0, st, iq, d_descs, d_ends, (int64_t)n_samples, (int)n_lead, n_total, rx->w->info.p, rx->w->hinv.p, eq_sig);
@@ -266,6 +270,7 @@ static int decode_frames_host_any(foa_rx *rx, const void *iq, bool f64, size_t n
     if (rc) return rc;
     uint8_t *b = rx->scratch.p;
     hipStream_t st = side_stream(rx);
+    if ((rc = wait_after(rx, st))) return rc;
     HIP_TRY(hipMemcpyAsync(b + o_iq, iq, n_samples * sample_bytes, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(b + o_desc, descs, n_frames * sizeof(foa_frame_desc), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(b + o_end, ends, n_frames * 8, hipMemcpyHostToDevice, st));
@@ -332,6 +337,7 @@ int foa_rx_submit_host_ctx(foa_rx *rx, const float *iq, size_t n_samples, const 
     const bool piped = rx->pipeline;
     hipStream_t st = side_stream(rx);
     uint8_t *b = job->dev.p;
+    if ((rc = wait_after(rx, st))) return rc;
     HIP_TRY(hipMemcpyAsync(b, job->pin, o_psdu, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(b + o_psdu, 0, n_frames * slot_bytes, st));
     if ((rc = inputs_queued(rx, st))) return rc;

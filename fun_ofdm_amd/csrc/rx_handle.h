@@ -118,6 +118,7 @@ struct foa_rx {
     int depth = 0;                     // how many calls' loops are in flight; 0 = by grid size (2, or 4 below kDeepBelow frames)
     int depth_saved = -1;              // (the stream engine pins its own while a stream is open and restores this)
     unsigned n_calls = 0;              // pipelined decode calls made so far (a call's lane is n_calls mod depth)
+    int max_dbps = 216;                // work sets hold this many trellis steps per 80 samples (option "max_dbps": the highest rate the caller's frames carry)
     int tb_segment = 960, tb_overlap = 96;   // chain-back: data steps per segment / run-in steps (multiples of 96)
     bool pipeline = true;        // the finish of one call overlaps the next calls' front end and forward pass (rotating work sets, several streams)
     bool record_eq = false;
@@ -155,6 +156,11 @@ struct foa_rx {
     bool sy_open = false;
     int32_t sy_ccap = 0;
     size_t sy_cap = 0;
+    // Device-side ordering against the caller's own streams (foa_rx_after / foa_rx_record_consumed / foa_rx_record_done):
+    std::vector<hipEvent_t> after;     // events the NEXT call that queues work makes its first stream wait for (one-shot)
+    hipStream_t join = nullptr;        // made on first use, high priority: carries event waits and the caller's record, never a kernel
+    hipEvent_t tx_done = nullptr;      // behind the most recent foa_tx_* call (they read caller buffers on `stream`)
+    bool tx_used = false, sy_used = false;
     foa_stream *open_stream = nullptr;      // the stream engine that owns this handle right now (stream_engine.h), if any
     int64_t ns_wait_set = 0;     // host time spent waiting for a work set to come free (the GPU is more than kSets - 1 calls behind)
 };
@@ -174,6 +180,15 @@ inline bool piped(const foa_rx *rx) { return rx->pipeline; }
 // the priority level of copy / pre-sync / look-ahead streams (foa_rx_create: hardware queues come in a pool per priority)
 inline int high_priority() { int least = 0, greatest = 0; (void)hipDeviceGetStreamPriorityRange(&least, &greatest); return greatest; }
 inline hipStream_t side_stream(foa_rx *rx) { return rx->pipeline ? rx->stream3 : rx->stream; }
+
+// foa_rx_after: whatever the caller registered is waited for by `st`, the stream the call's first kernel or copy goes to -- everything else
+// of the call is ordered behind that (lane -> walk -> stitch stream; side stream -> in_ready -> lane)
+inline int wait_after(foa_rx *rx, hipStream_t st)
+{
+    for (hipEvent_t e : rx->after) HIP_TRY(hipStreamWaitEvent(st, e, 0));
+    rx->after.clear();
+    return FOA_OK;
+}
 
 // ---- rx_decode.hip ----
 int upload_tables_decode(const DeviceTables &t);

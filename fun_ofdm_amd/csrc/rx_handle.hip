@@ -196,6 +196,8 @@ void foa_rx_destroy(foa_rx *rx)
         if (ws.walk_done) (void)hipEventDestroy(ws.walk_done);
     }
     if (rx->in_ready) (void)hipEventDestroy(rx->in_ready);
+    if (rx->tx_done) (void)hipEventDestroy(rx->tx_done);
+    if (rx->join) (void)hipStreamDestroy(rx->join);
     if (rx->sy_done) (void)hipEventDestroy(rx->sy_done);
     if (rx->sy_pin) (void)hipHostFree(rx->sy_pin);
     for (auto &j : rx->jobs) {
@@ -243,6 +245,11 @@ int foa_rx_set_option(foa_rx *rx, const char *name, int64_t value)
         rx->tb_overlap = (int)value;
         return FOA_OK;
     }
+    if (!strcmp(name, "max_dbps")) {
+        if (value < 24 || value > 216) return fail(FOA_E_INVALID, "max_dbps must lie in [24, 216] (data bits per OFDM symbol of the highest rate: rates.h:52-196)");
+        rx->max_dbps = (int)value;
+        return FOA_OK;
+    }
     if (!strcmp(name, "pipeline")) { int rc0 = drain(rx); if (rc0) return rc0; rx->pipeline = value != 0; return FOA_OK; }
     if (!strcmp(name, "record_eq")) { rx->record_eq = value != 0; return FOA_OK; }
     if (!strcmp(name, "record_soft")) { rx->record_soft = value != 0; return FOA_OK; }
@@ -280,6 +287,88 @@ int foa_rx_sync(foa_rx *rx)
 {
     if (!rx) return fail(FOA_E_INVALID, "rx is NULL");
     return drain(rx);
+}
+
+// ---- device-side ordering against the caller's own streams --------------------------------------------------------------------------
+// The library's streams are its own (several, at other priorities than the host's): what orders them against a caller's stream is an
+// event.  Nothing here makes the host wait.
+
+int foa_rx_after(foa_rx *rx, void *event)
+{
+    if (!rx || !event) return fail(FOA_E_INVALID, "NULL argument");
+    if (rx->open_stream) return fail(FOA_E_STATE, "a stream engine owns this handle");
+    if (rx->after.size() >= 16) return fail(FOA_E_STATE, "16 events are already waiting for the next call");
+    rx->after.push_back((hipEvent_t)event);
+    return FOA_OK;
+}
+
+// the stream that joins the library's streams for a caller's event: made when first asked for (a handle that never orders against
+// a caller's stream keeps the queue layout of foa_rx_create), at the high priority level (it only ever carries waits and one record)
+static int join_stream(foa_rx *rx)
+{
+    if (!rx->join) HIP_TRY(hipStreamCreateWithPriority(&rx->join, hipStreamNonBlocking, high_priority()));
+    return FOA_OK;
+}
+
+// Everything queued so far has READ what it reads of the caller's buffers (samples, descriptors, ends; payloads and frames of the transmit
+// calls) once `event` completes: the front ends of the decode calls in flight -- their data-symbol kernel is the last reader -- the pre-sync
+// and the transmit kernels.  Cheap: nothing is flushed, the deferred chain-back of a pipelined call stays deferred.
+int foa_rx_record_consumed(foa_rx *rx, void *event)
+{
+    if (!rx || !event) return fail(FOA_E_INVALID, "NULL argument");
+    if (rx->open_stream) return fail(FOA_E_STATE, "a stream engine owns this handle");
+    HIP_TRY(enter_device(rx->device));
+    if (!rx->pipeline) {                                               // calls in line: everything is on the handle's one stream
+        HIP_TRY(hipEventRecord((hipEvent_t)event, rx->stream));
+        return FOA_OK;
+    }
+    { int rc = join_stream(rx); if (rc) return rc; }
+    WorkSet *w = rx->w;
+    for (int i = 0; i < kSets - 1 && w && w->used; i++, w = w->before) HIP_TRY(hipStreamWaitEvent(rx->join, w->ev[3], 0));      // (one per lane and more: complete ones cost nothing)
+    if (rx->sy_used) HIP_TRY(hipStreamWaitEvent(rx->join, rx->sy_done, 0));
+    if (rx->tx_used) HIP_TRY(hipStreamWaitEvent(rx->join, rx->tx_done, 0));
+    HIP_TRY(hipEventRecord((hipEvent_t)event, rx->join));
+    return FOA_OK;
+}
+
+// Everything queued so far is COMPLETE once `event` completes: PSDU slots and results of every decode call, descriptors of the pre-sync,
+// frames and samples of the transmit calls.  A pipelined call's chain-back and finish, which would otherwise wait for the next call's
+// front end to be queued (rx_handle.h), are queued now.
+int foa_rx_record_done(foa_rx *rx, void *event)
+{
+    if (!rx || !event) return fail(FOA_E_INVALID, "NULL argument");
+    if (rx->open_stream) return fail(FOA_E_STATE, "a stream engine owns this handle");
+    HIP_TRY(enter_device(rx->device));
+    { int rc = flush_pending(rx, nullptr); if (rc) return rc; }
+    if (!rx->pipeline) {
+        HIP_TRY(hipEventRecord((hipEvent_t)event, rx->stream));
+        return FOA_OK;
+    }
+    { int rc = join_stream(rx); if (rc) return rc; }
+    WorkSet *w = rx->w;
+    for (int i = 0; i < kSets - 1 && w && w->used; i++, w = w->before) HIP_TRY(hipStreamWaitEvent(rx->join, w->done, 0));
+    if (rx->sy_used) HIP_TRY(hipStreamWaitEvent(rx->join, rx->sy_done, 0));
+    if (rx->tx_used) HIP_TRY(hipStreamWaitEvent(rx->join, rx->tx_done, 0));
+    HIP_TRY(hipStreamWaitEvent(rx->join, rx->in_ready, 0));            // (copies of a host-pointer entry point, if one was ever queued)
+    HIP_TRY(hipEventRecord((hipEvent_t)event, rx->join));
+    return FOA_OK;
+}
+
+int foa_rx_decode_frames_dev_after(foa_rx *rx, void *inputs_ready, const float *d_iq, size_t n_samples, const foa_frame_desc *d_descs, const int64_t *d_ends,
+                                   size_t n_frames, uint8_t *d_psdu, size_t slot_bytes, foa_frame_result *d_results)
+{
+    if (inputs_ready) { int rc = foa_rx_after(rx, inputs_ready); if (rc) return rc; }
+    const int rc = foa_rx_decode_frames_dev(rx, d_iq, n_samples, d_descs, d_ends, n_frames, d_psdu, slot_bytes, d_results);
+    if (rx) rx->after.clear();                                         // (a call refused before it queued anything leaves nothing behind)
+    return rc;
+}
+
+int foa_rx_sync_dev_begin_after(foa_rx *rx, void *inputs_ready, const float *d_iq, size_t n_samples, foa_frame_desc *d_descs, int64_t *d_ends, size_t cap)
+{
+    if (inputs_ready) { int rc = foa_rx_after(rx, inputs_ready); if (rc) return rc; }
+    const int rc = foa_rx_sync_dev_begin(rx, d_iq, n_samples, d_descs, d_ends, cap);
+    if (rx) rx->after.clear();
+    return rc;
 }
 
 int foa_rx_wait_age(foa_rx *rx, int age)
@@ -346,6 +435,7 @@ int foa_rx_forward_spacing_ms(foa_rx *rx, int age, float out[3])
     WorkSet *b = w ? w->before : nullptr;
     if (!w || !b || !w->piped || !b->piped || w == rx->w) return fail(FOA_E_STATE, "no two pipelined decode calls of that age");
     HIP_TRY(hipEventSynchronize(w->ev[5]));
+    HIP_TRY(hipEventSynchronize(b->ev[5]));                              // (the call before ran on ANOTHER lane: nothing orders its pass before w's)
     HIP_TRY(hipEventElapsedTime(&out[0], b->ev[7], w->ev[7]));          // start to start
     HIP_TRY(hipEventElapsedTime(&out[1], w->ev[7], b->ev[5]));          // > 0: the earlier pass was still running when this one started
     HIP_TRY(hipEventElapsedTime(&out[2], w->ev[7], w->ev[5]));          // this pass's own duration

@@ -67,7 +67,7 @@ int foa_conv_decode(foa_rx *rx, const uint8_t *symbols, uint8_t *data, int data_
                 seg2frame.insert(seg2frame.end(), (size_t)nseg, (int32_t)b);
             }
             const size_t total = n_blocks * (size_t)words + 64;
-            if ((rc = rx->w->info.ensure(n_blocks + 1)) || (rc = rx->w->dec.ensure(total)) || (rc = rx->w->sp.ensure(total)) || (rc = rx->w->decoded.ensure(total)) ||
+            if ((rc = rx->w->info.ensure(n_blocks + 1)) || (rc = rx->w->dec.ensure(total)) || (rc = rx->w->sp.ensure(total)) || (rc = rx->w->decoded.ensure(decoded_words_for(total))) ||
                 (rc = rx->w->seg2frame.ensure(seg2frame.size() + 64)) || (rc = rx->w->tb_state.ensure(seg2frame.size() + 64)) || (rc = rx->w->totals.ensure(8)))
                 return rc;
             HIP_TRY(hipMemcpyAsync(rx->w->info.p, info.data(), n_blocks * sizeof(FrameInfo), hipMemcpyHostToDevice, st));
@@ -202,7 +202,7 @@ int foa_decode_data_f64(foa_rx *rx, const double *carriers, const uint64_t *carr
     const size_t n_sym = sym2frame.size(), n_car = (size_t)carrier_off[n_frames];
     int rc;
     if ((rc = rx->w->info.ensure(n_frames + 1)) || (rc = rx->w->sym2frame.ensure(n_sym + 1)) ||
-        (rc = rx->w->dec.ensure((size_t)dec_off + 64)) || (rc = rx->w->sp.ensure((size_t)dec_off + 64)) || (rc = rx->w->decoded.ensure((size_t)dec_off + 64)) ||
+        (rc = rx->w->dec.ensure((size_t)dec_off + 64)) || (rc = rx->w->sp.ensure((size_t)dec_off + 64)) || (rc = rx->w->decoded.ensure(decoded_words_for((size_t)dec_off + 64))) ||
         (rc = rx->w->seg2frame.ensure(seg2frame.size() + 64)) || (rc = rx->w->tb_state.ensure(seg2frame.size() + 64)) || (rc = rx->w->totals.ensure(8)))
         return rc;
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };

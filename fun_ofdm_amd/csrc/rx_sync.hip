@@ -36,6 +36,7 @@ int foa::sync_dev_issue(foa_rx *rx, const float *d_iq, size_t n_samples, foa_fra
     // (nothing else orders this stage behind the decode call before it, whose header and data-symbol kernels may still be reading the
     // descriptor buffers a caller reuses from round to round)
     if (st != rx->stream && rx->w->used && rx->w->piped) HIP_TRY(hipStreamWaitEvent(st, rx->w->ev[3], 0));
+    if ((rc = wait_after(rx, st))) return rc;                          // foa_rx_after: the caller's producers, on the device
     const float2 *iq = (const float2 *)d_iq;
     hipLaunchKernelGGL(k_sync_flags, dim3((unsigned)((n + kFlagSamples - 1) / kFlagSamples)), dim3(64), 0, st, iq, n, rx->sy_flags.p, n_words);
     hipLaunchKernelGGL(k_sync_sts_end, dim3(n_blocks), dim3(kSyncBlockWords), 0, st, rx->sy_flags.p, n_words, 0, rx->sy_cnt.p, rx->sy_off.p, rx->sy_x.p, ccap);
@@ -66,12 +67,13 @@ int foa_rx_sync_dev_begin(foa_rx *rx, const float *d_iq, size_t n_samples, foa_f
     if (!rx->sy_done) HIP_TRY(hipEventCreateWithFlags(&rx->sy_done, hipEventDisableTiming));
     rx->sy_pin[0] = rx->sy_pin[1] = rx->sy_pin[2] = rx->sy_pin[3] = 0;
     rx->sy_cap = cap; rx->sy_ccap = 0;
-    if (n_samples == 0 || cap == 0) { rx->sy_cap = 0; rx->sy_open = true; return FOA_OK; }          // (nothing queued; _end reports 0)
+    if (n_samples == 0 || cap == 0) { rx->sy_cap = 0; rx->sy_open = true; rx->after.clear(); return FOA_OK; }          // (nothing queued; _end reports 0)
     { int rc = sync_dev_issue(rx, d_iq, n_samples, d_descs, d_ends, cap, &rx->sy_ccap, rx->sync_origin); if (rc) return rc; }
     hipStream_t st = side_stream(rx);
     HIP_TRY(hipMemcpyAsync(rx->sy_pin, rx->sy_n.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(rx->sy_done, st));
     HIP_TRY(hipGetLastError());
+    rx->sy_used = true;
     rx->sy_open = true;              // only now: a pre-sync whose launch failed half-way is not "in flight" (its _end would report an empty batch as a success)
     return FOA_OK;
 }

@@ -11,6 +11,15 @@ int foa::upload_tables_tx(const DeviceTables &t)
     return FOA_OK;
 }
 
+// (foa_rx_record_consumed / _done cover the transmit calls too: they read and write caller buffers on the handle's first stream)
+static int tx_queued(foa_rx *rx)
+{
+    if (!rx->tx_done) HIP_TRY(hipEventCreateWithFlags(&rx->tx_done, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(rx->tx_done, rx->stream));
+    rx->tx_used = true;
+    return FOA_OK;
+}
+
 extern "C" {
 
 int foa_tx_build_frames_dev(foa_rx *rx, const uint8_t *d_payloads, size_t payload_pitch, int length, int rate, size_t n_frames,
@@ -32,12 +41,13 @@ int foa_tx_build_frames_dev(foa_rx *rx, const uint8_t *d_payloads, size_t payloa
     if (rc) return rc;
     hipStream_t st = rx->stream;
     const int nf = (int)n_frames;
+    if ((rc = wait_after(rx, st))) return rc;
     hipLaunchKernelGGL(k_tx_prepare, dim3((nf + 63) / 64), dim3(64), 0, st, d_payloads, payload_pitch, length, nf, nbytes, rx->scratch.p, stride);
     const int64_t threads = (int64_t)nf * (nsym + 1);
     hipLaunchKernelGGL(k_tx_symbols, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, st, rx->scratch.p, stride, length, rate, nsym, nf,
                        (double2 *)d_frames, *frame_samples);
     HIP_TRY(hipGetLastError());
-    return FOA_OK;
+    return tx_queued(rx);
 }
 
 int foa_tx_channel_dev(foa_rx *rx, const double *d_frames, size_t n_frames, size_t frame_samples, size_t pitch, size_t lead, double snr_db,
@@ -51,10 +61,11 @@ int foa_tx_channel_dev(foa_rx *rx, const double *d_frames, size_t n_frames, size
     // sigma^2 per real component = P_ref / (2 10^(SNR/10)), P_ref = 0.0124
     const double sigma = std::sqrt(0.0124 / (2.0 * std::pow(10.0, snr_db / 10.0)));
     const int64_t total = (int64_t)n_frames * (int64_t)pitch;
+    { int rc = wait_after(rx, rx->stream); if (rc) return rc; }
     hipLaunchKernelGGL(k_tx_channel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, rx->stream, (const double2 *)d_frames, (int64_t)n_frames,
                        (int64_t)frame_samples, (int64_t)pitch, (int64_t)lead, sigma, cfo_hz, seed, (float2 *)d_iq);
     HIP_TRY(hipGetLastError());
-    return FOA_OK;
+    return tx_queued(rx);
 }
 
 }  // extern "C"

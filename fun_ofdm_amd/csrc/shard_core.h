@@ -77,7 +77,12 @@ public:
         const int rc = devs_[in.dev]->upload(slot, carry_[slot], stage_[slot], n_new, start);
         in.staged = rc == 0;
         staged_samples_ = pushed; n_staged_++;
-        if (rc == 0) advance_chain();
+        // A batch whose upload failed never gets a look-ahead: the chain steps over it (the core reports the error and does not submit
+        // it, so its slot record may be gone by the time the chain gets there -- hence a list of its own), the state passes through as
+        // if the batch had decided nothing, and the batches behind it still get their turn, so that a forced submit, flush and destroy
+        // all come back instead of waiting for a selection that is never queued.
+        if (rc != 0) { in.failed = in.sel_done = true; skipped_.push_back(k); }
+        advance_chain();
         return rc;
     }
 
@@ -87,6 +92,7 @@ public:
     void advance_chain()
     {
         for (;;) {
+            while (!skipped_.empty() && skipped_.front() <= chain_next_) { if (skipped_.front() == chain_next_) chain_next_++; skipped_.pop_front(); }
             int slot = -1;
             for (int i = 0; i < kSlots; i++) if (info_[i].batch == chain_next_ && info_[i].staged) { slot = i; break; }
             if (slot < 0) return;
@@ -147,6 +153,7 @@ private:
     int64_t n_staged_ = 0, n_submitted_ = 0, staged_samples_ = 0, chain_next_ = 0;
     ChainState state_ = { 0, 1.0, 0.0 };           // nothing decided yet; timing_sync's m_phase_acc before the first frame: 0
     std::deque<Flight> flight_;
+    std::deque<int64_t> skipped_;                  // batches whose upload failed, in stream order: the chain steps over them
     uint64_t next_handle_ = 1;
 };
 

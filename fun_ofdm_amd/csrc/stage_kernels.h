@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void k_conv_pack(const uint32_t *__restrict__ 
 {
     const int b = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
     if (x >= nbytes_out) return;
-    const uint8_t *src = (const uint8_t *)(decoded + info[b].dec_off);
+    const uint8_t *src = (const uint8_t *)(decoded + decoded_word_off(info[b].dec_off));
     data[(size_t)b * nbytes_out + x] = x < nbytes_have ? src[x] : (uint8_t)0;
 }
 

@@ -71,7 +71,7 @@ __device__ __forceinline__ void finish_crc_psdu(const FinishTables &t, FinishWav
     int maxw = nwords;
 #pragma unroll
     for (int o = 32; o; o >>= 1) maxw = max(maxw, __shfl_xor(maxw, o));
-    fw.base[lane] = live ? fi.dec_off : 0;
+    fw.base[lane] = live ? decoded_word_off(fi.dec_off) : 0;
     fw.nwords[lane] = nwords;
     wave_lds_sync();
     uint32_t crc = 0xFFFFFFFFu, given = 0;
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(64) void k_tb_walk(const FrameInfo *__restrict__ in
     const int cnt = live ? (n_hi - n_lo + kChunk3 - 1) / kChunk3 : 0;      // 48-step chunks this lane walks, numbered from its bottom
     const int own = live ? (n_own - n_lo + kChunk3 - 1) / kChunk3 : 0;     // of which the lowest `own` are its own
     const uint8_t *src = live ? (const uint8_t *)(dec + fi.dec_off) + (size_t)(n_lo / kChunk3) * 384 : (const uint8_t *)dec;
-    uint32_t *out = decoded + fi.dec_off + n_lo / 32;
+    uint32_t *out = decoded + decoded_word_off(fi.dec_off) + n_lo / 32;
     int cmax = cnt;
 #pragma unroll
     for (int o = 32; o; o >>= 1) cmax = max(cmax, __shfl_xor(cmax, o));
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(64) void k_tb_finish(const FrameInfo *__restrict__ 
             const int64_t off = __shfl(fi.dec_off, l);
             const int n_l = __shfl(N, l);
             const uint32_t sn = __shfl(s_next, l);
-            const uint32_t r = tb_rewalk((const uint16_t *)(dec + off), k * S, min(k * S + S, n_l), sn, decoded + off, rw, lane);
+            const uint32_t r = tb_rewalk((const uint16_t *)(dec + off), k * S, min(k * S + S, n_l), sn, decoded + decoded_word_off(off), rw, lane);
             if (lane == l) s_k = r;
         }
         if (has) s_next = s_k;

@@ -19,16 +19,6 @@ RATE_MBPS = (6, 8, 9, 12, 16, 18, 24, 32, 36, 48, 54)
 STANDARD_RATES = (0, 2, 3, 5, 6, 8, 9, 10)
 
 
-def _settle(t):
-    """The library's streams know nothing of torch's: before a call that reads or writes torch tensors, whatever torch's current stream still
-    has queued (a fill of an output tensor, the copy that made an input) must be through.  A query when the stream is idle -- the steady
-    state of a pipelined loop -- costs a microsecond; only a busy stream is waited for."""
-    import torch
-    s = torch.cuda.current_stream(t.device)
-    if not s.query():
-        s.synchronize()
-
-
 def _vp(a):
     return a.ctypes.data_as(C.c_void_p)
 
@@ -54,6 +44,45 @@ class Receiver:
             self._h = None
 
     __del__ = close
+
+    def _after_torch(self, t):
+        """The library's streams know nothing of torch's (and run at other priorities): before a call that reads or writes torch tensors,
+        whatever torch's CURRENT stream on the tensor's device still has queued -- the copy that made an input, the fill of an output
+        tensor -- must be through.  Ordered on the DEVICE (foa_rx_after with an event recorded on that stream): the host does not wait.
+        Work the caller has queued on OTHER torch streams (a side stream, a non_blocking copy stream) is not covered: record an event
+        there and hand it to after() yourself."""
+        import torch
+        s = torch.cuda.current_stream(t.device)
+        if s.query():
+            return                                       # idle (the steady state of a loop that orders by other means): nothing to wait for
+        ev = torch.cuda.Event()
+        ev.record(s)
+        self._check(self._lib.foa_rx_after(self._h, ev.cuda_event))
+        self._after_keep = ev                            # (alive until the call below has queued its wait)
+
+    def after(self, event):
+        """foa_rx_after: the next call that queues device work waits (on the device) for `event`, a torch.cuda.Event that has been recorded."""
+        self._check(self._lib.foa_rx_after(self._h, event.cuda_event))
+        self._after_keep = event
+
+    def record_consumed(self, event):
+        """foa_rx_record_consumed: `event` (a torch.cuda.Event that has been recorded once, so that its handle exists) completes when everything
+        queued so far has read its input buffers."""
+        self._check(self._lib.foa_rx_record_consumed(self._h, event.cuda_event))
+
+    def record_done(self, event):
+        """foa_rx_record_done: `event` completes when everything queued so far is complete (outputs final)."""
+        self._check(self._lib.foa_rx_record_done(self._h, event.cuda_event))
+
+    def torch_waits_for_done(self, device=None):
+        """Make torch's current stream wait, on the device, for everything queued on this handle so far (foa_rx_record_done): torch work queued
+        afterwards on that stream sees the final PSDUs and results; the host does not wait."""
+        import torch
+        s = torch.cuda.current_stream(device if device is not None else self.device)
+        ev = torch.cuda.Event()
+        ev.record(s)                                     # (creates the event's handle; the library's record below supersedes this one)
+        self.record_done(ev)
+        s.wait_event(ev)
 
     def set_option(self, name, value):
         self._check(self._lib.foa_rx_set_option(self._h, name.encode(), int(value)))
@@ -123,10 +152,11 @@ class Receiver:
         (looked at only for where they sit); n_context: the last ones are context only (foa_rx_decode_frames_lead_ctx_dev).
         Asynchronous on the handle's streams, which are NOT ordered against
         torch's (and run at other priorities: a fill torch has queued for an output tensor may land after the kernels
-        that write it), so the wrapper waits for torch's current stream if it still has work queued (_settle).  settle=False: the
+        that write it), so the wrapper makes the call wait, on the device, for what torch's current stream has queued
+        (_after_torch -> foa_rx_after).  settle=False: the
         caller orders torch's work on these tensors against the call itself (bench.py's loop does, with one event per output set)."""
         if settle:
-            _settle(iq)
+            self._after_torch(iq)
         n = iq.numel() if iq.is_complex() else iq.numel() // 2
         m = ends.numel() - n_context - n_lead
         assert descs.numel() * descs.element_size() == ends.numel() * frame_desc_dtype.itemsize
@@ -140,7 +170,7 @@ class Receiver:
         n = iq.numel() if iq.is_complex() else iq.numel() // 2
         cap = ends.numel()
         assert descs.numel() * descs.element_size() >= cap * frame_desc_dtype.itemsize
-        _settle(iq)
+        self._after_torch(iq)
         got = C.c_size_t(0)
         self._check(self._lib.foa_rx_sync_dev(self._h, iq.data_ptr(), n, descs.data_ptr(), ends.data_ptr(), cap, C.byref(got)))
         return int(got.value)
@@ -150,7 +180,7 @@ class Receiver:
         n = iq.numel() if iq.is_complex() else iq.numel() // 2
         cap = ends.numel()
         assert descs.numel() * descs.element_size() >= cap * frame_desc_dtype.itemsize
-        _settle(iq)
+        self._after_torch(iq)
         self._check(self._lib.foa_rx_sync_dev_begin(self._h, iq.data_ptr(), n, descs.data_ptr(), ends.data_ptr(), cap))
 
     def sync_dev_end(self):
@@ -171,7 +201,7 @@ class Receiver:
         s = self.tx_frame_samples(length, rate)
         out = torch.empty((n, s, 2), dtype=torch.float64, device=payloads.device)
         got = C.c_size_t(0)
-        torch.cuda.current_stream(payloads.device).synchronize()
+        self._after_torch(payloads)
         self._check(self._lib.foa_tx_build_frames_dev(self._h, payloads.data_ptr(), payloads.stride(0), int(length), int(rate), n, out.data_ptr(), C.byref(got)))
         self.sync()
         return out
@@ -181,7 +211,7 @@ class Receiver:
         import torch
         n, s, _ = frames.shape
         iq = torch.empty((n * pitch, 2), dtype=torch.float32, device=frames.device)
-        torch.cuda.current_stream(frames.device).synchronize()
+        self._after_torch(frames)
         self._check(self._lib.foa_tx_channel_dev(self._h, frames.data_ptr(), n, s, int(pitch), int(lead), float(snr_db), float(cfo_hz), int(seed), iq.data_ptr()))
         self.sync()
         return iq

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FOA_VERSION 100
+#define FOA_VERSION 110
 
 enum {
     FOA_OK = 0,
@@ -48,7 +48,7 @@ enum {
     FOA_ST_TRUNCATED = 3,    /* the samples handed over END before the alignment's LTS windows, its SIGNAL symbol or the last symbol its
                               * SIGNAL announces: with more of the stream the outcome would be another (a caller that cuts a stream into
                               * pieces decodes the alignment again when it has them) */
-    FOA_ST_NO_SPACE = 4,     /* workspace exhausted (overlapping frame ranges), or the CRC matched but the payload is longer
+    FOA_ST_NO_SPACE = 4,     /* workspace exhausted (overlapping frame ranges; a rate above option "max_dbps"), or the CRC matched but the payload is longer
                               * than slot_bytes (nothing is copied) */
     FOA_ST_SUPERSEDED = 5    /* a later alignment took the stream over before this one's frame was complete: its LTS or SIGNAL window is
                               * cut by the next LTS1 tag, or a valid SIGNAL arrived before the frame's last symbol (frame_decoder.cpp:52-76
@@ -103,7 +103,7 @@ void foa_rx_destroy(foa_rx *rx);
  * alignments, so that later decode calls allocate nothing. */
 int foa_rx_reserve(foa_rx *rx, size_t n_samples, size_t n_frames);
 
-/* Options.  Results are identical for every setting of the first group (they exist for measurement and diagnostics); the second
+/* Options.  Results are identical for every setting of the first group (they shape scheduling and memory; the diagnostic options are in fun_ofdm_amd_diag.h); the second
  * group says which reference behaviour the pre-sync reproduces.  Unknown names and out-of-range values: FOA_E_INVALID.
  *   "tb_segment"  data steps per chain-back segment, a multiple of 96 in [96, 3072] (default 960)
  *   "tb_overlap"  run-in steps above a segment, a multiple of 96 in [0, 3072] (default 96); any value gives the same result as a
@@ -116,8 +116,12 @@ int foa_rx_reserve(foa_rx *rx, size_t n_samples, size_t n_frames);
  *   "depth"       pipelined calls: how many calls' loops are in flight -- 0 (default) = by grid size: 2, or 4 for calls of up to 2048 frames,
  *                 whose forward pass leaves most SIMDs a single wave (1 000-frame batches decode 40-50 % faster in steady state); 2, 3, 4 =
  *                 fixed.  (the lanes sit on hardware queues of their own: stream priorities, see above)
- *   "record_soft" keep the depunctured soft bytes for foa_rx_get_taps (default 1; 0 saves their HBM writes)
- *   "record_eq"   keep the equalised carriers for foa_rx_get_taps (default 0)
+ *   "max_dbps"    what the work sets of later calls (and foa_rx_reserve) are sized for: the data bits per OFDM symbol of the HIGHEST rate the
+ *                 caller's frames carry, 24 (6 Mbps) .. 216 (54 Mbps, the default: any rate).  A call's per-step buffers -- 10.25 bytes per
+ *                 trellis step, several sets in rotation -- hold n_samples / 80 x max_dbps steps, so a capture of 6 Mbps frames needs a
+ *                 ninth of the default, and a call can take nine times the frames (machine-filling calls at 6-18 Mbps: DESIGN.md 4).  A
+ *                 promise, checked on the device: a frame that does not fit in what is left of its call's work set is reported
+ *                 FOA_ST_NO_SPACE, never decoded wrongly.  Results are otherwise identical for every value.
  *
  *   "sync_call"   foa_rx_sync_dev / the stream engine: the reference call size by which timing_sync.cpp:99 is decided (foa_sync_set_call, below);
  *                 default 4096 = receiver.h:16, 0 = as one call over the whole stream.  FOA_E_STATE while a stream engine is open.
@@ -218,42 +222,33 @@ int foa_rx_submit_host_ctx(foa_rx *rx, const float *iq, size_t n_samples, const 
                            size_t n_context, size_t slot_bytes, uint64_t *ticket);
 int foa_rx_collect(foa_rx *rx, uint64_t ticket, int wait, uint8_t *psdu, foa_frame_result *results);
 
-/* HIP-event durations (ms) of the kernels of the most recent decode call, measured on the handle's
- * stream: [0] header (LTS+SIGNAL), [1] offset scan, [2] data-symbol FFT/equalise/demap,
- * [3] Viterbi forward pass, [4] chain-back + descramble + CRC, [5] whole call.  Synchronises. */
-int foa_rx_last_kernel_ms(foa_rx *rx, float out_ms[6]);
-/* The same for the decode call before the most recent one: that call is complete (or nearly) while the most recent one
- * may still be running, so reading it does not stall a pipelined sequence of calls. */
-int foa_rx_prev_kernel_ms(foa_rx *rx, float out_ms[6]);
-/* ... and for the call `age` calls back (0 = most recent, 1 = previous, 2 = the one before: with pipelined calls that one is
- * certainly complete, so asking never delays the host, which matters because the next call's front end runs under the
- * forward pass that is on the GPU now). */
-int foa_rx_kernel_ms_age(foa_rx *rx, int age, float out_ms[6]);
-
-/* Pipelined calls: how the forward pass of the call `age` calls back (1 .. 3) lies against the one of the call before it, from the same HIP
- * events: out[0] = start to start, out[1] = how long the earlier pass was still running after this one had started (> 0: they overlapped;
- * consecutive passes run on different streams by design), out[2] = this pass's own duration (ms).  A launch that shares the machine with its
- * neighbour lasts longer than the step: bench.py reports both next to its roofline fraction. */
-int foa_rx_forward_spacing_ms(foa_rx *rx, int age, float out[3]);
-
-/* Issue-rate probe of the device the handle lives on (measurement aid for bench.py's roofline; nothing in the receive path
- * uses it): out[0..2] = SIMD clocks per wave64 `v_pk_add_u16 ... clamp`, shader clock (GHz) sustained meanwhile, wave-instructions
- * per second over the whole chip; out[3..5] the same for the plain 32-bit VOP2 `v_add_u32`.  Eight waves per SIMD issue from
- * independent chains for a fixed window of shader clocks (csrc/probe_kernels.h).  Synchronises; about a millisecond. */
-int foa_rx_probe_issue(foa_rx *rx, double out[6]);
-
-/* Intermediates of the most recent decode call, copied to HOST memory (parity tests).
- *   hinv    64 complex doubles (re,im) per frame: channel_est's m_chan_est (channel_est.cpp:53-58)
- *   eq      per frame (1 + num_symbols) * 48 complex doubles: phase_tracker output incl. SIGNAL
- *   soft    per frame 2 * num_symbols * dbps depunctured soft bytes (puncturer.cpp:78-123 output)
- * Any pointer may be NULL.  eq/soft are packed frame after frame in frame order for frames whose header
- * decoded; eq_off/soft_off (n_frames+1 entries each, may be NULL) receive the element offsets. */
-int foa_rx_get_taps(foa_rx *rx, size_t n_frames, double *hinv, double *eq, size_t eq_cap, uint64_t *eq_off,
-                    uint8_t *soft, size_t soft_cap, uint64_t *soft_off);
-/* Raw decision words of one frame of the most recent decode call (debugging / unit parity of the forward
- * kernel): n_steps = num_symbols * dbps words, the raw region of the forward pass's transposed layout (16-bit words
- * [block of 16 data steps][63 - slot], complemented bits, trellis steps 6.. only; see fun_ofdm_amd/csrc/viterbi_fwd.h). */
-int foa_rx_get_decisions(foa_rx *rx, size_t frame, uint64_t *out, size_t cap, size_t *n_steps);
+/* ---- device-side ordering against the caller's own HIP streams -------------------------------------------------------------------------
+ *
+ * The plain entry points above keep SURVEY 8(b)'s contract in its simplest form: buffers handed to a call must be COMPLETE when the call
+ * is made (and stay untouched until it has read them), and outputs are final after foa_rx_sync -- the host waits.  A caller whose samples
+ * are produced on the device by a stream of its own (an SDR's DMA engine, a channel simulator, another library) orders the two on the
+ * DEVICE instead: every `event` below is a hipEvent_t (passed as void * so that this header needs no HIP header), recorded or waited for
+ * with the caller's own HIP calls; the library never makes the host wait in any of these.
+ *
+ *   foa_rx_after(rx, e)             the NEXT call on the handle that queues device work (decode, pre-sync, transmit) starts only after
+ *                                   e -- recorded by the caller behind whatever produces that call's inputs and prepares its outputs (a
+ *                                   fill of the PSDU slots, say).  One-shot; up to 16 events may be registered for one call.
+ *   foa_rx_record_consumed(rx, e)   records e so that it completes when everything queued so far has READ what it reads of the caller's
+ *                                   input buffers: the caller's stream waits for e (hipStreamWaitEvent) before it refills them.  Cheap.
+ *   foa_rx_record_done(rx, e)       records e so that it completes when everything queued so far is complete (PSDU slots, results,
+ *                                   descriptors): the caller's stream waits for e before it reads them.  Queues the deferred chain-back of
+ *                                   a pipelined call at once (option "pipeline"), like foa_rx_sync does.
+ *   foa_rx_decode_frames_dev_after / foa_rx_sync_dev_begin_after = foa_rx_after(rx, inputs_ready) + the call (inputs_ready may be NULL).
+ *
+ * A capture loop over two device buffers with no host synchronisation in it: INTEGRATION.md 2; tests/cpp/test_ordering.cpp runs one
+ * against the oracle.  The library's lanes run BELOW the normal stream priority and its short stitch / copy streams above (see the
+ * top of this file), so an un-ordered producer on a normal-priority stream is overtaken in both directions: order with these calls, or
+ * complete the buffers before the call. */
+int foa_rx_after(foa_rx *rx, void *event);
+int foa_rx_record_consumed(foa_rx *rx, void *event);
+int foa_rx_record_done(foa_rx *rx, void *event);
+int foa_rx_decode_frames_dev_after(foa_rx *rx, void *inputs_ready, const float *d_iq, size_t n_samples, const foa_frame_desc *d_descs,
+                                   const int64_t *d_ends, size_t n_frames, uint8_t *d_psdu, size_t slot_bytes, foa_frame_result *d_results);
 
 /* ---- pre-sync: on the host (streaming) and on the device (whole resident streams), SURVEY 8f #1 ---- */
 
@@ -300,6 +295,8 @@ int foa_rx_sync_dev(foa_rx *rx, const float *d_iq, size_t n_samples, foa_frame_d
  * buffers of a batch must stay untouched from its _begin to the completion of the decode call that reads them. */
 int foa_rx_sync_dev_begin(foa_rx *rx, const float *d_iq, size_t n_samples, foa_frame_desc *d_descs, int64_t *d_ends, size_t cap);
 int foa_rx_sync_dev_end(foa_rx *rx, size_t *n_found);
+/* ... whose kernels start only after `inputs_ready` (a hipEvent_t of the caller's: "device-side ordering" above) */
+int foa_rx_sync_dev_begin_after(foa_rx *rx, void *inputs_ready, const float *d_iq, size_t n_samples, foa_frame_desc *d_descs, int64_t *d_ends, size_t cap);
 
 /* ---- process_samples() entirely on the device (SURVEY 8f #1 + #3): a stream engine over the calls above ------------
  *

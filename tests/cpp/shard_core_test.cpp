@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <set>
+#include <unistd.h>
 
 #include "../../fun_ofdm_amd/csrc/shard_core.h"
 
@@ -24,6 +26,8 @@ struct World {
     int64_t eager = 0;                              // look-aheads queued before the batch before them had been decoded (the chain runs ahead of the decode calls)
     std::vector<int> device_of_batch;
     int bad = 0;
+    int64_t fail_upload_at = -1;                    // the upload of this batch fails (the chain must step over it, nothing may hang)
+    std::set<int64_t> failed;
 };
 
 struct FakeDev {
@@ -41,6 +45,7 @@ struct FakeDev {
         const int64_t k = w->uploads++;
         w->device_of_batch.push_back(id);
         if (id != (int)(k % n_dev)) { w->bad++; printf("batch %lld went to device %d\n", (long long)k, id); }
+        if (k == w->fail_upload_at) { w->failed.insert(k); buf[slot] = Buf(); return -7; }
         // the carry: the C samples before the batch (zeros before the stream's start); the batch: the next n_new samples of the stream
         const int64_t b0 = start + w->C;            // stream index of the batch's first sample
         for (int64_t i = 0; i < w->C; i++) {
@@ -58,11 +63,13 @@ struct FakeDev {
     {
         std::lock_guard<std::mutex> lk(w->m);
         Buf &b = buf[slot];
+        while (w->failed.count(w->next_select_batch)) { w->next_select_batch++; w->selects_done++; }      // (a batch that was never uploaded has no look-ahead)
         if (b.batch != w->next_select_batch || w->selects_done != b.batch) { w->bad++; printf("look-ahead of batch %lld queued out of turn (%lld done)\n", (long long)b.batch, (long long)w->selects_done); }
         if (in.lo_abs != w->last.lo_abs || in.c != w->last.c || in.s != w->last.s) { w->bad++; printf("batch %lld got the wrong chain state\n", (long long)b.batch); }
         // tags are final up to kShardSettle before the buffer's end (all of it when the stream is over)
         if (n_eff != w->C + b.n_new - (final ? 0 : foa::kShardSettle)) { w->bad++; printf("batch %lld: n_eff %lld\n", (long long)b.batch, (long long)n_eff); }
-        if (in.lo_abs < b.start) { w->bad++; printf("batch %lld: the first undecided alignment lies before its buffer\n", (long long)b.batch); }
+        // (behind a batch that was lost an undecided frame may begin before the buffer: the stream is in error by then)
+        if (in.lo_abs < b.start && w->failed.empty()) { w->bad++; printf("batch %lld: the first undecided alignment lies before its buffer\n", (long long)b.batch); }
         if (w->decodes < b.batch) w->eager++;
         b.n_eff = n_eff; b.in = in;
         w->selects_queued++;
@@ -148,6 +155,77 @@ static void run(int n_dev, int64_t B, int64_t C, int64_t L, size_t total, unsign
            (long long)B, (long long)C, total, max_push, helpers, order.size(), (long long)w.eager);
 }
 
+// The upload of one batch fails: every call must come back (push / flush with the error, the destructor at all) -- the chain of
+// look-aheads steps over the batch instead of waiting for a selection that is never queued -- and the batches in front of it still come
+// out in order.  A watchdog turns a hang into a failure.
+static void run_upload_failure(int n_dev, int64_t fail_at, unsigned seed, bool one_push = false)
+{
+    const int64_t B = 4096, C = 1000, L = 600;
+    const size_t total = 40 * (size_t)B;
+    std::mt19937 rng(seed);
+    World w;
+    w.B = B; w.C = C; w.L = L; w.fail_upload_at = fail_at;
+    w.stream.resize(2 * total);
+    for (size_t i = 0; i < w.stream.size(); i++) w.stream[i] = (float)((int)(rng() % 20001) - 10000) / 64.0f;
+    std::vector<FakeDev *> devs;
+    for (int i = 0; i < n_dev; i++) devs.push_back(new FakeDev(&w, i, n_dev, 1 + (int)(rng() % 5)));
+    std::vector<std::vector<float> > stage(6, std::vector<float>(2 * B)), carry(6, std::vector<float>(2 * C));
+    float *sp[6], *cp[6];
+    for (int i = 0; i < 6; i++) { sp[i] = stage[i].data(); cp[i] = carry[i].data(); }
+    std::vector<int64_t> order;
+    int push_rc = 0, flush_rc = 0;
+    alarm(60);
+    {
+        foa::ShardBackend<FakeDev> be(devs, B, C, L, sp, cp);
+        foa::StreamCore<foa::ShardBackend<FakeDev> > core(&be, B, 1);
+        foa::StreamReady r;
+        size_t o = 0;
+        while (o < total && !push_rc) {
+            const size_t n = one_push ? total : std::min(total - o, (size_t)(1 + rng() % 9000));      // (one push: batches behind the lost one are closed before it is staged)
+            push_rc = core.push(w.stream.data() + 2 * o, n, nullptr, nullptr);
+            o += n;
+            while (core.take(false, &r) == 1) { int64_t k; memcpy(&k, r.bytes.data(), 8); order.push_back(k); r = foa::StreamReady(); }
+        }
+        flush_rc = core.flush();
+        while (core.take(true, &r) == 1) { int64_t k; memcpy(&k, r.bytes.data(), 8); order.push_back(k); r = foa::StreamReady(); }
+        CHECK(core.error() != 0, "the core does not report the failed upload");
+    }
+    alarm(0);
+    CHECK(push_rc != 0 || flush_rc != 0, "neither push nor flush reported the failed upload of batch %lld", (long long)fail_at);
+    for (size_t k = 0; k < order.size(); k++) CHECK(order[k] == (int64_t)k + (order[k] > fail_at ? 1 : 0), "batch %lld came back in place %zu", (long long)order[k], k);
+    CHECK(w.bad == 0, "%d violations", w.bad);
+    for (auto *d : devs) delete d;
+    printf("%d devices, upload of batch %lld fails: push %d, flush %d, %zu batches came back, nothing hung\n", n_dev, (long long)fail_at, push_rc, flush_rc, order.size());
+}
+
+// ... and the backend alone, the way the core drives it when every slot is staged (a forced submit): the batch behind a lost one must
+// get its look-ahead and its submit must return.
+static void run_forced_submit_behind_a_lost_batch(int n_dev)
+{
+    const int64_t B = 4096, C = 1000, L = 600;
+    World w;
+    w.B = B; w.C = C; w.L = L; w.fail_upload_at = 1;
+    w.stream.assign(2 * 6 * (size_t)B, 0.25f);
+    std::vector<FakeDev *> devs;
+    for (int i = 0; i < n_dev; i++) devs.push_back(new FakeDev(&w, i, n_dev, 3));
+    std::vector<std::vector<float> > stage(6, std::vector<float>(2 * B)), carry(6, std::vector<float>(2 * C));
+    float *sp[6], *cp[6];
+    for (int i = 0; i < 6; i++) { sp[i] = stage[i].data(); cp[i] = carry[i].data(); }
+    foa::ShardBackend<FakeDev> be(devs, B, C, L, sp, cp);
+    int rcs[4];
+    for (int k = 0; k < 4; k++) { for (int64_t i = 0; i < 2 * B; i++) sp[k][i] = 0.25f; rcs[k] = be.stage(k, B, false); }
+    CHECK(rcs[0] == 0 && rcs[1] != 0 && rcs[2] == 0 && rcs[3] == 0, "stage: %d %d %d %d", rcs[0], rcs[1], rcs[2], rcs[3]);
+    alarm(20);
+    uint64_t h = 0;
+    CHECK(be.submit(0, B, false, &h) == 0, "batch 0");
+    CHECK(be.submit(2, B, false, &h) == 0, "batch 2, behind the lost one");      // (round 5's chain never got past batch 1: this call span for ever)
+    CHECK(be.submit(3, B, false, &h) == 0, "batch 3");
+    alarm(0);
+    CHECK(w.bad == 0, "%d violations", w.bad);
+    for (auto *d : devs) delete d;
+    printf("%d devices, backend alone: submits behind a lost batch return\n", n_dev);
+}
+
 int main()
 {
     run(1, 4096, 1000, 600, 100000, 1, 3000, 0);
@@ -155,6 +233,15 @@ int main()
     run(8, 4096, 6000, 4000, 500000, 3, 20000, 3);          // a carry longer than a batch: it spans several batches
     run(8, 65536, 20000, 9000, 3000000, 4, 300000, 4);      // config 4's device count
     run(3, 5000, 700, 300, 65000, 5, 100, 1);               // total a multiple of the batch: the final batch is empty
+    run_upload_failure(1, 3, 6);
+    run_upload_failure(2, 0, 7);
+    run_upload_failure(3, 7, 8);
+    run_upload_failure(8, 5, 9);
+    run_forced_submit_behind_a_lost_batch(1);
+    run_forced_submit_behind_a_lost_batch(3);
+    run_upload_failure(1, 0, 10, true);
+    run_upload_failure(2, 1, 11, true);
+    run_upload_failure(3, 2, 12, true);
     printf(failures ? "FAILED (%d)\n" : "OK\n", failures);
     return failures ? 1 : 0;
 }

@@ -25,6 +25,21 @@ def test_cpp_adaptors(tmp_path, po):
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def test_device_side_ordering_against_the_callers_own_streams(tmp_path, po):
+    """tests/cpp/test_ordering.cpp: a capture loop with a device-side producer on the caller's own normal-priority streams and NO host
+    synchronisation between producing the samples and decoding them (foa_rx_decode_frames_dev_after, foa_rx_sync_dev_begin_after,
+    foa_rx_record_consumed, foa_rx_record_done) -- 200 pipelined rounds, 60 in line, 60 with the pre-sync in the loop, each round equal to
+    the oracle's decode of that round's capture."""
+    import fun_ofdm_amd as foa
+    exe = str(tmp_path / "test_ordering")
+    libdir, ora = os.path.dirname(foa.library_path()), os.path.join(ROOT, "oracle")
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "cpp", "test_ordering.cpp"), "-I", os.path.join(ROOT, "include"), "-I", ora,
+                    "-L", libdir, "-lfun_ofdm_amd", "-L", ora, "-loracle", "-Wl,-rpath," + libdir, "-Wl,-rpath," + ora, "-lm", "-lpthread", "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
 def test_mixed_chain_reference_presync_blocks_in_front_of_the_gpu_blocks(tmp_path, po):
     """tests/cpp/mixed_chain.cpp against the real library: the reference's compiled frame_detector and timing_sync (oracle/_ref, built
     from /root/reference in the dev container; the library travels) -> fun_amd::fft_symbols .. frame_decoder, and -> the fused

@@ -55,7 +55,7 @@ def _rel(a, b):
 
 def test_library_is_native_and_loaded():
     import fun_ofdm_amd as foa
-    assert foa.lib().foa_version() == 100
+    assert foa.lib().foa_version() == 110
     assert foa.lib().foa_device_count() >= 1
 
 

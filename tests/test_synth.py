@@ -106,15 +106,23 @@ def test_host_sync_decides_timing_sync_99_by_the_reference_call_size(po):
 
 def test_library_exports_every_declared_symbol():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # the product header (what INTEGRATION.md binds) and the diagnostics header (same library, no stability promise)
     hdr = open(os.path.join(root, "include", "fun_ofdm_amd.h")).read()
-    declared = set(re.findall(r"\b(foa_[a-z0-9_]+)\s*\(", hdr))
-    assert len(declared) >= 20
+    diag = open(os.path.join(root, "include", "fun_ofdm_amd_diag.h")).read()
+    product = set(re.findall(r"\b(foa_[a-z0-9_]+)\s*\(", hdr))
+    lab = set(re.findall(r"\b(foa_[a-z0-9_]+)\s*\(", diag)) - {"foa_rx_set_option"}
+    assert len(product) >= 20 and not (product & lab)
+    # the lab stays out of the product header: timings, taps, decisions and the probe are diagnostics
+    for name in ("foa_rx_probe_issue", "foa_rx_get_taps", "foa_rx_get_decisions", "foa_rx_forward_spacing_ms", "foa_rx_last_kernel_ms"):
+        assert name in lab and name not in product, name
+    assert "record_eq" not in hdr and "record_soft" not in hdr
+    declared = product | lab
     L = ctypes.CDLL(foa.library_path())
     for name in sorted(declared):
         assert hasattr(L, name), name
     from fun_ofdm_amd._lib import EXPORTS
     assert declared == set(EXPORTS)
-    assert L.foa_version() == 100
+    assert L.foa_version() == 110
 
 
 def test_no_cpu_fallback_without_gpu():

@@ -4,9 +4,12 @@
 set -e
 name=$1; shift
 src=fun_ofdm_amd/csrc; obj=build/var_$name.o.d
+rm -rf $obj build/var_$name.so          # never link a stale object of an earlier build of this variant name
 mkdir -p $obj
+pids=()
 for u in rx_handle rx_decode rx_sync rx_stage rx_tx rx_stream; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function "$@" -c -o $obj/$u.o $src/$u.hip &
+  pids+=($!)
 done
-wait
+for p in "${pids[@]}"; do wait $p || { echo "variant $name: a unit failed to compile" >&2; exit 1; }; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/var_$name.so $obj/*.o
