@@ -898,7 +898,7 @@ def extra_legs(args, rx, dev, iq, descs, ends, real, psdu_dev_path, res_dev_path
                 pitch0 = -(-(s0 + 576) // 4096) * 4096
                 nfill = int(min(args.fill_frames, budget // pitch0))
                 pays, d_iq, s, pitch = c3_workload(rate, nfill, length, 400 + rate)
-                row, found, dt, dt_cpu = c3_decode_and_check(d_iq, lambda pos, pays=pays, pitch=pitch: ((pos - 360) % pitch == 0, pays[((pos - 360) // pitch)[(pos - 360) % pitch == 0]]), length, 6, True)
+                row, found, dt, dt_cpu = c3_decode_and_check(d_iq, lambda pos, pays=pays, pitch=pitch: ((pos - 360) % pitch == 0, pays[((pos - 360) // pitch)[(pos - 360) % pitch == 0]]), length, 24, True)
                 row.update({"rate_enum": rate, "mbps": foa.RATE_MBPS[rate], "frames": nfill, "forward_waves_per_simd": round(nfill / 2 / 1024, 2), "frame_samples": s,
                             "Msamples_per_s": round(found * s / dt / 1e6, 1), "cpu_Msamples_per_s": round(found * s / dt_cpu / 1e6, 1)})
                 if nfill < args.fill_frames:

@@ -222,7 +222,14 @@ static int decode_frames_any(foa_rx *rx, const void *d_iq, bool f64, size_t n_sa
     HIP_TRY(hipEventRecord(rx->w->ev[2], st));
     // upper bound on data symbols in n_samples samples; waves beyond the real total exit at once
     const size_t max_sym = rx->w->sym_cap;
-    const dim3 q4_grid((unsigned)((max_sym + 16 * kQ4Waves - 1) / (16 * kQ4Waves)));
+    // (persistent workgroups: as many as the device holds at once walk over the groups of 64 symbols, frontend_q4.h)
+    if (rx->q4_resident == 0) {
+        int per_cu = 0, cus = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_data_symbols_q4<float2>, 64 * kQ4Waves, 0));
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, rx->device));
+        rx->q4_resident = std::max(1, per_cu) * std::max(1, cus);
+    }
+    const dim3 q4_grid((unsigned)std::min<size_t>((max_sym + 16 * kQ4Waves - 1) / (16 * kQ4Waves), (size_t)rx->q4_resident));
     if (f64) hipLaunchKernelGGL(k_data_symbols_q4<double2>, q4_grid, dim3(64 * kQ4Waves), 0, st, iq64, d_descs, rx->w->info.p, rx->w->sym2frame.p, rx->w->spec.p,
                                 rx->w->totals.p, rx->w->hinv.p, rx->w->sp.p, eq_data);
     else hipLaunchKernelGGL(k_data_symbols_q4<float2>, q4_grid, dim3(64 * kQ4Waves), 0, st, iq, d_descs, rx->w->info.p, rx->w->sym2frame.p, rx->w->spec.p,

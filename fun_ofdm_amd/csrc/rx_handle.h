@@ -118,6 +118,7 @@ struct foa_rx {
     int depth = 0;                     // how many calls' loops are in flight; 0 = by grid size (2, or 4 below kDeepBelow frames)
     int depth_saved = -1;              // (the stream engine pins its own while a stream is open and restores this)
     unsigned n_calls = 0;              // pipelined decode calls made so far (a call's lane is n_calls mod depth)
+    int q4_resident = 0;               // workgroups of the data-symbol kernel the device holds at once (its grid: rx_decode.hip)
     int max_dbps = 216;                // work sets hold this many trellis steps per 80 samples (option "max_dbps": the highest rate the caller's frames carry)
     int tb_segment = 960, tb_overlap = 96;   // chain-back: data steps per segment / run-in steps (multiples of 96)
     bool pipeline = true;        // the finish of one call overlaps the next calls' front end and forward pass (rotating work sets, several streams)

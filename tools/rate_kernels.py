@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--budget", type=int, default=300 * 1000 * 1000, help="cap on samples per call (0 = none)")
     ap.add_argument("--hint", action="store_true", help="set option max_dbps to the rate's dbps (work sets sized for the call's own rate)")
     ap.add_argument("--reps", type=int, default=6)
+    ap.add_argument("--alone-only", action="store_true", help="calls in line only (for counter runs)")
     args = ap.parse_args()
     import torch
     import fun_ofdm_amd as foa
@@ -65,6 +66,10 @@ def main():
                 for k, v in rx.kernel_ms().items():
                     acc[k] = acc.get(k, 0.0) + v / 3.0
         row["alone_ms"] = {k: round(v, 4) for k, v in acc.items()}
+        if args.alone_only:
+            print(json.dumps(row), flush=True)
+            rx.close()
+            continue
         rx.set_option("pipeline", 1)
         for _ in range(8):
             call()
