@@ -50,8 +50,9 @@ def parse_args(argv=None):
     ap.add_argument("--frames", type=int, default=10000, help="frames per GPU (BASELINE config 2: 10000)")
     ap.add_argument("--tb-segment", type=int, default=0, help="data steps per chain-back segment (0: library default)")
     ap.add_argument("--tb-overlap", type=int, default=-1, help="run-in steps of a chain-back segment (-1: library default)")
-    ap.add_argument("--tx", choices=("host", "device"), default="host",
-                    help="where the synthetic frames are built: numpy on the host (default) or foa_tx_* on the device")
+    ap.add_argument("--tx", choices=("host", "device"), default=None,
+                    help="where the synthetic frames are built and pre-synchronised: numpy + foa_sync_* on the host (default at one rank) or foa_tx_* + "
+                         "foa_rx_sync_dev on the device (default with several ranks: eight ranks do not share the host's cores before the clock starts)")
     ap.add_argument("--no-pipeline", action="store_true", help="finish of a step on the same stream as the rest (no overlap with the next step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sync-leg", action="store_true", help="skip the extra leg with the device pre-sync (profiling: keeps its launches out of the kernel averages)")
@@ -360,20 +361,29 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
     t0 = time.perf_counter()
     n_global = args.frames * world
     my_ids = shard.local_frame_ids(n_global, rank, world).numpy()       # global frame i -> rank i mod G
-    if args.tx == "device" and not on_cpu:
+    tx = args.tx or ("device" if (world > 1 and not on_cpu) else "host")
+    if tx == "device" and not on_cpu:
         # frame_builder + channel on the device; the samples come back once for the host-side checks
         gen = foa.Receiver(dev_index)
         pays = synth.splitmix64_bytes(SEED_BASE, len(my_ids), PAYLOAD, ids=my_ids)
         d_frames = gen.tx_build_frames(torch.from_numpy(pays).to(dev), RATE)
         d_gen = gen.tx_channel(d_frames, PITCH, LEAD, SNR_DB, seed=7919 * (rank + 1))
         iq = d_gen.cpu().numpy().reshape(-1).view(np.complex64)
-        del d_frames, d_gen
+        t1 = time.perf_counter()
+        # ... and frame_detector + timing_sync on the device as well: the descriptors come back once for the host-side checks
+        cap0 = iq.size // 300 + 16
+        g_desc = torch.zeros(cap0 * 48, dtype=torch.uint8, device=dev)
+        g_ends = torch.zeros(cap0, dtype=torch.int64, device=dev)
+        n0 = gen.sync_dev(d_gen, g_desc, g_ends)
+        descs = g_desc.cpu().numpy()[:n0 * 48].view(foa.frame_desc_dtype).copy()
+        ends = g_ends.cpu().numpy()[:n0].copy()
+        del d_frames, d_gen, g_desc, g_ends
         gen.close()
     else:
         iq, pays = make_workload(my_ids, 7919 * (rank + 1))
-    t1 = time.perf_counter()
-    descs = foa.find_alignments(iq)                       # host-side frame_detector + timing_sync
-    ends = foa.alignment_ends(descs, iq.size)
+        t1 = time.perf_counter()
+        descs = foa.find_alignments(iq)                       # host-side frame_detector + timing_sync
+        ends = foa.alignment_ends(descs, iq.size)
     t2 = time.perf_counter()
     real = np.nonzero((descs["lts1_pos"] - (LEAD + 184)) % PITCH == 0)[0]
     which = (descs["lts1_pos"][real] - (LEAD + 184)) // PITCH          # local frame index of each alignment that sits on a frame
@@ -402,30 +412,34 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
     # back and queued its successor late)
     LAG = 4
     n_out = LAG + 2 if multi else 1
-    # (one row more than alignments: row m is never written and stays zero -- the slot of a frame the detector missed)
-    out_full = [torch.zeros((m + 1, PAYLOAD), dtype=torch.uint8, device=dev) for _ in range(n_out)]
+    # (one row more than alignments: row m is never written and stays zero -- the slot of a frame the detector missed.  With several ranks
+    # every rank's output sets have the SAME number of rows, the largest m + 1 of any rank: what is gathered is the output set as the
+    # decode wrote it, and rank 0 puts the rows into global frame order after the clock)
+    rows = m + 1
+    if multi:
+        t_rows = torch.tensor([rows], dtype=torch.int64, device=cdev)
+        dist.all_reduce(t_rows, op=dist.ReduceOp.MAX)
+        rows = int(t_rows.item())
+    out_full = [torch.zeros((rows, PAYLOAD), dtype=torch.uint8, device=dev) for _ in range(n_out)]
     out_psdu = [t[:m] for t in out_full]
     out_res = [torch.zeros((m, 4), dtype=torch.int32, device=dev) for _ in range(n_out)]
     gathered = [None]
     read_done = [None] * n_out
     n_gathers = [0]
     if multi:
-        # local frame slot -> alignment row (a frame the detector missed -> the zero row, like a CRC failure): one index_select per
-        # step puts the PSDUs in local frame order; its destination and rank 0's receive buffers are allocated once
+        # local frame slot -> alignment row (a frame the detector missed -> the zero row, like a CRC failure).  Every rank's map goes to
+        # rank 0 ONCE, before the clock; the step's collective is one gather of the output set as it is -- no reordering pass per step on
+        # any rank (round 5 ran an index_select of 10 MB per step and rank in front of the gather: 5.5 % of the loop at world 1)
         perm = np.full(args.frames, m, np.int64)
         perm[which] = real
-        d_perm = torch.from_numpy(perm).to(dev)
-        local_bufs = [torch.zeros((args.frames, PAYLOAD), dtype=torch.uint8, device=dev) for _ in range(2)]
-        recv = shard.GatherBuffers(n_global, PAYLOAD, world, cdev) if rank == 0 else None
+        perms = shard.gather_maps(torch.from_numpy(perm).to(cdev), rank, world)        # rank 0: int64[world, frames]
+        recv = shard.SlotBuffers(rows, PAYLOAD, world, cdev) if rank == 0 else None
 
     def gather_now(i):
-        local = local_bufs[n_gathers[0] % 2]             # (the gather before last, which read this buffer, is complete: same stream)
-        torch.index_select(out_full[i], 0, d_perm, out=local)
+        # rank 0 receives every rank's rows; global frame order is formed from them (shard.order_gathered) after the clock has stopped
+        gathered[0] = shard.gather_slots(out_full[i] if cdev == dev else out_full[i].to(cdev), rank, world, buffers=recv)
         read_done[i] = _CpuEvent() if on_cpu else torch.cuda.Event()
         read_done[i].record()
-        # rank 0 reads the gathered slots in global frame order through a strided view of its receive buffer; the contiguous
-        # tensor is only formed for the check after the clock has stopped
-        gathered[0] = shard.gather_psdus(local.to(cdev), n_global, rank, world, force_collective=multi, buffers=recv, materialize=False)
         n_gathers[0] += 1
 
     issued = [0]          # steps queued since the last finish_steps()
@@ -607,8 +621,9 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
         dist.all_reduce(oks)
         ok_frames = int(oks.item())
         if rank == 0:
-            # the gathered slots are in global frame order: rows of rank 0's own frames must equal its local result
-            g = gathered[0].reshape(-1, PAYLOAD)[:n_global].cpu().numpy()      # [m_max, world, slot] view -> global frame order
+            # rank 0 puts the gathered rows into global frame order (frame r + k * world = row perms[r][k] of rank r's set); rows of its own
+            # frames must equal its local result
+            g = shard.order_gathered(gathered[0], perms, n_global).cpu().numpy()
             exact = exact and g.shape == (n_global, PAYLOAD) and bool(np.array_equal(g[0::world][which][okm], pays[which][okm]))
             all_pays = synth.splitmix64_bytes(SEED_BASE, n_global, PAYLOAD)
             nz = g.any(axis=1)                           # frames whose CRC failed leave their slot zeroed
@@ -624,7 +639,7 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
             "metric": "RX Msamples/s @20 MHz, 54 Mbps 64-QAM r=3/4; PSDU bit-exact vs CPU",
             "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic" if args.tx == "host" else "synthetic (built on the device: foa_tx_build_frames_dev + foa_tx_channel_dev)",
+            "dtype": "u8", "data": "synthetic" if tx == "host" else "synthetic (built and pre-synchronised on the device: foa_tx_build_frames_dev + foa_tx_channel_dev + foa_rx_sync_dev)",
             "config": {"workload": "BASELINE configs[1]: %d frames/GPU x 1024-byte PSDU payload, 64-QAM r=3/4 (54 Mbps), AWGN 25 dB"
                                    % args.frames,
                        "frames_per_gpu": args.frames, "frame_samples": FRAME_SAMPLES, "slot_pitch_samples": PITCH,
@@ -709,8 +724,13 @@ def roofline(args, kms, n_real, ms_per_step, piped, probe, space=None):
          "frac_at_step_rate": {"achieved": round(alg_ops / t_step / 1e12, 3), "frac": round(alg_ops / t_step / peak, 4),
                                "what": "the same ops / ms_per_step: a throughput figure -- two launches overlap on two hardware queues, so a launch lasts "
                                        "longer than a step (rounds 2-3 reported this one as `frac`)" if piped else "calls in line: equal to frac"}}
+    r["frac_step_rate"] = r["frac_at_step_rate"]["frac"]            # (scalars beside `frac`: records that keep only this object's plain values keep these)
+    r["achieved_step_rate"] = r["frac_at_step_rate"]["achieved"]
     if space and space[3]:
         k = space[3]
+        r["launch_start_to_start_ms"] = round(space[0] / k, 4)
+        r["launch_overlap_ms"] = round(space[1] / k, 4)
+        r["launch_ms"] = round(space[2] / k, 4)
         r["launch_overlap"] = {"start_to_start_ms": round(space[0] / k, 4), "overlap_with_the_pass_before_ms": round(space[1] / k, 4), "launch_ms": round(space[2] / k, 4),
                                "launches_read": k,
                                "what": "consecutive forward passes run on two streams and overlap: a launch starts every start_to_start_ms (= the step) and lasts launch_ms, "
@@ -771,6 +791,80 @@ def roofline(args, kms, n_real, ms_per_step, piped, probe, space=None):
                                               "hbm_GBps": round(gbps, 1), "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBPS, 4),
                                               "note": "duration live (HIP events; under the forward pass it shares the machine with when calls are pipelined)"}}
     return r
+
+
+DBPS = (24, 32, 36, 48, 64, 72, 96, 128, 144, 192, 216)             # data bits per OFDM symbol of fun::Rate 0..10 (rates.h:52-196)
+
+
+def leg_roofline(rx, call, res, ms_step, sync_ms=None, n_samples=None):
+    """The roofs of one leg's decode call (configs 3 and 5), the way `roofline` prices config 2: per kernel the HIP-event duration of a launch
+    that has the machine to itself (three calls in line) and of a launch inside the pipelined loop (the last three calls of the timed
+    loop, complete by now), its algorithmic work, its roof and the fraction reached; and which kernel bounds the leg.
+      k_data_symbols_q4   HBM: 640 B of samples in (a window's 64 samples and the 16 of its cyclic prefix: whole lines) + 2 B per trellis step out
+      k_viterbi_fwd3      VALU issue: 288 counted ops per trellis step and frame against 1024 SIMD-32 x 32 lane-ops x 2.4 GHz
+      k_tb_walk + finish  HBM: 8 B of decisions in per trellis step
+      k_sync_*            HBM: 8 B per sample of the stream (config 5)
+    The forward pass and the data-symbol kernel both live on the vector pipes, so under the pipelined loop they do not hide each other the
+    way the memory-bound chain-back hides under the forward pass: `step_over_sum_alone` says how much of the sum the loop saves.
+    res: the call's results (status, rate, length, num_symbols per alignment)."""
+    live = res[:, 1] >= 0
+    took = live & ((res[:, 0] == 0) | (res[:, 0] == 2))
+    nsym = int(res[took, 3].sum())
+    steps = int((res[took, 3].astype(np.int64) * np.array(DBPS)[res[took, 1]]).sum())
+    piped = {}
+    for back in (1, 2, 3):
+        try:
+            for k, v in rx.kernel_ms(age=back).items():
+                piped[k] = piped.get(k, 0.0) + v / 3.0
+        except Exception:
+            piped = {}
+            break
+    rx.sync()
+    rx.set_option("pipeline", 0)
+    alone = {}
+    for j in range(4):
+        call()
+        rx.sync()
+        if j:
+            for k, v in rx.kernel_ms().items():
+                alone[k] = alone.get(k, 0.0) + v / 3.0
+    rx.set_option("pipeline", 1)
+    peak_valu = N_SIMD * 32 * 2.4e9
+    kern = {}
+
+    def entry(name, key, bound, work, unit_scale, peak, unit, what):
+        a, l = alone.get(key, 0.0), piped.get(key, 0.0)
+        e = {"bound": bound, "ms_alone": round(a, 4), "ms_in_loop": round(l, 4) if piped else None, "algorithmic": int(work), "what": what, "unit": unit, "peak": peak}
+        if a > 0:
+            e["achieved_alone"] = round(work / (a * 1e-3) / unit_scale, 2)
+            e["frac_alone"] = round(work / (a * 1e-3) / unit_scale / peak, 4)
+        if piped and l > 0:
+            e["achieved_in_loop"] = round(work / (l * 1e-3) / unit_scale, 2)
+        kern[name] = e
+        return a
+    t_q4 = entry("k_data_symbols_q4", "symbols", "hbm", nsym * 640 + 2 * steps, 1e9, HBM_PEAK_GBPS, "GB/s", "640 B in per symbol + 2 B out per trellis step")
+    t_fw = entry("k_viterbi_fwd3", "viterbi_fwd", "valu", steps * ALG_LANE_OPS_PER_STEP, 1e12, round(peak_valu / 1e12, 2), "T ops/s", "288 counted ops per trellis step and frame")
+    t_tb = entry("k_tb_walk + k_tb_finish", "viterbi_finish", "hbm", steps * 8, 1e9, HBM_PEAK_GBPS, "GB/s", "8 B of decisions in per trellis step")
+    t_hd = alone.get("header", 0.0) + alone.get("scan", 0.0)
+    cand = [("k_data_symbols_q4", t_q4), ("k_viterbi_fwd3", t_fw), ("k_tb_walk + k_tb_finish", t_tb)]
+    if sync_ms is not None and n_samples:
+        kern["k_sync_*"] = {"bound": "hbm", "ms_alone": round(sync_ms, 4), "algorithmic": int(8 * n_samples), "unit": "GB/s", "peak": HBM_PEAK_GBPS,
+                            "achieved_alone": round(8 * n_samples / (sync_ms * 1e-3) / 1e9, 2), "frac_alone": round(8 * n_samples / (sync_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                            "what": "frame_detector + timing_sync over the whole stream: 8 B per sample in (host-clocked blocking call: includes the host's wait for the count)"}
+        cand.append(("k_sync_*", sync_ms))
+    name, t_b = max(cand, key=lambda t: t[1])
+    b = kern[name]
+    total = t_q4 + t_fw + t_tb + t_hd + (sync_ms or 0.0)
+    out = {"bound": b["bound"], "kernel": name, "achieved": b.get("achieved_alone"), "peak": b["peak"], "unit": b["unit"], "frac": b.get("frac_alone"),
+           "avg_kernel_ms": b["ms_alone"], "symbols": nsym, "trellis_steps": steps, "step_ms": round(ms_step, 4), "sum_alone_ms": round(total, 4),
+           "step_over_sum_alone": round(ms_step / total, 3) if total else None, "step_over_bounding_kernel_alone": round(ms_step / t_b, 3) if t_b else None,
+           "valu_share": {"what": "the forward pass and the data-symbol kernel both issue on the vector pipes (one VALU-issue-bound, one fp64): alone they take",
+                          "fwd_plus_symbols_alone_ms": round(t_fw + t_q4, 4), "step_over_it": round(ms_step / (t_fw + t_q4), 3) if (t_fw + t_q4) else None},
+           "kernels": kern,
+           "definition": "the kernel with the longest launch when alone bounds the leg; achieved / frac = its algorithmic work over that launch's duration (HIP events on its "
+                         "own stream, three calls in line in this run) against peak (HBM %d GB/s; VALU 1024 SIMD-32 x 32 lane-ops x 2.4 GHz, MI355X_MICROARCH.md); ms_in_loop = the "
+                         "same launch inside the pipelined loop, sharing the machine with the neighbouring calls" % HBM_PEAK_GBPS}
+    return out
 
 
 def extra_legs(args, rx, dev, iq, descs, ends, real, psdu_dev_path, res_dev_path):
@@ -838,8 +932,10 @@ def extra_legs(args, rx, dev, iq, descs, ends, real, psdu_dev_path, res_dev_path
         m = rx.sync_dev(d_iq, d_desc, d_end)
         d_psdu = torch.zeros((m, length), dtype=torch.uint8, device=dev)
         d_res = torch.zeros((m, 4), dtype=torch.int32, device=dev)
-        dt = timed(lambda: rx.decode_frames_dev(d_iq, d_desc[:m * 48], d_end[:m], d_psdu, d_res), reps)   # (steady state: the loops in flight fill and drain)
+        call = lambda: rx.decode_frames_dev(d_iq, d_desc[:m * 48], d_end[:m], d_psdu, d_res, settle=False)      # (nothing of torch's is queued on these tensors)
+        dt = timed(call, reps)                           # (steady state: the loops in flight fill and drain)
         r = d_res.cpu().numpy()
+        roof = leg_roofline(rx, call, r, dt * 1e3)
         d = d_desc.cpu().numpy()[:m * 48].view(foa.frame_desc_dtype)
         gp = d_psdu.cpu().numpy()
         on_mask, want = pays_of(d["lts1_pos"])
@@ -870,6 +966,7 @@ def extra_legs(args, rx, dev, iq, descs, ends, real, psdu_dev_path, res_dev_path
         same = bool(np.array_equal(ores.view(np.int32).reshape(-1, 4), r))
         okk = r[:, 0] == 0
         same = same and bool(np.array_equal(opsdu[okk], gp[okk]))
+        row["roofline"] = roof
         row.update({"alignments": int(m), "frames_found": int(on.size), "crc_ok": int(np.count_nonzero(okm)), "psdu_bit_exact": exact, "gpu_equals_cpu_on_all": same,
                     "cpu_checked_alignments": int(m), "cpu_crc_fail": int(np.count_nonzero(ores["status"] == foa.ST_CRC_FAIL)),
                     "gpu_crc_fail": int(np.count_nonzero(r[:, 0] == foa.ST_CRC_FAIL)), "ms": round(dt * 1e3, 3), "cpu_s": round(dt_cpu, 3), "cpu_threads": thr})
@@ -892,21 +989,28 @@ def extra_legs(args, rx, dev, iq, descs, ends, real, psdu_dev_path, res_dev_path
         legs["config3_rate_sweep"] = {"error": str(e)[-300:]}
     if not args.no_fill_legs:
         try:
-            length, rows, budget = 4092, [], 300 * 1000 * 1000
+            # (work sets sized for the leg's own rate -- option "max_dbps" -- so that every rate's call holds the 10 240 frames that give the
+            # forward pass five waves per SIMD: with the default, sized for 216 trellis steps per symbol whatever the capture holds, the 6 Mbps
+            # call stopped at 2 712 frames, 1.3 waves per SIMD (round 5))
+            length, rows, budget = 4092, [], 1300 * 1000 * 1000
             for rate in STD:
                 s0 = 320 + 80 * (1 + po.num_symbols(rate, length))
                 pitch0 = -(-(s0 + 576) // 4096) * 4096
                 nfill = int(min(args.fill_frames, budget // pitch0))
+                rx.sync()
+                rx.set_option("max_dbps", DBPS[rate])
                 pays, d_iq, s, pitch = c3_workload(rate, nfill, length, 400 + rate)
                 row, found, dt, dt_cpu = c3_decode_and_check(d_iq, lambda pos, pays=pays, pitch=pitch: ((pos - 360) % pitch == 0, pays[((pos - 360) // pitch)[(pos - 360) % pitch == 0]]), length, 24, True)
                 row.update({"rate_enum": rate, "mbps": foa.RATE_MBPS[rate], "frames": nfill, "forward_waves_per_simd": round(nfill / 2 / 1024, 2), "frame_samples": s,
                             "Msamples_per_s": round(found * s / dt / 1e6, 1), "cpu_Msamples_per_s": round(found * s / dt_cpu / 1e6, 1)})
-                if nfill < args.fill_frames:
-                    row["fewer_than_five_waves_because"] = "10 240 such frames are %d M samples; a call's workspaces are sized for the worst case (216 trellis steps per 80 samples, 14 B per step, several sets in rotation)" % (10240 * pitch0 // 1000000)
+                row["max_dbps"] = DBPS[rate]
                 rows.append(row)
                 del d_iq
                 torch.cuda.empty_cache()
-            legs["config3_machine_filling"] = {"table": "machine filling", "payload_bytes": length, "snr_db": 25.0, "counted_samples": "in-frame", "rates": rows}
+            rx.sync()
+            rx.set_option("max_dbps", 216)
+            legs["config3_machine_filling"] = {"table": "machine filling", "payload_bytes": length, "snr_db": 25.0, "counted_samples": "in-frame", "rates": rows,
+                                               "work_sets": "sized per rate by option max_dbps (10.25 B per trellis step of capacity)"}
         except Exception as e:
             legs["config3_machine_filling"] = {"error": str(e)[-300:]}
         # one call holding all eight rates (1 000 frames each, 4092-byte payloads): what a mixed-rate capture of long frames costs
@@ -978,6 +1082,14 @@ def extra_legs(args, rx, dev, iq, descs, ends, real, psdu_dev_path, res_dev_path
         dt = timed(go, 3)
         m = got[0]
         r = d_res[:m].cpu().numpy()
+        rx.sync()
+        t_sy = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            rx.sync_dev(stream, d_desc, d_end)
+            t_sy.append((time.perf_counter() - t0) * 1e3)
+        roof5 = leg_roofline(rx, lambda: rx.decode_frames_dev(stream, d_desc[:m * 48], d_end[:m], d_psdu[:m], d_res[:m], settle=False), r, dt * 1e3,
+                             sync_ms=sorted(t_sy)[2], n_samples=total)
         d = d_desc.cpu().numpy()[:m * 48].view(foa.frame_desc_dtype)
         start_of = {int(offs[i]) + 184: i for i in range(n)}
         okl = [(a, start_of[int(p)]) for a, p in enumerate(d["lts1_pos"]) if int(p) in start_of and r[a, 0] == 0]
@@ -1024,6 +1136,7 @@ def extra_legs(args, rx, dev, iq, descs, ends, real, psdu_dev_path, res_dev_path
                                   "gpu_equals_cpu_on_all": same, "cpu_checked_alignments": int(k), "ms_sync_plus_decode": round(dt * 1e3, 3),
                                   "Msamples_per_s": round(total / dt / 1e6, 1), "counted_samples": "whole stream",
                                   "what": "mixed 8 rates back to back, 1024-byte payloads, CFO uniform in +-4 kHz, 25 dB; foa_rx_sync_dev + foa_rx_decode_frames_dev"}
+        legs["config5_stream"]["roofline"] = roof5
         if piped5:
             legs["config5_stream"]["pipelined"] = piped5
     except Exception as e:
@@ -1091,26 +1204,22 @@ def extra_legs(args, rx, dev, iq, descs, ends, real, psdu_dev_path, res_dev_path
         pk = re.search(r"(\d+) packets", r.stdout)
         if not mm:
             raise RuntimeError((r.stdout + r.stderr)[-300:])
-        # what bounds this leg: every sample crosses PCIe once as complex<float> (8 B) after the host has narrowed it from complex<double> (16 B read)
+        # what bounds this leg: every sample crosses PCIe once as complex<float> (8 B) after the host has narrowed it from complex<double>
+        # (16 B read) -- measured the way the engine copies (foa_rx_probe_h2d: page-locked hipHostMalloc staging, hipMemcpyAsync on the
+        # library's copy stream, four 256-MB pieces in flight; round 5 clocked ONE torch pinned copy, 23.5 GB/s, and the leg went past it)
         try:
-            hb = torch.empty(1 << 28, dtype=torch.uint8).pin_memory()
-            db = torch.empty(1 << 28, dtype=torch.uint8, device=dev)
-            db.copy_(hb, non_blocking=True); torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(4):
-                db.copy_(hb, non_blocking=True)
-            torch.cuda.synchronize()
-            h2d = 4 * hb.numel() / (time.perf_counter() - t0) / 1e9
-            del hb, db
+            h2d = rx.probe_h2d(1 << 28, 4, 2)
         except Exception:
             h2d = None
         legs["process_samples_api"] = {"Msamples_per_s": float(mm.group(1)), "x_realtime_20MSps": round(float(mm.group(1)) / 20.0, 1), "samples": int(mm.group(2)),
                                        "seconds": float(mm.group(3)), "calls": int(mm.group(4)), "chunk": int(mm.group(5)),
                                        "packets": int(pk.group(1)) if pk else None, "frames_sent": n, "runs_Msamples_per_s": [t[0] for t in runs_ps], "protocol": "median of 3 runs",
                                        "same_list_as_batch_path": bool(same_list), "batch_path_payloads": len(batch_list),
-                                       "pcie_ceiling": {"h2d_GBps_pinned_measured": round(h2d, 1) if h2d else None, "Gsamples_per_s": round(h2d / 8.0, 2) if h2d else None,
-                                                        "what": "8 bytes per sample host to device: the leg cannot exceed this whatever the GPU does (the device-resident "
-                                                                "rate is `value`); the host also reads 16 bytes and writes 8 per sample to narrow complex<double>"},
+                                       "pcie_ceiling": {"h2d_GBps_measured": round(h2d, 1) if h2d else None, "Gsamples_per_s": round(h2d / 8.0, 2) if h2d else None,
+                                                        "leg_over_ceiling": round(float(mm.group(1)) / 1e3 / (h2d / 8.0), 3) if h2d else None,
+                                                        "what": "8 bytes per sample host to device, copied the way the engine copies (foa_rx_probe_h2d: page-locked staging, "
+                                                                "several pieces in flight on the library's copy stream): the ceiling of every leg that is handed host buffers "
+                                                                "(the device-resident rate is `value`); the host also reads 16 bytes and writes 8 per sample to narrow complex<double>"},
                                        "what": "fun_amd::receiver_chain::process_samples(std::vector<std::complex<double>>) in device mode: 4 Mi-sample "
                                                "batches, 8 helper threads (two core complexes), pre-sync and decode on the GPU, payloads through the callback; capture preloaded, the engine "
                                                "warmed with a copy of the capture's first batches before the clock starts (foa_sim --warm-batches)"}

@@ -55,6 +55,7 @@ _SIGS = {
     "foa_rx_wait_previous": (C.c_int, [C.c_void_p]),
     "foa_rx_kernel_ms_age": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
     "foa_rx_probe_issue": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "foa_rx_probe_h2d": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "foa_rx_forward_spacing_ms": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
     "foa_rx_prev_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "foa_rx_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),

@@ -481,6 +481,38 @@ int foa_rx_probe_issue(foa_rx *rx, double out[6])
     return FOA_OK;
 }
 
+// Host-to-device rate the way the stream engines move samples (stream_engine.h): hipMemcpyAsync out of page-locked hipHostMalloc staging
+// on the library's copy stream, `in_flight` pieces of `piece_bytes` queued at once, `rounds` times -- what 8 bytes per sample of a
+// process_samples() capture can reach on this host, whatever the kernels do.
+int foa_rx_probe_h2d(foa_rx *rx, size_t piece_bytes, int in_flight, int rounds, double *gbytes_per_s)
+{
+    if (!rx || !gbytes_per_s || piece_bytes == 0 || in_flight < 1 || in_flight > 16 || rounds < 1) return fail(FOA_E_INVALID, "bad argument");
+    HIP_TRY(enter_device(rx->device));
+    { int rc0 = drain(rx); if (rc0) return rc0; }
+    uint8_t *host = nullptr;
+    DevBuf<uint8_t> dev;
+    int rc = dev.ensure(piece_bytes * (size_t)in_flight);
+    if (rc) return rc;
+    HIP_TRY(hipHostMalloc((void **)&host, piece_bytes * (size_t)in_flight, hipHostMallocDefault));
+    memset(host, 1, piece_bytes * (size_t)in_flight);
+    hipStream_t st = rx->stream3;
+    auto pass = [&]() -> int {
+        for (int i = 0; i < in_flight; i++) HIP_TRY(hipMemcpyAsync(dev.p + (size_t)i * piece_bytes, host + (size_t)i * piece_bytes, piece_bytes, hipMemcpyHostToDevice, st));
+        return FOA_OK;
+    };
+    if ((rc = pass())) { (void)hipHostFree(host); return rc; }
+    HIP_TRY(hipStreamSynchronize(st));
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < rounds && !rc; r++) rc = pass();
+    if (!rc) { hipError_t e = hipStreamSynchronize(st); if (e != hipSuccess) rc = fail(FOA_E_HIP, "hipStreamSynchronize: %s", hipGetErrorString(e)); }
+    const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    (void)hipHostFree(host);
+    dev.release();
+    if (rc) return rc;
+    *gbytes_per_s = (double)piece_bytes * in_flight * rounds / s / 1e9;
+    return FOA_OK;
+}
+
 int foa_rx_get_taps(foa_rx *rx, size_t n_frames, double *hinv, double *eq, size_t eq_cap, uint64_t *eq_off, uint8_t *soft, size_t soft_cap,
                     uint64_t *soft_off)
 {

@@ -237,6 +237,12 @@ class Receiver:
         keys = ("clk_per_wave_instr", "ghz", "wave_instr_per_s")
         return {"pk_u16": dict(zip(keys, out[0:3])), "vop2_u32": dict(zip(keys, out[3:6]))}
 
+    def probe_h2d(self, piece_bytes=1 << 28, in_flight=4, rounds=2):
+        """foa_rx_probe_h2d: GB/s host to device the way the stream engines copy (page-locked staging, several pieces in flight)."""
+        out = C.c_double(0.0)
+        self._check(self._lib.foa_rx_probe_h2d(self._h, int(piece_bytes), int(in_flight), int(rounds), C.byref(out)))
+        return float(out.value)
+
     def kernel_ms(self, previous=False, age=None):
         """HIP-event durations of the last decode (previous=True: of the one before it; age=2: of the one before that,
         which is certainly complete in a pipelined sequence of calls) in ms: header, scan, symbols, viterbi_fwd,

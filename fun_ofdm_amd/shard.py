@@ -62,3 +62,55 @@ def gather_psdus(psdu_local, n_global, rank, world, group=None, force_collective
     # parts[r][k] is global frame r + k*world: interleave
     stacked = torch.stack(parts, dim=1).reshape(m_max * world, slot)
     return stacked[:n_global]
+
+
+# ---- the same gather without a reordering pass in the timed loop -------------------------------------------------------------------------
+# A rank's decode call writes one PSDU slot per ALIGNMENT (the frames of its shard plus whatever timing_sync placed on noise), in stream
+# order.  gather_psdus wants the slots in local frame order, which costs every rank an index_select over its output set per step.  Here
+# the output set travels as it is -- every rank with the same number of rows -- and rank 0, which is handed every rank's frame -> row map
+# once, forms the global frame order when somebody asks for it (bench.py: after the clock has stopped).
+
+class SlotBuffers:
+    """Receive buffers of gather_slots on rank 0: `world` slabs uint8[rows, slot] of one tensor on a GPU, separate tensors in host memory
+    (gloo: see GatherBuffers)."""
+
+    def __init__(self, rows, slot, world, device, dtype=torch.uint8):
+        device = torch.device(device)
+        self.rows = rows
+        if device.type == "cpu":
+            self.big = None
+            self.parts = [torch.empty((rows, slot), dtype=dtype) for _ in range(world)]
+        else:
+            self.big = torch.empty((world, rows, slot), dtype=dtype, device=device)
+            self.parts = list(self.big.unbind(0))
+
+
+def gather_maps(perm, rank, world, group=None):
+    """perm: int64[frames_per_rank], local frame k -> row of this rank's output set.  Returns int64[world, frames_per_rank] on rank 0 (None
+    elsewhere).  One gather, made once per workload.  (World 1 with an initialised process group makes the collective call too.)"""
+    if world == 1 and not dist.is_initialized():
+        return perm.reshape(1, -1)
+    parts = [torch.empty_like(perm) for _ in range(world)] if rank == 0 else None
+    dist.gather(perm, parts, dst=0, group=group)
+    return torch.stack(parts) if rank == 0 else None
+
+
+def gather_slots(slots, rank, world, group=None, buffers=None):
+    """slots: uint8[rows, slot], this rank's output set as the decode wrote it (the same `rows` on every rank).  One gather; returns on
+    rank 0 the list of the ranks' sets (views of `buffers` if given), None elsewhere."""
+    if rank == 0:
+        parts = buffers.parts if buffers is not None else [torch.empty_like(slots) for _ in range(world)]
+    else:
+        parts = None
+    dist.gather(slots, parts, dst=0, group=group)
+    return parts if rank == 0 else None
+
+
+def order_gathered(parts, perms, n_global):
+    """Rank 0: the gathered sets -> uint8[n_global, slot] in GLOBAL frame order (frame r + k * world = row perms[r][k] of rank r's set)."""
+    world = len(parts)
+    per = perms.shape[1]
+    out = torch.empty((per, world) + tuple(parts[0].shape[1:]), dtype=parts[0].dtype, device=parts[0].device)
+    for r in range(world):
+        out[:, r] = parts[r].index_select(0, perms[r].to(parts[r].device))
+    return out.reshape((per * world,) + tuple(parts[0].shape[1:]))[:n_global]

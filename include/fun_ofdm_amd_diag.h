@@ -43,6 +43,11 @@ int foa_rx_forward_spacing_ms(foa_rx *rx, int age, float out[3]);
  * independent chains for a fixed window of shader clocks (csrc/probe_kernels.h).  Synchronises; about a millisecond. */
 int foa_rx_probe_issue(foa_rx *rx, double out[6]);
 
+/* Host-to-device rate the way the stream engines move a capture (page-locked hipHostMalloc staging, hipMemcpyAsync on the library's copy
+ * stream, in_flight (1..16) pieces of piece_bytes queued at once, `rounds` times after one warm-up pass): the ceiling of every leg that
+ * hands over host buffers, 8 bytes per sample.  Synchronises; allocates and frees its own buffers. */
+int foa_rx_probe_h2d(foa_rx *rx, size_t piece_bytes, int in_flight, int rounds, double *gbytes_per_s);
+
 /* Intermediates of the most recent decode call, copied to HOST memory (parity tests).
  *   hinv    64 complex doubles (re,im) per frame: channel_est's m_chan_est (channel_est.cpp:53-58)
  *   eq      per frame (1 + num_symbols) * 48 complex doubles: phase_tracker output incl. SIGNAL

@@ -91,6 +91,19 @@ def test_bench_single_rank_line_has_the_contract_fields():
     assert ws["same_results_as_host_sync"] is True and ws["pipelined"]["same_results_as_host_sync"] is True
     ps = legs["process_samples_api"]
     assert ps["same_list_as_batch_path"] is True and ps["packets"] == ps["batch_path_payloads"]
+    # no leg that is handed host buffers goes past the ceiling the line states for them (measured the way the engine copies)
+    ceil = ps["pcie_ceiling"]
+    assert ceil["h2d_GBps_measured"] > 5 and ps["Msamples_per_s"] / 1e3 <= ceil["Gsamples_per_s"] * 1.02 and ceil["leg_over_ceiling"] <= 1.02
+    assert legs["end_to_end_host_pointers"]["Msamples_per_s"] / 1e3 <= ceil["Gsamples_per_s"] * 1.02
+    # every rate of config 3 and the stream of config 5 carry their own roofline: the bounding kernel, its roof and the fraction reached
+    for r in rows + fill + [mixed, c5]:
+        q = r["roofline"]
+        assert q["bound"] in ("valu", "hbm") and q["kernel"] in q["kernels"] and 0 < q["frac"] < 1 and q["avg_kernel_ms"] > 0 and q["trellis_steps"] > 0
+        k = q["kernels"][q["kernel"]]
+        assert abs(q["frac"] - k["algorithmic"] / (k["ms_alone"] * 1e-3) / ({"GB/s": 1e9, "T ops/s": 1e12}[k["unit"]] * k["peak"])) < 5e-3
+        assert set(q["kernels"]) >= {"k_data_symbols_q4", "k_viterbi_fwd3", "k_tb_walk + k_tb_finish"}
+    assert "k_sync_*" in c5["roofline"]["kernels"] and all(r["max_dbps"] == {0: 24, 2: 36, 3: 48, 5: 72, 6: 96, 8: 144, 9: 192, 10: 216}[r["rate_enum"]] for r in fill)
+    assert rf["frac_step_rate"] == rf["frac_at_step_rate"]["frac"] and rf["launch_ms"] > 0
 
 
 def test_bench_forced_collective_path_over_rccl_with_one_rank():

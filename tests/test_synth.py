@@ -113,7 +113,7 @@ def test_library_exports_every_declared_symbol():
     lab = set(re.findall(r"\b(foa_[a-z0-9_]+)\s*\(", diag)) - {"foa_rx_set_option"}
     assert len(product) >= 20 and not (product & lab)
     # the lab stays out of the product header: timings, taps, decisions and the probe are diagnostics
-    for name in ("foa_rx_probe_issue", "foa_rx_get_taps", "foa_rx_get_decisions", "foa_rx_forward_spacing_ms", "foa_rx_last_kernel_ms"):
+    for name in ("foa_rx_probe_issue", "foa_rx_probe_h2d", "foa_rx_get_taps", "foa_rx_get_decisions", "foa_rx_forward_spacing_ms", "foa_rx_last_kernel_ms"):
         assert name in lab and name not in product, name
     assert "record_eq" not in hdr and "record_soft" not in hdr
     declared = product | lab
