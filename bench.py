@@ -1257,6 +1257,8 @@ def main(argv=None):
     if world > 1 or os.environ.get("FOA_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         if dist.is_initialized():
+            sys.stdout.flush()
+            os.dup2(2, 1)                                  # (RCCL prints its version banner on stdout as the group goes down: the JSON line stays the only one there)
             dist.destroy_process_group()
 
 
