@@ -92,6 +92,7 @@ int foa::flush_pending(foa_rx *rx, hipEvent_t after_front_end)
                    p.psdu, p.slot_bytes, p.results, p.w->walk_done);
     HIP_TRY(hipEventRecord(p.w->ev[4], sb));
     HIP_TRY(hipEventRecord(p.w->done, sb));
+    rx->last_walk_done = p.w->walk_done;
     if (p.job) {
         HostJob &j = *p.job;
         HIP_TRY(hipMemcpyAsync(j.pin + j.o_psdu, j.dev.p + j.o_psdu, j.total - j.o_psdu, hipMemcpyDeviceToHost, sb));
@@ -255,6 +256,7 @@ static int decode_frames_any(foa_rx *rx, const void *d_iq, bool f64, size_t n_sa
     }
     HIP_TRY(hipGetLastError());
     rx->w->used = true;
+    rx->w->in_descs = d_descs - n_lead; rx->w->in_ends = d_ends - n_lead; rx->w->in_count = n_lead + n_frames + n_context;
     rx->w->have_timing = true;
     rx->w->piped = piped;
     rx->w->before = piped ? rx->prev : nullptr;

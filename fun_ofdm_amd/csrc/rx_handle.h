@@ -78,6 +78,8 @@ struct WorkSet {
     WorkSet *before = nullptr;   // the set of the call queued before this one (pipelined path)
     hipEvent_t done = nullptr, walk_done = nullptr;
     bool used = false, have_timing = false, piped = false;
+    const void *in_descs = nullptr, *in_ends = nullptr;      // the descriptor / end buffers the call's front end reads (until ev[3]) ...
+    size_t in_count = 0;                                      // ... and how many entries of them
     void release_all()
     {
         info.release(); hinv.release(); sym2frame.release(); seg2frame.release(); spec.release(); tb_state.release(); dec.release(); sp.release();
@@ -143,6 +145,7 @@ struct foa_rx {
         foa_frame_result *results = nullptr;
         foa::HostJob *job = nullptr; // submit_host: copy the outputs back once the finish is queued
     } pending;
+    hipEvent_t last_walk_done = nullptr;   // behind the most recent chain-back walk queued (the one-shot pre-sync goes behind it: rx_sync.hip)
     foa::HostJob jobs[foa::kMaxJobs];
     uint64_t next_ticket = 1;
     foa::HostJob *attach_job = nullptr;   // set by submit_host around its decode call
@@ -172,7 +175,9 @@ namespace foa {
 // thousand frames leaves most SIMDs one wave or none, its forward pass lasts as long as ONE wave needs for its frames' trellis steps
 // whatever the batch, and more loops in flight are what raises the throughput then (1 000 frames x 4 092 bytes at 54 Mbps: 1.43 ms per
 // batch with two, 0.94 with four).  The lanes sit on hardware queues of their own (stream priorities: foa_rx_create).
-constexpr int kDeepBelow = 2049;                 // frames: up to one forward-pass wave per SIMD
+constexpr int kDeepBelow = 4609;                 // frames: up to 2.25 forward-pass waves per SIMD.  (Round 5 drew the line at 2049; measured since: 3 000 frames per call
+                                                 // +9 % with four loops, 4 000 mixed-rate alignments -- BASELINE config 5 -- +14 %, 5 000 frames the same
+                                                 // either way, 6 000 and more 2-8 % better with two: profiles/r06_depth_by_frames.txt)
 constexpr int kSingleBelow = 1025;               // frames: below this -- up to one four-wave workgroup per CU -- the forward pass takes one frame per wave (launch_fwd3)
 
 inline bool piped(const foa_rx *rx) { return rx->pipeline; }
@@ -217,7 +222,8 @@ int upload_tables_sync(const DeviceTables &t);
 // The launching half of foa_rx_sync_dev: every kernel of the pre-sync stage queued on the side stream, nothing waited for.  The counts
 // stay on the device in rx->sy_n ([0] STS_END candidates, [3] alignments found); *ccap_out = the candidate capacity they are checked
 // against.  origin: stream index of d_iq[0].
-int sync_dev_issue(foa_rx *rx, const float *d_iq, size_t n_samples, foa_frame_desc *d_descs, int64_t *d_ends, size_t cap, int32_t *ccap_out, int64_t origin);
+int sync_dev_issue(foa_rx *rx, const float *d_iq, size_t n_samples, foa_frame_desc *d_descs, int64_t *d_ends, size_t cap, int32_t *ccap_out, int64_t origin,
+                   bool behind_walk = false);
 // The stream engines' look-ahead for one batch buffer, queued on st behind the buffer's pre-sync: which alignments are still to be
 // decided and final in their tags (k_stream_range: STS_END in [state->lo_abs, hz_abs), first one's c_prev patched from the state) ...
 void launch_stream_range(hipStream_t st, foa_frame_desc *descs, const int32_t *sy_n, int32_t cap, int64_t start_abs, int64_t hz_abs, const StreamState *state,

@@ -208,17 +208,29 @@ __device__ __forceinline__ int block1024_exclusive_scan(int v, int32_t *part, in
     return before + x - v;
 }
 
-// exclusive scan of block counts (one block); total -> out_total[0]
-__global__ __launch_bounds__(1024) void k_sync_scan(const int32_t *__restrict__ cnt, int n_blocks, int32_t *__restrict__ off, int32_t *__restrict__ out_total)
+// exclusive scan of block counts; total -> out_total[0].  ONE WAVE: the stage runs under the forward pass of a decode call in flight, where a
+// 1024-thread block waits for sixteen free wave slots on one CU -- 240-320 us in the pipelined loop for 8 us of work (a kernel trace of
+// BASELINE config 2 with the pre-sync in the loop, profiles/r06_presync_timeline.txt; the decode call's own scan learnt this in round 3).
+// 64 consecutive counts per turn (one coalesced load), four turns' loads in flight.
+__global__ __launch_bounds__(64) void k_sync_scan(const int32_t *__restrict__ cnt, int n_blocks, int32_t *__restrict__ off, int32_t *__restrict__ out_total)
 {
-    __shared__ int32_t part[16];
-    const int t = threadIdx.x, per = (n_blocks + 1023) / 1024, lo = t * per, hi = min(lo + per, n_blocks);
-    int s = 0;
-    for (int i = lo; i < hi; i++) s += cnt[i];
-    int total;
-    s = block1024_exclusive_scan(s, part, &total);
-    if (t == 0) out_total[0] = total;
-    for (int i = lo; i < hi; i++) { off[i] = s; s += cnt[i]; }
+    const int lane = threadIdx.x;
+    int carry = 0;
+    for (int base = 0; base < n_blocks; base += 256) {
+        int v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int i = base + 64 * u + lane; v[u] = i < n_blocks ? cnt[i] : 0; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            int x = v[u];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o); if (lane >= o) x += y; }
+            const int i = base + 64 * u + lane;
+            if (i < n_blocks) off[i] = carry + x - v[u];
+            carry += __shfl(x, 63);
+        }
+    }
+    if (lane == 0) out_total[0] = carry;
 }
 
 // (value, index) of the lane with the largest (value, then index); lanes with v < 0 never win
