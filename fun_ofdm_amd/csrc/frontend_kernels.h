@@ -270,19 +270,10 @@ __global__ __launch_bounds__(64) void k_scan_blocks_w(int64_t *__restrict__ blk,
 // maps (so that the data-symbol and chain-back kernels find their frame without a search; frames are short: <= 1368 symbols), and for
 // the rare frame that fills on beyond its own alignment the table of where each of those symbols comes from.
 // sym2frame[w] = f: symbol w is window k = w - sym_off + 1 of frame f's own alignment; -1: unused slot; <= -2: entry -2 - value of spec.
-__global__ __launch_bounds__(kScanBlock) void k_scan_apply(FrameInfo *__restrict__ info, int n_frames, int64_t sym_cap,
-                                                           int64_t dec_cap, int seg_steps, int64_t seg_cap, const int64_t *__restrict__ blk,
-                                                           int32_t *__restrict__ sym2frame, int32_t *__restrict__ seg2frame, SpecSym *__restrict__ spec)
+// frame f's share of pass 3, given its quantities and where its symbols (a), special symbols (sp0), per-step words (c) and segments (d) begin
+__device__ __forceinline__ void scan_apply_frame(FrameInfo *__restrict__ info, int f, const ScanQ &q, int cross, int64_t a, int64_t sp0, int64_t c, int64_t d, int64_t sym_cap,
+                                                 int64_t dec_cap, int64_t seg_cap, int32_t *__restrict__ sym2frame, int32_t *__restrict__ seg2frame, SpecSym *__restrict__ spec)
 {
-    __shared__ int64_t part[4][kScanBlock / 64];
-    const int f = blockIdx.x * kScanBlock + threadIdx.x;
-    int cross = -1;
-    const ScanQ q = scan_quantities(info, f, n_frames, seg_steps, &cross);
-    int64_t tot[4];
-    const ScanQ ex = block_exclusive_scan(q, tot, part);
-    if (f >= n_frames) return;
-    const int64_t a = ex.v[0] + blk[blockIdx.x], sp0 = ex.v[1] + blk[(size_t)gridDim.x + blockIdx.x],
-                  c = ex.v[2] + blk[(size_t)2 * gridDim.x + blockIdx.x], d = ex.v[3] + blk[(size_t)3 * gridDim.x + blockIdx.x];
     const int nsym = (int)q.v[0], nspec = (int)q.v[1];
     info[f].seg_off = (int32_t)d;
     const int ns = (int)q.v[3];
@@ -312,6 +303,38 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_apply(FrameInfo *__restrict
             k++;
         }
     }
+}
+
+__global__ __launch_bounds__(kScanBlock) void k_scan_apply(FrameInfo *__restrict__ info, int n_frames, int64_t sym_cap,
+                                                           int64_t dec_cap, int seg_steps, int64_t seg_cap, const int64_t *__restrict__ blk,
+                                                           int32_t *__restrict__ sym2frame, int32_t *__restrict__ seg2frame, SpecSym *__restrict__ spec)
+{
+    __shared__ int64_t part[4][kScanBlock / 64];
+    const int f = blockIdx.x * kScanBlock + threadIdx.x;
+    int cross = -1;
+    const ScanQ q = scan_quantities(info, f, n_frames, seg_steps, &cross);
+    int64_t tot[4];
+    const ScanQ ex = block_exclusive_scan(q, tot, part);
+    if (f >= n_frames) return;
+    scan_apply_frame(info, f, q, cross, ex.v[0] + blk[blockIdx.x], ex.v[1] + blk[(size_t)gridDim.x + blockIdx.x], ex.v[2] + blk[(size_t)2 * gridDim.x + blockIdx.x],
+                     ex.v[3] + blk[(size_t)3 * gridDim.x + blockIdx.x], sym_cap, dec_cap, seg_cap, sym2frame, seg2frame, spec);
+}
+
+// the three passes as ONE launch for a call of up to kScanBlock alignments (a stream engine's small batch: every launch it does not make
+// is 4-5 us of its submitter thread and one dependent kernel less between a frame's last sample and its payload)
+__global__ __launch_bounds__(kScanBlock) void k_scan_small(FrameInfo *__restrict__ info, int n_frames, int64_t sym_cap, int64_t dec_cap, int seg_steps, int64_t seg_cap,
+                                                           int64_t *__restrict__ totals, int32_t *__restrict__ sym2frame, int32_t *__restrict__ seg2frame,
+                                                           SpecSym *__restrict__ spec)
+{
+    __shared__ int64_t part[4][kScanBlock / 64];
+    const int f = threadIdx.x;
+    int cross = -1;
+    const ScanQ q = scan_quantities(info, f, n_frames, seg_steps, &cross);
+    int64_t tot[4];
+    const ScanQ ex = block_exclusive_scan(q, tot, part);
+    if (f == 0) { totals[0] = tot[0]; totals[1] = tot[1]; totals[2] = tot[2]; totals[3] = sym_cap; totals[4] = tot[3]; }
+    if (f >= n_frames) return;
+    scan_apply_frame(info, f, q, cross, ex.v[0], ex.v[1], ex.v[2], ex.v[3], sym_cap, dec_cap, seg_cap, sym2frame, seg2frame, spec);
 }
 
 // ... and the first of them that cannot: FOA_ST_TRUNCATED is "the samples ended before this alignment's frame was complete", i.e. it and

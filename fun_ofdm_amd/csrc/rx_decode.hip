@@ -87,10 +87,10 @@ int foa::flush_pending(foa_rx *rx, hipEvent_t after_front_end)
     // the walk follows its forward pass on the call's own lane -- no event between them -- and the next call of that lane
     // queues its front end behind it; the stitch/CRC kernel, which nothing on the loop waits for, goes to the second stream
     if (after_front_end) HIP_TRY(hipStreamWaitEvent(p.lane, after_front_end, 0));
-    HIP_TRY(hipEventRecord(p.w->ev[6], p.lane));
+    if (p.w->have_timing) HIP_TRY(hipEventRecord(p.w->ev[6], p.lane));
     launch_finish3(p.lane, sb, p.w->info.p, p.nf, p.w->dec.p, p.w->decoded.p, p.w->seg2frame.p, p.w->totals.p, p.w->tb_state.p, p.max_segs, p.S, p.L,
                    p.psdu, p.slot_bytes, p.results, p.w->walk_done);
-    HIP_TRY(hipEventRecord(p.w->ev[4], sb));
+    if (p.w->have_timing) HIP_TRY(hipEventRecord(p.w->ev[4], sb));
     HIP_TRY(hipEventRecord(p.w->done, sb));
     rx->last_walk_done = p.w->walk_done;
     if (p.job) {
@@ -207,20 +207,26 @@ static int decode_frames_any(foa_rx *rx, const void *d_iq, bool f64, size_t n_sa
 
     if (rx->in_wait) { HIP_TRY(hipStreamWaitEvent(st, rx->in_ready, 0)); rx->in_wait = false; }
     if ((rc = wait_after(rx, st))) return rc;                          // foa_rx_after: the caller's producers, on the device
-    HIP_TRY(hipEventRecord(rx->w->ev[0], st));
+    const bool tm = rx->timing;                                       // (the per-kernel timing events: seven runtime calls per decode call, off while a stream engine drives the handle)
+    if (tm) HIP_TRY(hipEventRecord(rx->w->ev[0], st));
     if (f64) hipLaunchKernelGGL(k_header<double2>, dim3(n_total), dim3(64), 0, st, iq64, d_descs, d_ends, (int64_t)n_samples, (int)n_lead, n_total, rx->w->info.p, rx->w->hinv.p, eq_sig);
     else hipLaunchKernelGGL(k_header<float2>, dim3(n_total), dim3(64), 0, st, iq, d_descs, d_ends, (int64_t)n_samples, (int)n_lead, n_total, rx->w->info.p, rx->w->hinv.p, eq_sig);
-    HIP_TRY(hipEventRecord(rx->w->ev[1], st));
+    if (tm) HIP_TRY(hipEventRecord(rx->w->ev[1], st));
     // segments of this call: at most (total data steps)/S + one per frame; lanes beyond the real total idle
     const size_t max_segs = std::min(rx->w->seg2frame.n, rx->w->dec_cap / (size_t)rx->tb_segment + n_frames + 1);
     const int n_sb = (nf + kScanBlock - 1) / kScanBlock;
     int64_t *blk = rx->w->totals.p + 8;
-    hipLaunchKernelGGL(k_scan_sums, dim3(n_sb), dim3(kScanBlock), 0, st, rx->w->info.p, nf, rx->tb_segment, blk);
-    if (n_sb <= 4096) hipLaunchKernelGGL(k_scan_blocks_w, dim3(1), dim3(64), 0, st, blk, n_sb, (int64_t)rx->w->sym_cap, rx->w->totals.p);
-    else hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, blk, n_sb, (int64_t)rx->w->sym_cap, rx->w->totals.p);
-    hipLaunchKernelGGL(k_scan_apply, dim3(n_sb), dim3(kScanBlock), 0, st, rx->w->info.p, nf, (int64_t)rx->w->sym_cap,
-                       (int64_t)rx->w->dec_cap, rx->tb_segment, (int64_t)rx->w->seg2frame.n, blk, rx->w->sym2frame.p, rx->w->seg2frame.p, rx->w->spec.p);
-    HIP_TRY(hipEventRecord(rx->w->ev[2], st));
+    if (n_sb == 1) {
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(kScanBlock), 0, st, rx->w->info.p, nf, (int64_t)rx->w->sym_cap, (int64_t)rx->w->dec_cap, rx->tb_segment,
+                           (int64_t)rx->w->seg2frame.n, rx->w->totals.p, rx->w->sym2frame.p, rx->w->seg2frame.p, rx->w->spec.p);
+    } else {
+        hipLaunchKernelGGL(k_scan_sums, dim3(n_sb), dim3(kScanBlock), 0, st, rx->w->info.p, nf, rx->tb_segment, blk);
+        if (n_sb <= 4096) hipLaunchKernelGGL(k_scan_blocks_w, dim3(1), dim3(64), 0, st, blk, n_sb, (int64_t)rx->w->sym_cap, rx->w->totals.p);
+        else hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, blk, n_sb, (int64_t)rx->w->sym_cap, rx->w->totals.p);
+        hipLaunchKernelGGL(k_scan_apply, dim3(n_sb), dim3(kScanBlock), 0, st, rx->w->info.p, nf, (int64_t)rx->w->sym_cap,
+                           (int64_t)rx->w->dec_cap, rx->tb_segment, (int64_t)rx->w->seg2frame.n, blk, rx->w->sym2frame.p, rx->w->seg2frame.p, rx->w->spec.p);
+    }
+    if (tm) HIP_TRY(hipEventRecord(rx->w->ev[2], st));
     // upper bound on data symbols in n_samples samples; waves beyond the real total exit at once
     const size_t max_sym = rx->w->sym_cap;
     // (persistent workgroups: as many as the device holds at once walk over the groups of 64 symbols, frontend_q4.h)
@@ -239,25 +245,25 @@ static int decode_frames_any(foa_rx *rx, const void *d_iq, bool f64, size_t n_sa
     if (piped) {
         // the previous call's chain-back + finish goes under this call's forward pass
         if ((rc = flush_pending(rx, rx->w->ev[3]))) return rc;
-        HIP_TRY(hipEventRecord(rx->w->ev[7], st));               // start of the forward pass
+        if (tm) HIP_TRY(hipEventRecord(rx->w->ev[7], st));       // start of the forward pass
         launch_fwd3(st, rx->w->info.p, nf, rx->w->sp.p, rx->w->dec.p);
-        HIP_TRY(hipEventRecord(rx->w->ev[5], st));
+        if (tm) HIP_TRY(hipEventRecord(rx->w->ev[5], st));
         foa_rx::Pending &p = rx->pending;
         p.valid = true; p.w = rx->w; p.nf = nf; p.S = rx->tb_segment; p.L = rx->tb_overlap; p.max_segs = max_segs; p.slot_bytes = slot_bytes;
         p.psdu = d_psdu; p.results = d_results; p.job = rx->attach_job; p.lane = st;
     } else {
         launch_fwd3(st, rx->w->info.p, nf, rx->w->sp.p, rx->w->dec.p);
-        HIP_TRY(hipEventRecord(rx->w->ev[5], st));
+        if (tm) HIP_TRY(hipEventRecord(rx->w->ev[5], st));
         launch_finish3(st, st, rx->w->info.p, nf, rx->w->dec.p, rx->w->decoded.p, rx->w->seg2frame.p, rx->w->totals.p, rx->w->tb_state.p, max_segs, rx->tb_segment,
                        rx->tb_overlap, d_psdu, slot_bytes, d_results);
-        HIP_TRY(hipEventRecord(rx->w->ev[6], st));                     // (not separable from the forward pass on one stream)
-        HIP_TRY(hipEventRecord(rx->w->ev[4], st));
+        if (tm) HIP_TRY(hipEventRecord(rx->w->ev[6], st));             // (not separable from the forward pass on one stream)
+        if (tm) HIP_TRY(hipEventRecord(rx->w->ev[4], st));
         HIP_TRY(hipEventRecord(rx->w->done, st));
     }
     HIP_TRY(hipGetLastError());
     rx->w->used = true;
     rx->w->in_descs = d_descs - n_lead; rx->w->in_ends = d_ends - n_lead; rx->w->in_count = n_lead + n_frames + n_context;
-    rx->w->have_timing = true;
+    rx->w->have_timing = tm;
     rx->w->piped = piped;
     rx->w->before = piped ? rx->prev : nullptr;
     rx->last_frames = n_frames;

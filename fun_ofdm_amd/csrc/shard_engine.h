@@ -73,7 +73,7 @@ struct ShardDev {
         if (!rc) rc = state.ensure(1);
         // everything a batch will need is allocated here, not by the first batches that need it (stream_engine.h)
         if (!rc) rc = foa_rx_reserve(rx, (size_t)(foa::kStreamCarry + B), (size_t)((foa::kStreamCarry + B) / 1200 + 64));
-        if (!rc) { rx->depth_saved = rx->depth; rx->depth = (B <= ((int64_t)1 << 20) && rx->max_depth >= 4) ? 4 : 2; }      // (as the single-device engine: small batches want four loops in flight)
+        if (!rc) { rx->depth_saved = rx->depth; rx->depth = (B <= ((int64_t)1 << 20) && rx->max_depth >= 4) ? 4 : 2; rx->timing = false; }      // (as the single-device engine: small batches want four loops in flight, nobody reads per-kernel times)
         return rc;
     }
     void release()

@@ -21,7 +21,7 @@ iq.tofile(cap)
 libdir = os.path.dirname(foa.library_path())
 subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "examples", "foa_sim.cpp"), "-I", os.path.join(ROOT, "include"), "-L", libdir,
                 "-lfun_ofdm_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lpthread", "-o", exe], check=True)
-for B, pace in ((1 << 14, 20), (1 << 14, 400), (1 << 16, 20), (1 << 16, 400), (1 << 18, 400), (1 << 22, 0)):
+for B, pace in ((1 << 12, 20), (1 << 13, 20), (1 << 14, 20), (1 << 14, 400), (1 << 16, 20), (1 << 16, 400), (1 << 18, 400), (1 << 22, 0)):
     extra = ["--chunk", "4096", "--device-batch", str(B), "--narrow-threads", "8"] + (["--pace", str(pace)] if pace else [])
     r = subprocess.run([exe, cap, "--format", "fc32", "--preload", "--latency", str(PITCH), str(LEAD), str(s)] + extra, capture_output=True, text=True, timeout=900)
     m = re.search(r"([\d.]+) Msamples/s through process_samples", r.stdout)
