@@ -220,6 +220,46 @@ def frames(rng):
     return out
 
 
+def frames_reftx(rng):
+    """Frames whose TRANSMIT side is assembled from the REAL reference: conv_encode, puncture and interleave of oracle/_ref produce the coded
+    bits (ppdu.cpp:115-165's order), and the real modulate / symbol_map are asserted equal to the oracle's on these very bits.  All eleven
+    rates at 1 and 4095 payload bytes.  Stored: payload, rate, the real pieces' interleaved coded bits (packed) -- a few KB per frame; the
+    tests rebuild the samples from the bits with the oracle's modulate / symbol_map / inverse DFT / preamble (pinned elsewhere against
+    the real ones; fft.cpp itself cannot be built here) and expect the PAYLOAD back, from the oracle's receiver on the CPU and from the
+    device.  What only reading pins after this: the header-field layout, the scrambler and where the CRC goes (ppdu.cpp:75-147)."""
+    R = po.Ref
+    out = {}
+    names = []
+    for r in range(po.NUM_RATES):
+        rp = po.rate_params(r)
+        for ln in (1, 4095):
+            pay = rng.integers(0, 256, ln, dtype=np.uint8)
+            nsym = po.num_symbols(r, ln)
+            nbits = nsym * rp["dbps"]
+            data = np.zeros(nbits // 8 + 1, np.uint8)
+            data[2:2 + ln] = pay
+            crc = po.crc32(data[:2 + ln])
+            data[2 + ln:6 + ln] = np.frombuffer(np.uint32(crc).tobytes(), np.uint8)
+            scr = np.zeros_like(data)
+            scr[:nbits // 8] = po.scramble(data[:nbits // 8])
+            enc = R.conv_encode(scr, nbits - 6)                      # REAL viterbi::conv_encode
+            inter = R.interleave(R.puncture(enc, r))                 # REAL puncturer::puncture, interleaver::interleave
+            car = R.modulate(inter, r)                               # REAL modulator::modulate
+            assert np.array_equal(car, po.modulate(inter, r)) and np.array_equal(car, po.encode_data(pay, r))
+            bins = R.symbol_map(np.concatenate([po.encode_header(r, ln), car]))      # REAL symbol_mapper::map
+            assert np.array_equal(bins, po.symbol_map(np.concatenate([po.encode_header(r, ln), car])))
+            frame = po.frame_from_coded_bits(inter, r, ln)
+            assert np.array_equal(frame, po.build_frame(pay, r))
+            name = "r%d_len%d" % (r, ln)
+            names.append(name)
+            out[name + "_payload"] = pay
+            out[name + "_bits"] = np.packbits(inter.astype(np.uint8))
+            out[name + "_nbits"] = np.array([inter.size], np.int64)
+            print("  %-12s %6d coded bits, %6d samples" % (name, inter.size, frame.size))
+    out["names"] = np.array(names)
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     po.build(ref=True)
@@ -232,6 +272,8 @@ def main():
         ("codec_ref.npz", codec_kat, 102, "real reference modulator/interleaver/puncturer/viterbi::conv_encode/symbol_mapper/tables via oracle/_ref"),
         ("blocks_ref.npz", blocks_kat, 103, "real reference frame_detector/timing_sync/channel_est/phase_tracker via oracle/_ref (fft_symbols: oracle)"),
         ("frames.npz", frames, 104, "oracle restatement (fo_oracle.c), itself pinned against the *_ref fixtures"),
+        ("frames_reftx.npz", frames_reftx, 106, "transmit side from the real reference's conv_encode / puncture / interleave (coded bits stored), modulate and symbol_map "
+                                               "asserted equal to the oracle's on them; all 11 rates at 1 and 4095 bytes; expected output = the payload"),
     ):
         if only and fname not in only:
             continue

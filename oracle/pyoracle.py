@@ -307,6 +307,15 @@ def ifft64(x):
     return d
 
 
+def frame_from_coded_bits(inter, rate, length):
+    """Samples of a frame from its interleaved coded bits: modulate, header, symbol_map, inverse DFT + cyclic prefix, preamble (oracle pieces,
+    each pinned against the real one except the inverse DFT, fft.cpp:68-96, which is pinned by definition).  Used by the tests as well."""
+    car = modulate(np.asarray(inter, np.uint8), rate)
+    bins = symbol_map(np.concatenate([encode_header(rate, length), car]))
+    td = np.concatenate([np.concatenate([ifft64(b)[48:], ifft64(b)]) for b in bins.reshape(-1, 64)])
+    return np.concatenate([preamble_samples(), td])
+
+
 def build_frame(payload, rate):
     p = np.ascontiguousarray(payload, np.uint8)
     o = np.zeros(frame_samples(rate, p.size), np.complex128)

@@ -212,6 +212,24 @@ def test_golden_frames(rx, po, golden):
     assert soft_mismatch == 0, "%d of %d soft bytes differ" % (soft_mismatch, soft_total)
 
 
+def test_golden_frames_with_the_real_reference_on_the_transmit_side(rx, po, golden):
+    """tests/golden/frames_reftx.npz: coded bits out of the REAL reference's conv_encode / puncture / interleave for all eleven rates at 1
+    and 4095 payload bytes (oracle/gen_golden.py); the device must hand back the PAYLOAD -- an expected output no restatement computed --
+    with the status, rate and length the frame was built with, and agree with the oracle's receiver on every field."""
+    from test_oracle_golden import _reftx_cases
+    n = 0
+    for name, rate, pay, s in _reftx_cases(po, golden):
+        descs = po.find_alignments_f32(s)
+        assert descs.size == 1, name
+        psdu, res = rx.decode_frames_host(s, descs, _ends(descs, s.size))
+        assert (res[0]["status"], res[0]["rate"], res[0]["length"]) == (0, rate, pay.size), (name, res[0])
+        assert np.array_equal(psdu[0, :pay.size], pay), name
+        ores, opsdu = po.decode_alignment_f32(s, descs[0])
+        assert res[0]["num_symbols"] == ores["num_symbols"] and np.array_equal(psdu[0, :pay.size], opsdu[:pay.size]), name
+        n += 1
+    assert n == 22
+
+
 def _make_stream(po, rng, specs, snr_db=25.0, gap=(150, 600), cfo_hz=0.0):
     parts, pays = [], []
     for rate, ln in specs:

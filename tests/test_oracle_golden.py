@@ -243,3 +243,32 @@ def test_batch_restatement_with_the_partial_vector_flush_equals_the_blocks(po):
     p2, r2 = po.decode_batch_v2_f32(s, d)
     assert d.size >= 4 and np.array_equal(r1.view(np.int32), r2.view(np.int32)) and np.array_equal(p1, p2)
     assert po.chain_from_tags_f32(s, d) == po.ReceiverChain().run_stream(s.astype(np.complex128))
+
+
+def _reftx_cases(po, golden):
+    """(name, rate, payload, noisy complex64 stream) per case of frames_reftx.npz: the samples rebuilt from the REAL reference's coded bits."""
+    g = golden.frames_reftx
+    rng = np.random.default_rng(606)
+    for name in g["names"]:
+        rate = int(str(name).split("_")[0][1:])
+        pay = g[name + "_payload"]
+        bits = np.unpackbits(g[name + "_bits"])[:int(g[name + "_nbits"][0])]
+        frame = po.frame_from_coded_bits(bits, rate, pay.size) * np.exp(1j * rng.uniform(0, 6.28))
+        s = np.concatenate([np.zeros(240, complex), frame, np.zeros(400, complex)])
+        sigma = np.sqrt(0.0124 / 2 / 10 ** 3.0)              # 30 dB
+        yield str(name), rate, pay, (s + (rng.normal(size=s.size) + 1j * rng.normal(size=s.size)) * sigma).astype(np.complex64)
+
+
+def test_oracle_receiver_returns_the_payloads_of_frames_the_real_reference_encoded(po, golden):
+    """frames_reftx.npz: the transmit side is the REAL conv_encode / puncture / interleave (oracle/gen_golden.py, modulate and symbol_map
+    asserted equal on the same bits), all eleven rates at 1 and 4095 bytes; the oracle's receive path must hand back the payload -- the
+    expected output is the input, not something the oracle computed."""
+    n = 0
+    for name, rate, pay, s in _reftx_cases(po, golden):
+        descs = po.find_alignments_f32(s)
+        assert descs.size == 1, name
+        res, psdu = po.decode_alignment_f32(s, descs[0])
+        assert (res["status"], res["rate"], res["length"]) == (po.ST_OK, rate, pay.size), (name, res)
+        assert np.array_equal(psdu[:pay.size], pay), name
+        n += 1
+    assert n == 22
