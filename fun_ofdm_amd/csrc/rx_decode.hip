@@ -197,7 +197,10 @@ static int decode_frames_any(foa_rx *rx, const void *d_iq, bool f64, size_t n_sa
     // that sets the step -- forward pass k, walk k, header, scan and data symbols of call k+2, forward pass k+2 -- is then one in-order
     // stream with no event packet in it, and nothing orders one lane behind the other (each call has its own work set), so a forward
     // pass starts the moment its front end is done, into the tail of the one before.
-    const int depth = rx->depth > 0 ? rx->depth : (n_frames < (size_t)kDeepBelow ? std::min(4, rx->max_depth) : 2);
+    // (big grids of BPSK-only captures -- the caller has said so: option "max_dbps" <= 36 -- spend a third of their time in the data-symbol
+    // kernel, which shares the vector pipes with the forward pass: three loops keep a forward pass on the machine while two front ends
+    // run, + 8-11 % at 6 / 9 Mbps; from QPSK on it is within 3 % either way and config 2 loses 12 % to a third loop: profiles/r06_depth_by_frames.txt)
+    const int depth = rx->depth > 0 ? rx->depth : (n_frames < (size_t)kDeepBelow ? std::min(4, rx->max_depth) : (rx->max_dbps <= 36 ? std::min(3, rx->max_depth) : 2));
     hipStream_t st = piped ? lane_stream(rx, (int)(rx->n_calls++ % (unsigned)depth)) : rx->stream;
     if (!piped && rx->prev->used && rx->prev != rx->w) HIP_TRY(hipStreamWaitEvent(st, rx->prev->done, 0));
     const int nf = (int)n_frames, n_total = (int)(n_frames + n_context);      // context alignments: header kernel only

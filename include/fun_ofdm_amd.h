@@ -113,7 +113,7 @@ int foa_rx_reserve(foa_rx *rx, size_t n_samples, size_t n_frames);
  *                 after foa_rx_sync (or, for the call before the most recent one, after foa_rx_wait_previous), and the INPUTS of a call
  *                 must be complete when it is made and stay untouched until then.  0 = every call runs start to end on the handle's
  *                 stream.  (Waits for everything in flight before it switches.)
- *   "depth"       pipelined calls: how many calls' loops are in flight -- 0 (default) = by grid size: 2, or 4 for calls of up to 4608 frames,
+ *   "depth"       pipelined calls: how many calls' loops are in flight -- 0 (default) = by grid size: 2 (3 for BPSK-only captures: option "max_dbps" <= 36), or 4 for calls of up to 4608 frames,
  *                 whose forward pass leaves most SIMDs a single wave (1 000-frame batches decode 40-50 % faster in steady state); 2, 3, 4 =
  *                 fixed.  (the lanes sit on hardware queues of their own: stream priorities, see above)
  *   "max_dbps"    what the work sets of later calls (and foa_rx_reserve) are sized for: the data bits per OFDM symbol of the HIGHEST rate the

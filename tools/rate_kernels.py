@@ -24,8 +24,9 @@ def main():
     ap.add_argument("--rates", default="0,2,3,5,6,8,9,10")
     ap.add_argument("--budget", type=int, default=300 * 1000 * 1000, help="cap on samples per call (0 = none)")
     ap.add_argument("--hint", action="store_true", help="set option max_dbps to the rate's dbps (work sets sized for the call's own rate)")
-    ap.add_argument("--reps", type=int, default=6)
+    ap.add_argument("--reps", type=int, default=24)
     ap.add_argument("--alone-only", action="store_true", help="calls in line only (for counter runs)")
+    ap.add_argument("--depth", type=int, default=0, help="library option depth for the pipelined part (0: by grid size)")
     args = ap.parse_args()
     import torch
     import fun_ofdm_amd as foa
@@ -71,6 +72,8 @@ def main():
             rx.close()
             continue
         rx.set_option("pipeline", 1)
+        if args.depth:
+            rx.set_option("depth", args.depth)
         for _ in range(8):
             call()
         rx.sync(); torch.cuda.synchronize()
