@@ -12,8 +12,8 @@
 //     terms live in lanes 1 and 2 and are broadcast so that every lane adds them in the reference's order;
 //   * soft bytes are scattered into the symbol's depunctured order in LDS ((carrier, bit) -> position table per
 //     rate), and leave in 8-byte stores, four trellis steps per lane and trip.
-// Its waves are small (<= 176 VGPRs), so several share a SIMD and hide each other's latencies, and they fit next to the forward
-// pass of the previous call when calls are pipelined (0.18 ms alone at config 2; HISTORY.md has the layouts it replaced).
+// The kernel is persistent and keeps three groups of symbols in flight per wave (below: "the kernel"): 256 VGPRs, two waves per SIMD,
+// one beside the five waves of a forward pass when calls are pipelined (0.15 ms alone at config 2; HISTORY.md has the forms it replaced).
 #pragma once
 
 #include "device_math.h"

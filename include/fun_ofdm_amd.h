@@ -13,7 +13,7 @@
  *
  * Conventions: plain C types only; every call returns 0 on success and a negative FOA_E_* code on
  * error (foa_last_error() gives the text, per thread); the library never frees caller memory; a handle
- * is used from one thread at a time; each handle owns one HIP stream; there is NO CPU fallback -- a
+ * is used from one thread at a time; each handle owns its HIP streams (below); there is NO CPU fallback -- a
  * call fails with FOA_E_NO_DEVICE when no gfx950 device/HIP runtime is usable.
  *
  * The reference-side binding a maintainer would add is shown in INTEGRATION.md.

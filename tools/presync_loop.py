@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--frames", type=int, default=10000)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--no-presync", action="store_true")
+    ap.add_argument("--depth", type=int, default=0)
     ap.add_argument("--decode-first", action="store_true", help="per step: end(k), decode(k), begin(k+1) instead of end(k), begin(k+1), decode(k)")
     args = ap.parse_args()
     import torch
@@ -38,6 +39,8 @@ def main():
     psdu = torch.zeros((m, 1024), dtype=torch.uint8, device=dev)
     res = torch.zeros((m, 4), dtype=torch.int32, device=dev)
     rx.set_option("record_soft", 0)
+    if args.depth:
+        rx.set_option("depth", args.depth)
     rx.reserve(d_iq.shape[0], m)
     for timed in (False, True):
         rx.sync(); torch.cuda.synchronize()
