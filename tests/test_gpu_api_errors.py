@@ -69,6 +69,21 @@ def test_every_entry_point_refuses_bad_arguments(po):
     assert L.foa_sync_create(C.byref(sy)) == 0
     refused(L.foa_sync_set_call(sy, 100), E_INVALID)
     L.foa_sync_destroy(sy)
+    # device-side ordering: NULL events, more than 16 events waiting for one call
+    refused(L.foa_rx_after(h, None), E_INVALID)
+    refused(L.foa_rx_record_consumed(h, None), E_INVALID)
+    refused(L.foa_rx_record_done(None, p), E_INVALID)
+    import torch
+    evs = [torch.cuda.Event() for _ in range(17)]
+    for e in evs:
+        e.record()
+    for e in evs[:16]:
+        assert L.foa_rx_after(h, e.cuda_event) == 0
+    refused(L.foa_rx_after(h, evs[16].cuda_event), E_STATE)
+    assert L.foa_rx_decode_frames_dev(h, p, 100, p, p, 0, p, 64, p) == 0      # (an empty call takes the registered events with it)
+    assert L.foa_rx_after(h, evs[16].cuda_event) == 0
+    assert L.foa_rx_record_done(h, evs[0].cuda_event) == 0 and L.foa_rx_record_consumed(h, evs[1].cuda_event) == 0
+    torch.cuda.synchronize()
     # wrong order
     refused(L.foa_rx_sync_dev_end(h, C.byref(sz)), E_STATE)
     refused(L.foa_rx_collect(h, 12345, 0, hp, hp))                                                     # no such ticket

@@ -1124,3 +1124,69 @@ def test_context_alignments_and_explicit_ends_follow_the_restatement(rx, po):
             o_p, o_r = po.decode_batch_v2_f32(s, d[k:], ends[k:])
             assert np.array_equal(alone_r.view(np.int32), o_r.view(np.int32)) and np.array_equal(alone_p, o_p), (seed, k, "no lead")
     assert n_split > 40 and n_trunc > 5 and n_late >= 3, (n_split, n_trunc, n_late)
+
+
+def test_many_frames_of_one_to_three_symbols_and_groups_of_mixed_frames(rx, po):
+    """The data-symbol kernel stages the channel estimates of a wave's sixteen symbols through LDS, four alignments' worth; a group that
+    holds more alignments than that -- frames of one to three symbols back to back, as here -- reads its taps from memory, and groups that
+    straddle frames of different rates take the generic demapper.  Every such path against the oracle, soft bytes included."""
+    rng = np.random.default_rng(4242)
+    specs = []
+    for _ in range(260):
+        rate = int(rng.choice((10, 9, 8, 6, 5, 3, 0)))
+        # payloads that give 1 .. 3 symbols at the frame's rate (ppdu.cpp:40-44), now and then a long one in between
+        dbps = po.rate_params(rate)["dbps"]
+        nsym = int(rng.integers(1, 4))
+        ln = max(0, (nsym * dbps - 22) // 8 - 4 - int(rng.integers(0, 2)))
+        specs.append((rate, ln if rng.random() > 0.05 else int(rng.integers(200, 700))))
+    s, pays = _make_stream(po, rng, specs, snr_db=27.0, gap=(40, 90))
+    descs = po.find_alignments_f32(s)
+    ends = _ends(descs, s.size)
+    rx.set_option("record_soft", 1)
+    psdu, res = rx.decode_frames_host(s, descs, ends)
+    opsdu, ores = po.decode_batch_f32(s, descs, ends)
+    assert np.array_equal(res.view(np.int32).reshape(-1, 4), ores.view(np.int32).reshape(-1, 4))
+    ok = res["status"] == 0
+    assert ok.sum() >= 200 and np.array_equal(psdu[ok], opsdu[ok])
+    short = (res["num_symbols"][ok] <= 3).sum()
+    assert short >= 150, short
+    t = rx.taps(descs.size)
+    for f in np.nonzero(ok)[0][:60]:
+        _, _, ot = po.decode_alignment_f32(s, descs[f], end=int(ends[f]), taps=True)
+        assert np.array_equal(t["soft"][t["soft_off"][f]:t["soft_off"][f + 1]], ot["soft"]), f
+
+
+def test_work_sets_sized_by_max_dbps_and_the_promise_is_checked_on_the_device(po):
+    """Option max_dbps: results are identical for every value that covers the capture's rates; a frame of a higher rate than promised, once
+    the work set is full, is FOA_ST_NO_SPACE -- reported, never decoded wrongly -- and the frames that fit are untouched."""
+    import fun_ofdm_amd as foa
+    rng = np.random.default_rng(77)
+    s, pays = _make_stream(po, rng, [(0, 300)] * 6 + [(2, 200)] * 4, snr_db=28.0)
+    descs = po.find_alignments_f32(s)
+    ends = _ends(descs, s.size)
+    opsdu, ores = po.decode_batch_f32(s, descs, ends)
+    for dbps in (216, 48, 36):
+        r = foa.Receiver(0)
+        r.set_option("max_dbps", dbps)
+        psdu, res = r.decode_frames_host(s, descs, ends)
+        assert np.array_equal(res.view(np.int32).reshape(-1, 4), ores.view(np.int32).reshape(-1, 4)), dbps
+        assert np.array_equal(psdu[res["status"] == 0], opsdu[ores["status"] == 0]), dbps
+        r.close()
+    # a dense capture of 54 Mbps frames under a promise of 6 Mbps: some fit into the slack of the work set, the rest are told so
+    s2, pays2 = _make_stream(po, rng, [(10, 1500)] * 40, snr_db=28.0, gap=(60, 80))
+    d2 = po.find_alignments_f32(s2)
+    e2 = _ends(d2, s2.size)
+    o2p, o2r = po.decode_batch_f32(s2, d2, e2)
+    r = foa.Receiver(0)
+    r.set_option("max_dbps", 24)
+    psdu, res = r.decode_frames_host(s2, d2, e2)
+    st = res["status"]
+    assert (st == foa.ST_NO_SPACE).sum() >= 5, st
+    fits = st != foa.ST_NO_SPACE
+    assert np.array_equal(res[fits].view(np.int32).reshape(-1, 4), o2r[fits].view(np.int32).reshape(-1, 4))
+    assert np.array_equal(psdu[st == 0], o2p[st == 0])
+    assert np.array_equal(res["rate"], o2r["rate"]) and np.array_equal(res["length"], o2r["length"])      # (the header fields are reported either way)
+    for bad in (23, 217, 0):
+        with pytest.raises(foa.FoaError):
+            r.set_option("max_dbps", bad)
+    r.close()
