@@ -1079,7 +1079,7 @@ def extra_legs(args, rx, dev, iq, descs, ends, real, psdu_dev_path, res_dev_path
         def go():
             got[0] = rx.sync_dev(stream, d_desc, d_end)
             rx.decode_frames_dev(stream, d_desc[:got[0] * 48], d_end[:got[0]], d_psdu[:got[0]], d_res[:got[0]])
-        dt = timed(go, 3)
+        dt = timed(go, 12)
         m = got[0]
         r = d_res[:m].cpu().numpy()
         rx.sync()
@@ -1113,7 +1113,7 @@ def extra_legs(args, rx, dev, iq, descs, ends, real, psdu_dev_path, res_dev_path
             sets5 = [(d_desc, d_end), (e_desc, e_end)]
             ref_desc, ref_end = d_desc.clone(), d_end.clone()
             dtps = []
-            for n_p in (8, 6, 6, 6):                     # one warm round, then the median of three
+            for n_p in (8, 24, 24, 24):                  # one warm round, then the median of three (24 passes each: with four loops in flight the fill and drain of six was a third of the region)
                 rx.sync(); torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 rx.sync_dev_begin(stream, *sets5[0])

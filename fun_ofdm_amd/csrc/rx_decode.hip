@@ -92,7 +92,10 @@ int foa::flush_pending(foa_rx *rx, hipEvent_t after_front_end)
                    p.psdu, p.slot_bytes, p.results, p.w->walk_done);
     if (p.w->have_timing) HIP_TRY(hipEventRecord(p.w->ev[4], sb));
     HIP_TRY(hipEventRecord(p.w->done, sb));
-    rx->last_walk_done = p.w->walk_done;
+    // (the one-shot pre-sync goes behind this walk -- rx_sync.hip -- when two loops are in flight: the walk is then about to run.  With
+    // three or four loops it waits for a forward pass that has two or three others in front of it, and a pre-sync behind it would hold up
+    // the host, which needs the count to queue the next call: BASELINE config 5, 55 -> 52 Gsample/s)
+    rx->last_walk_done = p.deep ? nullptr : p.w->walk_done;
     if (p.job) {
         HostJob &j = *p.job;
         HIP_TRY(hipMemcpyAsync(j.pin + j.o_psdu, j.dev.p + j.o_psdu, j.total - j.o_psdu, hipMemcpyDeviceToHost, sb));
@@ -253,7 +256,7 @@ static int decode_frames_any(foa_rx *rx, const void *d_iq, bool f64, size_t n_sa
         if (tm) HIP_TRY(hipEventRecord(rx->w->ev[5], st));
         foa_rx::Pending &p = rx->pending;
         p.valid = true; p.w = rx->w; p.nf = nf; p.S = rx->tb_segment; p.L = rx->tb_overlap; p.max_segs = max_segs; p.slot_bytes = slot_bytes;
-        p.psdu = d_psdu; p.results = d_results; p.job = rx->attach_job; p.lane = st;
+        p.psdu = d_psdu; p.results = d_results; p.job = rx->attach_job; p.lane = st; p.deep = depth > 2;
     } else {
         launch_fwd3(st, rx->w->info.p, nf, rx->w->sp.p, rx->w->dec.p);
         if (tm) HIP_TRY(hipEventRecord(rx->w->ev[5], st));

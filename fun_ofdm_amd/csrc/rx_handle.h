@@ -139,6 +139,7 @@ struct foa_rx {
     struct Pending {
         bool valid = false;
         hipStream_t lane = nullptr;  // the stream of the call's forward pass, where its walk follows
+        bool deep = false;           // more than two loops in flight when the call was made
         foa::WorkSet *w = nullptr;
         int nf = 0, S = 0, L = 0;            // (nf: the alignments that are decoded -- context alignments have no results)
         size_t max_segs = 0, slot_bytes = 0;
