@@ -1032,7 +1032,7 @@ def extra_legs(args, rx, dev, iq, descs, ends, real, psdu_dev_path, res_dev_path
                     mask |= inr
                     want[inr] = pays[(pos[inr] - lo - 360) // pitch]
                 return mask, want[mask]
-            row, found, dt, dt_cpu = c3_decode_and_check(d_all, pays_of, length, 6, True)
+            row, found, dt, dt_cpu = c3_decode_and_check(d_all, pays_of, length, 24, True)
             in_frame = sum(args.legs_frames * s for _, _, _, s, _ in metas)
             row.update({"frames": 8 * args.legs_frames, "samples_fed": int(d_all.shape[0]), "Msamples_per_s": round(in_frame / dt / 1e6, 1),
                         "cpu_Msamples_per_s": round(in_frame / dt_cpu / 1e6, 1), "what": "one call: %d frames of each of the eight rates, 4092-byte payloads, 25 dB" % args.legs_frames})
