@@ -580,7 +580,7 @@ def run(args, rank, world, local_rank, backend=None, make_receiver=None, on_cpu=
             t_ends = torch.zeros_like(s_ends)
             sets = [(s_desc, s_ends), (t_desc, t_ends)]
             s_psdu.zero_(); s_res.zero_()
-            n_p = 20
+            n_p = 60                                     # (sixty steps: a region of twenty is 5 % pipeline fill and drain)
             founds = []
             for timed_pass in (False, True):
                 rx.sync(); torch.cuda.synchronize()
