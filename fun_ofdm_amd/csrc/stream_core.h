@@ -151,7 +151,12 @@ public:
     // 1: *out = the payloads of the oldest finished batch; 0: nothing finished (wait: and nothing outstanding); < 0: error
     int take(bool wait, StreamReady *out)
     {
-        caller_seq_.fetch_add(1, std::memory_order_relaxed);
+        // (A poll -- take(false) -- does not count as "the caller is calling": a producer that waits for its pool of buffers to come back
+        // by polling would otherwise keep the submitter from ever publishing its last < kPublish cells: it publishes leftovers only when
+        // no call that could have done so came in between two of its wake-ups.  The poll itself publishes nothing -- the receive chain
+        // polls after every push and must not undo the publishing stride.  Seen as "a polling producer got 0 of 5 buffers back" in
+        // tests/cpp/stream_core_test.cpp when the box was busy; publish() and release_parked() are safe from both threads at once.)
+        if (wait) caller_seq_.fetch_add(1, std::memory_order_relaxed);
         release_parked();
         if (wait) publish();                                   // (a caller about to sleep must not sit on unpublished tasks)
         // (the common call -- "anything finished?" after every push -- answers from one atomic, without the lock)
