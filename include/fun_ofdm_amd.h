@@ -232,7 +232,9 @@ int foa_rx_collect(foa_rx *rx, uint64_t ticket, int wait, uint8_t *psdu, foa_fra
  *
  *   foa_rx_after(rx, e)             the NEXT call on the handle that queues device work (decode, pre-sync, transmit) starts only after
  *                                   e -- recorded by the caller behind whatever produces that call's inputs and prepares its outputs (a
- *                                   fill of the PSDU slots, say).  One-shot; up to 16 events may be registered for one call.
+ *                                   fill of the PSDU slots, say).  One-shot; up to 16 events may be registered for one call.  The event must
+ *                                   have been recorded, and must stay alive until that call has returned (the library keeps the handle, not
+ *                                   a reference); a call that queues nothing (n_frames = 0) takes the registered events with it.
  *   foa_rx_record_consumed(rx, e)   records e so that it completes when everything queued so far has READ what it reads of the caller's
  *                                   input buffers: the caller's stream waits for e (hipStreamWaitEvent) before it refills them.  Cheap.
  *   foa_rx_record_done(rx, e)       records e so that it completes when everything queued so far is complete (PSDU slots, results,
