@@ -435,6 +435,15 @@ public:
         check(foa_rx_set_option(dev_.get(), "stream_longest", samples), "foa_rx_set_option");
     }
 
+    // The highest rate this stream's frames carry, as data bits per OFDM symbol (24 = 6 Mbps .. 216 = 54 Mbps, the default): option
+    // "max_dbps" in include/fun_ofdm_amd.h -- the device's work sets are sized for it (a capture of low-rate frames needs a ninth of the
+    // default per call), and a frame beyond the promise is dropped like a frame that fails its CRC.  Before the first call.
+    void set_max_rate_bits(int dbps)
+    {
+        if (!devices_.empty()) throw std::runtime_error("receiver_chain: the multi-device mode keeps the default (any rate)");
+        check(foa_rx_set_option(dev_.get(), "max_dbps", dbps), "foa_rx_set_option");
+    }
+
     // Same signature and meaning as fun::receiver_chain::process_samples (src/receiver_chain.cpp:106-126): feed the
     // next chunk of the 20 MS/s stream, get the payloads of the frames that completed, in stream order.  A frame is
     // returned by the call that delivers its last sample (the reference returns it five calls later).
