@@ -118,8 +118,12 @@ __device__ __forceinline__ void q4_emit(Q4Shared &sh, Q4Wave &ws, const cpx (&X)
     // ---- the symbol's depunctured soft bytes leave as they are, two per trellis step (the forward pass forms the branch
     // metrics of viterbi.cpp:242-247 from them when it stages a chunk): 8 bytes = four steps per lane and trip ----
     if (valid) {
+        // (the lane's share of the addresses below does not change from group to group: hoisted out of the caller's loop it is three more
+        // registers held across it, and the compiler spills them -- a scratch reload here waits for the samples in flight)
+        int ms = m, qs = qd;
+        asm volatile("" : "+v"(ms), "+v"(qs));
         const int ngroups = rr.dbps / 4;
-        for (int g4 = m; g4 < ngroups; g4 += 4) *(uint2 *)(sp + my_out + 4 * g4) = *(const uint2 *)&ws.soft[qd][8 * g4];
+        for (int g4 = ms; g4 < ngroups; g4 += 4) *(uint2 *)(sp + my_out + 4 * g4) = *(const uint2 *)&ws.soft[qs][8 * g4];
     }
 }
 
