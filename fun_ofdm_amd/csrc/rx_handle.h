@@ -99,7 +99,7 @@ struct HostJob {
     hipEvent_t done = nullptr;
     bool copy_queued = false;
 };
-constexpr int kMaxJobs = 8;
+constexpr int kMaxJobs = 12;                      // >= kStreamBufs - 1: a stream of small batches keeps that many decode calls in flight
 constexpr int kSets = 6;
 
 }  // namespace foa

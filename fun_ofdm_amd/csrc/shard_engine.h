@@ -185,7 +185,7 @@ struct ShardDev {
 };
 
 typedef foa::ShardBackend<ShardDev> ShardBe;
-static_assert(ShardBe::kSlots == foa::StreamCore<ShardBe>::kSlots && ShardBe::kSlots == foa::kStreamBufs, "one staging slot, one carry and one device buffer per slot of the core");
+static_assert(ShardBe::kSlots <= foa::StreamCore<ShardBe>::kSlots && ShardBe::kSlots <= foa::kStreamBufs, "one staging slot, one carry and one device buffer per slot of the core");
 static_assert(sizeof(foa::ChainState) == sizeof(StreamState) && foa::kShardSettle == foa::kStreamSettle, "shard_core.h mirrors the device code's chain state");
 
 struct foa_shard {
@@ -251,7 +251,7 @@ int foa_shard_create(const int *devices, int n_devices, size_t batch_samples, in
     }
     if (rc) { foa_shard_destroy(s); return rc; }
     s->be = new ShardBe(s->devs, (int64_t)batch_samples, foa::kStreamCarry, foa::kStreamLongest, s->staging, s->carry);
-    s->core = new foa::StreamCore<ShardBe>(s->be, (int64_t)batch_samples, narrow_threads);
+    s->core = new foa::StreamCore<ShardBe>(s->be, (int64_t)batch_samples, narrow_threads, ShardBe::kSlots);
     *out = s;
     return FOA_OK;
 }

@@ -26,6 +26,7 @@
 #if defined(__linux__)
 #include <pthread.h>
 #include <sched.h>
+#include <sys/prctl.h>
 #include <stdio.h>
 #include <stdlib.h>
 #endif
@@ -51,10 +52,11 @@ struct StreamReady { std::vector<uint8_t> bytes; std::vector<uint32_t> len; };
 template <typename Backend>
 class StreamCore {
 public:
-    static constexpr int kSlots = 6;
+    static constexpr int kSlots = 12;                // at most; a core rotates through slots_ of them (constructor)
     typedef void (*release_fn)(void *);
 
-    StreamCore(Backend *be, int64_t batch, int narrow_threads) : be_(be), B_(batch), ring_(kRing)
+    StreamCore(Backend *be, int64_t batch, int narrow_threads, int slots = 6, int spin_us = 0)
+        : be_(be), B_(batch), spin_ns_((int64_t)spin_us * 1000), slots_(slots < 2 ? 2 : slots > kSlots ? kSlots : slots), ring_(kRing)
     {
         for (auto &x : need_) x.store(-1);
         for (size_t i = 0; i < kRing; i++) ring_[i].seq.store(i, std::memory_order_relaxed);
@@ -77,6 +79,10 @@ public:
             fprintf(stderr, "foa_stream: caller ms in push %.1f (%lld pushes, of which waiting for a staging slot %.1f; %lld tasks narrowed by the caller); "
                             "%d helpers: %lld tasks, %.1f ms busy in total\n", st_push_ns_ * 1e-6, (long long)st_pushes_, st_wait_slot_ns_ * 1e-6,
                     (long long)st_inline_, (int)helpers_.size(), (long long)st_helper_tasks_.load(), st_helper_ns_.load() * 1e-6);
+        if (stats_on_ && st_lat_n_)
+            fprintf(stderr, "foa_stream: a batch's way through the submitter, us on average over %lld batches (the first 64 left out): closed -> staging starts %.1f (of which until its last sample was narrowed %.1f), staging calls %.1f, "
+                            "upload + pre-sync until seen %.1f, decode calls %.1f, decode until collected %.1f\n", (long long)st_lat_n_,
+                    st_lat_[0] * 1e-3 / st_lat_n_, st_lat_[5] * 1e-3 / st_lat_n_, st_lat_[1] * 1e-3 / st_lat_n_, st_lat_[2] * 1e-3 / st_lat_n_, st_lat_[3] * 1e-3 / st_lat_n_, st_lat_[4] * 1e-3 / st_lat_n_);
     }
     StreamCore(const StreamCore &) = delete;
     StreamCore &operator=(const StreamCore &) = delete;
@@ -108,7 +114,7 @@ public:
         int rc = 0;
         while (n && !rc) {
             if (fill_ == 0 && (rc = wait_for_slot())) break;
-            const int slot = (int)(batch_ % kSlots);
+            const int slot = (int)(batch_ % slots_);
             const size_t take = (size_t)std::min<int64_t>((int64_t)n, B_ - fill_);
             Task t;
             t.src = iq; t.is_double = sizeof(T) == sizeof(double); t.dst = be_->staging(slot) + 2 * fill_; t.n = take; t.slot = slot; t.owner = own; t.landed = nullptr;
@@ -283,7 +289,7 @@ private:
         if (landed) landed->fetch_add((int64_t)t.n, std::memory_order_release);
         // the submitter sleeps (with a time-out) until the oldest closed batch is complete: nudge it when a batch's last sample lands
         const int64_t need = need_[t.slot].load(std::memory_order_acquire);
-        if (need >= 0 && now >= need) cv_sub_.notify_all();
+        if (need >= 0 && now >= need) { if (stats_on_) st_landed_[t.slot].store(now_ns(), std::memory_order_relaxed); cv_sub_.notify_all(); }
     }
     // a large push without ownership: the helpers share it, the caller waits until it is through
     void split_and_wait(const Task &t)
@@ -389,11 +395,11 @@ private:
         publish();
         const int64_t w0 = stats_on_ ? now_ns() : 0;
         std::unique_lock<std::mutex> lk(m_);
-        cv_room_.wait(lk, [this] { return stop_.load() || error_ || batch_ - submitted_ < kSlots; });
+        cv_room_.wait(lk, [this] { return stop_.load() || error_ || batch_ - submitted_ < slots_; });
         if (stats_on_) st_wait_slot_ns_ += now_ns() - w0;
         if (error_) return error_;
-        done_[batch_ % kSlots].store(0, std::memory_order_relaxed);
-        need_[batch_ % kSlots].store(-1, std::memory_order_release);
+        done_[batch_ % slots_].store(0, std::memory_order_relaxed);
+        need_[batch_ % slots_].store(-1, std::memory_order_release);
         return 0;
     }
     void close_batch(bool final)
@@ -401,22 +407,28 @@ private:
         publish();
         {
             std::lock_guard<std::mutex> lk(m_);
-            need_[batch_ % kSlots].store(fill_, std::memory_order_release);
-            final_[batch_ % kSlots] = final;
+            need_[batch_ % slots_].store(fill_, std::memory_order_release);
+            final_[batch_ % slots_] = final;
+            if (stats_on_) st_closed_[batch_ % slots_] = now_ns();
             closed_ = batch_ + 1;
         }
         cv_sub_.notify_all();
         batch_++;
         fill_ = 0;
     }
-    struct Staged { int slot; int64_t n_new; bool final; };
+    struct Staged { int slot; int64_t n_new; bool final; int64_t t_staged; };
     void submitter_loop()
     {
+#ifdef __linux__
+        // timed waits of this thread end when they are due: the default timer slack (50 us) is more than the waits themselves
+        (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);
+#endif
         std::deque<uint64_t> flight;
         std::deque<Staged> staged;
         int64_t staged_n = 0;                                        // batches staged so far (this thread only)
         bool tidy = false, had_left = false;
         uint64_t seen_seq = 0;
+        int64_t last_active = now_ns();                              // a batch was staged, submitted or collected (spin_ns_)
         for (;;) {
             int slot = -1;
             int64_t n_new = 0;
@@ -426,13 +438,22 @@ private:
                 for (;;) {
                     if (stop_.load()) return;
                     if (staged_n < closed_) {
-                        const int s = (int)(staged_n % kSlots);
+                        const int s = (int)(staged_n % slots_);
                         const int64_t need = need_[s].load(std::memory_order_acquire);
                         if (done_[s].load(std::memory_order_acquire) >= need) { slot = s; n_new = need; final = final_[s]; break; }
                     }
                     // (timed: a helper's nudge can fall between the test above and the wait; shorter while an upload or a batch is in flight)
                     const bool busy = !staged.empty() || !flight.empty();
-                    cv_sub_.wait_until(lk, std::chrono::system_clock::now() + std::chrono::microseconds(busy ? 40 : 200));   // (system clock: pthread_cond_timedwait, which ThreadSanitizer knows)
+                    // A stream of SMALL batches does not let this thread sleep while it is live: a sleeping thread takes 100-200 us to come
+                    // back on the machines measured (a batch closed while it slept was staged 115-210 us later, one closed while it
+                    // polled 35; profiles/r06_latency_stages.txt), which is a fifth of such a batch's whole way.  It polls -- a turn of this
+                    // loop is about a microsecond -- until nothing has happened for spin_ns_, then sleeps as above.
+                    if (spin_ns_ > 0 && now_ns() - last_active < spin_ns_) {
+                        lk.unlock();
+                        for (int k = 0; k < 32; k++) cpu_relax();
+                        lk.lock();
+                    } else
+                    cv_sub_.wait_until(lk, std::chrono::system_clock::now() + std::chrono::microseconds(busy ? 20 : 200));   // (system clock: pthread_cond_timedwait, which ThreadSanitizer knows)
                     // the caller's leftovers: cells it has written but not published, buffers parked for it to release.  Both are the
                     // caller's to deal with at its next call -- unless there is none: leftovers seen at two wake-ups in a row with no call
                     // in between (>= 40 us) are dealt with here
@@ -446,21 +467,27 @@ private:
             if (tidy) { publish(); release_parked(); tidy = false; }
             int rc = 0;
             if (slot >= 0) {
+                last_active = now_ns();
                 // a device buffer is written again kSlots batches later: at most kSlots - 1 batches staged or in flight, the one
                 // about to be staged included
-                while (!rc && (int)(staged.size() + flight.size()) >= kSlots - 1) {
+                while (!rc && (int)(staged.size() + flight.size()) >= slots_ - 1) {
                     if (flight.empty()) rc = submit_front(staged, flight);
                     else rc = collect_one(flight, true) < 0 ? -1 : 0;
                 }
+                const int64_t s0 = stats_on_ ? now_ns() : 0;
                 if (!rc) rc = be_->stage(slot, n_new, final);
                 staged_n++;
-                if (!rc) staged.push_back(Staged{ slot, n_new, final });
+                const int64_t s1 = stats_on_ ? now_ns() : 0;
+                if (stats_on_ && staged_n > kStatSkip) { st_lat_[0] += s0 - st_closed_[slot]; st_lat_[1] += s1 - s0; st_lat_[5] += std::max<int64_t>(0, st_landed_[slot].load(std::memory_order_relaxed) - st_closed_[slot]); st_landed_[slot].store(0, std::memory_order_relaxed); }
+                if (!rc) staged.push_back(Staged{ slot, n_new, final, s1 });
                 else fail_batch(rc);
             }
             // the oldest staged batch goes out once its samples are on the device
+            const size_t in_hand = staged.size() + 2 * flight.size();
             while (!staged.empty() && be_->uploaded(staged.front().slot)) (void)submit_front(staged, flight);
             // hand finished batches over as they complete (polling: a batch that becomes ready to stage must not wait for the GPU)
             while (!flight.empty() && collect_one(flight, false) > 0) {}
+            if (spin_ns_ > 0 && staged.size() + 2 * flight.size() != in_hand) last_active = now_ns();
         }
     }
     // a batch that could not be staged or submitted still counts as submitted (the caller waits for its staging slot) and as
@@ -476,9 +503,11 @@ private:
         const Staged s = staged.front();
         staged.pop_front();
         uint64_t h = 0;
+        const int64_t u0 = stats_on_ ? now_ns() : 0;
         const int rc = be_->submit(s.slot, s.n_new, s.final, &h);
         if (rc) { fail_batch(rc); return rc; }
         flight.push_back(h);
+        if (stats_on_) { const int64_t u1 = now_ns(); if (st_submits_++ >= kStatSkip) { st_lat_[2] += u0 - s.t_staged; st_lat_[3] += u1 - u0; } st_submitted_.push_back(u1); }
         { std::lock_guard<std::mutex> lk(m_); submitted_++; }
         cv_room_.notify_all();
         cv_ready_.notify_all();
@@ -490,8 +519,9 @@ private:
         const int rc = be_->collect(flight.front(), wait, &r);
         if (rc == 0) return 0;
         std::lock_guard<std::mutex> lk(m_);
-        if (rc < 0) { if (!error_) { error_ = rc; error_flag_.store(rc, std::memory_order_release); } flight.pop_front(); collected_++; cv_ready_.notify_all(); return rc; }
+        if (rc < 0) { if (!error_) { error_ = rc; error_flag_.store(rc, std::memory_order_release); } flight.pop_front(); collected_++; cv_ready_.notify_all(); if (!st_submitted_.empty()) st_submitted_.pop_front(); return rc; }
         flight.pop_front();
+        if (stats_on_ && !st_submitted_.empty()) { if (st_collects_++ >= kStatSkip) { st_lat_[4] += now_ns() - st_submitted_.front(); st_lat_n_++; } st_submitted_.pop_front(); }
         ready_.push_back(std::move(r));
         ready_n_.fetch_add(1, std::memory_order_acq_rel);
         collected_++;
@@ -501,6 +531,8 @@ private:
 
     Backend *be_;
     const int64_t B_;
+    const int64_t spin_ns_;                          // the submitter polls instead of sleeping until nothing has happened for this long (0: it sleeps)
+    const int slots_;                                // staging slots (= the backend's device buffers) in rotation
     // caller-side state
     int64_t batch_ = 0, fill_ = 0, pushed_ = 0;
     bool finished_ = false;
@@ -524,6 +556,11 @@ public:
     const bool stats_on_ = getenv("FOA_STREAM_STATS") != nullptr;
     int64_t st_push_ns_ = 0, st_wait_slot_ns_ = 0, st_inline_ = 0, st_pushes_ = 0;
     std::atomic<int64_t> st_helper_ns_{ 0 }, st_helper_tasks_{ 0 };
+    int64_t st_closed_[kSlots] = {}, st_lat_[6] = {}, st_lat_n_ = 0;
+    std::atomic<int64_t> st_landed_[kSlots] = {};     // a batch's way through the submitter (closed_ under the lock; the rest submitter only)
+    std::deque<int64_t> st_submitted_;
+    int64_t st_submits_ = 0, st_collects_ = 0;
+    static constexpr int64_t kStatSkip = 64;         // the first batches wait for the runtime to load the kernels (~0.25 s): not the stream's steady state
 private:
     std::atomic<int> ready_n_{ 0 };                  // = ready_.size(), readable without the lock
     std::atomic<Owner *> parked_{ nullptr };         // owners whose last reference a helper dropped: released by the caller

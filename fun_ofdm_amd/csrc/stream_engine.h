@@ -45,7 +45,7 @@ namespace foa {
 
 constexpr int64_t kStreamLongest = 110592;          // >= 320 + 80 * 1369 (4095 bytes at 6 Mbps) + 32 + timing_sync's 160-sample look-ahead
 constexpr int64_t kStreamCarry = kStreamLongest + 2048;
-constexpr int kStreamBufs = 6;                      // device sample buffers / pinned staging buffers in rotation (= StreamCore::kSlots)
+constexpr int kStreamBufs = 12;                     // at most this many device sample buffers / pinned staging buffers in rotation (= StreamCore::kSlots); a stream uses n_bufs of them
 
 }  // namespace foa
 
@@ -131,6 +131,7 @@ static int stream_collect_job(foa_rx *rx, uint64_t ticket, size_t n_frames, bool
 struct StreamGpu {
     foa_rx *rx = nullptr;
     int64_t B = 0;                                   // batch_samples
+    int n_bufs = 6;                                  // buffers in rotation (foa_stream_create)
     int64_t L = foa::kStreamLongest, C = foa::kStreamCarry;      // longest frame the stream may hold (+ look-ahead) and the carry it implies (option "stream_longest")
     size_t slot_bytes = 4096;
     float *pin[foa::kStreamBufs] = {};               // page-locked staging, B float2 each
@@ -183,7 +184,7 @@ struct StreamGpu {
     }
     int stage_impl(int k, int64_t n_new, bool final)
     {
-        const int kp = (k + foa::kStreamBufs - 1) % foa::kStreamBufs;
+        const int kp = (k + n_bufs - 1) % n_bufs;
         HIP_TRY(enter_device(rx->device));
         float *d = dev[k].p;
         if (n_staged == 0) HIP_TRY(hipMemsetAsync(d, 0, (size_t)C * 8, st_in));                     // silence before the stream
@@ -309,8 +310,14 @@ int foa_stream_create(foa_rx *rx, size_t batch_samples, int narrow_threads, foa_
     g.B = (int64_t)batch_samples;
     if (rx->stream_longest > 0) { g.L = rx->stream_longest; g.C = g.L + 2048; }
     g.desc_cap = (size_t)((g.C + g.B) / 300 + 64);
+    // Batches in rotation: a batch is about a millisecond on its way whatever its size (upload, pre-sync, the host's look at the count, a
+    // decode call whose forward pass walks the longest frame's trellis at the lone-wave rate), so batches that arrive every 0.2-0.8 ms
+    // -- 4 .. 16 Ki samples at 20 Msample/s -- need more than six of them on their way at once; with six the submitter stood waiting for the
+    // oldest batch before it could stage the newest (0.25 ms of a 4 Ki batch's 1.2, profiles/r06_latency_stages.txt).  FOA_STREAM_BUFS overrides (A/B).
+    g.n_bufs = batch_samples <= ((size_t)1 << 16) ? foa::kStreamBufs : 6;
+    if (const char *e = getenv("FOA_STREAM_BUFS")) { const int v = atoi(e); if (v >= 3 && v <= foa::kStreamBufs) g.n_bufs = v; }
     int rc = FOA_OK;
-    for (int i = 0; i < foa::kStreamBufs && !rc; i++) {
+    for (int i = 0; i < g.n_bufs && !rc; i++) {
         if (hipHostMalloc((void **)&g.pin[i], (size_t)g.B * 8, hipHostMallocDefault) != hipSuccess) rc = fail(FOA_E_NOMEM, "hipHostMalloc of a %zu-byte staging buffer failed", (size_t)g.B * 8);
         if (!rc) rc = g.dev[i].ensure((size_t)(g.C + g.B) * 2);
         if (!rc) rc = g.d_desc[i].ensure(g.desc_cap * sizeof(foa_frame_desc));
@@ -360,7 +367,10 @@ int foa_stream_create(foa_rx *rx, size_t batch_samples, int narrow_threads, foa_
     rx->depth_saved = rx->depth;
     rx->depth = (batch_samples <= ((size_t)1 << 20) && rx->max_depth >= 4) ? 4 : 2;
     if (const char *e = getenv("FOA_STREAM_DEPTH")) { const int v = atoi(e); if (v >= 2 && v <= 4) rx->depth = v; }
-    s->core = new foa::StreamCore<StreamGpu>(&g, g.B, narrow_threads);
+    // (and the submitter thread of such a stream polls instead of sleeping while batches keep coming: stream_core.h; FOA_STREAM_SPIN_US overrides, 0 = it sleeps)
+    int spin_us = batch_samples <= ((size_t)1 << 16) ? 2000 : 0;
+    if (const char *e = getenv("FOA_STREAM_SPIN_US")) { const int v = atoi(e); if (v >= 0 && v <= 1000000) spin_us = v; }
+    s->core = new foa::StreamCore<StreamGpu>(&g, g.B, narrow_threads, g.n_bufs, spin_us);
     rx->open_stream = s;
     *out = s;
     return FOA_OK;

@@ -268,6 +268,39 @@ __device__ __forceinline__ uint32_t fwd3_group(uint32_t M, const uint4 *bml, con
     return M;
 }
 
+// The same six steps for a wave that has its SIMD to itself (one frame per wave): the increments of the group AFTER this one (entries
+// ENEXT .., -1: none) are read before the group's own steps, which use the ones the group before fetched (w) -- a lone wave has nobody to
+// hide an LDS round trip behind, and with the reads at the head of their own group it stood still for one every six steps (forward pass
+// of 16 .. 256 frames of 1 024 bytes at 54 Mbps: 0.445 -> 0.430 ms; with five waves to a SIMD the same change bought nothing, HISTORY.md).
+// (Tried on top of it and dropped, round 6: the six steps run WITHOUT the renormalisation test, state 0's largest metric of the group
+// tested once behind them and the group run again step by step when it fires -- a renormalisation is due every ~9 steps at 54 Mbps, so
+// half the groups run twice: 0.52 ms.)
+template <int E0, int J0, int ENEXT, typename Flush>
+__device__ __forceinline__ uint32_t fwd3_group_ahead(uint32_t M, const uint4 *bml, const Fwd3Lane &c, uint32_t (&acc)[2], uint2 (&w)[6], const Flush &flush)
+{
+    uint2 n[6] = {};
+    if constexpr (ENEXT >= 0) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) n[i] = fwd3_inc(bml, ENEXT + i, c.ofs[i]);
+    }
+    M = fwd3_step<1, 0, J0 + 0>(M, w[0], acc, 0);
+    if constexpr (((J0 + 0) & 15) == 15) flush((J0 + 0) >> 4);
+    M = fwd3_step<1, 1, J0 + 1>(M, w[1], acc, 0);
+    if constexpr (((J0 + 1) & 15) == 15) flush((J0 + 1) >> 4);
+    M = fwd3_step<1, 2, J0 + 2>(M, w[2], acc, 0);
+    if constexpr (((J0 + 2) & 15) == 15) flush((J0 + 2) >> 4);
+    M = fwd3_step<1, 3, J0 + 3>(M, w[3], acc, 0);
+    if constexpr (((J0 + 3) & 15) == 15) flush((J0 + 3) >> 4);
+    M = fwd3_step<1, 4, J0 + 4>(M, w[4], acc, 0);
+    if constexpr (((J0 + 4) & 15) == 15) flush((J0 + 4) >> 4);
+    M = fwd3_step<1, 5, J0 + 5>(M, w[5], acc, 0);
+    if constexpr (((J0 + 5) & 15) == 15) flush((J0 + 5) >> 4);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 6; i++) w[i] = n[i];
+    return M;
+}
+
 template <int kPair>
 __device__ __forceinline__ uint32_t fwd3_step_dyn(uint32_t M, int j, const uint4 *bml, const Fwd3Lane &c, uint32_t (&acc)[2])
 {
@@ -393,7 +426,15 @@ __global__ __launch_bounds__(64 * kFwdWaves) void k_viterbi_fwd3(const FrameInfo
         get(n0 + kChunk3 + 6);
         if (n0 > 0) store_block(n0 - 16, late);
         n_chunk = n0;
-        if (nn == kChunk3) {
+        if (kPair == 1 && nn == kChunk3) {
+            uint2 w[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) w[i] = fwd3_inc(bml, i, c.ofs[i]);
+            M = fwd3_group_ahead<0, 0, 6>(M, bml, c, acc, w, flush);    M = fwd3_group_ahead<6, 6, 12>(M, bml, c, acc, w, flush);
+            M = fwd3_group_ahead<12, 12, 18>(M, bml, c, acc, w, flush); M = fwd3_group_ahead<18, 18, 24>(M, bml, c, acc, w, flush);
+            M = fwd3_group_ahead<24, 24, 30>(M, bml, c, acc, w, flush); M = fwd3_group_ahead<30, 30, 36>(M, bml, c, acc, w, flush);
+            M = fwd3_group_ahead<36, 36, 42>(M, bml, c, acc, w, flush); M = fwd3_group_ahead<42, 42, -1>(M, bml, c, acc, w, flush);
+        } else if (nn == kChunk3) {
             M = fwd3_group<kPair, 0, 0>(M, bml, c, acc, flush);   M = fwd3_group<kPair, 6, 6>(M, bml, c, acc, flush);   M = fwd3_group<kPair, 12, 12>(M, bml, c, acc, flush);
             M = fwd3_group<kPair, 18, 18>(M, bml, c, acc, flush); M = fwd3_group<kPair, 24, 24>(M, bml, c, acc, flush); M = fwd3_group<kPair, 30, 30>(M, bml, c, acc, flush);
             M = fwd3_group<kPair, 36, 36>(M, bml, c, acc, flush); M = fwd3_group<kPair, 42, 42>(M, bml, c, acc, flush);

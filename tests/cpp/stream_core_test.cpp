@@ -61,7 +61,7 @@ struct FakeGpu {
 static std::atomic<int> g_released(0);
 static void release_vec(void *p) { g_released++; delete (std::vector<double> *)p; }
 
-static void run(int64_t B, int helpers, size_t total, unsigned seed, size_t max_push)
+static void run(int64_t B, int helpers, size_t total, unsigned seed, size_t max_push, int slots = 6, int spin_us = 0)
 {
     std::mt19937 rng(seed);
     std::vector<double> src(2 * total);
@@ -72,7 +72,7 @@ static void run(int64_t B, int helpers, size_t total, unsigned seed, size_t max_
     int handed = 0;
     g_released = 0;
     {
-        foa::StreamCore<FakeGpu> core(&gpu, B, helpers);
+        foa::StreamCore<FakeGpu> core(&gpu, B, helpers, slots, spin_us);
         auto drain = [&](bool wait) {
             foa::StreamReady r;
             while (core.take(wait, &r) == 1) { int64_t n; memcpy(&n, r.bytes.data(), 8); batches.push_back(n); r = foa::StreamReady(); }
@@ -106,7 +106,7 @@ static void run(int64_t B, int helpers, size_t total, unsigned seed, size_t max_
     const size_t want_batches = total / B + 1;
     CHECK(batches.size() == want_batches, "%zu batches came back, expected %zu", batches.size(), want_batches);
     for (size_t k = 0; k < batches.size(); k++) CHECK(batches[k] == (k + 1 < want_batches ? B : (int64_t)(total % B)), "batch %zu has %lld samples", k, (long long)batches[k]);
-    printf("B %lld, %d helpers, %zu samples, pushes up to %zu: %zu batches, %d buffers handed over\n", (long long)B, helpers, total, max_push, batches.size(), handed);
+    printf("B %lld, %d helpers, %d slots, %zu samples, pushes up to %zu: %zu batches, %d buffers handed over\n", (long long)B, helpers, slots, total, max_push, batches.size(), handed);
 }
 
 int main()
@@ -116,6 +116,9 @@ int main()
     run(65536, 4, 2000000, 3, 300000);      // pushes larger than a batch, large borrowed pushes shared with the helpers
     run(8192, 2, 500000, 4, 100);           // many tiny pushes
     run(5000, 1, 65000, 5, 20000);          // total a multiple of the batch: the final batch is empty
+    run(4096, 3, 400000, 6, 9000, 12);      // twelve slots in rotation (streams of small batches)
+    run(4096, 1, 100000, 7, 5000, 3);       // three
+    run(4096, 2, 300000, 8, 6000, 12, 300); // a submitter that polls for 300 us after the last batch before it sleeps
     {   // an error on the submitter thread reaches the caller
         FakeGpu gpu(4096);
         gpu.fail_at = 2;
