@@ -335,8 +335,10 @@ int foa_rx_submit_host_ctx(foa_rx *rx, const float *iq, size_t n_samples, const 
     if (n_frames == 0 || !iq || !descs || !ends) return fail(FOA_E_INVALID, "empty call or NULL pointer");
     HIP_TRY(enter_device(rx->device));
     HostJob *job = nullptr;
-    for (auto &j : rx->jobs) if (!j.busy) { job = &j; break; }
-    if (!job) return fail(FOA_E_STATE, "%d calls are in flight: collect the oldest first", kMaxJobs);
+    int n_busy = 0;
+    for (auto &j : rx->jobs) { if (j.busy) n_busy++; else if (!job) job = &j; }
+    // (the documented limit of this entry point; the slots beyond it are the stream engines', which keep more small batches in flight)
+    if (!job || n_busy >= kMaxHostCalls) return fail(FOA_E_STATE, "%d calls are in flight: collect the oldest first", kMaxHostCalls);
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t n_all = n_frames + n_context;
     const size_t o_iq = 0, o_desc = o_iq + up(n_samples * 8), o_end = o_desc + up(n_all * sizeof(foa_frame_desc)), o_psdu = o_end + up(n_all * 8),

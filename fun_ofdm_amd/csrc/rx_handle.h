@@ -99,6 +99,7 @@ struct HostJob {
     hipEvent_t done = nullptr;
     bool copy_queued = false;
 };
+constexpr int kMaxHostCalls = 8;                  // foa_rx_submit_host: calls in flight (include/fun_ofdm_amd.h)
 constexpr int kMaxJobs = 12;                      // >= kStreamBufs - 1: a stream of small batches keeps that many decode calls in flight
 constexpr int kSets = 6;
 
