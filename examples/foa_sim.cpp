@@ -126,7 +126,8 @@ int main(int argc, char **argv)
                                                                              : new fun_amd::receiver_chain(devices, device_batch, narrow_threads));
             fun_amd::receiver_chain &chain = *chain_p;
             if (longest > 0) chain.set_stream_longest(longest);
-            chain.process_samples(std::vector<std::complex<double> >(512));            // creates the handle outside the timed loop
+            chain.prepare();                                                           // the handle and the engine come into being outside the timed loop
+            chain.process_samples(std::vector<std::complex<double> >(512));            // (and a first call: 512 samples of silence)
             // ... and the engine's pipeline: W batches' worth of the capture's own first samples (a copy), then silence until their payloads
             // have all come back, before the clock starts -- so that the timed loop meets threads that are on their cores, buffers that have been
             // touched and kernels that have been launched before (silence alone decodes nothing: the first real batches then paid ~15 ms of

@@ -14,6 +14,7 @@
 // acquire) -- and on the slot rotation: the caller may run at most kSlots - 1 batches ahead of the submitter.
 #pragma once
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -79,10 +80,13 @@ public:
             fprintf(stderr, "foa_stream: caller ms in push %.1f (%lld pushes, of which waiting for a staging slot %.1f; %lld tasks narrowed by the caller); "
                             "%d helpers: %lld tasks, %.1f ms busy in total\n", st_push_ns_ * 1e-6, (long long)st_pushes_, st_wait_slot_ns_ * 1e-6,
                     (long long)st_inline_, (int)helpers_.size(), (long long)st_helper_tasks_.load(), st_helper_ns_.load() * 1e-6);
-        if (stats_on_ && st_lat_n_)
-            fprintf(stderr, "foa_stream: a batch's way through the submitter, us on average over %lld batches (the first 64 left out): closed -> staging starts %.1f (of which until its last sample was narrowed %.1f), staging calls %.1f, "
-                            "upload + pre-sync until seen %.1f, decode calls %.1f, decode until collected %.1f\n", (long long)st_lat_n_,
-                    st_lat_[0] * 1e-3 / st_lat_n_, st_lat_[5] * 1e-3 / st_lat_n_, st_lat_[1] * 1e-3 / st_lat_n_, st_lat_[2] * 1e-3 / st_lat_n_, st_lat_[3] * 1e-3 / st_lat_n_, st_lat_[4] * 1e-3 / st_lat_n_);
+        if (stats_on_ && !st_lat_[4].empty()) {
+            // medians: a harness's warm-up (batches pushed as fast as they are taken) and the first launches are not the stream's steady state
+            auto med = [](std::vector<int64_t> &v) { if (v.empty()) return 0.0; std::nth_element(v.begin(), v.begin() + v.size() / 2, v.end()); return v[v.size() / 2] * 1e-3; };
+            fprintf(stderr, "foa_stream: a batch's way through the submitter, median us over %zu batches: closed -> staging starts %.1f (its last sample narrowed %.1f), staging calls %.1f, "
+                            "upload + pre-sync until seen %.1f, decode calls %.1f, decode until collected %.1f\n", st_lat_[4].size(),
+                    med(st_lat_[0]), med(st_lat_[5]), med(st_lat_[1]), med(st_lat_[2]), med(st_lat_[3]), med(st_lat_[4]));
+        }
     }
     StreamCore(const StreamCore &) = delete;
     StreamCore &operator=(const StreamCore &) = delete;
@@ -478,7 +482,7 @@ private:
                 if (!rc) rc = be_->stage(slot, n_new, final);
                 staged_n++;
                 const int64_t s1 = stats_on_ ? now_ns() : 0;
-                if (stats_on_ && staged_n > kStatSkip) { st_lat_[0] += s0 - st_closed_[slot]; st_lat_[1] += s1 - s0; st_lat_[5] += std::max<int64_t>(0, st_landed_[slot].load(std::memory_order_relaxed) - st_closed_[slot]); st_landed_[slot].store(0, std::memory_order_relaxed); }
+                if (stats_on_) { st_lat_[0].push_back(s0 - st_closed_[slot]); st_lat_[1].push_back(s1 - s0); st_lat_[5].push_back(std::max<int64_t>(0, st_landed_[slot].load(std::memory_order_relaxed) - st_closed_[slot])); st_landed_[slot].store(0, std::memory_order_relaxed); }
                 if (!rc) staged.push_back(Staged{ slot, n_new, final, s1 });
                 else fail_batch(rc);
             }
@@ -507,7 +511,7 @@ private:
         const int rc = be_->submit(s.slot, s.n_new, s.final, &h);
         if (rc) { fail_batch(rc); return rc; }
         flight.push_back(h);
-        if (stats_on_) { const int64_t u1 = now_ns(); if (st_submits_++ >= kStatSkip) { st_lat_[2] += u0 - s.t_staged; st_lat_[3] += u1 - u0; } st_submitted_.push_back(u1); }
+        if (stats_on_) { const int64_t u1 = now_ns(); st_lat_[2].push_back(u0 - s.t_staged); st_lat_[3].push_back(u1 - u0); st_submitted_.push_back(u1); }
         { std::lock_guard<std::mutex> lk(m_); submitted_++; }
         cv_room_.notify_all();
         cv_ready_.notify_all();
@@ -521,7 +525,7 @@ private:
         std::lock_guard<std::mutex> lk(m_);
         if (rc < 0) { if (!error_) { error_ = rc; error_flag_.store(rc, std::memory_order_release); } flight.pop_front(); collected_++; cv_ready_.notify_all(); if (!st_submitted_.empty()) st_submitted_.pop_front(); return rc; }
         flight.pop_front();
-        if (stats_on_ && !st_submitted_.empty()) { if (st_collects_++ >= kStatSkip) { st_lat_[4] += now_ns() - st_submitted_.front(); st_lat_n_++; } st_submitted_.pop_front(); }
+        if (stats_on_ && !st_submitted_.empty()) { st_lat_[4].push_back(now_ns() - st_submitted_.front()); st_submitted_.pop_front(); }
         ready_.push_back(std::move(r));
         ready_n_.fetch_add(1, std::memory_order_acq_rel);
         collected_++;
@@ -556,11 +560,10 @@ public:
     const bool stats_on_ = getenv("FOA_STREAM_STATS") != nullptr;
     int64_t st_push_ns_ = 0, st_wait_slot_ns_ = 0, st_inline_ = 0, st_pushes_ = 0;
     std::atomic<int64_t> st_helper_ns_{ 0 }, st_helper_tasks_{ 0 };
-    int64_t st_closed_[kSlots] = {}, st_lat_[6] = {}, st_lat_n_ = 0;
+    int64_t st_closed_[kSlots] = {};
+    std::vector<int64_t> st_lat_[6];                 // per batch, ns: closed -> staging, staging calls, upload until seen, decode calls, decode until collected, closed -> narrowed
     std::atomic<int64_t> st_landed_[kSlots] = {};     // a batch's way through the submitter (closed_ under the lock; the rest submitter only)
     std::deque<int64_t> st_submitted_;
-    int64_t st_submits_ = 0, st_collects_ = 0;
-    static constexpr int64_t kStatSkip = 64;         // the first batches wait for the runtime to load the kernels (~0.25 s): not the stream's steady state
 private:
     std::atomic<int> ready_n_{ 0 };                  // = ready_.size(), readable without the lock
     std::atomic<Owner *> parked_{ nullptr };         // owners whose last reference a helper dropped: released by the caller

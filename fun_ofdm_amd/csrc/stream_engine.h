@@ -312,8 +312,8 @@ int foa_stream_create(foa_rx *rx, size_t batch_samples, int narrow_threads, foa_
     g.desc_cap = (size_t)((g.C + g.B) / 300 + 64);
     // Batches in rotation: a batch is about a millisecond on its way whatever its size (upload, pre-sync, the host's look at the count, a
     // decode call whose forward pass walks the longest frame's trellis at the lone-wave rate), so batches that arrive every 0.2-0.8 ms
-    // -- 4 .. 16 Ki samples at 20 Msample/s -- need more than six of them on their way at once; with six the submitter stood waiting for the
-    // oldest batch before it could stage the newest (0.25 ms of a 4 Ki batch's 1.2, profiles/r06_latency_stages.txt).  FOA_STREAM_BUFS overrides (A/B).
+    // -- 4 .. 16 Ki samples at 20 Msample/s -- need more than six of them on their way at once; with six -- five staged or in flight -- the engine's capacity at 4 Ki
+    // samples is 23 Msample/s, and a backlog, once there, drains at 3 while the caller waits for staging slots (profiles/r06_latency_stages.txt).  FOA_STREAM_BUFS overrides (A/B).
     g.n_bufs = batch_samples <= ((size_t)1 << 16) ? foa::kStreamBufs : 6;
     if (const char *e = getenv("FOA_STREAM_BUFS")) { const int v = atoi(e); if (v >= 3 && v <= foa::kStreamBufs) g.n_bufs = v; }
     int rc = FOA_OK;

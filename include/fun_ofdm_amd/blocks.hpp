@@ -444,6 +444,18 @@ public:
         check(foa_rx_set_option(dev_.get(), "max_dbps", dbps), "foa_rx_set_option");
     }
 
+    // Brings the device handle -- and, in device mode, the stream engine with its threads, page-locked buffers and work sets -- into being
+    // NOW instead of under the first process_samples() call: creating a handle takes ~0.2 s (the runtime loads the library's kernels), in
+    // which a live radio's samples would pile up.  After the set_* options (they must precede the engine); idempotent.  (The reference's
+    // chain builds its blocks in its constructor, src/receiver_chain.cpp:32-74; here the options come in between.)
+    void prepare()
+    {
+        if (device_batch_ == 0) { (void)dev_.get(); return; }
+        if (stream_over_) return;                                       // after a flush: the next call starts a new stream
+        if (!devices_.empty()) { if (!shard_) check(foa_shard_create(devices_.data(), (int)devices_.size(), device_batch_, narrow_threads_, &shard_), "foa_shard_create"); }
+        else if (!stream_) check(foa_stream_create(dev_.get(), device_batch_, narrow_threads_, &stream_), "foa_stream_create");
+    }
+
     // Same signature and meaning as fun::receiver_chain::process_samples (src/receiver_chain.cpp:106-126): feed the
     // next chunk of the 20 MS/s stream, get the payloads of the frames that completed, in stream order.  A frame is
     // returned by the call that delivers its last sample (the reference returns it five calls later).

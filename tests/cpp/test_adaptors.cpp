@@ -156,6 +156,8 @@ int main()
     // ---- 2b. receiver_chain in asynchronous batches: the same payloads, in order, a few calls later ----
     for (int k : { 1, 3, 8 }) {
         fun_amd::receiver_chain rc(0, k);
+        rc.prepare();                                 // (the handle now, not under the first call; idempotent)
+        rc.prepare();
         payloads_t got;
         int calls_with_output = 0;
         for (size_t x = 0; x < stream.size(); x += chunk) {
