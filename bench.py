@@ -790,6 +790,18 @@ def roofline(args, kms, n_real, ms_per_step, piped, probe, space=None):
                            "frac": round(ach / probe["pk_u16"]["wave_instr_per_s"], 4),
                            "what": "VALU wave-instructions of the forward pass (count from profiles/, above) / %s against the live-probed issue rate of "
                                    "packed instructions" % ("ms_per_step" if piped else "launch duration")}
+    if nv and probe:
+        # the whole decode call on the vector pipes: SQ_ACTIVE_INST_VALU counts quad-cycles, x 4 = the cycles a SIMD's pipe is busy
+        call = [_profile_json("_pmc_sq.json", "per_launch", k, args.frames, "SQ_ACTIVE_INST_VALU")
+                for k in ("k_header", "k_scan_sums", "k_scan_blocks_w", "k_scan_apply", "k_data_symbols_q4", fwd_kernel, "k_tb_walk", "k_tb_finish")]
+        if all(call):
+            busy_ms = 4.0 * sum(c[0] for c in call) / N_SIMD / (probe["pk_u16"]["ghz"] * 1e9) * 1e3
+            r["valu_busy_call_ms"] = round(busy_ms, 4)
+            r["valu_busy_call_frac_of_step"] = round(busy_ms / (t_step * 1e3), 4)
+            r["valu_call"] = {"busy_ms": round(busy_ms, 4), "frac_of_step": round(busy_ms / (t_step * 1e3), 4), "file": call[0][1],
+                              "what": "sum over the decode call's kernels (header, scans, data symbols, forward pass, walk, finish) of SQ_ACTIVE_INST_VALU x 4 cycles, "
+                                      "per SIMD, at the live-probed clock: the time the vector pipes need for one call's instructions -- the floor of the "
+                                      "pipelined step whatever the schedule (DESIGN 4); the counts are from profiles/, the clock and the step are live"}
     # HBM: algorithmic bytes of this kernel = one soft pair (2 bytes) in, 64 decision bits out per trellis step
     alg_bytes = steps * (2 + 8)
     r["traffic"] = int(tr[0]) if tr else None

@@ -369,6 +369,10 @@ int foa_stream_create(foa_rx *rx, size_t batch_samples, int narrow_threads, foa_
     if (const char *e = getenv("FOA_STREAM_DEPTH")) { const int v = atoi(e); if (v >= 2 && v <= 4) rx->depth = v; }
     // (and the submitter thread of such a stream polls instead of sleeping while batches keep coming: stream_core.h; FOA_STREAM_SPIN_US overrides, 0 = it sleeps)
     int spin_us = batch_samples <= ((size_t)1 << 16) ? 2000 : 0;
+    {   // (a process confined to a few CPUs needs them for the caller and the helpers: the submitter sleeps as it always did)
+        cpu_set_t have;
+        if (spin_us && sched_getaffinity(0, sizeof have, &have) == 0 && CPU_COUNT(&have) < 4) spin_us = 0;
+    }
     if (const char *e = getenv("FOA_STREAM_SPIN_US")) { const int v = atoi(e); if (v >= 0 && v <= 1000000) spin_us = v; }
     s->core = new foa::StreamCore<StreamGpu>(&g, g.B, narrow_threads, g.n_bufs, spin_us);
     rx->open_stream = s;

@@ -129,10 +129,10 @@ __global__ __launch_bounds__(64, 3) void k_sync_flags(const float2 *__restrict__
             else { h0 = h0 + p0; h1 = h1 + p1; h2 = h2 + p2; }
             Sx += h0; Sy += h1; P += h2;
         }
-        const double q = Sx * Sx + Sy * Sy, lim = 0.81 * (P * P);
+        const double q = Sx * Sx + Sy * Sy, pp = P * P;
         bool above;
-        if (q > lim * (1.0 + 1e-9)) above = true;
-        else if (q < lim * (1.0 - 1e-9) || P == 0.0) above = false;         // no power: 0/0 or NaN/0, never above
+        if (q > pp * (0.81 * (1.0 + 1e-9))) above = true;                   // (the margins are constants: two multiplies per window less than 0.81 P.P scaled twice)
+        else if (q < pp * (0.81 * (1.0 - 1e-9)) || P == 0.0) above = false; // no power: 0/0 or NaN/0, never above
         else { above = false; slow |= 1u << r; }                             // too close to call, or not finite: settled below
         if (above && i0 + r < n) mask |= 1u << r;
     }
@@ -254,10 +254,11 @@ __global__ __launch_bounds__(64) void k_sync_lts(const float2 *__restrict__ iq, 
     auto at = [&](int64_t i) -> cpx { return (i >= 0 && i < n) ? widen(iq[i]) : cpx{ 0.0, 0.0 }; };
     // the candidate count lives on the device: a fixed grid strides over it, so the host need not learn it in between
     __shared__ double2 win[160];                          // samples x .. x+159 of the candidate, widened once
+    __shared__ double win_pw[160];                        // ... and their |a|^2, rounded as the reference's sum takes it in: every position's power sum adds the same 64 terms
     for (int c = blockIdx.x; c < nc; c += gridDim.x) {
     const int64_t x = cand_x[c];
     __syncthreads();                                      // (one wave) the window of the candidate before is no longer read
-    for (int i = lane; i < 160; i += 64) { const cpx a = at(x + i); win[i] = make_double2(a.x, a.y); }
+    for (int i = lane; i < 160; i += 64) { const cpx a = at(x + i); win[i] = make_double2(a.x, a.y); win_pw[i] = a.x * a.x + a.y * a.y; }
     __syncthreads();
     // corr_norm for p = x + lane and (lanes < 32) p = x + 64 + lane
     double v[2] = { -1.0, -1.0 };
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(64) void k_sync_lts(const float2 *__restrict__ iq, 
             const cpx a = { aw.x, aw.y };
             const cpx m = cmul(a, cpx{ g_tab.lts_conj_re[s], g_tab.lts_conj_im[s] });
             corr.x += m.x; corr.y += m.y;
-            power += a.x * a.x + a.y * a.y;
+            power += win_pw[p + s];
         }
         const double cn = hypot(corr.x, corr.y) / power;
         if (cn > 0.9) v[h] = cn;                         // NaN (no power) fails the test like in the reference

@@ -104,6 +104,8 @@ def test_bench_single_rank_line_has_the_contract_fields():
         assert set(q["kernels"]) >= {"k_data_symbols_q4", "k_viterbi_fwd3", "k_tb_walk + k_tb_finish"}
     assert "k_sync_*" in c5["roofline"]["kernels"] and all(r["max_dbps"] == {0: 24, 2: 36, 3: 48, 5: 72, 6: 96, 8: 144, 9: 192, 10: 216}[r["rate_enum"]] for r in fill)
     assert rf["frac_step_rate"] == rf["frac_at_step_rate"]["frac"] and rf.get("launch_ms", 1.0) > 0      # (launch_*: only with enough steps to read spacings)
+    if "valu_busy_call_frac_of_step" in rf:                        # (counts from profiles/ at this workload size; the clock and the step live)
+        assert 0.3 < rf["valu_busy_call_frac_of_step"] < 1.1 and rf["valu_busy_call_ms"] == rf["valu_call"]["busy_ms"]
 
 
 def test_bench_forced_collective_path_over_rccl_with_one_rank():
