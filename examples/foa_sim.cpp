@@ -132,7 +132,7 @@ int main(int argc, char **argv)
             // have all come back, before the clock starts -- so that the timed loop meets threads that are on their cores, buffers that have been
             // touched and kernels that have been launched before (silence alone decodes nothing: the first real batches then paid ~15 ms of
             // first-launch costs inside the timed region; single runs varied 3.1-4.4 Gsample/s cold).  At least two batches and 8 Mi samples:
-            // small batches go round four lanes, six staging slots and six work sets.
+            // small batches go round four lanes, twelve staging slots and six work sets.
             if (warm_batches < 0) warm_batches = device_batch > 0 ? (int)std::min<size_t>(128, std::max<size_t>(2, ((size_t)8 << 20) / device_batch)) : 0;
             if (warm_batches > 0 && device_batch > 0 && !chunks.empty()) {
                 const size_t warm = std::min((size_t)warm_batches * device_batch, total);

@@ -322,6 +322,10 @@ typedef struct foa_stream foa_stream;
  * sockets); the environment variable FOA_STREAM_AFFINITY=0 leaves them to the scheduler.  Measured on a 2 x EPYC 9575F host:
  * 4 Mi-sample batches carry 3.2-3.4 Gsample/s of complex<double> through process_samples with four helpers and 4.0-4.8 with eight (more than
  * four alternate between the caller's block of eight CPUs and its neighbour; FOA_STREAM_AFFINITY=1 keeps all on one) (profiles/).
+ * Streams of batches up to 65536 samples -- a live radio's -- keep twelve batch buffers in rotation (larger batches: six), and their submitter
+ * thread POLLS instead of sleeping while batches keep coming (until 2 ms pass without one): one CPU busy for the stream's lifetime buys the
+ * tail of the payload latency (4 Ki batches at 20 Msample/s: p99 1.2 ms instead of 1.4-3; profiles/r06_latency_stages.txt).  The environment
+ * variable FOA_STREAM_SPIN_US sets that interval (0: the thread sleeps, as it does by itself in a process confined to fewer than four CPUs).
  * One stream per handle: a second create while one is open fails with FOA_E_STATE (the engine's submitter thread owns the handle's
  * streams and work sets); destroying the HANDLE first stops the engine -- every later call on the stream then fails with FOA_E_STATE
  * and foa_stream_destroy only frees it.  Samples pushed with foa_stream_push_f64_owned into a batch that is still open may stay
