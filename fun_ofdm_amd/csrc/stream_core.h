@@ -448,10 +448,12 @@ private:
                     }
                     // (timed: a helper's nudge can fall between the test above and the wait; shorter while an upload or a batch is in flight)
                     const bool busy = !staged.empty() || !flight.empty();
-                    // A stream of SMALL batches does not let this thread sleep while it is live: a sleeping thread takes 100-200 us to come
-                    // back on the machines measured (a batch closed while it slept was staged 115-210 us later, one closed while it
-                    // polled 35; profiles/r06_latency_stages.txt), which is a fifth of such a batch's whole way.  It polls -- a turn of this
-                    // loop is about a microsecond -- until nothing has happened for spin_ns_, then sleeps as above.
+                    // A stream of SMALL batches does not let this thread sleep while it is live: every batch passes it three times (staged,
+                    // submitted once its alignment count is on the host, collected), and a timed sleep in front of each -- with whatever the
+                    // host adds to a wake-up -- is the tail of the payload latency: 4 Ki-sample batches at 20 Msample/s, twelve buffers,
+                    // p90 / p99 3.3-3.6 / 4.4-4.7 ms sleeping against 1.03-1.64 / 1.23-4.1 polling, three runs each
+                    // (profiles/r06_latency_stages.txt).  It polls -- a turn of this loop is about a microsecond -- until nothing has
+                    // happened for spin_ns_, then sleeps as above.
                     if (spin_ns_ > 0 && now_ns() - last_active < spin_ns_) {
                         lk.unlock();
                         for (int k = 0; k < 32; k++) cpu_relax();
