@@ -132,6 +132,7 @@ struct StreamGpu {
     foa_rx *rx = nullptr;
     int64_t B = 0;                                   // batch_samples
     int n_bufs = 6;                                  // buffers in rotation (foa_stream_create)
+    bool copies_in_line = false;                     // small batches: upload and carry copy on the pre-sync's own stream (stage_impl)
     int64_t L = foa::kStreamLongest, C = foa::kStreamCarry;      // longest frame the stream may hold (+ look-ahead) and the carry it implies (option "stream_longest")
     size_t slot_bytes = 4096;
     float *pin[foa::kStreamBufs] = {};               // page-locked staging, B float2 each
@@ -187,14 +188,17 @@ struct StreamGpu {
         const int kp = (k + n_bufs - 1) % n_bufs;
         HIP_TRY(enter_device(rx->device));
         float *d = dev[k].p;
-        if (n_staged == 0) HIP_TRY(hipMemsetAsync(d, 0, (size_t)C * 8, st_in));                     // silence before the stream
-        else HIP_TRY(hipMemcpyAsync(d, dev[kp].p + 2 * B, (size_t)C * 8, hipMemcpyDeviceToDevice, st_in));   // (every batch but the last is full)
-        if (n_new) HIP_TRY(hipMemcpyAsync(d + 2 * C, pin[k], (size_t)n_new * 8, hipMemcpyHostToDevice, st_in));
-        HIP_TRY(hipEventRecord(in_done[k], st_in));
         // ... and right behind it, on the side stream, the pre-sync over the whole buffer and the selection of this batch's alignments:
         // by the time the batch is submitted the host has nothing to wait for but four integers
         hipStream_t st = side_stream(rx);
-        HIP_TRY(hipStreamWaitEvent(st, in_done[k], 0));
+        // (the copies of a SMALL batch go to the side stream itself: a stream of their own lets a large upload run under the batch before's
+        // pre-sync, but the hop from one stream to the other is ~25 us -- more than a 32 KB upload and its carry copy take)
+        hipStream_t cs = copies_in_line ? st : st_in;
+        if (n_staged == 0) HIP_TRY(hipMemsetAsync(d, 0, (size_t)C * 8, cs));                        // silence before the stream
+        else HIP_TRY(hipMemcpyAsync(d, dev[kp].p + 2 * B, (size_t)C * 8, hipMemcpyDeviceToDevice, cs));      // (every batch but the last is full)
+        if (n_new) HIP_TRY(hipMemcpyAsync(d + 2 * C, pin[k], (size_t)n_new * 8, hipMemcpyHostToDevice, cs));
+        HIP_TRY(hipEventRecord(in_done[k], cs));
+        if (cs != st) HIP_TRY(hipStreamWaitEvent(st, in_done[k], 0));
         const int64_t n_buf = C + n_new, pushed = staged_samples + n_new;
         const int64_t start = pushed - n_new - C;                    // stream index of the buffer's first sample
         n_eff[k] = final ? n_buf : n_buf - foa::kStreamSettle;       // tags are final up to here: the batch decides as if the stream ended there
@@ -315,6 +319,7 @@ int foa_stream_create(foa_rx *rx, size_t batch_samples, int narrow_threads, foa_
     // -- 4 .. 16 Ki samples at 20 Msample/s -- need more than six of them on their way at once; with six -- five staged or in flight -- the engine's capacity at 4 Ki
     // samples is 23 Msample/s, and a backlog, once there, drains at 3 while the caller waits for staging slots (profiles/r06_latency_stages.txt).  FOA_STREAM_BUFS overrides (A/B).
     g.n_bufs = batch_samples <= ((size_t)1 << 16) ? foa::kStreamBufs : 6;
+    g.copies_in_line = batch_samples <= ((size_t)1 << 16) && !getenv("FOA_STREAM_COPY_STREAM");
     if (const char *e = getenv("FOA_STREAM_BUFS")) { const int v = atoi(e); if (v >= 3 && v <= foa::kStreamBufs) g.n_bufs = v; }
     int rc = FOA_OK;
     for (int i = 0; i < g.n_bufs && !rc; i++) {

@@ -324,7 +324,8 @@ typedef struct foa_stream foa_stream;
  * four alternate between the caller's block of eight CPUs and its neighbour; FOA_STREAM_AFFINITY=1 keeps all on one) (profiles/).
  * Streams of batches up to 65536 samples -- a live radio's -- keep twelve batch buffers in rotation (larger batches: six), and their submitter
  * thread POLLS instead of sleeping while batches keep coming (until 2 ms pass without one): one CPU busy for the stream's lifetime buys the
- * tail of the payload latency (4 Ki batches at 20 Msample/s: p99 1.2 ms instead of 1.4-3; profiles/r06_latency_stages.txt).  The environment
+ * tail of the payload latency (4 Ki batches at 20 Msample/s: a payload four calls of 4096 samples after its frame's last sample, p50 0.82 ms,
+ * p99 1.0-1.2 instead of 1.4-3; profiles/r06_latency_stages.txt).  The environment
  * variable FOA_STREAM_SPIN_US sets that interval (0: the thread sleeps, as it does by itself in a process confined to fewer than four CPUs).
  * One stream per handle: a second create while one is open fails with FOA_E_STATE (the engine's submitter thread owns the handle's
  * streams and work sets); destroying the HANDLE first stops the engine -- every later call on the stream then fails with FOA_E_STATE
