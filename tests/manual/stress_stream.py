@@ -35,7 +35,7 @@ def run(lo, hi):
         parts.append(np.zeros(int(rng.integers(200, 900)), complex))
         s = np.concatenate(parts).astype(np.complex64)
         want = po.ReceiverChain().run_stream(s.astype(np.complex128))
-        st = foa.Stream(rx, int(rng.choice((8192, 16384, 65536))), int(rng.integers(0, 3)))
+        st = foa.Stream(rx, int(rng.choice((4096, 8192, 16384, 65536))), int(rng.integers(0, 3)))
         got, i = [], 0
         while i < s.size:
             n = int(rng.integers(1, 20000))
