@@ -17,9 +17,11 @@ int foa::upload_tables_decode(const DeviceTables &t)
 
 void foa::launch_fwd3(hipStream_t st, const FrameInfo *info, int nf, const uint16_t *sp, uint64_t *dec)
 {
-    // (a call of up to 1 024 frames -- one four-wave workgroup per CU at most: one frame per wave -- half the renormalisation events per wave,
-    // 7-8 % more frames per second; with 1 100 frames some CUs get a second workgroup and two frames per wave win again by 6 %, from 2 000 on
-    // by 10 % and more: profiles/r05_ab_forward_one_frame_per_wave.txt)
+    // A call of up to 2 048 alignments -- two four-wave workgroups per CU at most -- takes ONE frame per wave: half the renormalisation events per
+    // wave, and a step whose test is a compare and a branch (viterbi_fwd.h).  Against two frames per wave, 1 024-byte frames at 54 Mbps
+    // (profiles/r06_forward_one_frame_crossover.txt): alone 0.47 against 0.59 ms at 1 200 - 2 000 frames, pipelined calls 9 % / 4 % / 0 % faster
+    // at 1 200 / 1 500 / 2 000; from 2 600 frames on two frames per wave win the pipelined loop by 6-9 % (alone still 7 % behind).
+    // (Round 5, before the one-frame form had its own test and read its increments ahead: the crossover was at 1 024.)
     if (nf < kSingleBelow) hipLaunchKernelGGL(k_viterbi_fwd3<1>, dim3((nf + kFwdWaves - 1) / kFwdWaves), dim3(64 * kFwdWaves), 0, st, info, nf, sp, dec);
     else hipLaunchKernelGGL(k_viterbi_fwd3<2>, dim3(((nf + 1) / 2 + kFwdWaves - 1) / kFwdWaves), dim3(64 * kFwdWaves), 0, st, info, nf, sp, dec);
 }

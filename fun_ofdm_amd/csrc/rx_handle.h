@@ -181,7 +181,7 @@ namespace foa {
 constexpr int kDeepBelow = 4609;                 // frames: up to 2.25 forward-pass waves per SIMD.  (Round 5 drew the line at 2049; measured since: 3 000 frames per call
                                                  // +9 % with four loops, 4 000 mixed-rate alignments -- BASELINE config 5 -- +14 %, 5 000 frames the same
                                                  // either way, 6 000 and more 2-8 % better with two: profiles/r06_depth_by_frames.txt)
-constexpr int kSingleBelow = 1025;               // frames: below this -- up to one four-wave workgroup per CU -- the forward pass takes one frame per wave (launch_fwd3)
+constexpr int kSingleBelow = 2049;               // alignments: below this -- up to two four-wave workgroups per CU -- the forward pass takes one frame per wave (launch_fwd3)
 
 inline bool piped(const foa_rx *rx) { return rx->pipeline; }
 // Host-pointer entry points copy their inputs (and the pre-sync stage runs) on the third stream when calls are pipelined, off the

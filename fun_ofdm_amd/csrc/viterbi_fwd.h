@@ -124,6 +124,7 @@ __device__ __forceinline__ uint32_t wave_min_lo16(uint32_t v)
 
 struct Fwd3Lane {
     uint32_t ofs[6];      // byte offset of this lane's variant inside a step's 64-byte staging entry: 16 cls + 8 side
+    uint32_t thr1;        // (one frame per wave) the renormalisation threshold as a per-lane operand: state 0's lane holds it, no other lane can exceed its 0xFFFF
 };
 
 __device__ __forceinline__ Fwd3Lane fwd3_lane_init(int lane)
@@ -136,6 +137,7 @@ __device__ __forceinline__ Fwd3Lane fwd3_lane_init(int lane)
         const uint32_t cls = ((__popc((2 * i) & 121) & 1) << 1) | (__popc((2 * i) & 91) & 1);   // viterbi.cpp:86-91
         c.ofs[ph] = 16u * cls + 8u * ((lane >> q) & 1);                   // the pair's high slot adds 63-m on the low branch
     }
+    c.thr1 = lane == 0 ? kRenormThr : 0xFFFFu;
     return c;
 }
 
@@ -209,10 +211,22 @@ constexpr int fwd3_acc_index(int j) { return (j >> 3) & 1; }
 // shadow of its way to the scalar unit (the two instructions do not depend on it; a wave issues in order); J == -1: no decision
 // is recorded (trellis steps 0..5); J == -2: data step jdyn (run time: a frame's last, partial chunk).
 template <int kPair, int PH, int J>
-__device__ __forceinline__ uint32_t fwd3_step(uint32_t M, const uint2 w, uint32_t (&acc)[2], int jdyn)
+__device__ __forceinline__ uint32_t fwd3_step(uint32_t M, const uint2 w, uint32_t (&acc)[2], int jdyn, uint32_t thr1 = 0xFFFFu)
 {
     uint32_t x, y;
     uint32_t Mn = fwd3_acs<PH>(M, w, x, y);
+    if constexpr (J >= 0 && kPair == 1) {
+        // One frame per wave: "state 0 exceeds 210" as a vector compare against a per-lane threshold (v_cmp_gt_u32_sdwa on the low half ->
+        // VCC) and s_cbranch_vccnz -- two instructions where v_readfirstlane + subtract + bit test + branch are four, all of them on a lone
+        // wave's chain: forward pass of 16 .. 256 frames of 1 024 bytes at 54 Mbps 0.430 -> 0.389 ms.  (With two frames per wave it would be
+        // two compares: one more VALU instruction per step where those are what the machine runs out of.)
+        constexpr uint32_t m = 0x01000100u << (J & 7);
+        uint32_t tmp;
+        const uint64_t due = __builtin_amdgcn_ballot_w64((uint16_t)Mn > (uint16_t)thr1);
+        asm volatile("v_pk_sub_u16 %1, %2, %3\n\tv_bfi_b32 %0, %4, %1, %0" : "+v"(acc[fwd3_acc_index(J)]), "=&v"(tmp) : "v"(x), "v"(y), "s"(m), "s"((uint32_t)due));
+        if (__builtin_expect(due != 0, 0)) { uint32_t s0 = __builtin_amdgcn_readfirstlane(Mn); Mn = fwd3_renorm<1>(Mn, s0); }
+        return Mn;
+    }
     if constexpr (J >= 0) {
         constexpr uint32_t m = 0x01000100u << (J & 7);
         uint32_t tmp;
@@ -283,17 +297,17 @@ __device__ __forceinline__ uint32_t fwd3_group_ahead(uint32_t M, const uint4 *bm
 #pragma unroll
         for (int i = 0; i < 6; i++) n[i] = fwd3_inc(bml, ENEXT + i, c.ofs[i]);
     }
-    M = fwd3_step<1, 0, J0 + 0>(M, w[0], acc, 0);
+    M = fwd3_step<1, 0, J0 + 0>(M, w[0], acc, 0, c.thr1);
     if constexpr (((J0 + 0) & 15) == 15) flush((J0 + 0) >> 4);
-    M = fwd3_step<1, 1, J0 + 1>(M, w[1], acc, 0);
+    M = fwd3_step<1, 1, J0 + 1>(M, w[1], acc, 0, c.thr1);
     if constexpr (((J0 + 1) & 15) == 15) flush((J0 + 1) >> 4);
-    M = fwd3_step<1, 2, J0 + 2>(M, w[2], acc, 0);
+    M = fwd3_step<1, 2, J0 + 2>(M, w[2], acc, 0, c.thr1);
     if constexpr (((J0 + 2) & 15) == 15) flush((J0 + 2) >> 4);
-    M = fwd3_step<1, 3, J0 + 3>(M, w[3], acc, 0);
+    M = fwd3_step<1, 3, J0 + 3>(M, w[3], acc, 0, c.thr1);
     if constexpr (((J0 + 3) & 15) == 15) flush((J0 + 3) >> 4);
-    M = fwd3_step<1, 4, J0 + 4>(M, w[4], acc, 0);
+    M = fwd3_step<1, 4, J0 + 4>(M, w[4], acc, 0, c.thr1);
     if constexpr (((J0 + 4) & 15) == 15) flush((J0 + 4) >> 4);
-    M = fwd3_step<1, 5, J0 + 5>(M, w[5], acc, 0);
+    M = fwd3_step<1, 5, J0 + 5>(M, w[5], acc, 0, c.thr1);
     if constexpr (((J0 + 5) & 15) == 15) flush((J0 + 5) >> 4);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
