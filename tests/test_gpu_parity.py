@@ -989,25 +989,25 @@ def test_random_batches_vs_oracle(rx, po, seed):
 
 
 def test_large_mixed_batch_vs_oracle(rx, po):
-    """More than kSingleBelow - 1 (1 024) alignments in ONE call, so that the forward pass takes two frames per wave (smaller calls take one): random
+    """More than kSingleBelow - 1 (2 048) alignments in ONE call, so that the forward pass takes two frames per wave (smaller calls take one): random
     rates and lengths side by side in a wave's two halves (different step counts, a dead alignment next to a live one, an odd count), some
     frames in noise.  Every alignment exactly as the oracle has it; the same stream cut into small calls (one frame per wave) must agree too."""
     rng = np.random.default_rng(77)
-    specs = [(int(rng.integers(0, 11)), int(rng.choice([0, 1, int(rng.integers(2, 120)), int(rng.integers(120, 500))], p=[0.03, 0.03, 0.7, 0.24]))) for _ in range(1900)]
+    specs = [(int(rng.integers(0, 11)), int(rng.choice([0, 1, int(rng.integers(2, 120)), int(rng.integers(120, 500))], p=[0.03, 0.03, 0.7, 0.24]))) for _ in range(2900)]
     iq, pays = _make_stream(po, rng, specs, snr_db=17.0, gap=(0, 300), cfo_hz=2500.0)
     descs = po.find_alignments_f32(iq)
-    assert descs.size >= 1400
+    assert descs.size >= 2200                                            # (> 2 048: two frames per wave)
     if descs.size % 2 == 0:
         descs = descs[:-1]                                               # an odd count: the last wave has one frame
     ends = _ends(descs, iq.size)
     opsdu, ores = po.decode_batch_f32(iq, descs, ends, threads=8)
-    assert 900 < int(np.count_nonzero(ores["status"] == 0)) and int(np.count_nonzero(ores["status"] != 0)) > 20
+    assert 1400 < int(np.count_nonzero(ores["status"] == 0)) and int(np.count_nonzero(ores["status"] != 0)) > 20
     psdu, res = rx.decode_frames_host(iq, descs, ends)
     assert np.array_equal(res.view(np.int32), ores.view(np.int32))
     ok = res["status"] == 0
     assert np.array_equal(psdu[ok], opsdu[ok])
-    for lo in range(0, descs.size, 500):                                 # ... and in calls of 500 alignments
-        d2, e2 = descs[lo:lo + 500], ends[lo:lo + 500].copy()
+    for lo, n2 in [(lo, 500) for lo in range(0, descs.size, 500)] + [(0, 1500), (600, 1501)]:   # ... and in calls of 500 and 1 500 alignments (one frame per wave: one / two workgroups per CU)
+        d2, e2 = descs[lo:lo + n2], ends[lo:lo + n2].copy()
         e2[-1] = min(int(e2[-1]), iq.size)
         p2, r2 = rx.decode_frames_host(iq, d2, e2)
         o2p, o2r = po.decode_batch_f32(iq, d2, e2, threads=8)
