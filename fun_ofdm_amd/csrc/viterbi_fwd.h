@@ -154,7 +154,7 @@ __device__ __forceinline__ bool fwd3_due(uint32_t s0)
 template <int kPair>
 __device__ __forceinline__ uint32_t fwd3_renorm(uint32_t Mn, uint32_t &s0)
 {
-    __builtin_amdgcn_s_setprio(1);                    // the wave's recursion stands still until this is through (profiles/r03_ab_renorm_prio.txt)
+    if constexpr (kPair == 2) __builtin_amdgcn_s_setprio(1);   // the wave's recursion stands still until this is through (profiles/r03_ab_renorm_prio.txt; a lone wave has nobody to overtake: +1.2 % there)
     // which halves: the low one iff bit 15 of s0 + 0x002D002D reads 0 (nothing carries into it), the high one by comparing it
     // alone; the amount is wave-uniform, so the bias comes off on the scalar side and the vector side is one v_sub per half
     // (the scalar subtractions are asm so that they stay scalar: the compiler reassociates Mn - (mn - bias) into two vector ops)
@@ -170,7 +170,7 @@ __device__ __forceinline__ uint32_t fwd3_renorm(uint32_t Mn, uint32_t &s0)
         Mn -= adj;
         s0 -= adj;
     }
-    __builtin_amdgcn_s_setprio(0);                    // back to the wave's own priority
+    if constexpr (kPair == 2) __builtin_amdgcn_s_setprio(0);   // back to the wave's own priority
     return Mn;
 }
 
