@@ -85,7 +85,10 @@ int foa::flush_pending(foa_rx *rx, hipEvent_t after_front_end)
 {
     foa_rx::Pending &p = rx->pending;
     if (!p.valid) return FOA_OK;
-    hipStream_t sb = rx->stream2;
+    // (Batches of a live stream that arrive 0.4 ms apart and more leave the lanes mostly idle: their finish and copy back follow the walk on the
+    // lane itself and save the hop to the stitch stream -- ~35 us of a batch's way, the tail unchanged.  At 4 Ki samples, a call every 0.2 ms, the
+    // four lanes are 3/4 occupied and holding one 60 us longer costs the tail more than the hop: profiles/r06_exp_finish_in_line.txt.)
+    hipStream_t sb = (rx->finish_in_line && p.deep && p.nf <= 256) ? p.lane : rx->stream2;
     // the walk follows its forward pass on the call's own lane -- no event between them -- and the next call of that lane
     // queues its front end behind it; the stitch/CRC kernel, which nothing on the loop waits for, goes to the second stream
     if (after_front_end) HIP_TRY(hipStreamWaitEvent(p.lane, after_front_end, 0));

@@ -124,6 +124,7 @@ struct foa_rx {
     int q4_resident = 0;               // workgroups of the data-symbol kernel the device holds at once (its grid: rx_decode.hip)
     int max_dbps = 216;                // work sets hold this many trellis steps per 80 samples (option "max_dbps": the highest rate the caller's frames carry)
     int tb_segment = 960, tb_overlap = 96;   // chain-back: data steps per segment / run-in steps (multiples of 96)
+    bool finish_in_line = false; // a small pipelined call's finish + copy back follow its walk on the call's own lane (a stream engine of 8 .. 64 Ki-sample batches sets it: flush_pending)
     bool timing = true;          // per-kernel HIP events around every decode call (foa_rx_*_kernel_ms); the stream engines switch them off while they own the handle
     bool pipeline = true;        // the finish of one call overlaps the next calls' front end and forward pass (rotating work sets, several streams)
     bool record_eq = false;

@@ -368,6 +368,7 @@ int foa_stream_create(foa_rx *rx, size_t batch_samples, int narrow_threads, foa_
     // frames' trellis at the lone-wave rate (0.65 ms for a 1024-byte frame at 54 Mbps) whatever the batch: what sets the rate of 64 Ki-sample
     // batches is loops in flight over that latency -- 0.36 ms per batch with two -- so batches below a million samples get four where the
     // runtime has the hardware queues for them (foa_rx_create).  FOA_STREAM_DEPTH overrides (A/B).
+    rx->finish_in_line = batch_samples >= 8192 && batch_samples <= ((size_t)1 << 16) && !getenv("FOA_STREAM_FINISH_STITCH");
     rx->timing = false;                              // (nobody reads per-kernel times of a stream's batches: seven runtime calls less per batch)
     rx->depth_saved = rx->depth;
     rx->depth = (batch_samples <= ((size_t)1 << 20) && rx->max_depth >= 4) ? 4 : 2;
@@ -423,6 +424,7 @@ void foa::stream_shutdown(foa_stream *s)
     (void)foa_rx_sync(g.rx);
     if (g.rx->depth_saved >= 0) { g.rx->depth = g.rx->depth_saved; g.rx->depth_saved = -1; }
     g.rx->timing = true;
+    g.rx->finish_in_line = false;
     // the job slots of batches nobody took are released
     while (!g.flight.empty()) { foa::StreamReady r; if (g.collect(g.flight.front().handle, true, &r) <= 0) break; }
     stream_free_buffers(g);
