@@ -224,18 +224,22 @@ static int decode_frames_any(foa_rx *rx, const void *d_iq, bool f64, size_t n_sa
     else hipLaunchKernelGGL(k_header<float2>, dim3(n_total), dim3(64), 0, st, iq, d_descs, d_ends, (int64_t)n_samples, (int)n_lead, n_total, rx->w->info.p, rx->w->hinv.p, eq_sig);
     if (tm) HIP_TRY(hipEventRecord(rx->w->ev[1], st));
     // segments of this call: at most (total data steps)/S + one per frame; lanes beyond the real total idle
-    const size_t max_segs = std::min(rx->w->seg2frame.n, rx->w->dec_cap / (size_t)rx->tb_segment + n_frames + 1);
+    // (960 data steps per lane keep the run-in at a tenth of the work when a call fills the machine.  A call of a few frames has lanes to spare
+    // and waits for ONE lane's walk: 192 + 96 steps instead of 960 + 96, 45 -> ~15 us; FOA_TB_SMALL_SEG=0 in the environment: off, for A/B)
+    static const int small_seg = [] { const char *e = getenv("FOA_TB_SMALL_SEG"); const int v = e ? atoi(e) : kSmallCallSegment; return (v >= 96 && v % 96 == 0) ? v : 0; }();
+    const int seg = (!rx->tb_segment_set && small_seg && nf <= 256) ? small_seg : rx->tb_segment;
+    const size_t max_segs = std::min(rx->w->seg2frame.n, rx->w->dec_cap / (size_t)seg + n_frames + 1);
     const int n_sb = (nf + kScanBlock - 1) / kScanBlock;
     int64_t *blk = rx->w->totals.p + 8;
     if (n_sb == 1) {
-        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(kScanBlock), 0, st, rx->w->info.p, nf, (int64_t)rx->w->sym_cap, (int64_t)rx->w->dec_cap, rx->tb_segment,
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(kScanBlock), 0, st, rx->w->info.p, nf, (int64_t)rx->w->sym_cap, (int64_t)rx->w->dec_cap, seg,
                            (int64_t)rx->w->seg2frame.n, rx->w->totals.p, rx->w->sym2frame.p, rx->w->seg2frame.p, rx->w->spec.p);
     } else {
-        hipLaunchKernelGGL(k_scan_sums, dim3(n_sb), dim3(kScanBlock), 0, st, rx->w->info.p, nf, rx->tb_segment, blk);
+        hipLaunchKernelGGL(k_scan_sums, dim3(n_sb), dim3(kScanBlock), 0, st, rx->w->info.p, nf, seg, blk);
         if (n_sb <= 4096) hipLaunchKernelGGL(k_scan_blocks_w, dim3(1), dim3(64), 0, st, blk, n_sb, (int64_t)rx->w->sym_cap, rx->w->totals.p);
         else hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, blk, n_sb, (int64_t)rx->w->sym_cap, rx->w->totals.p);
         hipLaunchKernelGGL(k_scan_apply, dim3(n_sb), dim3(kScanBlock), 0, st, rx->w->info.p, nf, (int64_t)rx->w->sym_cap,
-                           (int64_t)rx->w->dec_cap, rx->tb_segment, (int64_t)rx->w->seg2frame.n, blk, rx->w->sym2frame.p, rx->w->seg2frame.p, rx->w->spec.p);
+                           (int64_t)rx->w->dec_cap, seg, (int64_t)rx->w->seg2frame.n, blk, rx->w->sym2frame.p, rx->w->seg2frame.p, rx->w->spec.p);
     }
     if (tm) HIP_TRY(hipEventRecord(rx->w->ev[2], st));
     // upper bound on data symbols in n_samples samples; waves beyond the real total exit at once
@@ -260,12 +264,12 @@ static int decode_frames_any(foa_rx *rx, const void *d_iq, bool f64, size_t n_sa
         launch_fwd3(st, rx->w->info.p, nf, rx->w->sp.p, rx->w->dec.p);
         if (tm) HIP_TRY(hipEventRecord(rx->w->ev[5], st));
         foa_rx::Pending &p = rx->pending;
-        p.valid = true; p.w = rx->w; p.nf = nf; p.S = rx->tb_segment; p.L = rx->tb_overlap; p.max_segs = max_segs; p.slot_bytes = slot_bytes;
+        p.valid = true; p.w = rx->w; p.nf = nf; p.S = seg; p.L = rx->tb_overlap; p.max_segs = max_segs; p.slot_bytes = slot_bytes;
         p.psdu = d_psdu; p.results = d_results; p.job = rx->attach_job; p.lane = st; p.deep = depth > 2;
     } else {
         launch_fwd3(st, rx->w->info.p, nf, rx->w->sp.p, rx->w->dec.p);
         if (tm) HIP_TRY(hipEventRecord(rx->w->ev[5], st));
-        launch_finish3(st, st, rx->w->info.p, nf, rx->w->dec.p, rx->w->decoded.p, rx->w->seg2frame.p, rx->w->totals.p, rx->w->tb_state.p, max_segs, rx->tb_segment,
+        launch_finish3(st, st, rx->w->info.p, nf, rx->w->dec.p, rx->w->decoded.p, rx->w->seg2frame.p, rx->w->totals.p, rx->w->tb_state.p, max_segs, seg,
                        rx->tb_overlap, d_psdu, slot_bytes, d_results);
         if (tm) HIP_TRY(hipEventRecord(rx->w->ev[6], st));             // (not separable from the forward pass on one stream)
         if (tm) HIP_TRY(hipEventRecord(rx->w->ev[4], st));

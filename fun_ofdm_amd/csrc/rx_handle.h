@@ -124,6 +124,7 @@ struct foa_rx {
     int q4_resident = 0;               // workgroups of the data-symbol kernel the device holds at once (its grid: rx_decode.hip)
     int max_dbps = 216;                // work sets hold this many trellis steps per 80 samples (option "max_dbps": the highest rate the caller's frames carry)
     int tb_segment = 960, tb_overlap = 96;   // chain-back: data steps per segment / run-in steps (multiples of 96)
+    bool tb_segment_set = false;             // option "tb_segment" was given: also calls of a few frames use it (otherwise kSmallCallSegment)
     bool finish_in_line = false; // a small pipelined call's finish + copy back follow its walk on the call's own lane (a stream engine of 8 .. 64 Ki-sample batches sets it: flush_pending)
     bool timing = true;          // per-kernel HIP events around every decode call (foa_rx_*_kernel_ms); the stream engines switch them off while they own the handle
     bool pipeline = true;        // the finish of one call overlaps the next calls' front end and forward pass (rotating work sets, several streams)
@@ -182,6 +183,7 @@ namespace foa {
 constexpr int kDeepBelow = 4609;                 // frames: up to 2.25 forward-pass waves per SIMD.  (Round 5 drew the line at 2049; measured since: 3 000 frames per call
                                                  // +9 % with four loops, 4 000 mixed-rate alignments -- BASELINE config 5 -- +14 %, 5 000 frames the same
                                                  // either way, 6 000 and more 2-8 % better with two: profiles/r06_depth_by_frames.txt)
+constexpr int kSmallCallSegment = 192;           // chain-back segment of a call of up to 256 alignments: a lane walks segment + run-in steps one after the other, and such a call waits for exactly that
 constexpr int kSingleBelow = 2049;               // alignments: below this -- up to two four-wave workgroups per CU -- the forward pass takes one frame per wave (launch_fwd3)
 
 inline bool piped(const foa_rx *rx) { return rx->pipeline; }

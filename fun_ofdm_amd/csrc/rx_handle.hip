@@ -238,6 +238,7 @@ int foa_rx_set_option(foa_rx *rx, const char *name, int64_t value)
     if (!strcmp(name, "tb_segment")) {
         if (value < 96 || value > 3072 || value % 96) return fail(FOA_E_INVALID, "tb_segment must be a multiple of 96 in [96, 3072]");
         rx->tb_segment = (int)value;
+        rx->tb_segment_set = true;
         return FOA_OK;
     }
     if (!strcmp(name, "tb_overlap")) {
