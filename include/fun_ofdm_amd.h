@@ -105,7 +105,7 @@ int foa_rx_reserve(foa_rx *rx, size_t n_samples, size_t n_frames);
 
 /* Options.  Results are identical for every setting of the first group (they shape scheduling and memory; the diagnostic options are in fun_ofdm_amd_diag.h); the second
  * group says which reference behaviour the pre-sync reproduces.  Unknown names and out-of-range values: FOA_E_INVALID.
- *   "tb_segment"  data steps per chain-back segment, a multiple of 96 in [96, 3072] (default 960)
+ *   "tb_segment"  data steps per chain-back segment, a multiple of 96 in [96, 3072] (default 960; calls of up to 256 alignments take 192 unless this option was set)
  *   "tb_overlap"  run-in steps above a segment, a multiple of 96 in [0, 3072] (default 96); any value gives the same result as a
  *                 serial chain-back, small values cost re-walks (fun_ofdm_amd/csrc/viterbi_tb.h)
  *   "pipeline"    consecutive decode calls form a three-stage pipeline (front end | forward pass | chain-back and finish) over several
