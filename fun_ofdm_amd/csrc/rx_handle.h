@@ -234,6 +234,8 @@ int sync_dev_issue(foa_rx *rx, const float *d_iq, size_t n_samples, foa_frame_de
 // decided and final in their tags (k_stream_range: STS_END in [state->lo_abs, hz_abs), first one's c_prev patched from the state) ...
 void launch_stream_range(hipStream_t st, foa_frame_desc *descs, const int32_t *sy_n, int32_t cap, int64_t start_abs, int64_t hz_abs, const StreamState *state,
                          int32_t *range);
+// (a small batch buffer filled by one kernel: `carry` samples out of carry_src -- device memory, null = zeros --, then n_new out of page-locked host memory)
+void launch_stream_fill(hipStream_t st, float *dst, const float *carry_src, int64_t carry, const float *host_src, int64_t n_new);
 
 // ---- rx_stage.hip / rx_tx.hip ----
 int upload_tables_stage(const DeviceTables &t);

@@ -19,6 +19,14 @@ void foa::launch_stream_range(hipStream_t st, foa_frame_desc *descs, const int32
     hipLaunchKernelGGL(k_stream_range, dim3(1), dim3(64), 0, st, descs, sy_n, cap, start_abs, hz_abs, state, range);
 }
 
+void foa::launch_stream_fill(hipStream_t st, float *dst, const float *carry_src, int64_t carry, const float *host_src, int64_t n_new)
+{
+    const int64_t n = carry + n_new;
+    if (n <= 0) return;
+    const unsigned blocks = (unsigned)std::min<int64_t>((n + 1023) / 1024, 1024);
+    hipLaunchKernelGGL(k_stream_fill, dim3(blocks), dim3(256), 0, st, (float2 *)dst, (const float2 *)carry_src, carry, (const float2 *)host_src, n_new);
+}
+
 int foa::sync_dev_issue(foa_rx *rx, const float *d_iq, size_t n_samples, foa_frame_desc *d_descs, int64_t *d_ends, size_t cap, int32_t *ccap_out, int64_t origin, bool behind_walk)
 {
     const int64_t n = (int64_t)n_samples, n_words = (n + 31) / 32;

@@ -133,6 +133,7 @@ struct StreamGpu {
     int64_t B = 0;                                   // batch_samples
     int n_bufs = 6;                                  // buffers in rotation (foa_stream_create)
     bool copies_in_line = false;                     // small batches: upload and carry copy on the pre-sync's own stream (stage_impl)
+    bool fill_by_kernel = false;                     // ... and done by one kernel that reads the page-locked staging memory itself
     int64_t L = foa::kStreamLongest, C = foa::kStreamCarry;      // longest frame the stream may hold (+ look-ahead) and the carry it implies (option "stream_longest")
     size_t slot_bytes = 4096;
     float *pin[foa::kStreamBufs] = {};               // page-locked staging, B float2 each
@@ -194,9 +195,14 @@ struct StreamGpu {
         // (the copies of a SMALL batch go to the side stream itself: a stream of their own lets a large upload run under the batch before's
         // pre-sync, but the hop from one stream to the other is ~25 us -- more than a 32 KB upload and its carry copy take)
         hipStream_t cs = copies_in_line ? st : st_in;
+        if (copies_in_line && fill_by_kernel) {
+            // (... and by ONE kernel that reads the staging memory itself: no DMA engine in the batch's way, sync_kernels.h)
+            launch_stream_fill(cs, d, n_staged == 0 ? nullptr : dev[kp].p + 2 * B, C, pin[k], n_new);
+        } else {
         if (n_staged == 0) HIP_TRY(hipMemsetAsync(d, 0, (size_t)C * 8, cs));                        // silence before the stream
         else HIP_TRY(hipMemcpyAsync(d, dev[kp].p + 2 * B, (size_t)C * 8, hipMemcpyDeviceToDevice, cs));      // (every batch but the last is full)
         if (n_new) HIP_TRY(hipMemcpyAsync(d + 2 * C, pin[k], (size_t)n_new * 8, hipMemcpyHostToDevice, cs));
+        }
         HIP_TRY(hipEventRecord(in_done[k], cs));
         if (cs != st) HIP_TRY(hipStreamWaitEvent(st, in_done[k], 0));
         const int64_t n_buf = C + n_new, pushed = staged_samples + n_new;
@@ -320,6 +326,7 @@ int foa_stream_create(foa_rx *rx, size_t batch_samples, int narrow_threads, foa_
     // samples is 23 Msample/s, and a backlog, once there, drains at 3 while the caller waits for staging slots (profiles/r06_latency_stages.txt).  FOA_STREAM_BUFS overrides (A/B).
     g.n_bufs = batch_samples <= ((size_t)1 << 16) ? foa::kStreamBufs : 6;
     g.copies_in_line = batch_samples <= ((size_t)1 << 16) && !getenv("FOA_STREAM_COPY_STREAM");
+    g.fill_by_kernel = g.copies_in_line && !getenv("FOA_STREAM_DMA_UPLOAD");
     if (const char *e = getenv("FOA_STREAM_BUFS")) { const int v = atoi(e); if (v >= 3 && v <= foa::kStreamBufs) g.n_bufs = v; }
     int rc = FOA_OK;
     for (int i = 0; i < g.n_bufs && !rc; i++) {

@@ -369,6 +369,17 @@ __global__ __launch_bounds__(256) void k_sync_emit(const SyncCand *__restrict__ 
 // are final -- STS_END sample (rot_start) in [lo, hz), buffer-relative, lo from the state the batch before left on the device -- and the
 // phasor timing_sync had in force before the first of them (the phasor of the last alignment decided so far).  One wave; the descriptors
 // are in stream order, so the range is [#{rot_start < lo}, #{rot_start < hz}).
+// A small batch buffer filled by ONE kernel: the carry (the last `carry` samples of the buffer before: device memory; null = silence before the
+// stream) and the batch itself, read straight out of the engine's page-locked staging memory.  hipMemcpyAsync from host memory goes to a DMA
+// engine, and the hand-over between that engine and the compute queue the pre-sync runs on was ~25 us for a 64-KB copy
+// (profiles/r06_latency_stages.txt, section 6): more than the copy and the pre-sync's first kernels together.
+__global__ __launch_bounds__(256) void k_stream_fill(float2 *__restrict__ dst, const float2 *__restrict__ carry_src, int64_t carry, const float2 *__restrict__ host_src, int64_t n_new)
+{
+    const int64_t n = carry + n_new;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = i < carry ? (carry_src ? carry_src[i] : float2{ 0.f, 0.f }) : host_src[i - carry];
+}
+
 __global__ __launch_bounds__(64) void k_stream_range(foa_frame_desc *__restrict__ descs, const int32_t *__restrict__ sy_n, int32_t cap, int64_t start_abs, int64_t hz_abs,
                                                      const StreamState *__restrict__ state, int32_t *__restrict__ range)
 {
