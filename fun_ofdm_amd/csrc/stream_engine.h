@@ -213,8 +213,9 @@ struct StreamGpu {
         if (rc) return rc;
         launch_stream_range(st, (foa_frame_desc *)d_desc[k].p, rx->sy_n.p, (int32_t)desc_cap, start, hz_abs, state.p, la_range.p + 2 * k);
         launch_stream_resolve(st, d, n_eff[k], (const foa_frame_desc *)d_desc[k].p, d_ends[k].p, la_range.p + 2 * k, rx->sy_n.p, start, hz_abs, final, state.p,
-                              la_info.p, la_hinv.p, sel_dev.p + 8 * k, (unsigned)desc_cap);
-        HIP_TRY(hipMemcpyAsync(sel + 8 * k, sel_dev.p + 8 * k, 5 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+                              la_info.p, la_hinv.p, fill_by_kernel ? sel + 8 * k : sel_dev.p + 8 * k, (unsigned)desc_cap);
+        // (a small batch's look-ahead writes its five integers into the page-locked array itself: one copy launch less in front of the host's look at them)
+        if (!fill_by_kernel) HIP_TRY(hipMemcpyAsync(sel + 8 * k, sel_dev.p + 8 * k, 5 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipEventRecord(sel_done[k], st));
         HIP_TRY(hipGetLastError());
         staged_samples = pushed;
